@@ -1,0 +1,74 @@
+"""ctypes binding of libdanet_hip.so (the C ABI declared in include/danet_hip.h).
+
+There is no CPU fallback: every op of this package runs as a HIP kernel on gfx950, and using
+one without the built library (or on a CPU tensor) raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
+_lib = None
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_fl = ctypes.c_float
+
+_SIGNATURES = {
+    'danet_version': (c_i, []),
+    'danet_last_error': (ctypes.c_char_p, []),
+    'danet_smpl_lbs_ctx_floats': (c_sz, [c_i]),
+    'danet_smpl_lbs_fwd_ws_floats': (c_sz, [c_i, c_i, c_i]),
+    'danet_smpl_lbs_bwd_ws_floats': (c_sz, [c_i, c_i, c_i]),
+    'danet_smpl_lbs_forward': (c_i, [c_f, c_f, c_i] + [c_f] * 9 + [c_i] * 4 + [c_f] * 5 + [c_sz, c_f]),
+    'danet_smpl_lbs_backward': (c_i, [c_f, c_f, c_i] + [c_f] * 7 + [c_i] * 4 + [c_f] * 7 + [c_sz, c_f]),
+    'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f]),
+    'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
+    'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
+    'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),
+    'danet_rot6d_to_rotmat_backward': (c_i, [c_f, c_f, c_i, c_f, c_f]),
+}
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libdanet_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                'or `python danet-densepose2smpl_amd/csrc/build.py`. There is no CPU fallback.' % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)       # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().danet_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('danet_hip ops run on the GPU only (got a %s tensor); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('danet_hip ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,67 @@
+"""Builds libdanet_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+Each .hip translation unit is compiled separately (so per-file flags apply: the rasteriser
+needs -ffp-contract=off for bit-exact part ids) and linked into one shared library that sits
+next to the sources, in-tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, 'libdanet_hip.so')
+ARCH = 'gfx950'
+
+UNITS = {
+    'capi.hip': [],
+    'smpl_lbs.hip': [],
+    'iuv_raster.hip': ['-ffp-contract=off'],
+    'geometry.hip': [],
+}
+COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + os.path.join(ROOT, 'include'), '-I' + HERE,
+          '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(out, deps):
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')] + \
+              [os.path.join(ROOT, 'include', 'danet_hip.h'), os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for src, extra in UNITS.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([_hipcc()] + COMMON + extra + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([_hipcc(), '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,523 @@
+// Fused SMPL layer for gfx950: shape/pose blend-shapes, joint regression, 24-joint
+// kinematic chain and linear-blend skinning (forward and backward).
+//
+// Replaces the arithmetic behind /root/reference/models/smpl.py:27-46 (smplx LBS).
+//
+// Decomposition (all fp32):
+//   prep      one wave per batch item: rest joints J = J_template + J_shapedirs.beta (the
+//             J_regressor contraction is folded into constants at model load), the 24-joint
+//             chain, A_j = [Rg_j | Jp_j - Rg_j J_j], and the transposed pose feature pfT.
+//   main      grid (vertex tiles of 64, batch groups of 8).  One lane per vertex COORDINATE
+//             streams its posedirs column (coalesced 768-B rows); the pose feature of the 8
+//             batch items is wave-uniform, so it is fetched with scalar loads and the inner
+//             loop is 8 v_fmac per 4-byte load.  The 24 joint transforms of the 8 items sit in
+//             LDS for the skinning pass.  posedirs (17 MB, the dominant HBM term) is read once
+//             per batch group.
+//   finalize  landmark picks + fixed-order sum of the extra-joint partials (deterministic).
+// Backward mirrors this: main_bwd produces per-tile partials of dA, d(pose feature), d(beta);
+// finalize_bwd reduces them in fixed order and back-propagates through the chain.
+#include "common.h"
+
+namespace {
+
+constexpr int NJ = 24;
+constexpr int NPB = 207;           // pose-basis rows
+constexpr int NPB_PAD = 208;
+constexpr int TV = 64;             // vertices per tile
+constexpr int TC = TV * 3;         // coordinates per tile
+constexpr int NBG = 8;             // batch items per block
+constexpr int WPAD = 25;           // padded row of the staged skin weights (bank spread)
+
+// ctx layout per batch item (floats)
+constexpr int CTX_A = 0;           // [24][12]
+constexpr int CTX_J = 288;         // [24][3] rest joints
+constexpr int CTX_JP = 360;        // [24][3] posed joints
+constexpr int CTX_RG = 432;        // [24][9] global rotations
+constexpr int CTX_STRIDE = 648;
+
+inline int bpad_of(int B) { return (B + NBG - 1) / NBG * NBG; }
+inline int ntiles_of(int V) { return (V + TV - 1) / TV; }
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void smpl_prep_kernel(
+    const float* __restrict__ betas, const float* __restrict__ rot,
+    const float* __restrict__ J_template, const float* __restrict__ J_dirs,
+    const int* __restrict__ parents, int B, int NB, int Bpad, int NJ54,
+    float* __restrict__ ctx, float* __restrict__ pfT, float* __restrict__ joints54)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ float sR[216], sJ[72], sRg[216], sJp[72];
+    float* c = ctx + (size_t)b * CTX_STRIDE;
+    if (b >= B) {   // padding items of the last batch group: harmless zeros
+        for (int i = t; i < CTX_STRIDE; i += 64) c[i] = 0.f;
+        for (int k = t; k < NPB_PAD; k += 64) pfT[(size_t)k * Bpad + b] = 0.f;
+        return;
+    }
+    for (int i = t; i < 216; i += 64) sR[i] = rot[(size_t)b * 216 + i];
+    for (int i = t; i < 72; i += 64) {
+        float s = J_template[i];
+        for (int l = 0; l < NB; ++l) s += J_dirs[i * NB + l] * betas[(size_t)b * NB + l];
+        sJ[i] = s;
+    }
+    __syncthreads();
+    for (int k = t; k < NPB_PAD; k += 64) {
+        float v = 0.f;
+        if (k < NPB) {
+            const int e = k % 9;
+            v = sR[9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        }
+        pfT[(size_t)k * Bpad + b] = v;
+    }
+    for (int i = 0; i < NJ; ++i) {
+        const int p = parents[i];
+        if (t < 9) {
+            const int r = t / 3, cc = t % 3;
+            float s;
+            if (p < 0) s = sR[i * 9 + t];
+            else s = sRg[p * 9 + r * 3 + 0] * sR[i * 9 + 0 + cc] + sRg[p * 9 + r * 3 + 1] * sR[i * 9 + 3 + cc] +
+                     sRg[p * 9 + r * 3 + 2] * sR[i * 9 + 6 + cc];
+            sRg[i * 9 + t] = s;
+        } else if (t < 12) {
+            const int r = t - 9;
+            float s;
+            if (p < 0) s = sJ[i * 3 + r];
+            else {
+                s = sJp[p * 3 + r];
+                for (int m = 0; m < 3; ++m) s += sRg[p * 9 + r * 3 + m] * (sJ[i * 3 + m] - sJ[p * 3 + m]);
+            }
+            sJp[i * 3 + r] = s;
+        }
+        __syncthreads();
+    }
+    for (int idx = t; idx < 288; idx += 64) {
+        const int j = idx / 12, e = idx % 12, r = e / 4, cc = e % 4;
+        float v;
+        if (cc < 3) v = sRg[j * 9 + r * 3 + cc];
+        else {
+            v = sJp[j * 3 + r];
+            for (int m = 0; m < 3; ++m) v -= sRg[j * 9 + r * 3 + m] * sJ[j * 3 + m];
+        }
+        c[CTX_A + idx] = v;
+    }
+    for (int i = t; i < 72; i += 64) {
+        c[CTX_J + i] = sJ[i];
+        c[CTX_JP + i] = sJp[i];
+        if (joints54) joints54[(size_t)b * NJ54 * 3 + i] = sJp[i];
+    }
+    for (int i = t; i < 216; i += 64) c[CTX_RG + i] = sRg[i];
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
+    const float* __restrict__ v_template, const float* __restrict__ shapedirs,
+    const float* __restrict__ posedirs, const float* __restrict__ lbs_weights,
+    const float* __restrict__ Jx, const float* __restrict__ betas,
+    const float* __restrict__ ctx, const float* __restrict__ pfT,
+    int B, int Bpad, int V, int NB, int NE,
+    float* __restrict__ verts, float* __restrict__ v_posed_out, float* __restrict__ jx_partial)
+{
+    const int tile = blockIdx.x, b0 = blockIdx.y * NBG, t = threadIdx.x;
+    const int v0 = tile * TV;
+    const int C = V * 3;
+    __shared__ float sA[NBG][288];
+    __shared__ float sW[TV][WPAD];
+    __shared__ float sVp[NBG][TC];
+
+    for (int i = t; i < NBG * 288; i += 256) {
+        const int bb = i / 288, e = i % 288;
+        sA[bb][e] = ctx[(size_t)(b0 + bb) * CTX_STRIDE + CTX_A + e];
+    }
+    for (int i = t; i < TV * NJ; i += 256) {
+        const int vv = i / NJ, j = i % NJ, v = v0 + vv;
+        sW[vv][j] = v < V ? lbs_weights[(size_t)v * NJ + j] : 0.f;
+    }
+    if (t < TC) {
+        const int c = v0 * 3 + t;
+        const bool valid = c < C;
+        const int cl = valid ? c : C - 1;
+        float acc[NBG];
+        const float base = v_template[cl];
+#pragma unroll
+        for (int bb = 0; bb < NBG; ++bb) acc[bb] = base;
+        for (int l = 0; l < NB; ++l) {
+            const float s = shapedirs[(size_t)cl * NB + l];
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) {
+                const int b = b0 + bb < B ? b0 + bb : B - 1;
+                acc[bb] += s * betas[(size_t)b * NB + l];
+            }
+        }
+        const float* pcol = posedirs + cl;
+        const float* pf = pfT + b0;
+#pragma unroll 8
+        for (int k = 0; k < NPB; ++k) {
+            const float p = pcol[(size_t)k * C];
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) acc[bb] += pf[(size_t)k * Bpad + bb] * p;
+        }
+#pragma unroll
+        for (int bb = 0; bb < NBG; ++bb) {
+            sVp[bb][t] = acc[bb];
+            if (v_posed_out && valid && b0 + bb < B) v_posed_out[(size_t)(b0 + bb) * C + c] = acc[bb];
+        }
+    }
+    __syncthreads();
+    for (int pair = t; pair < TV * NBG; pair += 256) {
+        const int vv = pair & (TV - 1), bb = pair / TV;
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = sW[vv][j];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] += w * sA[bb][j * 12 + e];
+        }
+        const float x = sVp[bb][vv * 3 + 0], y = sVp[bb][vv * 3 + 1], z = sVp[bb][vv * 3 + 2];
+        float o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = T[r * 4 + 0] * x + T[r * 4 + 1] * y + T[r * 4 + 2] * z + T[r * 4 + 3];
+        const int v = v0 + vv, b = b0 + bb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sVp[bb][vv * 3 + r] = o[r];
+        if (v < V && b < B) {
+            float* dst = verts + ((size_t)b * V + v) * 3;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        }
+    }
+    __syncthreads();
+    if (jx_partial) {
+        const int NO = NE * 3;
+        for (int o = t; o < NBG * NO; o += 256) {
+            const int bb = o / NO, e = (o % NO) / 3, k = o % 3;
+            float s = 0.f;
+            const int nv = min(TV, V - v0);
+            for (int vv = 0; vv < nv; ++vv) s += Jx[(size_t)e * V + v0 + vv] * sVp[bb][vv * 3 + k];
+            jx_partial[((size_t)tile * Bpad + b0 + bb) * NO + e * 3 + k] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void smpl_finalize_kernel(
+    const float* __restrict__ verts, const float* __restrict__ jx_partial,
+    const int* __restrict__ landmark_verts, int Bpad, int V, int NL, int NE, int ntiles,
+    float* __restrict__ joints54)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int NJ54 = NJ + NL + NE;
+    float* jo = joints54 + (size_t)b * NJ54 * 3;
+    for (int i = t; i < NL * 3; i += 64)
+        jo[NJ * 3 + i] = verts[((size_t)b * V + landmark_verts[i / 3]) * 3 + i % 3];
+    const int NO = NE * 3;
+    for (int o = t; o < NO; o += 64) {
+        float s = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) s += jx_partial[((size_t)tile * Bpad + b) * NO + o];
+        jo[(NJ + NL) * 3 + o] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, main pass.  Per (tile, batch group): seeds, d v_posed, and per-tile partials of
+//   gA   [ntiles][Bpad][288]   d/dA_j (3x4 per joint)
+//   gPf  [ntiles][Bpad][208]   d/d pose feature
+//   gBt  [ntiles][Bpad][NBmax] d/d beta through v_shaped
+constexpr int KC = 52;             // posedirs rows per LDS chunk (4 chunks cover 208)
+constexpr int PPAD = TC + 1;
+constexpr int NB_MAX = 16;
+
+__global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
+    const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
+    const float* __restrict__ lbs_weights, const float* __restrict__ Jx,
+    const int* __restrict__ landmark_verts, const float* __restrict__ ctx,
+    const float* __restrict__ v_posed, const float* __restrict__ g_verts,
+    const float* __restrict__ g_j54,
+    int B, int Bpad, int V, int NB, int NL, int NE,
+    float* __restrict__ gA_part, float* __restrict__ gPf_part, float* __restrict__ gBt_part)
+{
+    const int tile = blockIdx.x, b0 = blockIdx.y * NBG, t = threadIdx.x;
+    const int v0 = tile * TV;
+    const int C = V * 3;
+    const int NJ54 = NJ + NL + NE;
+    __shared__ float sA[NBG][288];
+    __shared__ float sW[TV][WPAD];
+    __shared__ float sG[NBG][TC];            // seed gradient per vertex coordinate
+    __shared__ float sVp[NBG][TC];           // saved v_posed
+    __shared__ __attribute__((aligned(16))) float sGvpT[TC][NBG];   // d v_posed, transposed
+    __shared__ float sP[KC][PPAD];
+    __shared__ float sRed[4][KC][NBG];
+
+    for (int i = t; i < NBG * 288; i += 256) {
+        const int bb = i / 288, e = i % 288;
+        sA[bb][e] = ctx[(size_t)(b0 + bb) * CTX_STRIDE + CTX_A + e];
+    }
+    for (int i = t; i < TV * NJ; i += 256) {
+        const int vv = i / NJ, j = i % NJ, v = v0 + vv;
+        sW[vv][j] = v < V ? lbs_weights[(size_t)v * NJ + j] : 0.f;
+    }
+    // seeds + saved v_posed
+    for (int i = t; i < NBG * TC; i += 256) {
+        const int bb = i / TC, cc = i % TC, vv = cc / 3, k = cc % 3;
+        const int v = v0 + vv, b = b0 + bb;
+        float g = 0.f, vp = 0.f;
+        if (v < V && b < B) {
+            if (g_verts) g = g_verts[(size_t)b * C + v * 3 + k];
+            vp = v_posed[(size_t)b * C + v * 3 + k];
+            if (g_j54) {
+                const float* gj = g_j54 + (size_t)b * NJ54 * 3;
+                for (int l = 0; l < NL; ++l)
+                    if (landmark_verts[l] == v) g += gj[(NJ + l) * 3 + k];
+                for (int e = 0; e < NE; ++e) g += Jx[(size_t)e * V + v] * gj[(NJ + NL + e) * 3 + k];
+            }
+        }
+        sG[bb][cc] = g;
+        sVp[bb][cc] = vp;
+    }
+    __syncthreads();
+    // d v_posed = (sum_j w_vj Rg_j)^T g
+    for (int pair = t; pair < TV * NBG; pair += 256) {
+        const int vv = pair & (TV - 1), bb = pair / TV;
+        float T[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = sW[vv][j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) T[r * 3 + cc] += w * sA[bb][j * 12 + r * 4 + cc];
+        }
+        const float g0 = sG[bb][vv * 3 + 0], g1 = sG[bb][vv * 3 + 1], g2 = sG[bb][vv * 3 + 2];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) sGvpT[vv * 3 + cc][bb] = T[0 * 3 + cc] * g0 + T[1 * 3 + cc] * g1 + T[2 * 3 + cc] * g2;
+    }
+    __syncthreads();
+    // gA partial: thread <-> (bb, j)
+    if (t < NBG * NJ) {
+        const int bb = t / NJ, j = t % NJ;
+        float acc[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+        for (int vv = 0; vv < TV; ++vv) {
+            const float w = sW[vv][j];
+            if (w != 0.f) {
+                const float x = sVp[bb][vv * 3 + 0], y = sVp[bb][vv * 3 + 1], z = sVp[bb][vv * 3 + 2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float wg = w * sG[bb][vv * 3 + r];
+                    acc[r * 4 + 0] += wg * x; acc[r * 4 + 1] += wg * y; acc[r * 4 + 2] += wg * z; acc[r * 4 + 3] += wg;
+                }
+            }
+        }
+        float* dst = gA_part + ((size_t)tile * Bpad + b0 + bb) * 288 + j * 12;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) dst[e] = acc[e];
+    }
+    // d beta partial through v_shaped (= d v_posed): thread <-> (bb, l)
+    if (t < NBG * NB) {
+        const int bb = t / NB, l = t % NB;
+        float s = 0.f;
+        const int nc = min(TC, C - v0 * 3);
+        for (int cc = 0; cc < nc; ++cc) s += shapedirs[(size_t)(v0 * 3 + cc) * NB + l] * sGvpT[cc][bb];
+        gBt_part[((size_t)tile * Bpad + b0 + bb) * NB_MAX + l] = s;
+    }
+    // d pose-feature partial: posedirs tile staged through LDS in 4 chunks of 52 rows
+    for (int chunk = 0; chunk < NPB_PAD / KC; ++chunk) {
+        const int k0 = chunk * KC;
+        __syncthreads();
+        for (int i = t; i < KC * TC; i += 256) {
+            const int kk = i / TC, cc = i % TC, k = k0 + kk, c = v0 * 3 + cc;
+            sP[kk][cc] = (k < NPB && c < C) ? posedirs[(size_t)k * C + c] : 0.f;
+        }
+        __syncthreads();
+        if (t < 4 * KC) {
+            const int kk = t % KC, q = t / KC;
+            float acc[NBG];
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) acc[bb] = 0.f;
+            for (int cc = q * (TC / 4); cc < (q + 1) * (TC / 4); ++cc) {
+                const float p = sP[kk][cc];
+                const float4 ga = *reinterpret_cast<const float4*>(&sGvpT[cc][0]);
+                const float4 gb = *reinterpret_cast<const float4*>(&sGvpT[cc][4]);
+                acc[0] += p * ga.x; acc[1] += p * ga.y; acc[2] += p * ga.z; acc[3] += p * ga.w;
+                acc[4] += p * gb.x; acc[5] += p * gb.y; acc[6] += p * gb.z; acc[7] += p * gb.w;
+            }
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) sRed[q][kk][bb] = acc[bb];
+        }
+        __syncthreads();
+        for (int i = t; i < KC * NBG; i += 256) {
+            const int kk = i / NBG, bb = i % NBG;
+            const float s = sRed[0][kk][bb] + sRed[1][kk][bb] + sRed[2][kk][bb] + sRed[3][kk][bb];
+            gPf_part[((size_t)tile * Bpad + b0 + bb) * NPB_PAD + k0 + kk] = s;
+        }
+    }
+}
+
+// Backward, finalize: fixed-order reduction of the partials + chain back-propagation.
+__global__ __launch_bounds__(256) void smpl_finalize_bwd_kernel(
+    const float* __restrict__ rot, const float* __restrict__ J_dirs, const int* __restrict__ parents,
+    const float* __restrict__ ctx, const float* __restrict__ g_j54,
+    const float* __restrict__ gA_part, const float* __restrict__ gPf_part, const float* __restrict__ gBt_part,
+    int Bpad, int NB, int NL, int NE, int ntiles,
+    float* __restrict__ g_betas, float* __restrict__ g_rot)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int NJ54 = NJ + NL + NE;
+    __shared__ float sR[216], sRg[216], sJ[72];
+    __shared__ float gRg[216], gR[216], gJp[72], gJ[72], gtt[72], gPf[NPB_PAD], gBt[NB_MAX];
+    const float* c = ctx + (size_t)b * CTX_STRIDE;
+    for (int i = t; i < 216; i += 256) { sR[i] = rot[(size_t)b * 216 + i]; sRg[i] = c[CTX_RG + i]; }
+    for (int i = t; i < 72; i += 256) {
+        sJ[i] = c[CTX_J + i];
+        gJp[i] = g_j54 ? g_j54[(size_t)b * NJ54 * 3 + i] : 0.f;
+    }
+    for (int e = t; e < 288; e += 256) {
+        float s = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) s += gA_part[((size_t)tile * Bpad + b) * 288 + e];
+        const int j = e / 12, r = (e % 12) / 4, cc = e % 4;
+        if (cc < 3) gRg[j * 9 + r * 3 + cc] = s; else gtt[j * 3 + r] = s;
+    }
+    for (int k = t; k < NPB_PAD; k += 256) {
+        float s = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) s += gPf_part[((size_t)tile * Bpad + b) * NPB_PAD + k];
+        gPf[k] = s;
+    }
+    if (t < NB) {
+        float s = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) s += gBt_part[((size_t)tile * Bpad + b) * NB_MAX + t];
+        gBt[t] = s;
+    }
+    __syncthreads();
+    // tt_j = Jp_j - Rg_j J_j
+    if (t < 216) {
+        const int j = t / 9, r = (t % 9) / 3, cc = t % 3;
+        gRg[t] -= gtt[j * 3 + r] * sJ[j * 3 + cc];
+    }
+    if (t < 72) {
+        const int j = t / 3, cc = t % 3;
+        gJ[t] = -(sRg[j * 9 + 0 + cc] * gtt[j * 3 + 0] + sRg[j * 9 + 3 + cc] * gtt[j * 3 + 1] + sRg[j * 9 + 6 + cc] * gtt[j * 3 + 2]);
+        gJp[t] += gtt[t];
+    }
+    __syncthreads();
+    for (int i = NJ - 1; i >= 1; --i) {
+        const int p = parents[i];
+        if (t < 9) {
+            const int r = t / 3, cc = t % 3;
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                s += sRg[p * 9 + m * 3 + r] * gRg[i * 9 + m * 3 + cc];
+                s2 += gRg[i * 9 + r * 3 + m] * sR[i * 9 + cc * 3 + m];
+            }
+            gR[i * 9 + t] = s;
+            gRg[p * 9 + t] += s2 + gJp[i * 3 + r] * (sJ[i * 3 + cc] - sJ[p * 3 + cc]);
+        } else if (t < 12) {
+            const int cc = t - 9;
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) s += sRg[p * 9 + m * 3 + cc] * gJp[i * 3 + m];
+            gJ[i * 3 + cc] += s;
+            gJ[p * 3 + cc] -= s;
+            gJp[p * 3 + cc] += gJp[i * 3 + cc];
+        }
+        __syncthreads();
+    }
+    if (t < 9) gR[t] = gRg[t];
+    if (t < 3) gJ[t] += gJp[t];
+    __syncthreads();
+    if (t < 216) g_rot[(size_t)b * 216 + t] = gR[t] + (t >= 9 ? gPf[t - 9] : 0.f);
+    if (t < NB) {
+        float s = gBt[t];
+        for (int i = 0; i < 72; ++i) s += J_dirs[i * NB + t] * gJ[i];
+        g_betas[(size_t)b * NB + t] = s;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" size_t danet_smpl_lbs_ctx_floats(int B) {
+    return (size_t)bpad_of(B) * CTX_STRIDE;
+}
+extern "C" size_t danet_smpl_lbs_fwd_ws_floats(int B, int V, int NE) {
+    const size_t Bp = bpad_of(B);
+    return (size_t)NPB_PAD * Bp + (size_t)ntiles_of(V) * Bp * NE * 3;
+}
+extern "C" size_t danet_smpl_lbs_bwd_ws_floats(int B, int V, int NB) {
+    (void)NB;
+    const size_t Bp = bpad_of(B);
+    return (size_t)ntiles_of(V) * Bp * (288 + NPB_PAD + NB_MAX);
+}
+
+extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, int B,
+                                      const float* v_template, const float* shapedirs, const float* posedirs,
+                                      const float* J_template, const float* J_shapedirs,
+                                      const float* lbs_weights, const int32_t* parents,
+                                      const float* J_regressor_extra, const int32_t* landmark_verts,
+                                      int V, int NB, int NL, int NE,
+                                      float* verts, float* joints54, float* ctx, float* v_posed,
+                                      float* ws, size_t ws_floats, void* stream)
+{
+    DANET_CHECK_ARG(B > 0 && V > 0, "smpl_lbs_forward: B=%d V=%d", B, V);
+    DANET_CHECK_ARG(NB >= 1 && NB <= NB_MAX, "smpl_lbs_forward: NB=%d unsupported (1..%d)", NB, NB_MAX);
+    DANET_CHECK_ARG(NL >= 0 && NE >= 0 && NE <= 28, "smpl_lbs_forward: NL=%d NE=%d", NL, NE);
+    DANET_CHECK_ARG(betas && rotmats && v_template && shapedirs && posedirs && J_template && J_shapedirs &&
+                    lbs_weights && parents && verts && ctx && ws, "smpl_lbs_forward: null pointer");
+    DANET_CHECK_ARG((NL == 0 && NE == 0) || joints54, "smpl_lbs_forward: joints54 is null");
+    DANET_CHECK_ARG(NL == 0 || landmark_verts, "smpl_lbs_forward: landmark_verts is null");
+    DANET_CHECK_ARG(NE == 0 || J_regressor_extra, "smpl_lbs_forward: J_regressor_extra is null");
+    if (ws_floats < danet_smpl_lbs_fwd_ws_floats(B, V, NE))
+        return danet::fail(DANET_ERR_WORKSPACE, "smpl_lbs_forward: workspace %zu < %zu floats", ws_floats,
+                           danet_smpl_lbs_fwd_ws_floats(B, V, NE));
+    hipStream_t s = (hipStream_t)stream;
+    const int Bp = bpad_of(B), nt = ntiles_of(V);
+    float* pfT = ws;
+    float* jxp = ws + (size_t)NPB_PAD * Bp;
+    hipLaunchKernelGGL(smpl_prep_kernel, dim3(Bp), dim3(64), 0, s, betas, rotmats, J_template, J_shapedirs, parents,
+                       B, NB, Bp, NJ + NL + NE, ctx, pfT, joints54);
+    DANET_CHECK_LAUNCH("smpl_prep_kernel");
+    hipLaunchKernelGGL(smpl_lbs_fwd_kernel, dim3(nt, Bp / NBG), dim3(256), 0, s, v_template, shapedirs, posedirs,
+                       lbs_weights, J_regressor_extra, betas, ctx, pfT, B, Bp, V, NB, NE, verts, v_posed,
+                       NE > 0 ? jxp : nullptr);
+    DANET_CHECK_LAUNCH("smpl_lbs_fwd_kernel");
+    if (joints54 && (NL > 0 || NE > 0)) {
+        hipLaunchKernelGGL(smpl_finalize_kernel, dim3(B), dim3(64), 0, s, verts, jxp, landmark_verts, Bp, V, NL, NE, nt,
+                           joints54);
+        DANET_CHECK_LAUNCH("smpl_finalize_kernel");
+    }
+    return DANET_OK;
+}
+
+extern "C" int danet_smpl_lbs_backward(const float* betas, const float* rotmats, int B,
+                                       const float* shapedirs, const float* posedirs, const float* J_shapedirs,
+                                       const float* lbs_weights, const int32_t* parents,
+                                       const float* J_regressor_extra, const int32_t* landmark_verts,
+                                       int V, int NB, int NL, int NE,
+                                       const float* ctx, const float* v_posed,
+                                       const float* g_verts, const float* g_joints54,
+                                       float* g_betas, float* g_rotmats,
+                                       float* ws, size_t ws_floats, void* stream)
+{
+    (void)betas;
+    DANET_CHECK_ARG(B > 0 && V > 0, "smpl_lbs_backward: B=%d V=%d", B, V);
+    DANET_CHECK_ARG(NB >= 1 && NB <= NB_MAX, "smpl_lbs_backward: NB=%d unsupported (1..%d)", NB, NB_MAX);
+    DANET_CHECK_ARG(rotmats && shapedirs && posedirs && J_shapedirs && lbs_weights && parents && ctx && v_posed &&
+                    g_betas && g_rotmats && ws, "smpl_lbs_backward: null pointer");
+    DANET_CHECK_ARG(!g_joints54 || ((NL == 0 || landmark_verts) && (NE == 0 || J_regressor_extra)),
+                    "smpl_lbs_backward: joint tables missing");
+    if (ws_floats < danet_smpl_lbs_bwd_ws_floats(B, V, NB))
+        return danet::fail(DANET_ERR_WORKSPACE, "smpl_lbs_backward: workspace %zu < %zu floats", ws_floats,
+                           danet_smpl_lbs_bwd_ws_floats(B, V, NB));
+    hipStream_t s = (hipStream_t)stream;
+    const int Bp = bpad_of(B), nt = ntiles_of(V);
+    float* gA = ws;
+    float* gPf = gA + (size_t)nt * Bp * 288;
+    float* gBt = gPf + (size_t)nt * Bp * NPB_PAD;
+    hipLaunchKernelGGL(smpl_lbs_bwd_kernel, dim3(nt, Bp / NBG), dim3(256), 0, s, shapedirs, posedirs, lbs_weights,
+                       J_regressor_extra, landmark_verts, ctx, v_posed, g_verts, g_joints54, B, Bp, V, NB, NL, NE,
+                       gA, gPf, gBt);
+    DANET_CHECK_LAUNCH("smpl_lbs_bwd_kernel");
+    hipLaunchKernelGGL(smpl_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rotmats, J_shapedirs, parents, ctx,
+                       g_joints54, gA, gPf, gBt, Bp, NB, NL, NE, nt, g_betas, g_rotmats);
+    DANET_CHECK_LAUNCH("smpl_finalize_bwd_kernel");
+    return DANET_OK;
+}

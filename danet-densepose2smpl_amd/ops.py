@@ -1,0 +1,125 @@
+"""torch.autograd.Function wrappers over the C ABI (include/danet_hip.h)."""
+import torch
+
+from . import _lib
+from ._lib import ptr, check, stream
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class SmplLbsFunction(torch.autograd.Function):
+    """(betas [B,NB], rotmats [B,24,3,3], model buffers) -> (vertices [B,V,3], joints54 [B,54,3]).
+    Gradients flow to betas and rotmats (/root/reference/models/danet/smpl_regressor.py:176)."""
+
+    @staticmethod
+    def forward(ctx, betas, rotmats, m):
+        L = _lib.lib()
+        betas_c, rot_c = _f32c(betas), _f32c(rotmats).view(-1, 24, 3, 3)
+        B, NB = betas_c.shape
+        V = m.v_template.shape[0]
+        NL, NE = m.landmark_verts.numel(), m.J_regressor_extra.shape[0]
+        dev = betas_c.device
+        need_grad = betas.requires_grad or rotmats.requires_grad
+        verts = torch.empty(B, V, 3, device=dev, dtype=torch.float32)
+        j54 = torch.empty(B, 24 + NL + NE, 3, device=dev, dtype=torch.float32)
+        cbuf = torch.empty(L.danet_smpl_lbs_ctx_floats(B), device=dev, dtype=torch.float32)
+        vposed = torch.empty(B, V, 3, device=dev, dtype=torch.float32) if need_grad else None
+        nws = L.danet_smpl_lbs_fwd_ws_floats(B, V, NE)
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        check(L.danet_smpl_lbs_forward(
+            ptr(betas_c), ptr(rot_c), B, ptr(m.v_template), ptr(m.shapedirs), ptr(m.posedirs),
+            ptr(m.J_template), ptr(m.J_shapedirs), ptr(m.lbs_weights), ptr(m.parents),
+            ptr(m.J_regressor_extra), ptr(m.landmark_verts), V, NB, NL, NE,
+            ptr(verts), ptr(j54), ptr(cbuf), ptr(vposed), ptr(ws), nws, stream()), 'danet_smpl_lbs_forward')
+        if need_grad:
+            ctx.m = m
+            ctx.save_for_backward(betas_c, rot_c, cbuf, vposed)
+        return verts, j54
+
+    @staticmethod
+    def backward(ctx, g_verts, g_j54):
+        L = _lib.lib()
+        m = ctx.m
+        betas_c, rot_c, cbuf, vposed = ctx.saved_tensors
+        B, NB = betas_c.shape
+        V = m.v_template.shape[0]
+        NL, NE = m.landmark_verts.numel(), m.J_regressor_extra.shape[0]
+        dev = betas_c.device
+        gv = None if g_verts is None else _f32c(g_verts)
+        gj = None if g_j54 is None else _f32c(g_j54)
+        g_betas = torch.empty(B, NB, device=dev, dtype=torch.float32)
+        g_rot = torch.empty(B, 24, 3, 3, device=dev, dtype=torch.float32)
+        nws = L.danet_smpl_lbs_bwd_ws_floats(B, V, NB)
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        check(L.danet_smpl_lbs_backward(
+            ptr(betas_c), ptr(rot_c), B, ptr(m.shapedirs), ptr(m.posedirs), ptr(m.J_shapedirs),
+            ptr(m.lbs_weights), ptr(m.parents), ptr(m.J_regressor_extra), ptr(m.landmark_verts),
+            V, NB, NL, NE, ptr(cbuf), ptr(vposed), ptr(gv), ptr(gj), ptr(g_betas), ptr(g_rot),
+            ptr(ws), nws, stream()), 'danet_smpl_lbs_backward')
+        return g_betas, g_rot, None
+
+
+def smpl_lbs(betas, rotmats, model):
+    return SmplLbsFunction.apply(betas, rotmats, model)
+
+
+def iuv_raster(verts, cam, vert_mapping, faces, tex, focal, orig, out_size, return_aux=False):
+    """Forward-only (labels are rendered from detached meshes, danet.py:163-165)."""
+    L = _lib.lib()
+    v, c = _f32c(verts), _f32c(cam)
+    B, NV = v.shape[0], v.shape[1]
+    S = int(out_size)
+    out = torch.empty(B, 3, S, S, device=v.device, dtype=torch.float32)
+    fidx = torch.empty(B, S, S, device=v.device, dtype=torch.int32) if return_aux else None
+    depth = torch.empty(B, S, S, device=v.device, dtype=torch.float32) if return_aux else None
+    check(L.danet_iuv_raster_forward(ptr(v), ptr(c), B, NV, ptr(vert_mapping), vert_mapping.numel(),
+                                     ptr(faces), ptr(tex), faces.shape[0], float(focal), float(orig), S,
+                                     ptr(out), ptr(fidx), ptr(depth), stream()), 'danet_iuv_raster_forward')
+    return (out, fidx, depth) if return_aux else out
+
+
+def _rodrigues(theta, which):
+    L = _lib.lib()
+    if theta.requires_grad:
+        raise RuntimeError('%s is forward-only (the reference only applies it to labels)' % which)
+    th = _f32c(theta).view(-1, 3)
+    R = torch.empty(th.shape[0], 3, 3, device=th.device, dtype=torch.float32)
+    check(getattr(L, which)(ptr(th), th.shape[0], ptr(R), stream()), which)
+    return R
+
+
+def batch_rodrigues(theta):
+    """/root/reference/utils/geometry.py:9-23."""
+    return _rodrigues(theta, 'danet_batch_rodrigues')
+
+
+def rodrigues_smplx(theta):
+    return _rodrigues(theta, 'danet_rodrigues_smplx')
+
+
+class Rot6dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        xc = _f32c(x).view(-1, 6)
+        R = torch.empty(xc.shape[0], 3, 3, device=xc.device, dtype=torch.float32)
+        check(L.danet_rot6d_to_rotmat_forward(ptr(xc), xc.shape[0], ptr(R), stream()), 'danet_rot6d_to_rotmat_forward')
+        ctx.save_for_backward(xc)
+        ctx.in_shape = x.shape
+        return R
+
+    @staticmethod
+    def backward(ctx, gR):
+        L = _lib.lib()
+        (xc,) = ctx.saved_tensors
+        g = _f32c(gR)
+        gx = torch.empty_like(xc)
+        check(L.danet_rot6d_to_rotmat_backward(ptr(xc), ptr(g), xc.shape[0], ptr(gx), stream()), 'danet_rot6d_to_rotmat_backward')
+        return gx.view(ctx.in_shape)
+
+
+def rot6d_to_rotmat(x):
+    """/root/reference/utils/geometry.py:47-61."""
+    return Rot6dFunction.apply(x)

@@ -1,0 +1,108 @@
+/* libdanet_hip.so -- C ABI of the MI355X-native DaNet hot path.
+ *
+ * The reference (HongwenZhang/DaNet-DensePose2SMPL) is pure Python and has no FFI: its
+ * de-facto boundary is a set of Python call signatures.  Each entry point
+ * below replaces the arithmetic behind one of them; the Python host in
+ * danet-densepose2smpl_amd/ keeps the reference's class / method names and calls these
+ * through ctypes (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted "host";
+ *  - the caller owns all memory (tensors, workspaces); nothing is allocated or freed here;
+ *  - every call only enqueues work on `stream` (a hipStream_t passed as void*); no call
+ *    synchronises the device, so everything is hipGraph-capturable;
+ *  - return value 0 = ok, negative = error; the message is in danet_last_error()
+ *    (thread-local).  No C++ exceptions cross the boundary.
+ */
+#ifndef DANET_HIP_H
+#define DANET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DANET_OK 0
+#define DANET_ERR_ARG (-1)       /* invalid argument / unsupported shape */
+#define DANET_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define DANET_ERR_WORKSPACE (-3) /* workspace too small */
+
+int danet_version(void);
+const char* danet_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * SMPL layer.  Replaces the arithmetic behind SMPL.forward
+ * (/root/reference/models/smpl.py:27-46 -> smplx.SMPL.forward / smplx.lbs.lbs, and
+ * vertices2joints(J_regressor_extra, vertices) at models/smpl.py:30).
+ *
+ * Inputs  betas [B,NB] f32, rotmats [B,24,3,3] f32 (row-major; global_orient first).
+ * Model   v_template [V,3], shapedirs [V*3,NB], posedirs [207,V*3], J_template [24,3] and
+ *         J_shapedirs [24*3,NB] (= J_regressor . v_template / shapedirs, folded once at model
+ *         load), lbs_weights [V,24], parents [24] i32 (parents[0] < 0),
+ *         J_regressor_extra [NE,V], landmark_verts [NL] i32.
+ * Outputs verts [B,V,3]; joints54 [B,24+NL+NE,3] = 24 posed joints, NL landmark vertices,
+ *         NE extra regressed joints; ctx [danet_smpl_lbs_ctx_floats(B)] and
+ *         v_posed [B,V,3] are saved for the backward (v_posed may be NULL for inference).
+ * ws      scratch of danet_smpl_lbs_fwd_ws_floats(B,V,NE) floats.
+ */
+size_t danet_smpl_lbs_ctx_floats(int B);
+size_t danet_smpl_lbs_fwd_ws_floats(int B, int V, int NE);
+size_t danet_smpl_lbs_bwd_ws_floats(int B, int V, int NB);
+
+int danet_smpl_lbs_forward(const float* betas, const float* rotmats, int B,
+                           const float* v_template, const float* shapedirs, const float* posedirs,
+                           const float* J_template, const float* J_shapedirs,
+                           const float* lbs_weights, const int32_t* parents,
+                           const float* J_regressor_extra, const int32_t* landmark_verts,
+                           int V, int NB, int NL, int NE,
+                           float* verts, float* joints54, float* ctx, float* v_posed,
+                           float* ws, size_t ws_floats, void* stream);
+
+/* Gradient w.r.t. betas and rotmats (the reference's differentiable call site is
+ * /root/reference/models/danet/smpl_regressor.py:176).  g_verts [B,V,3] and
+ * g_joints54 [B,24+NL+NE,3] may each be NULL (= zero).  Outputs g_betas [B,NB],
+ * g_rotmats [B,24,3,3]. */
+int danet_smpl_lbs_backward(const float* betas, const float* rotmats, int B,
+                            const float* shapedirs, const float* posedirs, const float* J_shapedirs,
+                            const float* lbs_weights, const int32_t* parents,
+                            const float* J_regressor_extra, const int32_t* landmark_verts,
+                            int V, int NB, int NL, int NE,
+                            const float* ctx, const float* v_posed,
+                            const float* g_verts, const float* g_joints54,
+                            float* g_betas, float* g_rotmats,
+                            float* ws, size_t ws_floats, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * IUV renderer.  Replaces IUV_Renderer.verts2uvimg
+ * (/root/reference/utils/renderer.py:256-278 -> neural_renderer.Renderer, 'projection'
+ * camera, flat per-face colour, no anti-aliasing, fill_back=False).  Forward only: the
+ * reference renders detached label meshes (models/danet/danet.py:163-165).
+ *
+ * verts [B,NV,3] f32, cam [B,3] f32 (s,tx,ty), vert_mapping [NDV] i32 (DensePose vertex ->
+ * SMPL vertex), faces [F,3] i32 (into the NDV vertices), tex [F,3] f32; focal (5000),
+ * orig (INIMG_SIZE), S (HEATMAP_SIZE).  out [B,3,S,S] f32; face_idx [B,S,S] i32 (-1 = bg)
+ * and depth [B,S,S] f32 (+inf = bg) may be NULL.
+ */
+int danet_iuv_raster_forward(const float* verts, const float* cam, int B, int NV,
+                             const int32_t* vert_mapping, int NDV,
+                             const int32_t* faces, const float* tex, int F,
+                             float focal, float orig, int S,
+                             float* out, int32_t* face_idx, float* depth, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Geometry helpers (/root/reference/utils/geometry.py).
+ *  danet_batch_rodrigues          geometry.py:9-45   theta [N,3] -> R [N,3,3] (via quaternion)
+ *  danet_rodrigues_smplx          smplx.lbs.batch_rodrigues (pose2rot=True inside SMPL.forward)
+ *  danet_rot6d_to_rotmat_*        geometry.py:47-61  x [N,6] (viewed [N,3,2]) -> R [N,3,3]
+ */
+int danet_batch_rodrigues(const float* theta, int N, float* R, void* stream);
+int danet_rodrigues_smplx(const float* theta, int N, float* R, void* stream);
+int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream);
+int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANET_HIP_H */
