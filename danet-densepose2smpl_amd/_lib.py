@@ -23,7 +23,8 @@ _SIGNATURES = {
     'danet_smpl_lbs_bwd_ws_floats': (c_sz, [c_i, c_i, c_i]),
     'danet_smpl_lbs_forward': (c_i, [c_f, c_f, c_i] + [c_f] * 9 + [c_i] * 4 + [c_f] * 5 + [c_sz, c_f]),
     'danet_smpl_lbs_backward': (c_i, [c_f, c_f, c_i] + [c_f] * 7 + [c_i] * 4 + [c_f] * 7 + [c_sz, c_f]),
-    'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f]),
+    'danet_iuv_raster_ws_bytes': (c_sz, [c_i, c_i, c_i]),
+    'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),
@@ -39,6 +40,9 @@ def lib():
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7): it must be
+        # mapped BEFORE this library so that both share ONE runtime (streams, device memory).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 'libdanet_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; g.build()"` '

@@ -21,6 +21,10 @@ inline int fail(int code, const char* fmt, ...) {
 #define DANET_CHECK_ARG(cond, ...) \
     do { if (!(cond)) return ::danet::fail(DANET_ERR_ARG, __VA_ARGS__); } while (0)
 
+// first statement of every enqueueing entry point: drop any sticky error left by an earlier,
+// unrelated HIP call so that DANET_CHECK_LAUNCH reports only our own launch failures
+#define DANET_ENTER() (void)hipGetLastError()
+
 #define DANET_CHECK_LAUNCH(name) \
     do { hipError_t e_ = hipGetLastError(); \
          if (e_ != hipSuccess) return ::danet::fail(DANET_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); } while (0)

@@ -108,24 +108,28 @@ __global__ void rot6d_bwd_kernel(const float* __restrict__ x, const float* __res
     hipLaunchKernelGGL(kernel, dim3(danet::cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" int danet_batch_rodrigues(const float* theta, int N, float* R, void* stream) {
+    DANET_ENTER();
     DANET_CHECK_ARG(theta && R && N > 0, "batch_rodrigues: bad arguments");
     LAUNCH_1D(batch_rodrigues_kernel, N, stream, theta, N, R);
     DANET_CHECK_LAUNCH("batch_rodrigues_kernel");
     return DANET_OK;
 }
 extern "C" int danet_rodrigues_smplx(const float* theta, int N, float* R, void* stream) {
+    DANET_ENTER();
     DANET_CHECK_ARG(theta && R && N > 0, "rodrigues_smplx: bad arguments");
     LAUNCH_1D(rodrigues_smplx_kernel, N, stream, theta, N, R);
     DANET_CHECK_LAUNCH("rodrigues_smplx_kernel");
     return DANET_OK;
 }
 extern "C" int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream) {
+    DANET_ENTER();
     DANET_CHECK_ARG(x && R && N > 0, "rot6d_to_rotmat_forward: bad arguments");
     LAUNCH_1D(rot6d_fwd_kernel, N, stream, x, N, R);
     DANET_CHECK_LAUNCH("rot6d_fwd_kernel");
     return DANET_OK;
 }
 extern "C" int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream) {
+    DANET_ENTER();
     DANET_CHECK_ARG(x && gR && gx && N > 0, "rot6d_to_rotmat_backward: bad arguments");
     LAUNCH_1D(rot6d_bwd_kernel, N, stream, x, gR, N, gx);
     DANET_CHECK_LAUNCH("rot6d_bwd_kernel");

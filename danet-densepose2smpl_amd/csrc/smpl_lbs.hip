@@ -27,6 +27,11 @@ constexpr int TV = 64;             // vertices per tile
 constexpr int TC = TV * 3;         // coordinates per tile
 constexpr int NBG = 8;             // batch items per block
 constexpr int WPAD = 25;           // padded row of the staged skin weights (bank spread)
+constexpr int KC = 52;             // posedirs rows per LDS chunk in the backward (4 chunks cover 208)
+constexpr int PPAD = TC + 1;
+constexpr int NB_MAX = 16;
+constexpr int NE_MAX = 28;
+constexpr int NL_MAX = 32;
 
 // ctx layout per batch item (floats)
 constexpr int CTX_A = 0;           // [24][12]
@@ -122,15 +127,56 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
     __shared__ float sA[NBG][288];
     __shared__ float sW[TV][WPAD];
     __shared__ float sVp[NBG][TC];
+    __shared__ float sPart[4][NBG][TC];
 
-    for (int i = t; i < NBG * 288; i += 256) {
+#pragma unroll
+    for (int it_ = 0; it_ < (NBG * 288 + 255) / 256; ++it_) {
+        const int i = t + it_ * 256;
+        if (i >= NBG * 288) break;
         const int bb = i / 288, e = i % 288;
         sA[bb][e] = ctx[(size_t)(b0 + bb) * CTX_STRIDE + CTX_A + e];
     }
-    for (int i = t; i < TV * NJ; i += 256) {
+#pragma unroll
+    for (int it_ = 0; it_ < (TV * NJ + 255) / 256; ++it_) {
+        const int i = t + it_ * 256;
+        if (i >= TV * NJ) break;
         const int vv = i / NJ, j = i % NJ, v = v0 + vv;
         sW[vv][j] = v < V ? lbs_weights[(size_t)v * NJ + j] : 0.f;
     }
+    {
+        // pose blend-shapes: wave w owns 52 pose-basis rows, each lane 3 coordinates of the tile;
+        // 39 independent 4-byte loads are in flight per unrolled batch, the pose feature arrives
+        // through scalar loads (wave-uniform)
+        const int w = t >> 6, lane = t & 63;
+        float acc[3][NBG];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) acc[q][bb] = 0.f;
+        int cq[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int c = v0 * 3 + lane + 64 * q; cq[q] = c < C ? c : C - 1; }
+        const float* pf = pfT + b0;
+        const int kbeg = w * (NPB_PAD / 4);
+#pragma unroll 13
+        for (int kk = 0; kk < NPB_PAD / 4; ++kk) {
+            const int k = kbeg + kk;                       // row 207 of pfT is zero padding
+            const int kr = k < NPB ? k : NPB - 1;
+            const float p0 = posedirs[(size_t)kr * C + cq[0]];
+            const float p1 = posedirs[(size_t)kr * C + cq[1]];
+            const float p2 = posedirs[(size_t)kr * C + cq[2]];
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) {
+                const float f = pf[(size_t)k * Bpad + bb];
+                acc[0][bb] += f * p0; acc[1][bb] += f * p1; acc[2][bb] += f * p2;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) sPart[w][bb][lane + 64 * q] = acc[q][bb];
+    }
+    __syncthreads();
     if (t < TC) {
         const int c = v0 * 3 + t;
         const bool valid = c < C;
@@ -138,22 +184,15 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
         float acc[NBG];
         const float base = v_template[cl];
 #pragma unroll
-        for (int bb = 0; bb < NBG; ++bb) acc[bb] = base;
-        for (int l = 0; l < NB; ++l) {
-            const float s = shapedirs[(size_t)cl * NB + l];
+        for (int bb = 0; bb < NBG; ++bb) acc[bb] = base + ((sPart[0][bb][t] + sPart[1][bb][t]) + (sPart[2][bb][t] + sPart[3][bb][t]));
+#pragma unroll
+        for (int l = 0; l < NB_MAX; ++l) {
+            const float sd = l < NB ? shapedirs[(size_t)cl * NB + l] : 0.f;
 #pragma unroll
             for (int bb = 0; bb < NBG; ++bb) {
                 const int b = b0 + bb < B ? b0 + bb : B - 1;
-                acc[bb] += s * betas[(size_t)b * NB + l];
+                acc[bb] += sd * (l < NB ? betas[(size_t)b * NB + l] : 0.f);
             }
-        }
-        const float* pcol = posedirs + cl;
-        const float* pf = pfT + b0;
-#pragma unroll 8
-        for (int k = 0; k < NPB; ++k) {
-            const float p = pcol[(size_t)k * C];
-#pragma unroll
-            for (int bb = 0; bb < NBG; ++bb) acc[bb] += pf[(size_t)k * Bpad + bb] * p;
         }
 #pragma unroll
         for (int bb = 0; bb < NBG; ++bb) {
@@ -190,14 +229,33 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
         for (int o = t; o < NBG * NO; o += 256) {
             const int bb = o / NO, e = (o % NO) / 3, k = o % 3;
             float s = 0.f;
-            const int nv = min(TV, V - v0);
-            for (int vv = 0; vv < nv; ++vv) s += Jx[(size_t)e * V + v0 + vv] * sVp[bb][vv * 3 + k];
+#pragma unroll 16
+            for (int vv = 0; vv < TV; ++vv) {
+                const int v = v0 + vv;
+                s += (v < V ? Jx[(size_t)e * V + v] : 0.f) * sVp[bb][vv * 3 + k];
+            }
             jx_partial[((size_t)tile * Bpad + b0 + bb) * NO + e * 3 + k] = s;
         }
     }
 }
 
-__global__ __launch_bounds__(64) void smpl_finalize_kernel(
+// sum over tiles of part[(tile*Bpad + b)*stride + o] in a FIXED order: 8 lanes own interleaved
+// tile subsets (loads batched 4 deep), then a 3-step butterfly -> deterministic.
+__device__ inline float tile_sum8(const float* __restrict__ part, size_t tile_stride, int ntiles, int sub) {
+    float s = 0.f;
+    for (int t0 = sub; t0 < ntiles; t0 += 32) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int tile = t0 + 8 * u; v[u] = tile < ntiles ? part[(size_t)tile * tile_stride] : 0.f; }
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void smpl_finalize_kernel(
     const float* __restrict__ verts, const float* __restrict__ jx_partial,
     const int* __restrict__ landmark_verts, int Bpad, int V, int NL, int NE, int ntiles,
     float* __restrict__ joints54)
@@ -205,13 +263,15 @@ __global__ __launch_bounds__(64) void smpl_finalize_kernel(
     const int b = blockIdx.x, t = threadIdx.x;
     const int NJ54 = NJ + NL + NE;
     float* jo = joints54 + (size_t)b * NJ54 * 3;
-    for (int i = t; i < NL * 3; i += 64)
+    for (int i = t; i < NL * 3; i += 256)
         jo[NJ * 3 + i] = verts[((size_t)b * V + landmark_verts[i / 3]) * 3 + i % 3];
     const int NO = NE * 3;
-    for (int o = t; o < NO; o += 64) {
-        float s = 0.f;
-        for (int tile = 0; tile < ntiles; ++tile) s += jx_partial[((size_t)tile * Bpad + b) * NO + o];
-        jo[(NJ + NL) * 3 + o] = s;
+    const int o = t >> 3, sub = t & 7;              // 32 outputs per pass, 8 lanes each
+    for (int o0 = 0; o0 < NO; o0 += 32) {
+        const int oo = o0 + o;
+        const int ol = oo < NO ? oo : NO - 1;
+        const float s = tile_sum8(jx_partial + (size_t)b * NO + ol, (size_t)Bpad * NO, ntiles, sub);
+        if (oo < NO && sub == 0) jo[(NJ + NL) * 3 + oo] = s;
     }
 }
 
@@ -220,9 +280,6 @@ __global__ __launch_bounds__(64) void smpl_finalize_kernel(
 //   gA   [ntiles][Bpad][288]   d/dA_j (3x4 per joint)
 //   gPf  [ntiles][Bpad][208]   d/d pose feature
 //   gBt  [ntiles][Bpad][NBmax] d/d beta through v_shaped
-constexpr int KC = 52;             // posedirs rows per LDS chunk (4 chunks cover 208)
-constexpr int PPAD = TC + 1;
-constexpr int NB_MAX = 16;
 
 __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
@@ -244,6 +301,8 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     __shared__ __attribute__((aligned(16))) float sGvpT[TC][NBG];   // d v_posed, transposed
     __shared__ float sP[KC][PPAD];
     __shared__ float sRed[4][KC][NBG];
+    __shared__ float sJx[NE_MAX][TV];
+    __shared__ int sLm[NL_MAX];
 
     for (int i = t; i < NBG * 288; i += 256) {
         const int bb = i / 288, e = i % 288;
@@ -253,8 +312,17 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
         const int vv = i / NJ, j = i % NJ, v = v0 + vv;
         sW[vv][j] = v < V ? lbs_weights[(size_t)v * NJ + j] : 0.f;
     }
+    for (int i = t; i < NE_MAX * TV; i += 256) {
+        const int e = i / TV, vv = i % TV, v = v0 + vv;
+        sJx[e][vv] = (g_j54 && e < NE && v < V) ? Jx[(size_t)e * V + v] : 0.f;
+    }
+    if (t < NL_MAX) sLm[t] = (g_j54 && t < NL) ? landmark_verts[t] - v0 : -1;
+    __syncthreads();
     // seeds + saved v_posed
-    for (int i = t; i < NBG * TC; i += 256) {
+#pragma unroll
+    for (int it_ = 0; it_ < (NBG * TC + 255) / 256; ++it_) {
+        const int i = t + it_ * 256;
+        if (i >= NBG * TC) break;
         const int bb = i / TC, cc = i % TC, vv = cc / 3, k = cc % 3;
         const int v = v0 + vv, b = b0 + bb;
         float g = 0.f, vp = 0.f;
@@ -264,8 +332,8 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
             if (g_j54) {
                 const float* gj = g_j54 + (size_t)b * NJ54 * 3;
                 for (int l = 0; l < NL; ++l)
-                    if (landmark_verts[l] == v) g += gj[(NJ + l) * 3 + k];
-                for (int e = 0; e < NE; ++e) g += Jx[(size_t)e * V + v] * gj[(NJ + NL + e) * 3 + k];
+                    if (sLm[l] == vv) g += gj[(NJ + l) * 3 + k];
+                for (int e = 0; e < NE; ++e) g += sJx[e][vv] * gj[(NJ + NL + e) * 3 + k];
             }
         }
         sG[bb][cc] = g;
@@ -315,15 +383,21 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     if (t < NBG * NB) {
         const int bb = t / NB, l = t % NB;
         float s = 0.f;
-        const int nc = min(TC, C - v0 * 3);
-        for (int cc = 0; cc < nc; ++cc) s += shapedirs[(size_t)(v0 * 3 + cc) * NB + l] * sGvpT[cc][bb];
+#pragma unroll 16
+        for (int cc = 0; cc < TC; ++cc) {
+            const int c = v0 * 3 + cc;
+            s += (c < C ? shapedirs[(size_t)c * NB + l] : 0.f) * sGvpT[cc][bb];
+        }
         gBt_part[((size_t)tile * Bpad + b0 + bb) * NB_MAX + l] = s;
     }
     // d pose-feature partial: posedirs tile staged through LDS in 4 chunks of 52 rows
     for (int chunk = 0; chunk < NPB_PAD / KC; ++chunk) {
         const int k0 = chunk * KC;
         __syncthreads();
-        for (int i = t; i < KC * TC; i += 256) {
+#pragma unroll
+        for (int it_ = 0; it_ < (KC * TC + 255) / 256; ++it_) {           // 39 independent loads per lane
+            const int i = t + it_ * 256;
+            if (i >= KC * TC) break;
             const int kk = i / TC, cc = i % TC, k = k0 + kk, c = v0 * 3 + cc;
             sP[kk][cc] = (k < NPB && c < C) ? posedirs[(size_t)k * C + c] : 0.f;
         }
@@ -370,21 +444,25 @@ __global__ __launch_bounds__(256) void smpl_finalize_bwd_kernel(
         sJ[i] = c[CTX_J + i];
         gJp[i] = g_j54 ? g_j54[(size_t)b * NJ54 * 3 + i] : 0.f;
     }
-    for (int e = t; e < 288; e += 256) {
-        float s = 0.f;
-        for (int tile = 0; tile < ntiles; ++tile) s += gA_part[((size_t)tile * Bpad + b) * 288 + e];
-        const int j = e / 12, r = (e % 12) / 4, cc = e % 4;
-        if (cc < 3) gRg[j * 9 + r * 3 + cc] = s; else gtt[j * 3 + r] = s;
-    }
-    for (int k = t; k < NPB_PAD; k += 256) {
-        float s = 0.f;
-        for (int tile = 0; tile < ntiles; ++tile) s += gPf_part[((size_t)tile * Bpad + b) * NPB_PAD + k];
-        gPf[k] = s;
-    }
-    if (t < NB) {
-        float s = 0.f;
-        for (int tile = 0; tile < ntiles; ++tile) s += gBt_part[((size_t)tile * Bpad + b) * NB_MAX + t];
-        gBt[t] = s;
+    {
+        const int o = t >> 3, sub = t & 7;            // 32 outputs per pass, 8 lanes each
+        for (int e0 = 0; e0 < 288; e0 += 32) {
+            const int e = e0 + o;
+            const float s = tile_sum8(gA_part + (size_t)b * 288 + e, (size_t)Bpad * 288, ntiles, sub);
+            const int j = e / 12, r = (e % 12) / 4, cc = e % 4;
+            if (sub == 0) { if (cc < 3) gRg[j * 9 + r * 3 + cc] = s; else gtt[j * 3 + r] = s; }
+        }
+        for (int k0 = 0; k0 < NPB_PAD; k0 += 32) {
+            const int k = k0 + o;
+            const int kl = k < NPB_PAD ? k : NPB_PAD - 1;
+            const float s = tile_sum8(gPf_part + (size_t)b * NPB_PAD + kl, (size_t)Bpad * NPB_PAD, ntiles, sub);
+            if (sub == 0 && k < NPB_PAD) gPf[k] = s;
+        }
+        {
+            const int l = o < NB_MAX ? o : NB_MAX - 1;
+            const float s = tile_sum8(gBt_part + (size_t)b * NB_MAX + l, (size_t)Bpad * NB_MAX, ntiles, sub);
+            if (sub == 0 && o < NB) gBt[o] = s;
+        }
     }
     __syncthreads();
     // tt_j = Jp_j - Rg_j J_j
@@ -427,6 +505,7 @@ __global__ __launch_bounds__(256) void smpl_finalize_bwd_kernel(
     if (t < 216) g_rot[(size_t)b * 216 + t] = gR[t] + (t >= 9 ? gPf[t - 9] : 0.f);
     if (t < NB) {
         float s = gBt[t];
+#pragma unroll 24
         for (int i = 0; i < 72; ++i) s += J_dirs[i * NB + t] * gJ[i];
         g_betas[(size_t)b * NB + t] = s;
     }
@@ -457,9 +536,10 @@ extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, 
                                       float* verts, float* joints54, float* ctx, float* v_posed,
                                       float* ws, size_t ws_floats, void* stream)
 {
+    DANET_ENTER();
     DANET_CHECK_ARG(B > 0 && V > 0, "smpl_lbs_forward: B=%d V=%d", B, V);
     DANET_CHECK_ARG(NB >= 1 && NB <= NB_MAX, "smpl_lbs_forward: NB=%d unsupported (1..%d)", NB, NB_MAX);
-    DANET_CHECK_ARG(NL >= 0 && NE >= 0 && NE <= 28, "smpl_lbs_forward: NL=%d NE=%d", NL, NE);
+    DANET_CHECK_ARG(NL >= 0 && NL <= NL_MAX && NE >= 0 && NE <= NE_MAX, "smpl_lbs_forward: NL=%d NE=%d unsupported", NL, NE);
     DANET_CHECK_ARG(betas && rotmats && v_template && shapedirs && posedirs && J_template && J_shapedirs &&
                     lbs_weights && parents && verts && ctx && ws, "smpl_lbs_forward: null pointer");
     DANET_CHECK_ARG((NL == 0 && NE == 0) || joints54, "smpl_lbs_forward: joints54 is null");
@@ -480,7 +560,7 @@ extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, 
                        NE > 0 ? jxp : nullptr);
     DANET_CHECK_LAUNCH("smpl_lbs_fwd_kernel");
     if (joints54 && (NL > 0 || NE > 0)) {
-        hipLaunchKernelGGL(smpl_finalize_kernel, dim3(B), dim3(64), 0, s, verts, jxp, landmark_verts, Bp, V, NL, NE, nt,
+        hipLaunchKernelGGL(smpl_finalize_kernel, dim3(B), dim3(256), 0, s, verts, jxp, landmark_verts, Bp, V, NL, NE, nt,
                            joints54);
         DANET_CHECK_LAUNCH("smpl_finalize_kernel");
     }
@@ -497,6 +577,7 @@ extern "C" int danet_smpl_lbs_backward(const float* betas, const float* rotmats,
                                        float* g_betas, float* g_rotmats,
                                        float* ws, size_t ws_floats, void* stream)
 {
+    DANET_ENTER();
     (void)betas;
     DANET_CHECK_ARG(B > 0 && V > 0, "smpl_lbs_backward: B=%d V=%d", B, V);
     DANET_CHECK_ARG(NB >= 1 && NB <= NB_MAX, "smpl_lbs_backward: NB=%d unsupported (1..%d)", NB, NB_MAX);
@@ -504,6 +585,7 @@ extern "C" int danet_smpl_lbs_backward(const float* betas, const float* rotmats,
                     g_betas && g_rotmats && ws, "smpl_lbs_backward: null pointer");
     DANET_CHECK_ARG(!g_joints54 || ((NL == 0 || landmark_verts) && (NE == 0 || J_regressor_extra)),
                     "smpl_lbs_backward: joint tables missing");
+    DANET_CHECK_ARG(NL >= 0 && NL <= NL_MAX && NE >= 0 && NE <= NE_MAX, "smpl_lbs_backward: NL=%d NE=%d unsupported", NL, NE);
     if (ws_floats < danet_smpl_lbs_bwd_ws_floats(B, V, NB))
         return danet::fail(DANET_ERR_WORKSPACE, "smpl_lbs_backward: workspace %zu < %zu floats", ws_floats,
                            danet_smpl_lbs_bwd_ws_floats(B, V, NB));

@@ -74,9 +74,11 @@ def iuv_raster(verts, cam, vert_mapping, faces, tex, focal, orig, out_size, retu
     out = torch.empty(B, 3, S, S, device=v.device, dtype=torch.float32)
     fidx = torch.empty(B, S, S, device=v.device, dtype=torch.int32) if return_aux else None
     depth = torch.empty(B, S, S, device=v.device, dtype=torch.float32) if return_aux else None
+    nws = L.danet_iuv_raster_ws_bytes(B, vert_mapping.numel(), S)
+    ws = torch.empty((nws + 7) // 8, device=v.device, dtype=torch.int64)
     check(L.danet_iuv_raster_forward(ptr(v), ptr(c), B, NV, ptr(vert_mapping), vert_mapping.numel(),
                                      ptr(faces), ptr(tex), faces.shape[0], float(focal), float(orig), S,
-                                     ptr(out), ptr(fidx), ptr(depth), stream()), 'danet_iuv_raster_forward')
+                                     ptr(out), ptr(fidx), ptr(depth), ptr(ws), nws, stream()), 'danet_iuv_raster_forward')
     return (out, fidx, depth) if return_aux else out
 
 

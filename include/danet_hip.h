@@ -83,13 +83,16 @@ int danet_smpl_lbs_backward(const float* betas, const float* rotmats, int B,
  * verts [B,NV,3] f32, cam [B,3] f32 (s,tx,ty), vert_mapping [NDV] i32 (DensePose vertex ->
  * SMPL vertex), faces [F,3] i32 (into the NDV vertices), tex [F,3] f32; focal (5000),
  * orig (INIMG_SIZE), S (HEATMAP_SIZE).  out [B,3,S,S] f32; face_idx [B,S,S] i32 (-1 = bg)
- * and depth [B,S,S] f32 (+inf = bg) may be NULL.
+ * and depth [B,S,S] f32 (+inf = bg) may be NULL.  ws: 8-byte-aligned scratch of
+ * danet_iuv_raster_ws_bytes(B,NDV,S) bytes (projected vertices + 64-bit depth/id buffer).
  */
+size_t danet_iuv_raster_ws_bytes(int B, int NDV, int S);
 int danet_iuv_raster_forward(const float* verts, const float* cam, int B, int NV,
                              const int32_t* vert_mapping, int NDV,
                              const int32_t* faces, const float* tex, int F,
                              float focal, float orig, int S,
-                             float* out, int32_t* face_idx, float* depth, void* stream);
+                             float* out, int32_t* face_idx, float* depth,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Geometry helpers (/root/reference/utils/geometry.py).
