@@ -25,6 +25,12 @@ _SIGNATURES = {
     'danet_smpl_lbs_backward': (c_i, [c_f, c_f, c_i] + [c_f] * 7 + [c_i] * 4 + [c_f] * 7 + [c_sz, c_f]),
     'danet_iuv_raster_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'danet_conv_nt': (c_i, [c_i]),
+    'danet_conv_packed_elems': (c_sz, [c_i] * 6),
+    'danet_conv_pack_weights': (c_i, [c_f, c_f] + [c_i] * 6 + [c_f]),
+    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f]),
+    'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
+    'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),

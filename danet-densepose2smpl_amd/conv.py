@@ -1,0 +1,123 @@
+"""Convolution ops on the HIP MFMA kernels (csrc/conv_igemm.hip, conv_wgrad.hip).
+
+Activations are bf16 NHWC (torch channels_last, logical shape [B,C,H,W]); parameters stay fp32
+in the torch layout (state-dict compatible with the reference) and are packed to bf16 once per
+parameter version.  Gradients: dX through the transposed gather of the same MFMA kernel, dW
+through the wgrad kernel (fp32), dbias as a channel sum.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401  (only for nn.init helpers / shape utils)
+
+from . import _lib
+from ._lib import ptr, check, stream
+
+_PACK_CACHE = {}
+
+
+def nhwc_bf16(x):
+    """bf16, channels_last-contiguous view/copy of a [B,C,H,W] tensor."""
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.contiguous(memory_format=torch.channels_last)
+        if not x.permute(0, 2, 3, 1).is_contiguous():       # degenerate strides (C == 1 or H*W == 1)
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x
+
+
+def _empty_nhwc(B, C, H, W, dtype, device):
+    return torch.empty(B, H, W, C, dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def pack_weight(weight, groups, mode):
+    """Packed bf16 copy of an fp32 conv weight, cached per (storage, version, mode)."""
+    key = (weight.data_ptr(), mode, groups)
+    ver = weight._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2] == tuple(weight.shape):
+        return hit[1]
+    L = _lib.lib()
+    Cout, Cin_g, R, S = weight.shape
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    n = L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode)
+    wp = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+    check(L.danet_conv_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, stream()), 'danet_conv_pack_weights')
+    _PACK_CACHE[key] = (ver, wp, tuple(weight.shape))
+    return wp
+
+
+def conv_out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32):
+    L = _lib.lib()
+    y = _empty_nhwc(B, Cout, OH, OW, torch.float32 if out_fp32 else torch.bfloat16, x.device)
+    check(L.danet_conv_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(bias), ptr(y.permute(0, 2, 3, 1)),
+                               B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed),
+                               int(relu), int(out_fp32), stream()), 'danet_conv_forward')
+    return y
+
+
+class Conv2dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32):
+        x = nhwc_bf16(x)
+        B, Cin, H, W = x.shape
+        Cout, Cin_g, R, S = weight.shape
+        if Cin_g * groups != Cin:
+            raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
+        OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+        wp = pack_weight(weight, groups, 0)
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, groups, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, groups, has_bias = ctx.cfg
+        B, Cin, H, W = x.shape
+        Cout, Cin_g, R, S = weight.shape
+        gy = nhwc_bf16(gy)
+        OH, OW = gy.shape[2], gy.shape[3]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wp1 = pack_weight(weight, groups, 1)
+            gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
+            nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
+                                     B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, stream()),
+                  'danet_conv_wgrad')
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.float().sum(dim=(0, 2, 3))
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False):
+    return Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d with the same parameters / state-dict keys, computed by the HIP MFMA kernels."""
+
+    def __init__(self, *args, out_fp32=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert self.padding_mode == 'zeros'
+        assert self.kernel_size[0] == self.kernel_size[1] or True
+        self.out_fp32 = out_fp32
+
+    def forward(self, x):
+        s, p, d = self.stride, self.padding, self.dilation
+        if s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
+            raise ValueError('danet Conv2d supports square stride/padding/dilation only')
+        return conv2d(x, self.weight, self.bias, s[0], p[0], d[0], self.groups, self.out_fp32)

@@ -19,6 +19,8 @@ UNITS = {
     'smpl_lbs.hip': [],
     'iuv_raster.hip': ['-ffp-contract=off'],
     'geometry.hip': [],
+    'conv_igemm.hip': [],
+    'conv_wgrad.hip': [],
 }
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + os.path.join(ROOT, 'include'), '-I' + HERE,
           '-Wall', '-Wno-unused-function']

@@ -1,0 +1,287 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_16x16x32_bf16).
+//
+// Replaces the cuDNN/ATen convolutions behind every nn.Conv2d of the reference's hot path
+// (/root/reference/models/module/hr_module.py, res_module.py; shapes in SURVEY.md A.2).
+//
+// Layout.  Activations are NHWC bf16 (torch channels_last), so the GEMM K axis
+// k = (r, s, cin) is contiguous in memory over cin.  Weights are re-packed once per step into
+// bf16 [group][Cout_pad][Kp] (K zero-padded to a multiple of 32): both MFMA operands are then
+// read as 16-byte, 8-element runs of K.
+//
+// Operand roles.  The MFMA computes D[i][j] = sum_k A[i][k] B[k][j] with the D fragment holding
+// four consecutive ROWS i per lane.  Weights are the A operand (i = cout) and pixels the B
+// operand (j = pixel), so every lane ends with 4 consecutive output channels of one pixel --
+// an 8-byte contiguous NHWC store, no transposition, and the bias/ReLU epilogue is per-lane.
+// Any consistent assignment of the 8 per-lane K elements works because A and B use the same
+// one; lane group g = lane>>4 takes k = k0 + 8g .. 8g+7.
+//
+// One kernel covers forward convolution (any R,S,stride,pad,dilation,groups) and, through the
+// `transposed` gather (t = o + pad - r, valid when stride divides t), data gradients and
+// transposed convolutions.  Weight gradients are in conv_wgrad.hip.
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace danet_conv;
+
+template <int MT, int NT, bool VEC8>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
+{
+    extern __shared__ __attribute__((aligned(16))) int4 sTab[];     // [Kp/8] {dh, dw, cin, valid}
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int g = blockIdx.z;
+
+    if (VEC8) {
+        for (int e = t; e < p.Kp / 8; e += 256) {
+            const int k = e * 8;
+            int4 v = {0, 0, 0, 0};
+            if (k < p.K) {
+                const int tap = k / p.Cin_g, cin = k - tap * p.Cin_g;
+                const int r = tap / p.S, s = tap - r * p.S;
+                v.x = p.transposed ? p.pad - r * p.dil : r * p.dil - p.pad;
+                v.y = p.transposed ? p.pad - s * p.dil : s * p.dil - p.pad;
+                v.z = cin;
+                v.w = 1;
+            }
+            sTab[e] = v;
+        }
+        __syncthreads();
+    }
+
+    // pixels of this wave: MT tiles of 16 consecutive output pixels
+    const long m0 = (long)blockIdx.x * (64 * MT) + wave * (16 * MT);
+    int pb[MT], ph[MT], pw[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        long m = m0 + mt * 16 + li;
+        if (m >= p.M) m = p.M - 1;
+        const int ohw = p.OH * p.OW;
+        const int b = (int)(m / ohw), rem = (int)(m - (long)b * ohw);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        pb[mt] = b;
+        ph[mt] = p.transposed ? oh : oh * p.stride;
+        pw[mt] = p.transposed ? ow : ow * p.stride;
+    }
+    const int n0 = blockIdx.y * (16 * NT);
+    const bf16_t* wbase = p.w + ((size_t)g * p.Cout_pad + n0 + li) * p.Kp + lg * 8;
+    const bf16_t* xg = p.x + (size_t)g * p.Cin_g;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nks = p.Kp / 32;
+    for (int ks = 0; ks < nks; ++ks) {
+        bf16x8 a[NT], bq[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            a[nt] = *reinterpret_cast<const bf16x8*>(wbase + (size_t)nt * 16 * p.Kp + ks * 32);
+        if (VEC8) {
+            const int4 e = sTab[ks * 4 + lg];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int ih = ph[mt] + e.x, iw = pw[mt] + e.y;
+                bool ok = e.w != 0;
+                if (p.transposed) {
+                    ok = ok && ih >= 0 && iw >= 0 && (ih % p.stride) == 0 && (iw % p.stride) == 0;
+                    ih /= p.stride; iw /= p.stride;
+                    ok = ok && ih < p.H && iw < p.W;
+                } else {
+                    ok = ok && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
+                }
+                uint4 raw = {0u, 0u, 0u, 0u};
+                if (ok) raw = *reinterpret_cast<const uint4*>(xg + (((size_t)pb[mt] * p.H + ih) * p.W + iw) * p.Cin + e.z);
+                bq[mt] = __builtin_bit_cast(bf16x8, raw);
+            }
+        } else {
+            // channel counts that are not a multiple of 8 (3-channel stem, 12-channel heads):
+            // element-wise gather; rare and tiny layers only
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                unsigned short v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 32 + lg * 8 + j;
+                    unsigned short val = 0;
+                    if (k < p.K) {
+                        const int tap = k / p.Cin_g, cin = k - tap * p.Cin_g;
+                        const int r = tap / p.S, s = tap - r * p.S;
+                        int ih, iw;
+                        bool ok;
+                        if (p.transposed) {
+                            ih = ph[mt] + p.pad - r * p.dil; iw = pw[mt] + p.pad - s * p.dil;
+                            ok = ih >= 0 && iw >= 0 && (ih % p.stride) == 0 && (iw % p.stride) == 0;
+                            ih /= p.stride; iw /= p.stride;
+                            ok = ok && ih < p.H && iw < p.W;
+                        } else {
+                            ih = ph[mt] + r * p.dil - p.pad; iw = pw[mt] + s * p.dil - p.pad;
+                            ok = ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
+                        }
+                        if (ok) val = xg[(((size_t)pb[mt] * p.H + ih) * p.W + iw) * p.Cin + cin];
+                    }
+                    v[j] = val;
+                }
+                uint4 raw;
+                raw.x = v[0] | ((unsigned)v[1] << 16); raw.y = v[2] | ((unsigned)v[3] << 16);
+                raw.z = v[4] | ((unsigned)v[5] << 16); raw.w = v[6] | ((unsigned)v[7] << 16);
+                bq[mt] = __builtin_bit_cast(bf16x8, raw);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bq[mt], acc[mt][nt], 0, 0, 0);
+    }
+
+    // epilogue: lane holds couts n0 + nt*16 + lg*4 + {0..3} of pixel m0 + mt*16 + li
+    const bool vec_ok = (p.Cout % 4 == 0) && (p.Cout_g % 4 == 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long m = m0 + mt * 16 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cl = n0 + nt * 16 + lg * 4;          // channel within the group
+            if (cl >= p.Cout_g) continue;
+            const int c = g * p.Cout_g + cl;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[mt][nt][r];
+                if (p.bias && cl + r < p.Cout_g) x += p.bias[c + r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[r] = x;
+            }
+            const size_t off = (size_t)m * p.Cout + c;
+            if (p.out_fp32) {
+                float* y = reinterpret_cast<float*>(p.y) + off;
+                if (vec_ok) *reinterpret_cast<float4*>(y) = float4{v[0], v[1], v[2], v[3]};
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (cl + r < p.Cout_g) y[r] = v[r];
+            } else {
+                bf16_t* y = reinterpret_cast<bf16_t*>(p.y) + off;
+                if (vec_ok) {
+                    uint2 pk;
+                    pk.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(y) = pk;
+                } else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (cl + r < p.Cout_g) y[r] = f2bf(v[r]);
+            }
+        }
+    }
+}
+
+// Weight packing: fp32 torch layout W[Cout][Cin_g][R][S] -> bf16 Wp[G][rows_pad][Kp].
+//  mode 0 (forward):  rows = cout within group, k = (r*S+s)*Cin_g + cin
+//  mode 1 (dgrad):    rows = cin  within group, k = (r*S+s)*Cout_g + cout   (used with the transposed gather)
+__global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp,
+                                    int Cout_g, int Cin_g, int R, int S, int G, int rows_pad, int Kp, int mode)
+{
+    const long total = (long)G * rows_pad * Kp;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % Kp);
+    const long rest = idx / Kp;
+    const int row = (int)(rest % rows_pad), g = (int)(rest / rows_pad);
+    const int inner = mode == 0 ? Cin_g : Cout_g;      // channels folded into K
+    const int rows = mode == 0 ? Cout_g : Cin_g;
+    float v = 0.f;
+    if (row < rows && k < R * S * inner) {
+        const int tap = k / inner, ch = k - tap * inner;
+        const int r = tap / S, s = tap - r * S;
+        const int cout = mode == 0 ? row : ch, cin = mode == 0 ? ch : row;
+        v = w[(((size_t)(g * Cout_g + cout) * Cin_g + cin) * R + r) * S + s];
+    }
+    wp[idx] = f2bf(v);
+}
+
+template <int MT, int NT>
+int launch_conv(const ConvP& p, bool vec8, hipStream_t st) {
+    const dim3 grid((unsigned)((p.M + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)p.groups);
+    const size_t lds = vec8 ? (size_t)(p.Kp / 8) * sizeof(int4) : 0;
+    if (vec8) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, false>), grid, dim3(256), lds, st, p);
+    return 0;
+}
+
+}  // namespace
+
+// Output-channel tile count per block chosen for a group width: the packed weights have
+// Cout_pad = roundup(Cout_g, 16*NT) rows.
+extern "C" int danet_conv_nt(int Cout_g) {
+    if (Cout_g <= 16) return 1;
+    if (Cout_g <= 32) return 2;
+    if (Cout_g % 48 == 0 || Cout_g <= 48) return 3;
+    return 4;
+}
+extern "C" size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode) {
+    const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
+    const int nt = danet_conv_nt(rows);
+    const int rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
+    const int Kp = (R * S * inner + 31) / 32 * 32;
+    return (size_t)groups * rows_pad * Kp;
+}
+
+extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
+                                       int mode, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(w && wp && Cout > 0 && Cin_g > 0 && R > 0 && S > 0 && groups > 0 && Cout % groups == 0 && (mode == 0 || mode == 1),
+                    "conv_pack_weights: bad arguments");
+    const int Cout_g = Cout / groups;
+    const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
+    const int nt = danet_conv_nt(rows);
+    const int rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
+    const int Kp = (R * S * inner + 31) / 32 * 32;
+    const long total = (long)groups * rows_pad * Kp;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (bf16_t*)wp, Cout_g, Cin_g, R, S, groups, rows_pad, Kp, mode);
+    DANET_CHECK_LAUNCH("pack_weights_kernel");
+    return DANET_OK;
+}
+
+// y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], wp) (+bias)(ReLU).  `transposed` selects the
+// fractionally-strided gather (data gradient / ConvTranspose2d), in which case (H,W) is the size
+// of the tensor being gathered FROM and `Cin`/`Cout` are its / the result's channel counts.
+extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
+                                  int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                                  int R, int S, int stride, int pad, int dil, int groups, int transposed,
+                                  int relu, int out_fp32, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && wp && y, "conv_forward: null pointer");
+    DANET_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 &&
+                    pad >= 0 && dil > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0,
+                    "conv_forward: bad sizes B=%d H=%d W=%d Cin=%d OH=%d OW=%d Cout=%d R=%d S=%d stride=%d pad=%d groups=%d",
+                    B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, groups);
+    ConvP p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.bias = bias; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.dil = dil; p.groups = groups; p.transposed = transposed;
+    p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
+    p.K = R * S * p.Cin_g; p.Kp = (p.K + 31) / 32 * 32;
+    const int nt = danet_conv_nt(p.Cout_g);
+    p.Cout_pad = (p.Cout_g + 16 * nt - 1) / (16 * nt) * (16 * nt);
+    p.relu = relu; p.out_fp32 = out_fp32;
+    p.M = (long)B * OH * OW;
+    const bool vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
+    DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
+    hipStream_t st = (hipStream_t)stream;
+    // pixel tiles per wave: fewer for small problems so that the grid still fills 256 CUs
+    const long blocks4 = (p.M + 255) / 256 * (p.Cout_pad / (16 * nt)) * groups;
+    const bool small = blocks4 < 512;
+    if (nt == 1) { if (small) launch_conv<1, 1>(p, vec8, st); else launch_conv<4, 1>(p, vec8, st); }
+    else if (nt == 2) { if (small) launch_conv<1, 2>(p, vec8, st); else launch_conv<4, 2>(p, vec8, st); }
+    else if (nt == 3) { if (small) launch_conv<1, 3>(p, vec8, st); else launch_conv<4, 3>(p, vec8, st); }
+    else { if (small) launch_conv<1, 4>(p, vec8, st); else launch_conv<4, 4>(p, vec8, st); }
+    DANET_CHECK_LAUNCH("conv_igemm_kernel");
+    return DANET_OK;
+}

@@ -105,6 +105,34 @@ int danet_rodrigues_smplx(const float* theta, int N, float* R, void* stream);
 int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream);
 int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Convolution (replaces the cuDNN/ATen kernels behind every nn.Conv2d on the hot path:
+ * /root/reference/models/module/hr_module.py:15-378, res_module.py:21-535; shapes SURVEY.md A.2).
+ * Activations are NHWC bf16 (torch channels_last), accumulation fp32 on MFMA.
+ *
+ *  danet_conv_pack_weights  fp32 W[Cout][Cin/groups][R][S] (torch layout) -> packed bf16
+ *      mode 0: forward operand      [G][rows_pad][Kp], rows = cout, k = (r*S+s)*Cin_g + cin
+ *      mode 1: data-gradient operand [G][rows_pad][Kp], rows = cin,  k = (r*S+s)*Cout_g + cout
+ *      (danet_conv_packed_elems gives the element count; rows_pad = roundup(rows, 16*danet_conv_nt(rows)))
+ *  danet_conv_forward       y = conv(x, wp) (+bias[Cout])(ReLU); y is bf16 or fp32 NHWC.
+ *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
+ *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
+ *      Cout := size / channels of dX) and also ConvTranspose2d.
+ *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
+ */
+int danet_conv_nt(int rows_per_group);
+size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode);
+int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
+                            int mode, void* stream);
+int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
+                       int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                       int R, int S, int stride, int pad, int dil, int groups, int transposed,
+                       int relu, int out_fp32, void* stream);
+size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
+int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
+                     int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                     int R, int S, int stride, int pad, int dil, int groups, float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,90 @@
+"""GPU parity of the MFMA convolution kernels against a plain PyTorch fp32 reference of the same
+op (F.conv2d on the bf16-rounded operands).  Tolerances: the kernels accumulate in fp32 and round
+the output once to bf16 (rel 2^-9), so fwd/dgrad must agree to 1e-2 of the output scale;
+wgrad is fp32 out: 2e-3 of scale (atomics reorder the fp32 sum)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (Cin, Cout, k, stride, pad, groups, H, W, bias) -- the HRNet-W48 shapes of SURVEY.md A.2 plus the
+# regressor / partial-IUV shapes; B kept small
+SHAPES = [
+    (48, 48, 3, 1, 1, 1, 64, 64, False), (96, 96, 3, 1, 1, 1, 32, 32, False),
+    (192, 192, 3, 1, 1, 1, 16, 16, False), (384, 384, 3, 1, 1, 1, 8, 8, False),
+    (64, 64, 3, 1, 1, 1, 64, 64, False), (256, 48, 3, 1, 1, 1, 64, 64, False),
+    (64, 256, 1, 1, 0, 1, 64, 64, False), (48, 96, 3, 2, 1, 1, 64, 64, False),
+    (256, 96, 3, 2, 1, 1, 64, 64, False), (256, 64, 1, 1, 0, 1, 64, 64, False),
+    (64, 64, 3, 2, 1, 1, 128, 128, False), (48, 25, 3, 1, 1, 1, 64, 64, True),
+    (48, 24, 3, 1, 1, 1, 64, 64, True), (96, 48, 1, 1, 0, 1, 32, 32, False),
+    (3, 64, 3, 2, 1, 1, 256, 256, False), (48, 15, 3, 1, 1, 1, 64, 64, True),
+    (12, 12, 3, 1, 1, 1, 64, 64, False), (48, 12, 1, 1, 0, 1, 64, 64, False),
+    (12, 48, 1, 1, 0, 1, 64, 64, False), (384, 48, 1, 1, 0, 1, 8, 8, False),
+    (48 * 24, 21 * 24, 3, 1, 1, 24, 32, 32, True),          # predict_partial_iuv (grouped)
+    (64, 64, 7, 2, 3, 1, 64, 64, False),                    # SmplResNet stem
+    (75, 64, 1, 1, 0, 1, 64, 64, False), (21, 64, 1, 1, 0, 1, 64, 64, False),
+    (256 * 24, 128 * 24, 3, 2, 1, 24, 4, 4, False),         # limb_reslayer grouped layer4
+    (256 * 24, 128 * 24, 1, 2, 0, 24, 4, 4, False),
+    (128 * 24, 6 * 24, 1, 1, 0, 24, 1, 1, True),            # grouped 1x1 pose regressors
+    (128, 256, 3, 2, 1, 1, 16, 16, False), (512, 512, 3, 1, 1, 1, 2, 2, False),
+]
+
+
+def _ref_inputs(shape, B, seed):
+    Cin, Cout, k, stride, pad, groups, H, W, bias = shape
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin // groups, k, k, generator=g) / np.sqrt(k * k * Cin / groups)).bfloat16().float()
+    b = torch.randn(Cout, generator=g) if bias else None
+    return x.cuda(), w.cuda(), None if b is None else b.cuda()
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s[:8])))
+def test_conv_forward_backward_vs_torch_fp32(shape):
+    from danet_densepose2smpl_amd import conv
+    Cin, Cout, k, stride, pad, groups, H, W, bias = shape
+    B = 2 if H * W >= 1024 else 4
+    x, w, b = _ref_inputs(shape, B, 1234)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = None if b is None else b.clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=True, allow_tf32=False):
+        yr = F.conv2d(xr, wr, br, stride, pad, 1, groups)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(7)).bfloat16().float().cuda()
+    yr.backward(gy)
+
+    xt = x.clone().requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    bt = None if b is None else b.clone().requires_grad_(True)
+    y = conv.conv2d(xt, wt, bt, stride, pad, 1, groups)
+    assert y.dtype == torch.bfloat16 and y.shape == yr.shape
+    y.backward(gy.bfloat16())
+
+    def close(a, r, rel, what):
+        scale = r.abs().max().item() + 1e-6
+        err = (a.float() - r).abs().max().item()
+        assert err <= rel * scale, '%s: max err %g vs scale %g (%s)' % (what, err, scale, shape)
+    close(y, yr, 1e-2, 'forward')
+    close(xt.grad, xr.grad, 1e-2, 'dgrad')
+    close(wt.grad, wr.grad, 3e-3, 'wgrad')
+    if b is not None:
+        close(bt.grad, br.grad, 2e-3, 'dbias')
+
+
+def test_conv_fp32_output_and_full_batch():
+    """B=32 at the dominant HRNet shape, fp32 epilogue (used by the heads)."""
+    from danet_densepose2smpl_amd import conv
+    shape = (48, 48, 3, 1, 1, 1, 64, 64, True)
+    x, w, b = _ref_inputs(shape, 32, 5)
+    y = conv.conv2d(x, w, b, 1, 1, 1, 1, out_fp32=True)
+    yr = F.conv2d(x, w, b, 1, 1)
+    assert y.dtype == torch.float32
+    assert (y - yr).abs().max().item() <= 2e-3 * yr.abs().max().item()
+
+
+def test_conv_rejects_bad_shapes():
+    from danet_densepose2smpl_amd import conv
+    with pytest.raises(ValueError):
+        conv.conv2d(torch.zeros(1, 5, 8, 8, device='cuda'), torch.zeros(4, 3, 3, 3, device='cuda'))
