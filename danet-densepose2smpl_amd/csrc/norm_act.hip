@@ -1,0 +1,381 @@
+// BatchNorm (+ReLU, +residual add) and the HRNet multi-resolution fuse, on NHWC bf16.
+//
+// Replaces the ~300 BatchNorm2d / ReLU / add / nearest-Upsample launches per forward of the
+// reference's backbone (/root/reference/models/module/hr_module.py:111-177,
+// res_module.py:27-97).  All kernels are HBM-bound streams over the flat [M*C] array: a lane
+// owns one 16-byte run of 8 channels whose channel index never changes across its grid-stride
+// loop (the stride is a multiple of C/8), so per-channel statistics live in registers.
+//
+//   bn_stats        per-channel sum / sum of squares (fp32, block-reduced, one atomic per block)
+//   bn_apply        y = [relu]( (x-mean)*invstd*gamma + beta [+ res] ); also writes mean/invstd
+//                   for the backward and updates the running statistics (training)
+//   bn_bwd_reduce   per-channel sum(dy') and sum(dy' * xhat), dy' = dy * (y > 0) under ReLU
+//   bn_bwd_apply    dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)), d_res = dy'
+//   sum_relu        y = relu(sum_t nearest_upsample_{f_t}(in_t)) (HRNet fuse layer), and its
+//                   per-term backward (window sum of the masked gradient)
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace danet_conv;
+
+constexpr int VW = 4;     // channels per lane (8-byte runs; every BN width on the path is a multiple of 4)
+
+struct Vec { float v[VW]; };
+
+__device__ inline Vec load_bf(const bf16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    Vec o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    return o;
+}
+__device__ inline void store_bf(bf16_t* p, const Vec& a) {
+    uint2 r;
+    r.x = f2bf(a.v[0]) | ((unsigned)f2bf(a.v[1]) << 16);
+    r.y = f2bf(a.v[2]) | ((unsigned)f2bf(a.v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+
+// Flat mapping: vector id v = blockIdx.x*span + t + k*gridspan, span = RY*CV (CV = C/VW).
+// Requires t < span; then v % CV == t % CV for every k.
+struct FlatMap { long nvec; long M; int CV; int span; long gridspan; int ldv; int coff; };
+
+// A lane's vectors: fixed channel-vector cv = t % CV, rows row0, row0 + rstep, ... (no division in the loop)
+#define DANET_ROW_LOOP(fm, t)                                                                  \
+    const int cv_ = (t) % (fm).CV;                                                             \
+    const long rstep_ = (fm).gridspan / (fm).CV;                                               \
+    for (long row_ = ((long)blockIdx.x * (fm).span + (t)) / (fm).CV; row_ < (fm).M; row_ += rstep_)
+#define DANET_ROW_OFF(fm) (((size_t)row_ * (fm).ldv + (fm).coff + cv_) * VW)
+
+__device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int CV, int span, float* dst /* [C] */) {
+    // sm: [256][VW]; lanes with equal (t % CV) are summed in a fixed order, then one atomic per channel
+    if (t < span) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) sm[t][j] = a.v[j];
+    }
+    __syncthreads();
+    if (t < CV) {
+        Vec s;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) s.v[j] = 0.f;
+        for (int u = t; u < span; u += CV)
+#pragma unroll
+            for (int j = 0; j < VW; ++j) s.v[j] += sm[u][j];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) atomicAdd(dst + t * VW + j, s.v[j]);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, FlatMap fm, float* __restrict__ sums /* [2][Cst] */, int Cst)
+{
+    __shared__ float sm[256][VW];
+    const int t = threadIdx.x;
+    Vec s, q;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { s.v[j] = 0.f; q.v[j] = 0.f; }
+    if (t < fm.span) {
+        DANET_ROW_LOOP(fm, t) {
+            const Vec a = load_bf(x + DANET_ROW_OFF(fm));
+#pragma unroll
+            for (int j = 0; j < VW; ++j) { s.v[j] += a.v[j]; q.v[j] += a.v[j] * a.v[j]; }
+        }
+    }
+    block_channel_reduce(sm, s, t, fm.CV, fm.span, sums);
+    block_channel_reduce(sm, q, t, fm.CV, fm.span, sums + Cst);
+}
+
+// mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, FlatMap fm,
+    const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved /* [2][Cst] mean, invstd */,
+    int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu)
+{
+    const int t = threadIdx.x;
+    if (t >= fm.span) return;
+    const int C = Cst;
+    const int c0 = (t % fm.CV) * VW;
+    float sc[VW], sh[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+        float mean, var;
+        if (mode == 0) {
+            mean = sums[c0 + j] * inv_count;
+            var = fmaxf(sums[C + c0 + j] * inv_count - mean * mean, 0.f);
+        } else {
+            mean = running_mean[c0 + j];
+            var = running_var[c0 + j];
+        }
+        const float invstd = rsqrtf(var + eps);
+        const float g = gamma ? gamma[c0 + j] : 1.f, b = beta ? beta[c0 + j] : 0.f;
+        sc[j] = invstd * g;
+        sh[j] = b - mean * sc[j];
+        if (mode == 0 && blockIdx.x == 0 && t < fm.CV) {
+            if (saved) { saved[c0 + j] = mean; saved[C + c0 + j] = invstd; }
+            if (running_mean) {
+                running_mean[c0 + j] = (1.f - momentum) * running_mean[c0 + j] + momentum * mean;
+                running_var[c0 + j] = (1.f - momentum) * running_var[c0 + j] + momentum * var * unbias;
+            }
+        }
+    }
+    DANET_ROW_LOOP(fm, t) {
+        const size_t off = DANET_ROW_OFF(fm);
+        Vec a = load_bf(x + off);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) a.v[j] = a.v[j] * sc[j] + sh[j];
+        if (res) {
+            const Vec r = load_bf(res + off);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) a.v[j] += r.v[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) a.v[j] = fmaxf(a.v[j], 0.f);
+        }
+        store_bf(y + off, a);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */)
+{
+    __shared__ float sm[256][VW];
+    const int t = threadIdx.x;
+    const int C = Cst;
+    Vec s1, s2;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { s1.v[j] = 0.f; s2.v[j] = 0.f; }
+    if (t < fm.span) {
+        const int c0 = (t % fm.CV) * VW;
+        float mean[VW], invstd[VW];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) { mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j]; }
+        DANET_ROW_LOOP(fm, t) {
+            const size_t off = DANET_ROW_OFF(fm);
+            Vec g = load_bf(dy + off);
+            const Vec a = load_bf(x + off);
+            if (relu) {
+                const Vec o = load_bf(y + off);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) g.v[j] = o.v[j] > 0.f ? g.v[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < VW; ++j) { s1.v[j] += g.v[j]; s2.v[j] += g.v[j] * (a.v[j] - mean[j]) * invstd[j]; }
+        }
+    }
+    block_channel_reduce(sm, s1, t, fm.CV, fm.span, red);
+    block_channel_reduce(sm, s2, t, fm.CV, fm.span, red + C);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
+    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres)
+{
+    const int t = threadIdx.x;
+    if (t >= fm.span) return;
+    const int C = Cst;
+    const int c0 = (t % fm.CV) * VW;
+    float mean[VW], invstd[VW], k0[VW], m1[VW], m2[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+        mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j];
+        k0[j] = (gamma ? gamma[c0 + j] : 1.f) * invstd[j];
+        m1[j] = red[c0 + j] * inv_count; m2[j] = red[C + c0 + j] * inv_count;
+    }
+    DANET_ROW_LOOP(fm, t) {
+        const size_t off = DANET_ROW_OFF(fm);
+        Vec g = load_bf(dy + off);
+        const Vec a = load_bf(x + off);
+        if (relu) {
+            const Vec o = load_bf(y + off);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) g.v[j] = o.v[j] > 0.f ? g.v[j] : 0.f;
+        }
+        if (dres) store_bf(dres + off, g);
+        Vec d;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) d.v[j] = k0[j] * (g.v[j] - m1[j] - (a.v[j] - mean[j]) * invstd[j] * m2[j]);
+        store_bf(dx + off, d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct SumP {
+    const bf16_t* in[4]; int shift[4]; int nterms;
+    int B, H, W, C;
+};
+
+__global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, bf16_t* __restrict__ y, int relu)
+{
+    const int CV = p.C / VW;
+    const long nvec = (long)p.B * p.H * p.W * CV;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const int cv = (int)(v % CV);
+        long pix = v / CV;
+        const int w = (int)(pix % p.W); pix /= p.W;
+        const int h = (int)(pix % p.H);
+        const int b = (int)(pix / p.H);
+        Vec s;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) s.v[j] = 0.f;
+        for (int tt = 0; tt < p.nterms; ++tt) {
+            const int sh = p.shift[tt];
+            const int Ht = p.H >> sh, Wt = p.W >> sh;
+            const Vec a = load_bf(p.in[tt] + ((((size_t)b * Ht + (h >> sh)) * Wt + (w >> sh)) * CV + cv) * VW);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) s.v[j] += a.v[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) s.v[j] = fmaxf(s.v[j], 0.f);
+        }
+        store_bf(y + v * VW, s);
+    }
+}
+
+// d_term[b,h',w',c] = sum over the 2^sh x 2^sh window of gy * (y > 0)
+__global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                           int B, int H, int W, int C, int sh, int relu, bf16_t* __restrict__ d)
+{
+    const int CV = C / VW;
+    const int Ht = H >> sh, Wt = W >> sh, f = 1 << sh;
+    const long nvec = (long)B * Ht * Wt * CV;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const int cv = (int)(v % CV);
+        long pix = v / CV;
+        const int w = (int)(pix % Wt); pix /= Wt;
+        const int h = (int)(pix % Ht);
+        const int b = (int)(pix / Ht);
+        Vec s;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) s.v[j] = 0.f;
+        for (int dh = 0; dh < f; ++dh)
+            for (int dw = 0; dw < f; ++dw) {
+                const size_t off = ((((size_t)b * H + (h * f + dh)) * W + (w * f + dw)) * CV + cv) * VW;
+                const Vec g = load_bf(gy + off);
+                if (relu) {
+                    const Vec o = load_bf(y + off);
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) s.v[j] += o.v[j] > 0.f ? g.v[j] : 0.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) s.v[j] += g.v[j];
+                }
+            }
+        store_bf(d + v * VW, s);
+    }
+}
+
+// slab [c_begin, c_begin + Cs) of a [M, C] tensor; Cs <= 1024
+inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* grid) {
+    if (C % VW != 0 || Cs % VW != 0 || c_begin % VW != 0 || Cs / VW > 256) return -1;
+    fm->CV = Cs / VW;
+    fm->ldv = C / VW;
+    fm->coff = c_begin / VW;
+    fm->nvec = M * fm->CV;
+    fm->M = M;
+    fm->span = (256 / fm->CV) * fm->CV;
+    long blocks = (fm->nvec + fm->span - 1) / fm->span;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    *grid = (int)blocks;
+    fm->gridspan = (long)fm->span * blocks;
+    return 0;
+}
+
+}  // namespace
+
+// Tensors wider than 1024 channels (the grouped limb layers, 3072) are processed in channel slabs.
+constexpr int SLAB = 1024;
+
+extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float* saved, float* sums_ws, float momentum, float eps, int training, int relu, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && y && M > 0 && C > 0, "bn_forward: bad arguments");
+    DANET_CHECK_ARG(training ? (saved && sums_ws) : (running_mean && running_var), "bn_forward: missing buffers");
+    DANET_CHECK_ARG(C % VW == 0, "bn_forward: C=%d must be a multiple of %d", C, VW);
+    hipStream_t st = (hipStream_t)stream;
+    if (training) {
+        hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C, st);
+        if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_forward: memset: %s", hipGetErrorString(e));
+    }
+    const float inv = 1.0f / (float)M, unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    for (int c0 = 0; c0 < C; c0 += SLAB) {
+        const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
+        FlatMap fm; int grid;
+        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_forward: C=%d unsupported", C);
+        // per-slab views of the per-channel buffers: [2][C] buffers are addressed as base+c0 with stride C
+        if (training) {
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, fm, sums_ws + c0, C);
+            DANET_CHECK_LAUNCH("bn_stats_kernel");
+        }
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, fm,
+                           sums_ws ? sums_ws + c0 : nullptr, gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr,
+                           running_mean ? running_mean + c0 : nullptr, running_var ? running_var + c0 : nullptr,
+                           saved ? saved + c0 : nullptr, C, inv, unbias, momentum, eps, training ? 0 : 1, relu);
+        DANET_CHECK_LAUNCH("bn_apply_kernel");
+    }
+    return DANET_OK;
+}
+
+// red_ws: [2][C] scratch; on return red_ws[0:C] = d beta, red_ws[C:2C] = d gamma.
+extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
+                                 const float* gamma, const float* saved, int relu,
+                                 void* dx, void* dres, float* red_ws, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(dy && x && dx && saved && red_ws && M > 0 && C > 0 && (!relu || y), "bn_backward: bad arguments");
+    DANET_CHECK_ARG(C % VW == 0, "bn_backward: C=%d must be a multiple of %d", C, VW);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * C, st);
+    if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
+    for (int c0 = 0; c0 < C; c0 += SLAB) {
+        const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
+        FlatMap fm; int grid;
+        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d unsupported", C);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
+                           fm, saved + c0, C, relu, red_ws + c0);
+        DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
+                           fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (bf16_t*)dx, (bf16_t*)dres);
+        DANET_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    }
+    return DANET_OK;
+}
+
+extern "C" int danet_sum_relu_forward(const void* const* terms /* host array */, const int* shifts /* host */, int nterms,
+                                      int B, int H, int W, int C, int relu, void* y, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(terms && shifts && y && nterms >= 1 && nterms <= 4 && C % VW == 0, "sum_relu_forward: bad arguments");
+    SumP p;
+    p.nterms = nterms; p.B = B; p.H = H; p.W = W; p.C = C;
+    for (int i = 0; i < 4; ++i) { p.in[i] = i < nterms ? (const bf16_t*)terms[i] : nullptr; p.shift[i] = i < nterms ? shifts[i] : 0; }
+    for (int i = 0; i < nterms; ++i)
+        DANET_CHECK_ARG(p.in[i] && p.shift[i] >= 0 && (H % (1 << p.shift[i])) == 0 && (W % (1 << p.shift[i])) == 0, "sum_relu_forward: term %d", i);
+    const long nvec = (long)B * H * W * (C / VW);
+    long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)y, relu);
+    DANET_CHECK_LAUNCH("sum_relu_kernel");
+    return DANET_OK;
+}
+
+extern "C" int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
+                                       void* d_term, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(gy && d_term && (!relu || y) && C % VW == 0 && shift >= 0, "sum_relu_backward: bad arguments");
+    const long nvec = (long)B * (H >> shift) * (W >> shift) * (C / VW);
+    long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gy,
+                       (const bf16_t*)y, B, H, W, C, shift, relu, (bf16_t*)d_term);
+    DANET_CHECK_LAUNCH("sum_relu_bwd_kernel");
+    return DANET_OK;
+}

@@ -1,0 +1,130 @@
+"""Layer modules on the HIP kernels, with nn.Module parameter/buffer names identical to the
+reference's torch modules (state-dict compatible)."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ptr, check, stream
+from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc  # noqa: F401
+
+
+class BatchNormActFunction(torch.autograd.Function):
+    """y = [relu](batch_norm(x) [+ res]) on NHWC bf16; training or eval statistics."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        L = _lib.lib()
+        x = nhwc_bf16(x)
+        B, C, H, W = x.shape
+        M = B * H * W
+        if res is not None:
+            res = nhwc_bf16(res)
+            if res.shape != x.shape:
+                raise ValueError('residual shape %s != %s' % (tuple(res.shape), tuple(x.shape)))
+        y = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
+        saved = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
+        sums = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
+        g = None if gamma is None else gamma.detach().float().contiguous()
+        b = None if beta is None else beta.detach().float().contiguous()
+        check(L.danet_bn_forward(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
+                                 ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(b), ptr(running_mean), ptr(running_var),
+                                 ptr(saved), ptr(sums), float(momentum), float(eps), int(training), int(relu), stream()),
+              'danet_bn_forward')
+        if training:
+            ctx.save_for_backward(x, y if relu else None, g, saved)
+            ctx.relu = relu
+            ctx.has_res = res is not None
+            ctx.has_affine = gamma is not None
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.training:
+            raise RuntimeError('BatchNorm backward in eval mode is not on the hot path')
+        L = _lib.lib()
+        x, y, g, saved = ctx.saved_tensors
+        gy = nhwc_bf16(gy)
+        B, C, H, W = x.shape
+        M = B * H * W
+        dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
+        dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
+        red = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
+                                  None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
+                                  int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
+                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(red), stream()),
+              'danet_bn_backward')
+        dgamma = red[1] if ctx.has_affine else None
+        dbeta = red[0] if ctx.has_affine else None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters / buffers) with optional fused residual add and ReLU."""
+
+    def forward(self, x, res=None, relu=False):
+        training = self.training or not self.track_running_stats
+        if training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        momentum = 0.1 if self.momentum is None else self.momentum
+        return BatchNormActFunction.apply(x, res, self.weight, self.bias,
+                                          self.running_mean if self.track_running_stats else None,
+                                          self.running_var if self.track_running_stats else None,
+                                          training, momentum, self.eps, relu)
+
+
+class SumReluFunction(torch.autograd.Function):
+    """y = [relu](sum_t nearest_upsample_{2^shift_t}(term_t)) -- HRNet fuse layer (hr_module.py:166-177)."""
+
+    @staticmethod
+    def forward(ctx, relu, shifts, *terms):
+        L = _lib.lib()
+        terms = [nhwc_bf16(t) for t in terms]
+        n = len(terms)
+        B, C = terms[0].shape[0], terms[0].shape[1]
+        H = max(t.shape[2] << s for t, s in zip(terms, shifts))
+        W = max(t.shape[3] << s for t, s in zip(terms, shifts))
+        for t, s in zip(terms, shifts):
+            if t.shape[1] != C or (t.shape[2] << s) != H or (t.shape[3] << s) != W:
+                raise ValueError('sum_relu: term %s with shift %d does not match output %dx%dx%d' % (tuple(t.shape), s, C, H, W))
+        y = _empty_nhwc(B, C, H, W, torch.bfloat16, terms[0].device)
+        ptrs = (ctypes.c_void_p * n)(*[ptr(t.permute(0, 2, 3, 1)) for t in terms])
+        sh = (ctypes.c_int * n)(*shifts)
+        check(L.danet_sum_relu_forward(ptrs, sh, n, B, H, W, C, int(relu), ptr(y.permute(0, 2, 3, 1)), stream()),
+              'danet_sum_relu_forward')
+        ctx.save_for_backward(y if relu else None)
+        ctx.cfg = (relu, tuple(shifts), B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (y,) = ctx.saved_tensors
+        relu, shifts, B, C, H, W = ctx.cfg
+        gy = nhwc_bf16(gy)
+        outs = []
+        cache = {}
+        for i, s in enumerate(shifts):
+            if not ctx.needs_input_grad[2 + i]:
+                outs.append(None)
+                continue
+            if s not in cache:
+                d = _empty_nhwc(B, C, H >> s, W >> s, torch.bfloat16, gy.device)
+                check(L.danet_sum_relu_backward(ptr(gy.permute(0, 2, 3, 1)), None if y is None else ptr(y.permute(0, 2, 3, 1)),
+                                                B, H, W, C, s, int(relu), ptr(d.permute(0, 2, 3, 1)), stream()),
+                      'danet_sum_relu_backward')
+                cache[s] = d
+            outs.append(cache[s])
+        return (None, None) + tuple(outs)
+
+
+def sum_relu(terms, shifts=None, relu=True):
+    shifts = [0] * len(terms) if shifts is None else list(shifts)
+    return SumReluFunction.apply(relu, shifts, *terms)
+
+
+def relu(x):
+    return sum_relu([x], [0], True)

@@ -133,6 +133,31 @@ int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,
                      int R, int S, int stride, int pad, int dil, int groups, float beta, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm2d (+ReLU, +residual add) and the HRNet fuse, NHWC bf16 viewed as [M = B*H*W, C].
+ * Replaces nn.BatchNorm2d / ReLU / `out += residual` / nn.Upsample(nearest) + sum
+ * (/root/reference/models/module/res_module.py:39-56,77-97; hr_module.py:111-177).
+ *
+ *  danet_bn_forward   training: batch statistics (biased variance for normalisation, unbiased for
+ *                     the running estimate, torch semantics); y = [relu](bn(x) [+ res]);
+ *                     saved [2][C] (mean, invstd) and sums_ws [2][C] are fp32 scratch/outputs.
+ *                     eval: running statistics.  gamma/beta may be NULL (1 / 0).
+ *  danet_bn_backward  dx, optional dres (= masked dy), red_ws [2][C] -> (d beta, d gamma).
+ *  danet_sum_relu_*   y = [relu](sum_t nearest_upsample_{2^shift_t}(term_t)), up to 4 terms; `terms`
+ *                     and `shifts` are HOST arrays of nterms entries.  The backward of one term is
+ *                     the window sum of gy * (y > 0).
+ */
+int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float* saved, float* sums_ws, float momentum, float eps, int training, int relu, void* stream);
+int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
+                      const float* gamma, const float* saved, int relu,
+                      void* dx, void* dres, float* red_ws, void* stream);
+int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,
+                           int B, int H, int W, int C, int relu, void* y, void* stream);
+int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
+                            void* d_term, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
