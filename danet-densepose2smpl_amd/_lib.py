@@ -35,6 +35,8 @@ _SIGNATURES = {
     'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f]),
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
+    'danet_stn_gather_backward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),

@@ -5,6 +5,8 @@ in the torch layout (state-dict compatible with the reference) and are packed to
 parameter version.  Gradients: dX through the transposed gather of the same MFMA kernel, dW
 through the wgrad kernel (fp32), dbias as a channel sum.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (only for nn.init helpers / shape utils)
@@ -31,12 +33,15 @@ def _empty_nhwc(B, C, H, W, dtype, device):
 
 
 def pack_weight(weight, groups, mode):
-    """Packed bf16 copy of an fp32 conv weight, cached per (storage, version, mode)."""
-    key = (weight.data_ptr(), mode, groups)
+    """Packed bf16 copy of an fp32 conv weight.  Cached per nn.Parameter object and version (so a
+    parameter is re-packed once per optimizer step); temporaries are never cached."""
+    cacheable = isinstance(weight, nn.Parameter)
+    key = (id(weight), mode, groups)
     ver = weight._version
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[2] == tuple(weight.shape):
-        return hit[1]
+    if cacheable:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0] == ver and hit[2]() is weight:
+            return hit[1]
     L = _lib.lib()
     Cout, Cin_g, R, S = weight.shape
     w = weight.detach()
@@ -45,7 +50,8 @@ def pack_weight(weight, groups, mode):
     n = L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode)
     wp = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
     check(L.danet_conv_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, stream()), 'danet_conv_pack_weights')
-    _PACK_CACHE[key] = (ver, wp, tuple(weight.shape))
+    if cacheable:
+        _PACK_CACHE[key] = (ver, wp, weakref.ref(weight))
     return wp
 
 
@@ -103,7 +109,36 @@ class Conv2dFunction(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+def _pad_channels_nhwc(x, mult=8):
+    """bf16 NHWC tensor whose channel count is padded with zeros to a multiple of `mult`
+    (autograd-tracked, so the gradient is sliced back)."""
+    x = nhwc_bf16(x)
+    padc = (-x.shape[1]) % mult
+    if padc == 0:
+        return x
+    return F.pad(x.permute(0, 2, 3, 1), (0, padc)).permute(0, 3, 1, 2)
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False):
+    """Convolution on the MFMA kernels.  Channel counts that are not a multiple of 8 (3-channel image,
+    21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
+    forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
+    Cout = weight.shape[0]
+    if groups == 1 and x.shape[1] % 8 != 0:
+        padc = (-x.shape[1]) % 8
+        x = _pad_channels_nhwc(x)
+        weight = F.pad(weight, (0, 0, 0, 0, 0, padc))
+    Cout_g = Cout // groups
+    if Cout_g % 8 != 0:
+        padn = (-Cout_g) % 8
+        wv = weight.view(groups, Cout_g, *weight.shape[1:])
+        weight = F.pad(wv, (0, 0, 0, 0, 0, 0, 0, padn)).reshape(groups * (Cout_g + padn), *weight.shape[1:])
+        if bias is not None:
+            bias = F.pad(bias.view(groups, Cout_g), (0, padn)).reshape(-1)
+        y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
+        B, _, OH, OW = y.shape
+        y = y.permute(0, 2, 3, 1).reshape(B, OH, OW, groups, Cout_g + padn)[..., :Cout_g]
+        return y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
     return Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
 
 

@@ -22,6 +22,7 @@ UNITS = {
     'conv_igemm.hip': [],
     'conv_wgrad.hip': [],
     'norm_act.hip': [],
+    'stn.hip': [],
 }
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + os.path.join(ROOT, 'include'), '-I' + HERE,
           '-Wall', '-Wno-unused-function']

@@ -1,0 +1,179 @@
+// Joint-centric part decomposition: 24 affine bilinear resamplings of the backbone feature map,
+// written straight into the channel-concatenated NHWC tensor the grouped partial-IUV conv reads.
+//
+// Replaces the loop of 24 x (F.affine_grid + F.grid_sample) + torch.cat at
+// /root/reference/models/danet/iuv_estimator.py:193-204 (bilinear, zero padding; the thetas are
+// detached there, so only the feature map gets a gradient).
+//
+//   forward   y[b,oh,ow,p*C+c] = bilinear(x[b,:,:,c] at theta[b,p] . (xn(ow), yn(oh), 1))
+//   backward  dx as a GATHER (no atomics): affine_para (iuv_estimator.py:293-296) only builds
+//             axis-aligned thetas [[sx,0,cx],[0,sy,cy]], so the sample position is separable and
+//             monotone in (oh, ow); each input pixel sums tent(iy-y)*tent(ix-x)*dy over the output
+//             window that can reach it.
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace danet_conv;
+
+__device__ inline float norm_coord(int o, int n, int align) {
+    return align ? (n > 1 ? -1.0f + 2.0f * (float)o / (float)(n - 1) : 0.0f) : (2.0f * (float)o + 1.0f) / (float)n - 1.0f;
+}
+__device__ inline float unnorm_coord(float g, int n, int align) {
+    return align ? (g + 1.0f) * 0.5f * (float)(n - 1) : ((g + 1.0f) * (float)n - 1.0f) * 0.5f;
+}
+
+struct V8 { float v[8]; };
+__device__ inline V8 load8(const bf16_t* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o.v[2 * j] = __uint_as_float(w[j] << 16); o.v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+    return o;
+}
+__device__ inline void store8(bf16_t* p, const V8& a) {
+    uint4 r;
+    r.x = f2bf(a.v[0]) | ((unsigned)f2bf(a.v[1]) << 16); r.y = f2bf(a.v[2]) | ((unsigned)f2bf(a.v[3]) << 16);
+    r.z = f2bf(a.v[4]) | ((unsigned)f2bf(a.v[5]) << 16); r.w = f2bf(a.v[6]) | ((unsigned)f2bf(a.v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+
+// x [B,H,W,C] bf16, theta [B,P,2,3] f32 -> y [B,OH,OW,P*C] bf16.  C % 8 == 0.
+__global__ __launch_bounds__(256) void stn_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ theta,
+                                                      int B, int H, int W, int C, int P, int OH, int OW, int align,
+                                                      bf16_t* __restrict__ y)
+{
+    const int CV = C / 8;
+    const long total = (long)B * OH * OW * P * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long r = i / CV;
+        const int p = (int)(r % P); r /= P;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const float* th = theta + ((size_t)b * P + p) * 6;
+        const float xn = norm_coord(ow, OW, align), yn = norm_coord(oh, OH, align);
+        const float gx = th[0] * xn + th[1] * yn + th[2];
+        const float gy = th[3] * xn + th[4] * yn + th[5];
+        const float ix = unnorm_coord(gx, W, align), iy = unnorm_coord(gy, H, align);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        V8 acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int yy = y0 + dy, xx = x0 + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float w = (dy ? wy1 : wy0) * (dx ? wx1 : wx0);
+                    const V8 a = load8(x + (((size_t)b * H + yy) * W + xx) * C + cv * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.v[j] += w * a.v[j];
+                }
+            }
+        store8(y + (((size_t)b * OH + oh) * OW + ow) * ((size_t)P * C) + (size_t)p * C + cv * 8, acc);
+    }
+}
+
+// range of output indices o in [0,n_out) with |a*o + b0 - target| < 1
+__device__ inline void reach(float a, float b0, float target, int n_out, int* lo, int* hi) {
+    if (fabsf(a) < 1e-12f) {
+        if (fabsf(b0 - target) < 1.0f) { *lo = 0; *hi = n_out - 1; } else { *lo = 1; *hi = 0; }
+        return;
+    }
+    float l = (target - 1.0f - b0) / a, h = (target + 1.0f - b0) / a;
+    if (l > h) { const float t = l; l = h; h = t; }
+    // one-index slack on both sides; the tent weight zeroes anything outside
+    const float lf = floorf(l) - 1.0f, hf = ceilf(h) + 1.0f;
+    *lo = lf < 0.0f ? 0 : (lf > (float)n_out ? n_out : (int)lf);
+    *hi = hf > (float)(n_out - 1) ? n_out - 1 : (hf < -1.0f ? -1 : (int)hf);
+}
+
+// dx [B,H,W,C] bf16 from dy [B,OH,OW,P*C] bf16; axis-aligned thetas only.
+__global__ __launch_bounds__(256) void stn_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ theta,
+                                                      int B, int H, int W, int C, int P, int OH, int OW, int align,
+                                                      bf16_t* __restrict__ dx)
+{
+    const int CV = C / 8;
+    const long total = (long)B * H * W * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long r = i / CV;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        V8 acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float* th = theta + ((size_t)b * P + p) * 6;
+            // ix(ow) and iy(oh) evaluated with exactly the forward's expressions
+            const float x_at0 = unnorm_coord(th[0] * norm_coord(0, OW, align) + th[2], W, align);
+            const float x_at1 = unnorm_coord(th[0] * norm_coord(OW > 1 ? 1 : 0, OW, align) + th[2], W, align);
+            const float y_at0 = unnorm_coord(th[4] * norm_coord(0, OH, align) + th[5], H, align);
+            const float y_at1 = unnorm_coord(th[4] * norm_coord(OH > 1 ? 1 : 0, OH, align) + th[5], H, align);
+            int ow0, ow1, oh0, oh1;
+            reach(x_at1 - x_at0, x_at0, (float)xx, OW, &ow0, &ow1);
+            reach(y_at1 - y_at0, y_at0, (float)yy, OH, &oh0, &oh1);
+            for (int oh = oh0; oh <= oh1; ++oh) {
+                const float iy = unnorm_coord(th[4] * norm_coord(oh, OH, align) + th[5], H, align);
+                // bilinear corner weights as the forward computes them (floor-based), so that the
+                // gradient matches the forward bit pattern of the weights
+                const float fy = floorf(iy);
+                float wy;
+                if ((int)fy == yy) wy = 1.0f - (iy - fy);
+                else if ((int)fy + 1 == yy) wy = iy - fy;
+                else continue;
+                for (int ow = ow0; ow <= ow1; ++ow) {
+                    const float ix = unnorm_coord(th[0] * norm_coord(ow, OW, align) + th[2], W, align);
+                    const float fx = floorf(ix);
+                    float wx;
+                    if ((int)fx == xx) wx = 1.0f - (ix - fx);
+                    else if ((int)fx + 1 == xx) wx = ix - fx;
+                    else continue;
+                    const float w = wy * wx;
+                    const V8 g = load8(dy + (((size_t)b * OH + oh) * OW + ow) * ((size_t)P * C) + (size_t)p * C + cv * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.v[j] += w * g.v[j];
+                }
+            }
+        }
+        store8(dx + (((size_t)b * H + yy) * W + xx) * C + cv * 8, acc);
+    }
+}
+
+}  // namespace
+
+extern "C" int danet_stn_gather_forward(const void* x, const float* theta, int B, int H, int W, int C, int P,
+                                        int OH, int OW, int align_corners, void* y, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && theta && y && B > 0 && H > 0 && W > 0 && P > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0,
+                    "stn_gather_forward: bad arguments (C=%d must be a multiple of 8)", C);
+    const long total = (long)B * OH * OW * P * (C / 8);
+    long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(stn_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const danet_conv::bf16_t*)x,
+                       theta, B, H, W, C, P, OH, OW, align_corners, (danet_conv::bf16_t*)y);
+    DANET_CHECK_LAUNCH("stn_fwd_kernel");
+    return DANET_OK;
+}
+
+extern "C" int danet_stn_gather_backward(const void* dy, const float* theta, int B, int H, int W, int C, int P,
+                                         int OH, int OW, int align_corners, void* dx, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(dy && theta && dx && B > 0 && H > 0 && W > 0 && P > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0,
+                    "stn_gather_backward: bad arguments");
+    const long total = (long)B * H * W * (C / 8);
+    long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(stn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const danet_conv::bf16_t*)dy,
+                       theta, B, H, W, C, P, OH, OW, align_corners, (danet_conv::bf16_t*)dx);
+    DANET_CHECK_LAUNCH("stn_bwd_kernel");
+    return DANET_OK;
+}

@@ -1,0 +1,186 @@
+"""HRNet-W48 backbone (+IUV heads) on the HIP kernels.
+
+Mirrors the module tree / state-dict keys of /root/reference/models/module/hr_module.py
+(HighResolutionModule :15-179, PoseHighResolutionNet :188-410).  Each cross-resolution fuse
+(1x1 conv + BN + nearest upsample, strided 3x3 chains, sum, ReLU; hr_module.py:111-177) is one
+sum_relu launch over at most four terms that reads the low-resolution terms in place.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .config import cfg
+from .nn import sum_relu
+from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
+from .nn import Conv2d, BatchNorm2d
+
+blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
+
+
+class _Chain(nn.Module):
+    """Sequence of ConvBN stages indexed '0','1',... (same keys as the reference's nested Sequentials)."""
+
+    def __init__(self, stages):
+        super().__init__()
+        for i, s in enumerate(stages):
+            self.add_module(str(i), s)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            x = m(x)
+        return x
+
+
+class HighResolutionModule(nn.Module):
+    def __init__(self, num_branches, block, num_blocks, num_inchannels, num_channels, fuse_method, multi_scale_output=True):
+        super().__init__()
+        if not (num_branches == len(num_blocks) == len(num_channels) == len(num_inchannels)):
+            raise ValueError('NUM_BRANCHES(%d) does not match NUM_BLOCKS/NUM_CHANNELS/NUM_INCHANNELS' % num_branches)
+        self.num_inchannels = num_inchannels
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        branches = []
+        for i in range(num_branches):
+            self.inplanes = num_inchannels[i]
+            branches.append(make_res_layer(self, block, num_channels[i], num_blocks[i]))
+            num_inchannels[i] = num_channels[i] * block.expansion
+        del self.inplanes
+        self.branches = nn.ModuleList(branches)
+        self.fuse_layers = self._make_fuse_layers()
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        nb, ch = self.num_branches, self.num_inchannels
+        rows = []
+        for i in range(nb if self.multi_scale_output else 1):
+            row = []
+            for j in range(nb):
+                if j > i:        # low -> high resolution: 1x1 conv + BN, upsampled inside sum_relu
+                    row.append(ConvBN(ch[j], ch[i], 1, 1, 0, momentum=0.1))
+                elif j == i:
+                    row.append(None)
+                else:            # high -> low: (i-j) strided 3x3 convs, ReLU on all but the last
+                    stages = []
+                    for k in range(i - j):
+                        last = k == i - j - 1
+                        stages.append(ConvBN(ch[j], ch[i] if last else ch[j], 3, 2, 1, momentum=0.1, relu=not last))
+                    row.append(_Chain(stages))
+            rows.append(nn.ModuleList(row))
+        return nn.ModuleList(rows)
+
+    def get_num_inchannels(self):
+        return self.num_inchannels
+
+    def forward(self, x):
+        if self.num_branches == 1:
+            return [self.branches[0](x[0])]
+        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        out = []
+        for i in range(len(self.fuse_layers)):
+            terms, shifts = [], []
+            for j in range(self.num_branches):
+                if j == i:
+                    terms.append(x[j]); shifts.append(0)
+                elif j > i:
+                    terms.append(self.fuse_layers[i][j](x[j])); shifts.append(j - i)
+                else:
+                    terms.append(self.fuse_layers[i][j](x[j])); shifts.append(0)
+            out.append(sum_relu(terms, shifts, relu=True))
+        return out
+
+
+class PoseHighResolutionNet(nn.Module):
+    def __init__(self, part_out_dim=25):
+        super().__init__()
+        extra = cfg.HR_MODEL.EXTRA
+        self.inplanes = 64
+        self.conv1 = Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.conv2 = Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.layer1 = make_res_layer(self, Bottleneck, 64, 4)
+
+        self.stage2_cfg = extra['STAGE2']
+        ch = self._widths(self.stage2_cfg)
+        self.transition1 = self._make_transition_layer([256], ch)
+        self.stage2, pre = self._make_stage(self.stage2_cfg, ch)
+        self.stage3_cfg = extra['STAGE3']
+        ch = self._widths(self.stage3_cfg)
+        self.transition2 = self._make_transition_layer(pre, ch)
+        self.stage3, pre = self._make_stage(self.stage3_cfg, ch)
+        self.stage4_cfg = extra['STAGE4']
+        ch = self._widths(self.stage4_cfg)
+        self.transition3 = self._make_transition_layer(pre, ch)
+        self.stage4, pre = self._make_stage(self.stage4_cfg, ch, multi_scale_output=False)
+        self.final_feat_dim = pre[0]
+        self.final_pred = IUV_predict_layer(feat_dim=self.final_feat_dim, part_out_dim=part_out_dim)
+        self.pretrained_layers = extra.get('PRETRAINED_LAYERS', ['*'])
+
+    @staticmethod
+    def _widths(stage_cfg):
+        block = blocks_dict[stage_cfg['BLOCK']]
+        return [c * block.expansion for c in stage_cfg['NUM_CHANNELS']]
+
+    def _make_transition_layer(self, pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                layers.append(ConvBN(pre[i], cur[i], 3, 1, 1, momentum=0.1, relu=True) if cur[i] != pre[i] else None)
+            else:
+                stages = []
+                for j in range(i + 1 - len(pre)):
+                    outc = cur[i] if j == i - len(pre) else pre[-1]
+                    stages.append(ConvBN(pre[-1], outc, 3, 2, 1, momentum=0.1, relu=True))
+                layers.append(_Chain(stages))
+        return nn.ModuleList(layers)
+
+    def _make_stage(self, layer_config, num_inchannels, multi_scale_output=True):
+        block = blocks_dict[layer_config['BLOCK']]
+        modules = []
+        for i in range(layer_config['NUM_MODULES']):
+            mso = multi_scale_output or i != layer_config['NUM_MODULES'] - 1
+            modules.append(HighResolutionModule(layer_config['NUM_BRANCHES'], block, layer_config['NUM_BLOCKS'],
+                                                num_inchannels, layer_config['NUM_CHANNELS'], layer_config['FUSE_METHOD'], mso))
+            num_inchannels = modules[-1].get_num_inchannels()
+        return nn.Sequential(*modules), num_inchannels
+
+    def _run_stage(self, stage, xs):
+        for m in stage:
+            xs = m(xs)
+        return xs
+
+    def forward(self, x):
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
+        x = self.layer1(x)
+        xs = [t(x) if t is not None else x for t in self.transition1]
+        ys = self._run_stage(self.stage2, xs)
+        xs = [self.transition2[i](ys[-1]) if self.transition2[i] is not None else ys[i]
+              for i in range(self.stage3_cfg['NUM_BRANCHES'])]
+        ys = self._run_stage(self.stage3, xs)
+        xs = [self.transition3[i](ys[-1]) if self.transition3[i] is not None else ys[i]
+              for i in range(self.stage4_cfg['NUM_BRANCHES'])]
+        ys = self._run_stage(self.stage4, xs)
+        feat = ys[0]
+        out = self.final_pred(feat)
+        out['xd'] = feat
+        return out
+
+    def init_weights(self, pretrained=''):
+        """hr_module.py:380-410: conv weights ~ N(0, 0.001), BN (1, 0), optional checkpoint."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if pretrained and os.path.isfile(pretrained):
+            sd = torch.load(pretrained, map_location='cpu')
+            keep = {k: v for k, v in sd.items() if k.split('.')[0] in self.pretrained_layers or self.pretrained_layers[0] == '*'}
+            self.load_state_dict(keep, strict=False)
+        elif pretrained:
+            raise ValueError('{} is not exist!'.format(pretrained))

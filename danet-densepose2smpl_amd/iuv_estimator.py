@@ -1,0 +1,243 @@
+"""IUV estimator: backbone + global IUV heads + joint-centric part decomposition + IUV losses.
+
+Mirrors /root/reference/models/danet/iuv_estimator.py (IUV_Estimator :17-301, body_uv_losses
+:304-341, part_iuv_simp :422-445) for the default path (INPUT_MODE 'iuv', DECOMPOSED).  The 24
+affine resamplings of the feature map are one HIP launch (nn.stn_gather); all batch filtering by
+has_iuv is expressed as per-sample weights, so there is no boolean-mask indexing, no
+torch.unique and no host synchronisation inside the step (hipGraph-capturable).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import cfg
+from .geometry import softmax_integral_tensor
+from .hrnet import PoseHighResolutionNet
+from .iuvmap import iuv_img2map, iuvmap_clean
+from .nn import stn_gather
+from .resnet import PoseResNet
+
+# kinematic tables of /root/reference/utils/smpl_utlis.py:13-17,30-79
+SMPL_PARENTS = [0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+SMPL_CHILDREN = [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 10, 11, 15, 16, 17, 15, 18, 19, 20, 21, 22, 23, 22, 23]
+SMPL2DP_PART = [[1, 2], [8, 10], [7, 9], [1, 2], [8, 10, 12, 14], [7, 9, 11, 13], [1, 2], [12, 14, 5], [11, 13, 6],
+                [1, 2], [12, 14, 5], [11, 13, 6], [1, 2, 23, 24], [15, 17], [16, 18], [23, 24], [15, 17], [16, 18],
+                [15, 17, 19, 21], [16, 18, 20, 22], [19, 21, 4], [20, 22, 3], [19, 21, 4], [20, 22, 3]]
+DP2SMPL_MAPPING = [[7, 8, 9, 10, 1, 2], [1, 2, 8, 10, 12, 14], [1, 2, 7, 9, 11, 13], [7, 8, 9, 10, 1, 2],
+                   [1, 2, 8, 10, 12, 14], [1, 2, 7, 9, 11, 13], [7, 8, 9, 10, 1, 2], [8, 10, 12, 14, 5, 5],
+                   [7, 9, 11, 13, 6, 6], [7, 8, 9, 10, 1, 2], [8, 10, 12, 14, 5, 5], [7, 9, 11, 13, 6, 6],
+                   [1, 2, 23, 24, 23, 24], [1, 2, 15, 17, 19, 21], [1, 2, 16, 18, 20, 22], [1, 2, 23, 24, 23, 24],
+                   [1, 2, 15, 17, 19, 21], [1, 2, 16, 18, 20, 22], [1, 2, 15, 17, 19, 21], [1, 2, 16, 18, 20, 22],
+                   [15, 17, 19, 21, 4, 4], [16, 18, 20, 22, 3, 3], [15, 17, 19, 21, 4, 4], [16, 18, 20, 22, 3, 3]]
+
+_LEARNED_RATIO_PATHS = ('data/pretrained_model/learned_ratio.pkl',)
+
+
+def load_learned_ratio(path=None):
+    """The 24 per-joint ratio/offset constants (iuv_estimator.py:21-31).  The reference ships them as
+    data/pretrained_model/learned_ratio.pkl; without the file a neutral (1.0, 0.1) pair is used."""
+    for p in ([path] if path else []) + list(_LEARNED_RATIO_PATHS):
+        if p and os.path.isfile(p):
+            with open(p, 'rb') as f:
+                d = pickle.load(f, encoding='iso-8859-1')
+            return np.asarray(d['ratio'], np.float32), np.asarray(d['offset'], np.float32)
+    return np.ones(24, np.float32), 0.1 * np.ones(24, np.float32)
+
+
+def _sample_points(maps, pts, align):
+    """Bilinear sample of maps [B,J,H,W] at one point per (b,j): pts [B,J,2] in [-1,1] (x,y); zero
+    padding -- the single-point grid_sample of iuv_estimator.py:180."""
+    B, J, H, W = maps.shape
+    x, y = pts[..., 0], pts[..., 1]
+    if align:
+        ix, iy = (x + 1) * 0.5 * (W - 1), (y + 1) * 0.5 * (H - 1)
+    else:
+        ix, iy = ((x + 1) * W - 1) * 0.5, ((y + 1) * H - 1) * 0.5
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    out = torch.zeros(B, J, device=maps.device, dtype=torch.float32)
+    flat = maps.reshape(B, J, H * W).float()
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = x0 + dx, y0 + dy
+            w = (1 - (ix - xx).abs()) * (1 - (iy - yy).abs())
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long()
+            out = out + torch.where(ok, w, torch.zeros_like(w)) * flat.gather(2, idx.unsqueeze(-1)).squeeze(-1)
+    return out
+
+
+class IUV_Estimator(nn.Module):
+    def __init__(self, pretrained=True, learned_ratio_path=None):
+        super().__init__()
+        if cfg.DANET.INPUT_MODE != 'iuv':
+            raise NotImplementedError("only DANET.INPUT_MODE == 'iuv' (the default) is on the hot path")
+        ratio, offset = load_learned_ratio(learned_ratio_path) if cfg.DANET.USE_LEARNED_RATIO else (None, None)
+        if ratio is not None:
+            self.register_buffer('learned_ratio', torch.from_numpy(ratio))
+            self.register_buffer('learned_offset', torch.from_numpy(offset))
+        else:
+            self.learned_ratio = nn.Parameter(cfg.DANET.PART_UVI_SCALE * torch.ones(24))
+            self.learned_offset = nn.Parameter(cfg.DANET.PART_UVI_LR_OFFSET * torch.ones(24))
+        self.smpl_parents = [SMPL_PARENTS, None]
+        self.smpl_children = [None, SMPL_CHILDREN]
+        self.smpl2dp_part = SMPL2DP_PART
+        self.dp2smpl_mapping = DP2SMPL_MAPPING
+        part_out_dim = 1 + len(DP2SMPL_MAPPING[0])
+        if cfg.DANET.IUV_REGRESSOR == 'resnet':
+            self.iuv_est = PoseResNet(part_out_dim=part_out_dim)
+            if pretrained:
+                self.iuv_est.init_weights(cfg.MSRES_MODEL.get('PRETRAINED', ''))
+        elif cfg.DANET.IUV_REGRESSOR == 'hrnet':
+            self.iuv_est = PoseHighResolutionNet(part_out_dim=part_out_dim)
+            if pretrained:
+                key = {'imagenet': 'PRETRAINED_IM', 'coco': 'PRETRAINED_COCO'}.get(cfg.HR_MODEL.PRETR_SET)
+                self.iuv_est.init_weights(cfg.HR_MODEL.get(key, '') if key else '')
+        else:
+            raise ValueError('unknown DANET.IUV_REGRESSOR %r' % cfg.DANET.IUV_REGRESSOR)
+        vis = torch.zeros(24, 25)
+        for i, parts in enumerate(SMPL2DP_PART):
+            vis[i, parts] = 1
+        self.register_buffer('_vis_membership', vis, persistent=False)
+        self.register_buffer('_dp_sel', torch.tensor(DP2SMPL_MAPPING, dtype=torch.long), persistent=False)
+        self.register_buffer('_parent_idx', torch.tensor(SMPL_PARENTS, dtype=torch.long), persistent=False)
+        self.register_buffer('_child_idx', torch.tensor(SMPL_CHILDREN, dtype=torch.long), persistent=False)
+        self.bodyfeat_channels = 1024
+        self.part_channels = 256
+
+    # --------------------------------------------------------------------------------------
+    def affine_para(self, stn_centers, part_hidden=None):
+        """iuv_estimator.py:262-301, vectorised over the 24 joints.
+        Returns thetas [B,24,2,3] ([[s,0,cx],[0,s,cy]]) and scales [B,24]."""
+        c = stn_centers
+        box = c.max(dim=1)[0] - c.min(dim=1)[0]
+        scale_box = box.max(dim=1)[0] / 2.
+        scale_c = torch.norm(c[:, self._child_idx] - c, dim=2) / 2.
+        scale_p = torch.norm(c[:, self._parent_idx] - c, dim=2) / 2.
+        scale = 2 * torch.maximum(scale_c, scale_p)
+        scale = torch.cat([scale_box.unsqueeze(1), scale[:, 1:]], dim=1).detach()
+        scale = scale * F.relu(self.learned_ratio) + F.relu(self.learned_offset)
+        jit = cfg.DANET.STN_SCALE_JITTER if self.training else 0
+        if jit > 0:
+            scale = scale * (1 + jit * (torch.rand_like(scale) - 0.5))
+        if part_hidden is not None:
+            hidden = part_hidden.clone()
+            hidden[:, 0] = False
+            scale = torch.where(hidden, 0.8 * scale_box.unsqueeze(1).expand_as(scale), scale)
+        if jit > 0:
+            scale = scale * (1 + jit * (torch.rand_like(scale) - 0.5))
+        B = c.shape[0]
+        theta = torch.zeros(B, 24, 2, 3, device=c.device, dtype=torch.float32)
+        theta[:, :, 0, 0] = scale
+        theta[:, :, 1, 1] = scale
+        theta[:, :, :, 2] = c.detach()
+        return theta, scale
+
+    def part_iuv_simp(self, U, V, I):
+        """Per-joint 7-channel (background + 6 DensePose parts) U,V,I maps (iuv_estimator.py:422-445):
+        [B,25,H,W] x3 -> [B,24,3,7,H,W]."""
+        sel = self._dp_sel                                   # [24,6]
+        Us, Vs, Is = U[:, sel], V[:, sel], I[:, sel]         # [B,24,6,H,W]
+        zeros = torch.zeros_like(Us[:, :, :1])
+        bg = (Is.sum(dim=2, keepdim=True) < 0.5).to(Is.dtype)
+        return torch.stack([torch.cat([zeros, Us], 2), torch.cat([zeros, Vs], 2), torch.cat([bg, Is], 2)], dim=2)
+
+    @staticmethod
+    def body_uv_losses(u_pred, v_pred, index_pred, ann_pred, uvia_list, has_iuv=None, class_dim=1):
+        """iuv_estimator.py:304-341 with has_iuv as per-sample weights.  Tensors may carry extra
+        leading 'joint' dims after the batch dim; `class_dim` is the channel (class) axis."""
+        Umap, Vmap, Imap, Annmap = uvia_list
+        B = u_pred.shape[0]
+        dev = u_pred.device
+        if has_iuv is None:
+            w = torch.ones(B, device=dev)
+        else:
+            w = has_iuv.to(torch.float32)
+        wshape = [B] + [1] * (u_pred.dim() - 1)
+        wb = w.view(wshape)
+        fg = (Imap > 0).to(torch.float32) * wb
+        loss_U = (F.smooth_l1_loss(u_pred.float(), Umap, reduction='none') * fg).sum() / B
+        loss_V = (F.smooth_l1_loss(v_pred.float(), Vmap, reduction='none') * fg).sum() / B
+        loss_U = loss_U * cfg.DANET.POINT_REGRESSION_WEIGHTS
+        loss_V = loss_V * cfg.DANET.POINT_REGRESSION_WEIGHTS
+
+        def ce(pred, target_map):
+            logp = F.log_softmax(pred.float(), dim=class_dim)
+            tgt = torch.argmax(target_map, dim=class_dim, keepdim=True)
+            nll = -logp.gather(class_dim, tgt)                       # [B,...,1,H,W]
+            per_sample = nll.numel() / B
+            return (nll * wb).sum() / (w.sum().clamp(min=1.0) * per_sample)
+        loss_IndexUV = ce(index_pred, Imap)
+        loss_segAnn = None if ann_pred is None else ce(ann_pred, Annmap)
+        return loss_U, loss_V, loss_IndexUV, loss_segAnn
+
+    # --------------------------------------------------------------------------------------
+    def forward(self, data, iuv_image_gt=None, smpl_kps_gt=None, kps3d_gt=None, uvia_dp_gt=None, has_iuv=None, has_dp=None):
+        rd = {'losses': {}, 'metrics': {}, 'visualization': {}}
+        align = bool(cfg.DANET.get('ALIGN_CORNERS', True))
+        est = self.iuv_est(data)
+        u_pred, v_pred = est['predict_u'], est['predict_v']
+        index_pred, ann_pred = est['predict_uv_index'], est['predict_ann_index']
+
+        uvia_list = None
+        if self.training and iuv_image_gt is not None:
+            uvia_list = iuv_img2map(iuv_image_gt)
+            lU, lV, lI, lA = self.body_uv_losses(u_pred, v_pred, index_pred, ann_pred, uvia_list, has_iuv)
+            rd['losses'].update({'loss_U': lU, 'loss_V': lV, 'loss_IndexUV': lI, 'loss_segAnn': lA})
+        if self.training and uvia_dp_gt is not None:
+            # DensePose-COCO point supervision (iuv_estimator.py:106-121) is the next-row f3 of
+            # SURVEY.md 8f; with has_dp == 0 the reference itself reports zeros (:118-121).
+            z = torch.zeros(1, device=data.device)
+            rd['losses'].update({'loss_Udp': z, 'loss_Vdp': z.clone(), 'loss_IndexUVdp': z.clone(), 'loss_segAnndp': z.clone()})
+        rd['uvia_pred'] = [u_pred, v_pred, index_pred, ann_pred]
+        if not cfg.DANET.DECOMPOSED:
+            return rd
+
+        _, _, index_cl, _ = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
+        feat = est['xd']
+        hm = est['predict_hm']
+        S = hm.size(-1)
+        rd['skps_hm_pred'] = hm.detach()
+        centers = softmax_integral_tensor(10 * hm, hm.size(1), hm.size(-2), hm.size(-1))
+        centers = centers / (0.5 * S) - 1
+
+        if self.training and smpl_kps_gt is not None:
+            if cfg.DANET.STN_KPS_WEIGHTS > 0 and smpl_kps_gt.shape[-1] == 3:
+                wk = smpl_kps_gt[:, :, 2:3]
+                l = (F.smooth_l1_loss(centers, smpl_kps_gt[:, :, :2], reduction='none') * wk).sum() / smpl_kps_gt.size(0)
+                rd['losses']['loss_roi'] = l * cfg.DANET.STN_KPS_WEIGHTS
+            if cfg.DANET.STN_CENTER_JITTER > 0:
+                centers = centers + cfg.DANET.STN_CENTER_JITTER * (torch.rand_like(centers) - 0.5)
+
+        hidden = None
+        if cfg.DANET.STN_PART_VIS_SCORE > 0:
+            score_maps = torch.einsum('jc,bchw->bjhw', self._vis_membership, index_cl.detach())
+            score = _sample_points(score_maps, centers.detach(), align)
+            hidden = score < cfg.DANET.STN_PART_VIS_SCORE
+
+        thetas, _ = self.affine_para(centers, hidden)
+        rd['stn_kps_pred'] = centers.detach()
+        part_maps = stn_gather(feat, thetas, align_corners=align)                       # [B,24*C,H,W]
+        part_pred = self.iuv_est.final_pred.predict_partial_iuv(part_maps)
+        Sp = part_pred.size(-1)
+        part_pred = part_pred.reshape(part_pred.size(0), 24, 3, -1, Sp, Sp)              # [B,24,3,7,H,W]
+
+        if self.training and iuv_image_gt is not None:
+            simp = self.part_iuv_simp(*uvia_list[:3])                                    # [B,24,3,7,H,W]
+            B = simp.shape[0]
+            flat = simp.reshape(B * 24, 21, Sp, Sp)
+            grid = F.affine_grid(thetas.detach().reshape(B * 24, 2, 3), list(flat.shape), align_corners=align)
+            part_gt = F.grid_sample(flat, grid, mode='bilinear', padding_mode='zeros', align_corners=align)
+            part_gt = part_gt.reshape(B, 24, 3, 7, Sp, Sp)
+            rd['part_iuv_gt'] = part_gt
+            lU, lV, lI, _ = self.body_uv_losses(part_pred[:, :, 0], part_pred[:, :, 1], part_pred[:, :, 2], None,
+                                                [part_gt[:, :, 0], part_gt[:, :, 1], part_gt[:, :, 2], None], has_iuv,
+                                                class_dim=2)
+            # the reference sums 24 per-joint losses and divides by 24: U/V are sums over pixels (/B),
+            # the index loss a mean over pixels -- the joint axis is already inside the mean here
+            rd['losses'].update({'loss_pU': lU / 24., 'loss_pV': lV / 24., 'loss_pIndexUV': lI})
+        rd['part_iuv_pred'] = part_pred
+        return rd

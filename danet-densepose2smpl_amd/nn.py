@@ -128,3 +128,39 @@ def sum_relu(terms, shifts=None, relu=True):
 
 def relu(x):
     return sum_relu([x], [0], True)
+
+
+class StnGatherFunction(torch.autograd.Function):
+    """x [B,C,H,W], theta [B,P,2,3] -> [B,P*C,OH,OW]; gradient to x only (theta is detached in the
+    reference, iuv_estimator.py:197)."""
+
+    @staticmethod
+    def forward(ctx, x, theta, out_hw, align_corners):
+        L = _lib.lib()
+        x = nhwc_bf16(x)
+        B, C, H, W = x.shape
+        th = theta.detach().float().contiguous()
+        P = th.shape[1]
+        OH, OW = out_hw
+        y = _empty_nhwc(B, P * C, OH, OW, torch.bfloat16, x.device)
+        check(L.danet_stn_gather_forward(ptr(x.permute(0, 2, 3, 1)), ptr(th), B, H, W, C, P, OH, OW, int(align_corners),
+                                         ptr(y.permute(0, 2, 3, 1)), stream()), 'danet_stn_gather_forward')
+        ctx.save_for_backward(th)
+        ctx.cfg = (B, C, H, W, P, OH, OW, int(align_corners))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (th,) = ctx.saved_tensors
+        B, C, H, W, P, OH, OW, align = ctx.cfg
+        gy = nhwc_bf16(gy)
+        dx = _empty_nhwc(B, C, H, W, torch.bfloat16, gy.device)
+        check(L.danet_stn_gather_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(th), B, H, W, C, P, OH, OW, align,
+                                          ptr(dx.permute(0, 2, 3, 1)), stream()), 'danet_stn_gather_backward')
+        return dx, None, None, None
+
+
+def stn_gather(x, theta, out_hw=None, align_corners=True):
+    out_hw = (x.shape[2], x.shape[3]) if out_hw is None else out_hw
+    return StnGatherFunction.apply(x, theta, out_hw, align_corners)

@@ -1,0 +1,241 @@
+"""Residual blocks, IUV heads and the regressor CNNs on the HIP conv / BatchNorm kernels.
+
+Mirrors the module tree (and therefore the state-dict keys) of
+/root/reference/models/module/res_module.py: BasicBlock (:27-56), Bottleneck (:59-97),
+PoseResNet (:107-278), IUV_predict_layer (:281-390), SmplResNet (:393-497),
+LimbResLayers (:500-535).  Conv -> BatchNorm -> (+residual) -> ReLU runs as one MFMA conv launch
+plus a fused BatchNorm/add/ReLU pass; activations are bf16 NHWC.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import cfg
+from .nn import Conv2d, BatchNorm2d, relu as relu_op
+from .deconv import ConvTranspose2d
+
+BN_MOMENTUM = 0.1
+
+
+class ConvBN(nn.Module):
+    """Children '0' (conv) and '1' (bn): the same keys as the reference's nn.Sequential(conv, bn[, relu])."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, groups=1, momentum=BN_MOMENTUM, relu=False):
+        super().__init__()
+        self.add_module('0', Conv2d(cin, cout, k, stride, pad, bias=False, groups=groups))
+        self.add_module('1', BatchNorm2d(cout, momentum=momentum))
+        self.relu = relu
+
+    def forward(self, x, res=None, relu=None):
+        return self._modules['1'](self._modules['0'](x), res=res, relu=self.relu if relu is None else relu)
+
+
+def conv3x3(in_planes, out_planes, stride=1, bias=False, groups=1):
+    return Conv2d(in_planes * groups, out_planes * groups, 3, stride, 1, bias=bias, groups=groups)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride, groups=groups)
+        self.bn1 = BatchNorm2d(planes * groups, momentum=BN_MOMENTUM)
+        self.conv2 = conv3x3(planes, planes, groups=groups)
+        self.bn2 = BatchNorm2d(planes * groups, momentum=BN_MOMENTUM)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), res=residual, relu=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes * groups, planes * groups, 1, bias=False, groups=groups)
+        self.bn1 = BatchNorm2d(planes * groups, momentum=BN_MOMENTUM)
+        self.conv2 = Conv2d(planes * groups, planes * groups, 3, stride, 1, bias=False, groups=groups)
+        self.bn2 = BatchNorm2d(planes * groups, momentum=BN_MOMENTUM)
+        self.conv3 = Conv2d(planes * groups, planes * self.expansion * groups, 1, bias=False, groups=groups)
+        self.bn3 = BatchNorm2d(planes * self.expansion * groups, momentum=BN_MOMENTUM)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), res=residual, relu=True)
+
+
+resnet_spec = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
+               101: (Bottleneck, [3, 4, 23, 3]), 152: (Bottleneck, [3, 8, 36, 3])}
+
+
+def make_res_layer(owner, block, planes, blocks, stride=1, groups=1, momentum=BN_MOMENTUM):
+    """Stack of residual blocks; `owner.inplanes` tracks the running width (per group)."""
+    downsample = None
+    if stride != 1 or owner.inplanes != planes * block.expansion:
+        downsample = ConvBN(owner.inplanes * groups, planes * block.expansion * groups, 1, stride, 0, groups=groups,
+                            momentum=momentum)
+    layers = [block(owner.inplanes, planes, stride, downsample, groups=groups) if groups != 1
+              else block(owner.inplanes, planes, stride, downsample)]
+    owner.inplanes = planes * block.expansion
+    for _ in range(1, blocks):
+        layers.append(block(owner.inplanes, planes, groups=groups) if groups != 1 else block(owner.inplanes, planes))
+    return nn.Sequential(*layers)
+
+
+class IUV_predict_layer(nn.Module):
+    """Global heads U,V,Index (25) and Ann (15), the SMPL-joint heat-map head, and the grouped
+    partial-IUV head (res_module.py:281-390).  Head outputs are fp32 (they feed the losses)."""
+
+    def __init__(self, feat_dim=256, final_cov_k=3, part_out_dim=25):
+        super().__init__()
+        pad = 1 if final_cov_k == 3 else 0
+        self.predict_u = Conv2d(feat_dim, 25, final_cov_k, 1, pad, out_fp32=True)
+        self.predict_v = Conv2d(feat_dim, 25, final_cov_k, 1, pad, out_fp32=True)
+        self.predict_ann_index = Conv2d(feat_dim, 15, final_cov_k, 1, pad, out_fp32=True)
+        self.predict_uv_index = Conv2d(feat_dim, 25, final_cov_k, 1, pad, out_fp32=True)
+        self.inplanes = feat_dim
+        # BatchNorm in this head uses torch's default momentum (res_module.py:364)
+        self.predict_hm = nn.Sequential(make_res_layer(self, Bottleneck, int(feat_dim / 4), 3, momentum=0.1),
+                                        Conv2d(feat_dim, 24, 3, 1, 1, bias=True, out_fp32=True))
+        if cfg.DANET.DECOMPOSED:
+            self.predict_partial_iuv = Conv2d(feat_dim * 24, part_out_dim * 3 * 24, final_cov_k, 1, pad, groups=24,
+                                              out_fp32=True)
+
+    def forward(self, x):
+        return {'predict_u': self.predict_u(x), 'predict_v': self.predict_v(x),
+                'predict_uv_index': self.predict_uv_index(x), 'predict_ann_index': self.predict_ann_index(x),
+                'predict_hm': self.predict_hm(x)}
+
+
+def _maxpool3x3s2(x):
+    # TODO(next): HIP kernel; torch's channels_last bf16 max-pool is used for the two regressor stems
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+class PoseResNet(nn.Module):
+    """ResNet trunk + 3 transposed convs (k4 s2) + IUV heads (res_module.py:107-278)."""
+
+    def __init__(self, part_out_dim=25):
+        super().__init__()
+        self.inplanes = 64
+        extra = cfg.MSRES_MODEL.EXTRA
+        self.deconv_with_bias = extra['DECONV_WITH_BIAS']
+        block, layers = resnet_spec[extra['NUM_LAYERS']]
+        self.conv1 = Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.layer1 = make_res_layer(self, block, 64, layers[0])
+        self.layer2 = make_res_layer(self, block, 128, layers[1], stride=2)
+        self.layer3 = make_res_layer(self, block, 256, layers[2], stride=2)
+        self.layer4 = make_res_layer(self, block, 512, layers[3], stride=2)
+        mods = []
+        for planes, kernel in zip(extra['NUM_DECONV_FILTERS'], extra['NUM_DECONV_KERNELS']):
+            pad, outpad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[kernel]
+            mods += [ConvTranspose2d(self.inplanes, planes, kernel, 2, pad, outpad, bias=self.deconv_with_bias),
+                     BatchNorm2d(planes, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)]
+            self.inplanes = planes
+        self.deconv_layers = nn.Sequential(*mods)
+        self.final_feat_dim = extra['NUM_DECONV_FILTERS'][-1]
+        self.final_pred = IUV_predict_layer(feat_dim=self.final_feat_dim, part_out_dim=part_out_dim)
+
+    def forward(self, x):
+        x = _maxpool3x3s2(self.bn1(self.conv1(x), relu=True))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        mods = list(self.deconv_layers)
+        for i in range(0, len(mods), 3):
+            x = mods[i + 1](mods[i](x), relu=True)
+        out = self.final_pred(x)
+        out['xd'] = x
+        return out
+
+    def init_weights(self, pretrained=''):
+        for m in self.deconv_layers.modules():
+            if isinstance(m, ConvTranspose2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        for m in self.final_pred.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        if pretrained:
+            _load_backbone(self, pretrained)
+
+
+class SmplResNet(nn.Module):
+    """ResNet on IUV maps (res_module.py:393-497): 7x7 s2 stem on `in_channels`, optional truncation,
+    average pool + linear."""
+
+    def __init__(self, resnet_nums, in_channels=3, num_classes=229, last_stride=2, n_extra_feat=0, truncate=0, **kwargs):
+        super().__init__()
+        self.inplanes = 64
+        self.truncate = truncate
+        block, layers = resnet_spec[resnet_nums]
+        self.conv1 = Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.layer1 = make_res_layer(self, block, 64, layers[0])
+        self.layer2 = make_res_layer(self, block, 128, layers[1], stride=2)
+        self.layer3 = make_res_layer(self, block, 256, layers[2], stride=2) if truncate < 2 else None
+        self.layer4 = make_res_layer(self, block, 512, layers[3], stride=last_stride) if truncate < 1 else None
+        self.num_classes = num_classes
+        if num_classes > 0:
+            self.final_layer = nn.Linear(512 * block.expansion, num_classes)
+            nn.init.xavier_uniform_(self.final_layer.weight, gain=0.01)
+        self.n_extra_feat = n_extra_feat
+        if n_extra_feat > 0:
+            raise NotImplementedError('n_extra_feat > 0 is only used by INPUT_MODE variants outside the hot path')
+
+    def forward(self, x, infeat=None):
+        x = _maxpool3x3s2(self.bn1(self.conv1(x), relu=True))
+        x2 = self.layer2(self.layer1(x))
+        x3 = self.layer3(x2) if self.truncate < 2 else x2
+        x4 = self.layer4(x3) if self.truncate < 1 else x3
+        cls = None
+        if self.num_classes > 0:
+            xp = x4.float().mean(dim=(2, 3))
+            cls = self.final_layer(xp)
+        return cls, {'x4': x4}
+
+    def init_weights(self, pretrained=''):
+        if pretrained:
+            _load_backbone(self, pretrained, drop_mismatched=True)
+
+
+class LimbResLayers(nn.Module):
+    """Grouped (x24) layer4 + average pool (res_module.py:500-535)."""
+
+    def __init__(self, resnet_nums, inplanes, outplanes=None, groups=1, **kwargs):
+        super().__init__()
+        self.inplanes = inplanes
+        block, layers = resnet_spec[resnet_nums]
+        self.outplanes = 512 if outplanes is None else outplanes
+        self.layer4 = make_res_layer(self, block, self.outplanes, layers[3], stride=2, groups=groups)
+
+    def forward(self, x):
+        x = self.layer4(x)
+        return x.float().mean(dim=(2, 3), keepdim=True)
+
+
+def _load_backbone(module, path, drop_mismatched=False):
+    """Checkpoint loading with the reference's conventions (res_module.py:253-278, 466-497): plain
+    state dict or {'state_dict': ...} with optional 'module.' prefixes; strict=False."""
+    import os
+    from collections import OrderedDict
+    if not os.path.isfile(path):
+        raise ValueError('pretrained model does not exist: %s' % path)
+    ckpt = torch.load(path, map_location='cpu')
+    if isinstance(ckpt, dict) and 'state_dict' in ckpt:
+        ckpt = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in ckpt['state_dict'].items())
+    if drop_mismatched:
+        own = module.state_dict()
+        ckpt = OrderedDict((k, v) for k, v in ckpt.items() if k not in own or own[k].shape == v.shape)
+    module.load_state_dict(ckpt, strict=False)

@@ -1,0 +1,90 @@
+"""Training step with the contract of the reference's Trainer.train_step
+(/root/reference/train/trainer.py:117-244): ``train_step(in_dict) -> (output, losses)`` =
+forward, sum of the loss dict (trainer.py:217-220), backward, Adam step (lr 1e-4, trainer.py:42-44).
+The in_dict is the one the reference builds at trainer.py:184-212; `synthetic_in_dict` produces it
+from seeded random labels.  Data loading, FitsDict, TensorBoard and
+checkpoints are out of scope."""
+import types
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import cfg
+from .danet import DaNet
+from .distributed import GradReducer
+from .geometry import perspective_projection
+
+
+def default_options(batch_size=32):
+    return types.SimpleNamespace(batch_size=batch_size, openpose_train_weight=0., gt_train_weight=1.)
+
+
+def synthetic_in_dict(model, B, device, seed=1234, img_size=None):
+    """Seeded synthetic training batch with the reference's keys and shapes (trainer.py:184-212;
+    datasets/base_dataset.py:228-298)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    S = img_size or cfg.DANET.INIMG_SIZE
+    img = torch.randn(B, 3, S, S, generator=g).to(device)
+    betas = torch.randn(B, 10, generator=g).clamp(-3, 3).to(device)
+    pose = (torch.randn(B, 72, generator=g) * 0.2).to(device)
+    cam = torch.stack([torch.rand(B, generator=g) * 0.5 + 0.6, torch.rand(B, generator=g) * 0.2 - 0.1,
+                       torch.rand(B, generator=g) * 0.2 - 0.1], dim=1).to(device)
+    smpl = model.iuv2smpl.smpl
+    with torch.no_grad():
+        out = smpl(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3])
+        cam_t = torch.stack([cam[:, 1], cam[:, 2], 2 * 5000. / (S * cam[:, 0] + 1e-9)], dim=-1)
+        zero_c = torch.zeros(B, 2, device=device)
+        kp2d = perspective_projection(out.joints, None, cam_t, 5000., zero_c) / (S / 2.)
+        conf = torch.cat([torch.zeros(B, 25, 1, device=device), torch.ones(B, 24, 1, device=device)], dim=1)
+        keypoints = torch.cat([kp2d, conf], dim=-1)
+        pose_3d = torch.cat([out.joints[:, 25:], torch.ones(B, 24, 1, device=device)], dim=-1)
+        skps = perspective_projection(out.smpl_joints, None, cam_t, 5000., zero_c) / (S / 2.)
+        target_smpl_kps = torch.cat([skps, torch.ones(B, 24, 1, device=device)], dim=-1)
+    ones = torch.ones(B, device=device)
+    return {'img': img, 'opt_pose': pose, 'opt_betas': betas, 'keypoints': keypoints, 'pose_3d': pose_3d,
+            'has_pose_3d': ones.clone(), 'valid_fit': ones.clone(), 'has_iuv': ones.clone(), 'has_dp': torch.zeros(B, device=device),
+            'target_smpl_kps': target_smpl_kps, 'target_verts': out.vertices.detach(), 'target_cam': cam,
+            'vis_on': False, 'pretrain_mode': False}
+
+
+class Trainer(object):
+    """Single-process-per-GPU trainer; with world_size > 1 gradients are averaged by GradReducer
+    (bucketed RCCL all-reduce overlapped with backward)."""
+
+    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None):
+        self.options = options or default_options()
+        self.device = device or torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.model = (model or DaNet(self.options, None, pretrained=False, smpl_model=smpl_model)).to(self.device)
+        self.smpl = self.model.iuv2smpl.smpl
+        self.optimizer = torch.optim.Adam(params=[p for p in self.model.parameters() if p.requires_grad],
+                                          lr=lr or cfg.SOLVER.BASE_LR, weight_decay=0,
+                                          **({'capturable': True, 'foreach': True} if self.device.type == 'cuda' else {}))
+        self.step_count = 0
+        self.reducer = None
+        if distributed is None:
+            distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1
+        if distributed:
+            self.reducer = GradReducer(self.model, device=self.device)
+            self.reducer.broadcast_parameters()
+
+    def train_step(self, in_dict):
+        self.model.train()
+        # manual step-LR decay (trainer.py:120-128)
+        for i, s in enumerate(cfg.SOLVER.STEPS):
+            if i > 0 and self.step_count == s:
+                for group in self.optimizer.param_groups:
+                    group['lr'] *= cfg.SOLVER.GAMMA
+        out = self.model(in_dict)
+        losses = out['losses']
+        loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.prepare()
+        loss_total.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        self.step_count += 1
+        return out, losses

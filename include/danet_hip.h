@@ -158,6 +158,19 @@ int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nter
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
                             void* d_term, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Joint-centric part decomposition (STN).  Replaces the 24 x (F.affine_grid + F.grid_sample) +
+ * torch.cat of /root/reference/models/danet/iuv_estimator.py:193-204.
+ *  x [B,H,W,C] bf16 NHWC (C % 8 == 0), theta [B,P,2,3] f32 -> y [B,OH,OW,P*C] bf16 (part-major
+ *  channels, i.e. torch.cat(dim=1) order).  Bilinear, zero padding, align_corners as given.
+ *  The backward (w.r.t. x only: the reference detaches theta) requires axis-aligned thetas
+ *  ([[sx,0,cx],[0,sy,cy]], which is all affine_para ever builds).
+ */
+int danet_stn_gather_forward(const void* x, const float* theta, int B, int H, int W, int C, int P,
+                             int OH, int OW, int align_corners, void* y, void* stream);
+int danet_stn_gather_backward(const void* dy, const float* theta, int B, int H, int W, int C, int P,
+                              int OH, int OW, int align_corners, void* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,31 @@ def test_sum_relu_fuse():
     r.backward(gy.bfloat16())
     _close(r, F.relu(a), 1e-2, 'relu')
     _close(xt.grad, gy * (a > 0), 1e-2, 'drelu')
+
+
+@pytest.mark.parametrize('align', [True, False])
+def test_stn_gather_vs_torch_grid_sample(align):
+    from danet_densepose2smpl_amd import nn as dnn
+    g = torch.Generator().manual_seed(3)
+    B, C, H, P = 3, 48, 32, 24
+    x = torch.randn(B, C, H, H, generator=g).bfloat16().float().cuda()
+    s = torch.rand(B, P, generator=g) * 0.9 + 0.05
+    s[0, 0] = 0.0                       # degenerate scale
+    s[1, 3] = 1.6                       # samples outside the map (zero padding)
+    c = (torch.rand(B, P, 2, generator=g) - 0.5) * 1.6
+    theta = torch.zeros(B, P, 2, 3)
+    theta[:, :, 0, 0] = s; theta[:, :, 1, 1] = s; theta[:, :, :, 2] = c
+    theta = theta.cuda()
+    gy = torch.randn(B, P * C, H, H, generator=g).bfloat16().float().cuda()
+    xr = x.clone().requires_grad_(True)
+    outs = []
+    for p in range(P):
+        grid = F.affine_grid(theta[:, p], x.size(), align_corners=align)
+        outs.append(F.grid_sample(xr, grid, align_corners=align))
+    yr = torch.cat(outs, dim=1)
+    yr.backward(gy)
+    xt = x.clone().requires_grad_(True)
+    y = dnn.stn_gather(xt, theta, align_corners=align)
+    y.backward(gy.bfloat16())
+    _close(y, yr, 1e-2, 'stn y')
+    _close(xt.grad, xr.grad, 1e-2, 'stn dx')
