@@ -1,0 +1,160 @@
+"""Headline benchmark (BASELINE.json): images/sec of the full DaNet training step -- forward +
+backward (+ gradient all-reduce for N > 1) + Adam -- HRNet-W48 + SMPL LBS + IUV render,
+256x256 input, 32 images per GPU, synthetic data, random-init weights.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` is the whole-job aggregate (all ranks), timed over
+exactly K steps between barrier + synchronize pairs, max over ranks.  `roofline` is for the
+kernel instance with the largest total time (measured live with HIP events on the launch
+stream during the timed steps); `cpu_baseline` times the CPU oracle (plain-torch fp32 HRNet
+step + C LBS + C raster) on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU (BASELINE: 32)')
+    ap.add_argument('--size', type=int, default=256, help='input resolution (BASELINE: 256)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, cpu_batch):
+    """The oracle timed on the host cores on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    from oracle import torch_ref
+    from danet_densepose2smpl_amd import assets
+    torch.manual_seed(0)
+    net = torch_ref.HRNet(part_out_dim=7)
+    img = torch.randn(cpu_batch, 3, size, size)
+    torch_ref.hrnet_step_cpu(net, img, 1)                                   # warm-up
+    t_net = torch_ref.hrnet_step_cpu(net, img, 1)
+    model = assets.make_synthetic_smpl(0)
+    vm, faces, tex = assets.densepose_render_tables(assets.make_synthetic_densepose(model, 0))
+    rng = np.random.default_rng(0)
+    betas = rng.normal(0, 1, (cpu_batch, 10)).astype(np.float32)
+    pose = rng.normal(0, 0.2, (cpu_batch, 72)).astype(np.float32)
+    t0 = time.time()
+    for _ in range(4):                                                       # 4 SMPL forwards per train step
+        verts, _ = oracle.lbs_forward(model, betas, pose, False, np.float32)
+    rot = np.tile(np.eye(3, dtype=np.float32), (cpu_batch, 24, 1, 1))
+    oracle.lbs_backward(model, betas, rot, verts, None, np.float32)          # 1 SMPL backward
+    cam = np.tile(np.array([[0.9, 0.0, 0.0]], np.float32), (cpu_batch, 1))
+    oracle.raster_forward(verts, cam, vm, faces, tex, 5000.0, float(size), size // 4)
+    t_geo = time.time() - t0
+    return {'value': round(cpu_batch / (t_net + t_geo), 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': 'B=%d of the B=32 step: oracle/torch_ref.HRNet-W48 + global IUV heads fwd+bwd fp32 (%.2fs) + '
+                      '4x C SMPL fwd, 1x C SMPL bwd, 1x C IUV raster (%.2fs); partial-IUV head, regressor nets and Adam not included'
+                      % (cpu_batch, t_net, t_geo)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from danet_densepose2smpl_amd import conv
+    from danet_densepose2smpl_amd.config import cfg_from_dict, reset_cfg
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    reset_cfg()
+    cfg_from_dict({'DANET.INIMG_SIZE': args.size, 'DANET.HEATMAP_SIZE': args.size // 4})
+    torch.manual_seed(1234)
+    B = args.batch
+    tr = Trainer(default_options(B), device=dev, distributed=world > 1)
+    batch = synthetic_in_dict(tr.model, B, dev, seed=1234 + rank)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # warm-up; the last warm-up step times every conv launch to find the dominant kernel instance
+    for w in range(args.warmup):
+        if w == args.warmup - 1:
+            conv.PROFILER = conv.KernelProfiler()
+        tr.train_step(batch)
+    dominant = None
+    if conv.PROFILER is not None:
+        torch.cuda.synchronize(dev)
+        summ = conv.PROFILER.summary()
+        if summ:
+            dominant = max(summ.items(), key=lambda kv: kv[1][1])[0]
+    conv.PROFILER = conv.KernelProfiler(only=dominant) if dominant else None
+
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        tr.train_step(batch)
+    sync()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    if conv.PROFILER is not None:
+        summ = conv.PROFILER.summary()
+        conv.PROFILER = None
+        if dominant in summ:
+            n, secs, flops = summ[dominant]
+            ach = flops / secs / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': None, 'kernel': dominant,
+                    'launches': n, 'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3)}
+
+    if rank == 0:
+        ips = world * B * args.steps / elapsed
+        line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                'config': {'workload': 'full DaNet train step (HRNet-W48 + part-wise IUV heads + SMPL LBS x4 + IUV render + '
+                                       'regressor + losses, fwd+bwd+Adam), %dx%d, %d img/GPU; convs bf16 MFMA fp32-acc, '
+                                       'LBS/raster/losses fp32' % (args.size, args.size, B),
+                           'global_batch': B * world, 'parallelism': 'dp%d' % world},
+                'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(args.size, args.cpu_batch)
+            except Exception as e:                                   # the bench line must still be printed
+                line['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -26,13 +26,16 @@ _SIGNATURES = {
     'danet_iuv_raster_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'danet_conv_nt': (c_i, [c_i]),
+    'danet_conv_kernel_id': (c_i, [c_i] * 6),
+    'danet_conv_wgrad_kernel_id': (c_i, [c_i] * 3),
     'danet_conv_packed_elems': (c_sz, [c_i] * 6),
     'danet_conv_pack_weights': (c_i, [c_f, c_f] + [c_i] * 6 + [c_f]),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_fl, c_fl, c_i, c_i, c_f]),
-    'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f]),
+    'danet_bn_ws_floats': (c_sz, [c_i]),
+    'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f]),
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),

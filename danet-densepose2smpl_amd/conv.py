@@ -15,6 +15,36 @@ from . import _lib
 from ._lib import ptr, check, stream
 
 _PACK_CACHE = {}
+PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
+
+
+class KernelProfiler(object):
+    """HIP-event timing of individual conv launches on the stream they are launched on."""
+
+    def __init__(self, only=None):
+        self.only = only
+        self.records = []
+
+    def begin(self, key, flops):
+        if self.only is not None and key != self.only:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (key, flops, e0, e1)
+
+    def end(self, tok):
+        if tok is not None:
+            tok[3].record()
+            self.records.append(tok)
+
+    def summary(self):
+        """{key: (launches, total_seconds, total_flops)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            n, t, f = out.get(key, (0, 0.0, 0.0))
+            out[key] = (n + 1, t + e0.elapsed_time(e1) * 1e-3, f + flops)
+        return out
+
 
 
 def nhwc_bf16(x):
@@ -62,9 +92,16 @@ def conv_out_size(n, k, stride, pad, dil):
 def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32):
     L = _lib.lib()
     y = _empty_nhwc(B, Cout, OH, OW, torch.float32 if out_fp32 else torch.bfloat16, x.device)
+    tok = None
+    if PROFILER is not None:
+        kid = L.danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups)
+        tok = PROFILER.begin('conv_igemm_kernel<%d, %d, %s>' % (kid // 100, (kid // 10) % 10, 'true' if kid % 10 else 'false'),
+                             2.0 * B * OH * OW * Cout * (Cin // groups) * R * S)
     check(L.danet_conv_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(bias), ptr(y.permute(0, 2, 3, 1)),
                                B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed),
                                int(relu), int(out_fp32), stream()), 'danet_conv_forward')
+    if tok is not None:
+        PROFILER.end(tok)
     return y
 
 
@@ -101,9 +138,16 @@ class Conv2dFunction(torch.autograd.Function):
             gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
             nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            tok = None
+            if PROFILER is not None:
+                kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups)
+                tok = PROFILER.begin('conv_wgrad_kernel<%d, %d>' % (kid // 10, kid % 10),
+                                     2.0 * B * OH * OW * Cout * Cin_g * R * S)
             check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
                                      B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, stream()),
                   'danet_conv_wgrad')
+            if tok is not None:
+                PROFILER.end(tok)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum(dim=(0, 2, 3))
         return gx, gw, gb, None, None, None, None, None

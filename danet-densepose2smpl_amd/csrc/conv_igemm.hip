@@ -222,6 +222,20 @@ extern "C" int danet_conv_nt(int Cout_g) {
     if (Cout_g % 48 == 0 || Cout_g <= 48) return 3;
     return 4;
 }
+// Which template instance danet_conv_forward dispatches to: MT*100 + NT*10 + vec8
+// (kernel name conv_igemm_kernel<MT, NT, vec8>); used by bench.py to attribute timings.
+extern "C" int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, int groups) {
+    const int Cout_g = Cout / groups, Cin_g = Cin / groups;
+    const int nt = danet_conv_nt(Cout_g);
+    const int Cout_pad = (Cout_g + 16 * nt - 1) / (16 * nt) * (16 * nt);
+    const long M = (long)B * OH * OW;
+    // pixel tiles per wave: fewer for small problems so that the grid still fills 256 CUs
+    const long blocks4 = (M + 255) / 256 * (Cout_pad / (16 * nt)) * groups;
+    const int mt = blocks4 < 512 ? 1 : 4;
+    const int vec8 = (Cin_g % 8 == 0) && (Cin % 8 == 0);
+    return mt * 100 + nt * 10 + vec8;
+}
+
 extern "C" size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode) {
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
     const int nt = danet_conv_nt(rows);
@@ -275,9 +289,7 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     const bool vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
-    // pixel tiles per wave: fewer for small problems so that the grid still fills 256 CUs
-    const long blocks4 = (p.M + 255) / 256 * (p.Cout_pad / (16 * nt)) * groups;
-    const bool small = blocks4 < 512;
+    const bool small = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100 == 1;
     if (nt == 1) { if (small) launch_conv<1, 1>(p, vec8, st); else launch_conv<4, 1>(p, vec8, st); }
     else if (nt == 2) { if (small) launch_conv<1, 2>(p, vec8, st); else launch_conv<4, 2>(p, vec8, st); }
     else if (nt == 3) { if (small) launch_conv<1, 3>(p, vec8, st); else launch_conv<4, 3>(p, vec8, st); }

@@ -174,6 +174,13 @@ inline int tiles_for(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : ((c % 48 == 0 
 
 }  // namespace
 
+// Template instance of conv_wgrad_kernel<CT, NI>: CT*10 + NI.
+extern "C" int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups) {
+    int ct = tiles_for(Cout / groups), ni = tiles_for(Cin / groups);
+    if (ct * ni > 9) { if (ct == 4) ct = 2; if (ni == 4 && ct * ni > 9) ni = 2; }
+    return ct * 10 + ni;
+}
+
 extern "C" size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S) {
     return (size_t)Cout * Cin_g * R * S;
 }
@@ -201,8 +208,8 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
     if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "conv_wgrad: memset: %s", hipGetErrorString(e));
     const int taps = R * S;
     p.ntapgroups = (taps + MAX_TG - 1) / MAX_TG;
-    int ct = tiles_for(p.Cout_g), ni = tiles_for(p.Cin_g);
-    if (ct * ni > 9) { if (ct == 4) ct = 2; if (ni == 4 && ct * ni > 9) ni = 2; }       // bound registers
+    const int kid = danet_conv_wgrad_kernel_id(Cin, Cout, groups);                      // bounds registers
+    const int ct = kid / 10, ni = kid % 10;
     const int nco = (p.Cout_g + ct * 16 - 1) / (ct * 16), nci = (p.Cin_g + ni * 16 - 1) / (ni * 16);
     const long other = (long)nco * nci * p.ntapgroups * groups;
     const long nchunks = (p.M + CHUNK - 1) / CHUNK;

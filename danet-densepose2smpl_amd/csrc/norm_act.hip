@@ -20,6 +20,7 @@ namespace {
 
 using namespace danet_conv;
 
+constexpr int NCOPY = 32;   // replicas of the per-channel accumulators: block b adds into replica b % NCOPY (cuts same-address atomic contention)
 constexpr int VW = 4;     // channels per lane (8-byte runs; every BN width on the path is a multiple of 4)
 
 struct Vec { float v[VW]; };
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
             for (int j = 0; j < VW; ++j) { s.v[j] += a.v[j]; q.v[j] += a.v[j] * a.v[j]; }
         }
     }
-    block_channel_reduce(sm, s, t, fm.CV, fm.span, sums);
-    block_channel_reduce(sm, q, t, fm.CV, fm.span, sums + Cst);
+    float* dst = sums + (size_t)(blockIdx.x % NCOPY) * 2 * Cst;
+    block_channel_reduce(sm, s, t, fm.CV, fm.span, dst);
+    block_channel_reduce(sm, q, t, fm.CV, fm.span, dst + Cst);
 }
 
 // mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
@@ -103,8 +105,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     for (int j = 0; j < VW; ++j) {
         float mean, var;
         if (mode == 0) {
-            mean = sums[c0 + j] * inv_count;
-            var = fmaxf(sums[C + c0 + j] * inv_count - mean * mean, 0.f);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < NCOPY; ++r) { s0 += sums[(size_t)r * 2 * C + c0 + j]; s1 += sums[(size_t)r * 2 * C + C + c0 + j]; }
+            mean = s0 * inv_count;
+            var = fmaxf(s1 * inv_count - mean * mean, 0.f);
         } else {
             mean = running_mean[c0 + j];
             var = running_var[c0 + j];
@@ -167,14 +172,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             for (int j = 0; j < VW; ++j) { s1.v[j] += g.v[j]; s2.v[j] += g.v[j] * (a.v[j] - mean[j]) * invstd[j]; }
         }
     }
-    block_channel_reduce(sm, s1, t, fm.CV, fm.span, red);
-    block_channel_reduce(sm, s2, t, fm.CV, fm.span, red + C);
+    float* dst = red + (size_t)(blockIdx.x % NCOPY) * 2 * C;
+    block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
+    block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
-    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres)
+    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam)
 {
     const int t = threadIdx.x;
     if (t >= fm.span) return;
@@ -185,7 +191,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     for (int j = 0; j < VW; ++j) {
         mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j];
         k0[j] = (gamma ? gamma[c0 + j] : 1.f) * invstd[j];
-        m1[j] = red[c0 + j] * inv_count; m2[j] = red[C + c0 + j] * inv_count;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < NCOPY; ++r) { s0 += red[(size_t)r * 2 * C + c0 + j]; s1 += red[(size_t)r * 2 * C + C + c0 + j]; }
+        m1[j] = s0 * inv_count; m2[j] = s1 * inv_count;
+        if (blockIdx.x == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
     }
     DANET_ROW_LOOP(fm, t) {
         const size_t off = DANET_ROW_OFF(fm);
@@ -281,7 +291,7 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
     fm->M = M;
     fm->span = (256 / fm->CV) * fm->CV;
     long blocks = (fm->nvec + fm->span - 1) / fm->span;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     *grid = (int)blocks;
     fm->gridspan = (long)fm->span * blocks;
@@ -303,7 +313,7 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
     DANET_CHECK_ARG(C % VW == 0, "bn_forward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
     if (training) {
-        hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C, st);
+        hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_forward: memset: %s", hipGetErrorString(e));
     }
     const float inv = 1.0f / (float)M, unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
@@ -325,16 +335,18 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
     return DANET_OK;
 }
 
-// red_ws: [2][C] scratch; on return red_ws[0:C] = d beta, red_ws[C:2C] = d gamma.
+// red_ws: danet_bn_ws_floats(C) floats of scratch; dparam [2][C] (may be NULL) receives (d beta, d gamma).
+extern "C" size_t danet_bn_ws_floats(int C) { return (size_t)NCOPY * 2 * C; }
+
 extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                                  const float* gamma, const float* saved, int relu,
-                                 void* dx, void* dres, float* red_ws, void* stream)
+                                 void* dx, void* dres, float* dparam, float* red_ws, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(dy && x && dx && saved && red_ws && M > 0 && C > 0 && (!relu || y), "bn_backward: bad arguments");
     DANET_CHECK_ARG(C % VW == 0, "bn_backward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * C, st);
+    hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
     if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
@@ -344,7 +356,8 @@ extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, i
                            fm, saved + c0, C, relu, red_ws + c0);
         DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
-                           fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (bf16_t*)dx, (bf16_t*)dres);
+                           fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (bf16_t*)dx, (bf16_t*)dres,
+                           dparam ? dparam + c0 : nullptr);
         DANET_CHECK_LAUNCH("bn_bwd_apply_kernel");
     }
     return DANET_OK;

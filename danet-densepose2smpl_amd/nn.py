@@ -25,7 +25,7 @@ class BatchNormActFunction(torch.autograd.Function):
                 raise ValueError('residual shape %s != %s' % (tuple(res.shape), tuple(x.shape)))
         y = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         saved = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
-        sums = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
+        sums = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device) if training else None
         g = None if gamma is None else gamma.detach().float().contiguous()
         b = None if beta is None else beta.detach().float().contiguous()
         check(L.danet_bn_forward(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
@@ -51,14 +51,15 @@ class BatchNormActFunction(torch.autograd.Function):
         M = B * H * W
         dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
-        red = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+        dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)
         check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
-                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(red), stream()),
+                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), stream()),
               'danet_bn_backward')
-        dgamma = red[1] if ctx.has_affine else None
-        dbeta = red[0] if ctx.has_affine else None
+        dgamma = dparam[1] if ctx.has_affine else None
+        dbeta = dparam[0] if ctx.has_affine else None
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 

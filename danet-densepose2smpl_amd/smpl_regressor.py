@@ -125,8 +125,7 @@ class SMPL_Regressor(nn.Module):
                 gt_pts = self.smpl(betas=target[:, 3:13].contiguous(), body_pose=gt_rotmat[:, 1:].contiguous(),
                                    global_orient=gt_rotmat[:, :1].contiguous(), pose2rot=False).smpl_joints
             for i, pos in enumerate(out['joint_position']):
-                s = (pos - gt_pts).abs().sum(dim=(1, 2))
-                rd['losses']['joint_position%d' % i] = _masked_mean(s, has_smpl, 1) * D.JOINT_POSITION_WEIGHTS
+                rd['losses']['joint_position%d' % i] = self.l1_losses(pos, gt_pts, has_smpl) * D.JOINT_POSITION_WEIGHTS
 
         pred_camera, pred_betas = para[:, :3], para[:, 3:13]
         pred_rotmat = para[:, 13:].reshape(B, 24, 3, 3)
@@ -138,26 +137,10 @@ class SMPL_Regressor(nn.Module):
         kp2d = perspective_projection(pred_joints, None, pred_cam_t, self.focal_length, torch.zeros(B, 2, device=dev))
         kp2d = kp2d / (D.INIMG_SIZE / 2.)
 
-        # SMPL parameter losses (:199, 291-298)
-        s_pose = ((pred_rotmat - gt_rotmat) ** 2).sum(dim=(1, 2, 3))
-        s_beta = ((pred_betas - target[:, 3:13]) ** 2).sum(dim=1)
-        loss_pose = _masked_mean(s_pose, has_smpl, 216)
-        loss_betas = _masked_mean(s_beta, has_smpl, 10)
-        # 2-D keypoints (:248-257): confidence-weighted MSE over all [B,49,2]
-        conf = target_kps[:, :, -1:].clone()
-        conf = torch.cat([conf[:, :25] * self.options.openpose_train_weight, conf[:, 25:] * self.options.gt_train_weight], dim=1)
-        loss_kp2d = (conf * (kp2d - target_kps[:, :, :-1]) ** 2).mean()
-        # 3-D keypoints (:259-276): last 24 joints, pelvis-centred, rows with has_kp3d
-        p3 = pred_joints[:, 25:, :]
-        g3 = target_kps3d[:, :, :-1]
-        c3 = target_kps3d[:, :, -1:]
-        g3 = g3 - ((g3[:, 2] + g3[:, 3]) / 2)[:, None, :]
-        p3 = p3 - ((p3[:, 2] + p3[:, 3]) / 2)[:, None, :]
-        s3 = (c3 * (p3 - g3) ** 2).sum(dim=(1, 2))
-        loss_kp3d = _masked_mean(s3, has_kp3d, 72)
-        # per-vertex L1 (:278-285)
-        sv = (pred_vertices - target_vertices).abs().sum(dim=(1, 2))
-        loss_verts = _masked_mean(sv, has_smpl, pred_vertices.shape[1] * 3)
+        loss_pose, loss_betas = self.smpl_losses(pred_rotmat, pred_betas, gt_rotmat, target[:, 3:13], has_smpl)
+        loss_kp2d = self.keypoint_loss(kp2d, target_kps, self.options.openpose_train_weight, self.options.gt_train_weight)
+        loss_kp3d = self.keypoint_3d_loss(pred_joints, target_kps3d, has_kp3d)
+        loss_verts = self.shape_loss(pred_vertices, target_vertices, has_smpl)
 
         rd['losses'].update({'keypoints_2d': loss_kp2d * D.PROJ_KPS_WEIGHTS,
                              'keypoints_3d': loss_kp3d * D.KPS3D_WEIGHTS,
@@ -172,6 +155,47 @@ class SMPL_Regressor(nn.Module):
                 if v.dim() == 0:
                     rd[key][k] = v.unsqueeze(0)
         return rd
+
+
+    # ---- loss helpers: reference names and semantics (smpl_regressor.py:233-298), with row selection
+    # expressed as per-sample weights (mask in {0,1}) instead of boolean indexing ----
+    @staticmethod
+    def l1_losses(pred, target, mask):
+        """:233-238  sum |pred-target| over selected rows / number of selected rows."""
+        s = (pred - target).abs().reshape(pred.shape[0], -1).sum(dim=1)
+        return _masked_mean(s, mask, 1)
+
+    @staticmethod
+    def smpl_losses(pred_rotmat, pred_betas, gt_rotmat, gt_betas, has_smpl):
+        """:287-298  MSE (mean over the selected rows' elements) on rotation matrices and betas."""
+        B = pred_betas.shape[0]
+        s_pose = ((pred_rotmat.reshape(B, -1) - gt_rotmat.reshape(B, -1)) ** 2).sum(dim=1)
+        s_beta = ((pred_betas - gt_betas) ** 2).sum(dim=1)
+        return _masked_mean(s_pose, has_smpl, 216), _masked_mean(s_beta, has_smpl, pred_betas.shape[1])
+
+    @staticmethod
+    def keypoint_loss(pred_keypoints_2d, gt_keypoints_2d, openpose_weight, gt_weight):
+        """:248-257  confidence-weighted squared error, mean over all [B,49,2] elements."""
+        conf = gt_keypoints_2d[:, :, -1:]
+        conf = torch.cat([conf[:, :25] * openpose_weight, conf[:, 25:] * gt_weight], dim=1)
+        return (conf * (pred_keypoints_2d - gt_keypoints_2d[:, :, :-1]) ** 2).mean()
+
+    @staticmethod
+    def keypoint_3d_loss(pred_keypoints_3d, gt_keypoints_3d, has_pose_3d):
+        """:259-276  last 24 joints, both pelvis-centred (mid of joints 2,3), rows with has_pose_3d."""
+        p3 = pred_keypoints_3d[:, 25:, :]
+        g3 = gt_keypoints_3d[:, :, :-1]
+        c3 = gt_keypoints_3d[:, :, -1:]
+        g3 = g3 - ((g3[:, 2] + g3[:, 3]) / 2)[:, None, :]
+        p3 = p3 - ((p3[:, 2] + p3[:, 3]) / 2)[:, None, :]
+        s3 = (c3 * (p3 - g3) ** 2).sum(dim=(1, 2))
+        return _masked_mean(s3, has_pose_3d, 72)
+
+    @staticmethod
+    def shape_loss(pred_vertices, gt_vertices, has_smpl):
+        """:278-285  per-vertex L1, mean over the selected rows' elements."""
+        sv = (pred_vertices - gt_vertices).abs().sum(dim=(1, 2))
+        return _masked_mean(sv, has_smpl, pred_vertices.shape[1] * 3)
 
 
 class DecomposedPredictor(nn.Module):

@@ -121,6 +121,8 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
  */
 int danet_conv_nt(int rows_per_group);
+int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, int groups);   /* MT*100 + NT*10 + vec8 */
+int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups);                      /* CT*10 + NI */
 size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode);
 int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
                             int mode, void* stream);
@@ -140,9 +142,10 @@ int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
  *
  *  danet_bn_forward   training: batch statistics (biased variance for normalisation, unbiased for
  *                     the running estimate, torch semantics); y = [relu](bn(x) [+ res]);
- *                     saved [2][C] (mean, invstd) and sums_ws [2][C] are fp32 scratch/outputs.
- *                     eval: running statistics.  gamma/beta may be NULL (1 / 0).
- *  danet_bn_backward  dx, optional dres (= masked dy), red_ws [2][C] -> (d beta, d gamma).
+ *                     saved [2][C] (mean, invstd) is an fp32 output, sums_ws is scratch of
+ *                     danet_bn_ws_floats(C) floats.  eval: running statistics.  gamma/beta may be NULL.
+ *  danet_bn_backward  dx, optional dres (= masked dy), dparam [2][C] <- (d beta, d gamma);
+ *                     red_ws: danet_bn_ws_floats(C) floats of scratch.
  *  danet_sum_relu_*   y = [relu](sum_t nearest_upsample_{2^shift_t}(term_t)), up to 4 terms; `terms`
  *                     and `shifts` are HOST arrays of nterms entries.  The backward of one term is
  *                     the window sum of gy * (y > 0).
@@ -150,9 +153,10 @@ int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
 int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* saved, float* sums_ws, float momentum, float eps, int training, int relu, void* stream);
+size_t danet_bn_ws_floats(int C);
 int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                       const float* gamma, const float* saved, int relu,
-                      void* dx, void* dres, float* red_ws, void* stream);
+                      void* dx, void* dres, float* dparam, float* red_ws, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,
                            int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,

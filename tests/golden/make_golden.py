@@ -34,8 +34,8 @@ def formula_tensor(key, shape, dtype=torch.float32):
         v = (u - 0.5) * 0.2
     elif leaf == 'num_batches_tracked':
         return torch.zeros(shape, dtype=torch.long)
-    elif leaf == 'weight' and len(shape) == 1:        # BN / norm gamma
-        v = 0.8 + 0.4 * u
+    elif leaf == 'weight' and len(shape) == 1:        # BN / norm gamma: small residual branches keep the
+        v = 0.25 + 0.2 * u                             # random deep net well conditioned (bf16-vs-fp32 comparable)
     elif leaf == 'bias':
         v = (u - 0.5) * 0.1
     else:                                             # conv / linear / gcn weights
@@ -43,7 +43,20 @@ def formula_tensor(key, shape, dtype=torch.float32):
         if leaf == 'weight' and len(shape) == 2 and 'gc.' in key:
             fan_in = shape[0]
         v = (u - 0.5) * 2.0 * np.sqrt(3.0 / max(fan_in, 1))
+        if key.endswith('predict_hm.1.weight'):
+            v = v * 0.02       # keep the x10-temperature soft-argmax of the joint heat-maps smooth (the
+                               # reference initialises these with std 0.001, hr_module.py:383-396)
     return torch.from_numpy(v.reshape(shape).astype(np.float32)).to(dtype)
+
+
+def formula_input(name, shape, lo=0.0, hi=1.0):
+    """Deterministic input tensor (no RNG, nothing to store): values in [lo, hi)."""
+    n = int(np.prod(shape))
+    seed = zlib.crc32(name.encode()) & 0x7fffffff
+    idx = np.arange(n, dtype=np.float64)
+    base = np.sin(idx * 78.233 + (seed % 997) * 0.11) * 12543.7453
+    u = base - np.floor(base)
+    return torch.from_numpy((lo + (hi - lo) * u).reshape(shape).astype(np.float32))
 
 
 def formula_params(module, skip=()):
@@ -167,7 +180,138 @@ def g3_graph():
 
 ALL = {'g1': g1_geometry, 'g2': g2_iuvmap, 'g3': g3_graph}
 
-if __name__ == '__main__':
+# ----------------------------------------------------------------------------------------------
+# network-level fixtures (parameters = formula_params, so only inputs/outputs are stored)
+def _img(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 3, S, S, generator=g)
+
+
+def g6_backbones():
+    ref_env({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16})
+    from models.module.hr_module import PoseHighResolutionNet
+    from models.module.res_module import PoseResNet
+    for name, cls in (('g6_hrnet', PoseHighResolutionNet), ('g6_poseresnet', PoseResNet)):
+        torch.manual_seed(0)
+        net = cls(part_out_dim=7)
+        formula_params(net)
+        net.train()
+        img = _img(2 if name == 'g6_hrnet' else 4, 64, 11).requires_grad_(True)      # ResNet-50 layer4 is 2x2: B=4 keeps BN sane
+        out = net(img)
+        keys = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
+        loss = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32).view_as(out[k]) * 0.37)).sum() for k in keys[:5])
+        loss.backward()
+        gw = {k.replace('.', '__'): p.grad for k, p in net.named_parameters()
+              if k in ('conv1.weight', 'final_pred.predict_u.weight', 'final_pred.predict_hm.1.bias', 'bn1.weight')}
+        save(name, img=img.detach(), img_grad=img.grad, bn1_running_mean=net.bn1.running_mean,
+             **{k: (out[k].detach() if k != 'xd' or name == 'g6_hrnet' else out[k].detach()[:, ::4]) for k in keys},
+             **{'grad__' + k: v for k, v in gw.items()})
+
+
+def g7_estimator():
+    for align in (False, True):
+        cfg = ref_env({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16, 'DANET.STN_CENTER_JITTER': 0.,
+                       'DANET.STN_SCALE_JITTER': 0., 'DANET.PARTDROP_RATE': 0.})
+        import torch.nn.functional as F
+        ag, gs = F.affine_grid, F.grid_sample
+        if align:
+            F.affine_grid = lambda theta, size, align_corners=None: ag(theta, size, align_corners=True)
+            F.grid_sample = lambda x, grid, mode='bilinear', padding_mode='zeros', align_corners=None: gs(x, grid, mode, padding_mode, align_corners=True)
+        try:
+            from models.danet.iuv_estimator import IUV_Estimator
+            torch.manual_seed(0)
+            est = IUV_Estimator(pretrained=False)
+            formula_params(est, skip=('learned_ratio', 'learned_offset'))
+            est.train()
+            g = torch.Generator().manual_seed(5)
+            img = _img(2, 64, 12)
+            part = torch.randint(0, 25, (2, 16, 16), generator=g)
+            part[:, :3] = 0
+            gt = torch.stack([part.float() / 24., torch.rand(2, 16, 16, generator=g), torch.rand(2, 16, 16, generator=g)], 1)
+            gt[:, 1:] *= (part > 0).float().unsqueeze(1)
+            kps = torch.cat([torch.rand(2, 24, 2, generator=g) * 1.6 - 0.8, torch.ones(2, 24, 1)], -1)
+            kps[0, 3, 2] = 0.0
+            has_iuv = torch.tensor([1, 1], dtype=torch.uint8).bool()
+            rd = est(img, gt, kps, has_iuv=has_iuv)
+            save('g7_estimator_align%d' % int(align), img=img, iuv_gt=gt, kps=kps,
+                 learned_ratio=est.learned_ratio, learned_offset=est.learned_offset,
+                 u=rd['uvia_pred'][0], v=rd['uvia_pred'][1], index=rd['uvia_pred'][2], ann=rd['uvia_pred'][3],
+                 stn_kps_pred=rd['stn_kps_pred'], part_iuv_pred=rd['part_iuv_pred'], part_iuv_gt=rd['part_iuv_gt'],
+                 **{'loss__' + k: v.detach().reshape(-1) for k, v in rd['losses'].items()})
+        finally:
+            F.affine_grid, F.grid_sample = ag, gs
+
+
+def g9_predictor():
+    ref_env({'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from models.danet.smpl_regressor import DecomposedPredictor
+    torch.manual_seed(0)
+    pose6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(24).unsqueeze(0)
+    mean = (torch.tensor([[0.9, 0., 0.]]), torch.zeros(1, 10), pose6)
+    net = DecomposedPredictor(None, mean, pretrained=False)
+    formula_params(net, skip=('mean_', 'I_n', 'A_link', 'A_mask', 'A', 'r2p_A', 'p2r_A'))
+    iuv = formula_input('g9.iuv', (4, 75, 64, 64))
+    part = formula_input('g9.part', (4, 24, 3, 7, 64, 64))
+    net.train()
+    rd = net(iuv, part)
+    buf = {k: getattr(net, k) for k in ('I_n', 'A_link', 'A_mask', 'A', 'r2p_A', 'p2r_A')}
+    out = dict(para_train=rd['para'], jp0=rd['joint_position'][0], jp1=rd['joint_position'][1],
+               jr0=rd['joint_rotation'][0], **buf)
+    net.eval()
+    with torch.no_grad():
+        out['para_eval'] = net(iuv, part)['para']
+    save('g9_predictor', **out)
+
+
+def g10_losses():
+    ref_env()
+    from models.danet.smpl_regressor import SMPL_Regressor
+    from models.danet.iuv_estimator import IUV_Estimator
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(10)
+    B = 6
+    dummy = types.SimpleNamespace(criterion_shape=nn.L1Loss(), criterion_keypoints=nn.MSELoss(reduction='none'),
+                                  criterion_regr=nn.MSELoss(), device=torch.device('cpu'))
+    pred_rot, gt_rot = torch.randn(B, 24, 3, 3, generator=g), torch.randn(B, 216, generator=g)
+    pb, gb = torch.randn(B, 10, generator=g), torch.randn(B, 10, generator=g)
+    has_smpl = torch.tensor([1, 0, 1, 1, 0, 1])
+    has_kp3d = torch.tensor([0, 1, 1, 0, 1, 1])
+    lp, lb = SMPL_Regressor.smpl_losses(dummy, pred_rot, pb, gt_rot, gb, has_smpl)
+    kp2 = torch.randn(B, 49, 2, generator=g)
+    gk2 = torch.cat([torch.randn(B, 49, 2, generator=g), torch.rand(B, 49, 1, generator=g)], -1)
+    l2d = SMPL_Regressor.keypoint_loss(dummy, kp2, gk2, 0.25, 1.0)
+    pj = torch.randn(B, 49, 3, generator=g)
+    g3 = torch.cat([torch.randn(B, 24, 3, generator=g), torch.rand(B, 24, 1, generator=g)], -1)
+    l3d = SMPL_Regressor.keypoint_3d_loss(dummy, pj, g3, has_kp3d)
+    pv, gv = torch.randn(B, 50, 3, generator=g), torch.randn(B, 50, 3, generator=g)
+    lv = SMPL_Regressor.shape_loss(dummy, pv, gv, has_smpl)
+    a, b = torch.randn(B, 24, 3, generator=g), torch.randn(B, 24, 3, generator=g)
+    l1 = SMPL_Regressor.l1_losses(dummy, a, b, has_smpl)
+    # body_uv_losses (global, 25 classes) with a partial has_iuv mask
+    u, v, idx = (torch.randn(B, 25, 8, 8, generator=g) for _ in range(3))
+    ann = torch.randn(B, 15, 8, 8, generator=g)
+    part = torch.randint(0, 25, (B, 8, 8), generator=g)
+    from utils.iuvmap import iuv_img2map
+    gt = torch.stack([part.float() / 24., torch.rand(B, 8, 8, generator=g), torch.rand(B, 8, 8, generator=g)], 1)
+    gt[:, 1:] *= (part > 0).float().unsqueeze(1)
+    uvia = iuv_img2map(gt)
+    has_iuv = torch.tensor([1, 1, 0, 1, 0, 1]).bool()
+    est = types.SimpleNamespace()
+    lU, lV, lI, lA = IUV_Estimator.body_uv_losses(est, u, v, idx, ann, uvia, has_iuv)
+    save('g10_losses', pred_rot=pred_rot, gt_rot=gt_rot, pb=pb, gb=gb, has_smpl=has_smpl, has_kp3d=has_kp3d,
+         loss_pose=lp, loss_betas=lb, kp2=kp2, gk2=gk2, loss_kp2d=l2d, pj=pj, g3=g3, loss_kp3d=l3d,
+         pv=pv, gv=gv, loss_verts=lv, a=a, b=b, loss_l1=l1,
+         u=u, v=v, idx=idx, ann=ann, iuv_gt=gt, has_iuv=has_iuv, loss_U=lU, loss_V=lV, loss_I=lI, loss_A=lA)
+
+
+ALL.update({'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses})
+
+
+def _main():
     names = sys.argv[1:] or list(ALL)
     for n in names:
         ALL[n]()
+
+
+if __name__ == '__main__':
+    _main()

@@ -88,3 +88,31 @@ def test_conv_rejects_bad_shapes():
     from danet_densepose2smpl_amd import conv
     with pytest.raises(ValueError):
         conv.conv2d(torch.zeros(1, 5, 8, 8, device='cuda'), torch.zeros(4, 3, 3, 3, device='cuda'))
+
+
+@pytest.mark.parametrize('cin,cout,k,pad,outpad,H', [(2048, 256, 4, 1, 0, 4), (256, 256, 4, 1, 0, 16), (64, 32, 3, 1, 1, 8), (32, 48, 2, 0, 0, 8)])
+def test_conv_transpose_vs_torch_fp32(cin, cout, k, pad, outpad, H):
+    """PoseResNet deconv head (res_module.py:169-194): k4 s2 p1, plus the k3/k2 variants of _get_deconv_cfg."""
+    from danet_densepose2smpl_amd.deconv import ConvTranspose2d
+    g = torch.Generator().manual_seed(cin + k)
+    x = torch.randn(2, cin, H, H, generator=g).bfloat16().float().cuda()
+    m = ConvTranspose2d(cin, cout, k, 2, pad, outpad, bias=False).cuda()
+    with torch.no_grad():
+        m.weight.copy_((torch.randn(m.weight.shape, generator=g) / np.sqrt(cin * k * k / 4)).bfloat16().float())
+    xr = x.clone().requires_grad_(True)
+    wr = m.weight.detach().clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2, pad, outpad)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().float().cuda()
+    yr.backward(gy)
+    xt = x.clone().requires_grad_(True)
+    y = m(xt)
+    assert y.shape == yr.shape
+    y.backward(gy.bfloat16())
+
+    def close(a, r, rel, what):
+        scale = r.abs().max().item() + 1e-6
+        err = (a.float() - r).abs().max().item()
+        assert err <= rel * scale, '%s: max err %g vs scale %g' % (what, err, scale)
+    close(y, yr, 1e-2, 'deconv forward')
+    close(xt.grad, xr.grad, 1e-2, 'deconv dgrad')
+    close(m.weight.grad, wr.grad, 3e-3, 'deconv wgrad')

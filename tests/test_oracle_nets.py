@@ -1,0 +1,53 @@
+"""Pins oracle/torch_ref.py (plain-torch fp32 restatement of the reference's networks) against
+golden vectors produced by the reference itself with formula parameters (make_golden.py g6)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from conftest import golden, GOLDEN
+sys.path.insert(0, GOLDEN)
+from make_golden import formula_params    # noqa: E402  (pure function, does not touch the reference)
+from oracle import torch_ref              # noqa: E402
+
+KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
+
+
+def _run(net, g):
+    formula_params(net)
+    net.train()
+    img = torch.from_numpy(g['img']).requires_grad_(True)
+    out = net(img)
+    loss = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32).view_as(out[k]) * 0.37)).sum() for k in KEYS[:5])
+    loss.backward()
+    return out, img
+
+
+def _check(net, name):
+    g = golden(name)
+    out, img = _run(net, g)
+    for k in KEYS:
+        ref = g[k]
+        o = out[k].detach().numpy()
+        if o.shape != ref.shape:
+            o = o[:, ::4]                  # the ResNet-50 fixture stores every 4th feature channel
+        assert np.abs(o - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-6), k
+    np.testing.assert_allclose(img.grad.numpy(), g['img_grad'], atol=2e-3 * np.abs(g['img_grad']).max())
+    np.testing.assert_allclose(net.bn1.running_mean.numpy(), g['bn1_running_mean'], atol=1e-5)
+    gw = {k: p.grad for k, p in net.named_parameters()}
+    for k in g.files:
+        if k.startswith('grad__'):
+            name_ = k[len('grad__'):].replace('__', '.')
+            ref = g[k]
+            assert np.abs(gw[name_].numpy() - ref).max() <= 3e-3 * (np.abs(ref).max() + 1e-6), name_
+
+
+def test_hrnet_w48_oracle_matches_reference():
+    torch.manual_seed(0)
+    _check(torch_ref.HRNet(part_out_dim=7), 'g6_hrnet')
+
+
+def test_poseresnet50_oracle_matches_reference():
+    torch.manual_seed(0)
+    _check(torch_ref.PoseResNet(part_out_dim=7), 'g6_poseresnet')
