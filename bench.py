@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (BASELINE: 32)')
     ap.add_argument('--size', type=int, default=256, help='input resolution (BASELINE: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--cpu-batch', type=int, default=2)
     return ap.parse_args()
 
@@ -101,23 +102,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # warm-up; the last warm-up step times every conv launch to find the dominant kernel instance
-    for w in range(args.warmup):
-        if w == args.warmup - 1:
-            conv.PROFILER = conv.KernelProfiler()
-        tr.train_step(batch)
-    dominant = None
-    if conv.PROFILER is not None:
-        torch.cuda.synchronize(dev)
-        summ = conv.PROFILER.summary()
-        if summ:
-            dominant = max(summ.items(), key=lambda kv: kv[1][1])[0]
-    conv.PROFILER = conv.KernelProfiler(only=dominant) if dominant else None
+    # One eager step with every conv launch bracketed by HIP events (on the launch stream) finds the
+    # dominant kernel instance and gives its per-launch durations -- the same kernels, shapes and
+    # data as the timed steps (which replay them from a hipGraph, where events cannot be recorded).
+    conv.PROFILER = conv.KernelProfiler()
+    tr.train_step(batch)
+    torch.cuda.synchronize(dev)
+    conv.PROFILER = conv.KernelProfiler()
+    tr.train_step(batch)
+    torch.cuda.synchronize(dev)
+    summ = conv.PROFILER.summary()
+    conv.PROFILER = None
+    dominant = max(summ.items(), key=lambda kv: kv[1][1])[0] if summ else None
 
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            tr.capture(batch)
+            step = tr.train_step_graphed
+        except Exception as e:                       # keep the bench alive: fall back to eager launches
+            sys.stderr.write('hipGraph capture failed (%r); running eagerly\n' % (e,))
+            use_graph = False
+    if not use_graph:
+        step = lambda: tr.train_step(batch)
+    for _ in range(args.warmup):
+        step()
     sync()
     t0 = time.time()
     for _ in range(args.steps):
-        tr.train_step(batch)
+        step()
     sync()
     elapsed = time.time() - t0
     if world > 1:
@@ -126,9 +139,7 @@ def main():
         elapsed = float(t.item())
 
     roof = None
-    if conv.PROFILER is not None:
-        summ = conv.PROFILER.summary()
-        conv.PROFILER = None
+    if dominant is not None:
         if dominant in summ:
             n, secs, flops = summ[dominant]
             ach = flops / secs / 1e12
@@ -141,6 +152,7 @@ def main():
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                'exec': 'hipgraph' if use_graph else 'eager',
                 'config': {'workload': 'full DaNet train step (HRNet-W48 + part-wise IUV heads + SMPL LBS x4 + IUV render + '
                                        'regressor + losses, fwd+bwd+Adam), %dx%d, %d img/GPU; convs bf16 MFMA fp32-acc, '
                                        'LBS/raster/losses fp32' % (args.size, args.size, B),

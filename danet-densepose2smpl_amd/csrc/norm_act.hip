@@ -70,6 +70,24 @@ __device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int C
     __syncthreads();
 }
 
+constexpr int SLAB = 1024;   // channels per launch (wider tensors are processed in channel slabs)
+
+// Sum the NCOPY replicas of a [2][Cst] accumulator for the Cs channels of this slab into LDS: the
+// 2*Cs sums are spread over the block's lanes, each issuing NCOPY independent loads (fixed order).
+__device__ inline void reduce_replicas(const float* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
+    for (int i = t; i < 2 * Cs; i += 256) {
+        const int which = i / Cs, c = i - which * Cs;
+        float v[NCOPY];
+#pragma unroll
+        for (int r = 0; r < NCOPY; ++r) v[r] = rep[(size_t)r * 2 * Cst + (size_t)which * Cst + c];
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < NCOPY; ++r) s += v[r];
+        sStat[which][c] = s;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, FlatMap fm, float* __restrict__ sums /* [2][Cst] */, int Cst)
 {
     __shared__ float sm[256][VW];
@@ -97,19 +115,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu)
 {
     const int t = threadIdx.x;
-    if (t >= fm.span) return;
     const int C = Cst;
+    __shared__ float sStat[2][SLAB];
+    if (mode == 0) reduce_replicas(sums, C, fm.CV * VW, t, sStat);
+    if (t >= fm.span) return;
     const int c0 = (t % fm.CV) * VW;
     float sc[VW], sh[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
         float mean, var;
         if (mode == 0) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < NCOPY; ++r) { s0 += sums[(size_t)r * 2 * C + c0 + j]; s1 += sums[(size_t)r * 2 * C + C + c0 + j]; }
-            mean = s0 * inv_count;
-            var = fmaxf(s1 * inv_count - mean * mean, 0.f);
+            mean = sStat[0][c0 + j] * inv_count;
+            var = fmaxf(sStat[1][c0 + j] * inv_count - mean * mean, 0.f);
         } else {
             mean = running_mean[c0 + j];
             var = running_var[c0 + j];
@@ -183,17 +200,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam)
 {
     const int t = threadIdx.x;
-    if (t >= fm.span) return;
     const int C = Cst;
+    __shared__ float sStat[2][SLAB];
+    reduce_replicas(red, C, fm.CV * VW, t, sStat);
+    if (t >= fm.span) return;
     const int c0 = (t % fm.CV) * VW;
     float mean[VW], invstd[VW], k0[VW], m1[VW], m2[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
         mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j];
         k0[j] = (gamma ? gamma[c0 + j] : 1.f) * invstd[j];
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < NCOPY; ++r) { s0 += red[(size_t)r * 2 * C + c0 + j]; s1 += red[(size_t)r * 2 * C + C + c0 + j]; }
+        const float s0 = sStat[0][c0 + j], s1 = sStat[1][c0 + j];
         m1[j] = s0 * inv_count; m2[j] = s1 * inv_count;
         if (blockIdx.x == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
     }
@@ -299,9 +316,6 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
 }
 
 }  // namespace
-
-// Tensors wider than 1024 channels (the grouped limb layers, 3072) are processed in channel slabs.
-constexpr int SLAB = 1024;
 
 extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -122,6 +122,12 @@ class GradReducer(object):
                     p.grad.copy_(g)
         self._works = []
 
+    def reduce_now(self):
+        """Average all gradients after a backward that ran without hooks (hipGraph replay): every
+        bucket is packed and all-reduced on the communication stream, back to back."""
+        self.prepare()
+        self.finish()
+
     def remove(self):
         for h in self._hooks:
             h.remove()

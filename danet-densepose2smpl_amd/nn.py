@@ -52,23 +52,27 @@ class BatchNormActFunction(torch.autograd.Function):
         dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
         red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
-        dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)      # rows: d beta, d gamma
         check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
                                   None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), stream()),
               'danet_bn_backward')
-        dgamma = dparam[1] if ctx.has_affine else None
-        dbeta = dparam[0] if ctx.has_affine else None
+        # unbind gives two independent-looking tensors that AccumulateGrad can keep without a clone
+        dbeta, dgamma = (dparam[0], dparam[1]) if ctx.has_affine else (None, None)
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d (same parameters / buffers) with optional fused residual add and ReLU."""
 
+    # per-module `num_batches_tracked += 1` is one tiny launch per layer (353 per step); a trainer may
+    # switch it off and bump all counters with one multi-tensor op (bump_batch_counters)
+    count_batches = True
+
     def forward(self, x, res=None, relu=False):
         training = self.training or not self.track_running_stats
-        if training and self.track_running_stats and self.num_batches_tracked is not None:
+        if training and self.track_running_stats and self.num_batches_tracked is not None and BatchNorm2d.count_batches:
             self.num_batches_tracked.add_(1)
         momentum = 0.1 if self.momentum is None else self.momentum
         return BatchNormActFunction.apply(x, res, self.weight, self.bias,
@@ -165,3 +169,14 @@ class StnGatherFunction(torch.autograd.Function):
 def stn_gather(x, theta, out_hw=None, align_corners=True):
     out_hw = (x.shape[2], x.shape[3]) if out_hw is None else out_hw
     return StnGatherFunction.apply(x, theta, out_hw, align_corners)
+
+
+def bump_batch_counters(module):
+    """num_batches_tracked += 1 for every BatchNorm of `module`, as ONE multi-tensor launch."""
+    counters = getattr(module, '_bn_counters', None)
+    if counters is None:
+        counters = [m.num_batches_tracked for m in module.modules()
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
+        module._bn_counters = counters
+    if counters:
+        torch._foreach_add_(counters, 1)

@@ -13,6 +13,7 @@ from . import ops
 from .config import cfg
 from .danet import DaNet
 from .distributed import GradReducer
+from .nn import BatchNorm2d, bump_batch_counters
 from .geometry import perspective_projection
 
 
@@ -57,10 +58,15 @@ class Trainer(object):
         self.device = device or torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.model = (model or DaNet(self.options, None, pretrained=False, smpl_model=smpl_model)).to(self.device)
         self.smpl = self.model.iuv2smpl.smpl
+        on_gpu = self.device.type == 'cuda'
+        lr0 = lr or cfg.SOLVER.BASE_LR
+        # a tensor learning rate keeps the manual step decay (trainer.py:120-128) effective under hipGraph replay
         self.optimizer = torch.optim.Adam(params=[p for p in self.model.parameters() if p.requires_grad],
-                                          lr=lr or cfg.SOLVER.BASE_LR, weight_decay=0,
-                                          **({'capturable': True, 'foreach': True} if self.device.type == 'cuda' else {}))
+                                          lr=torch.tensor(lr0, device=self.device) if on_gpu else lr0, weight_decay=0,
+                                          **({'capturable': True, 'fused': True} if on_gpu else {}))
         self.step_count = 0
+        self._graph = None
+        self._static = None
         self.reducer = None
         if distributed is None:
             distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
@@ -69,14 +75,25 @@ class Trainer(object):
             self.reducer = GradReducer(self.model, device=self.device)
             self.reducer.broadcast_parameters()
 
-    def train_step(self, in_dict):
-        self.model.train()
-        # manual step-LR decay (trainer.py:120-128)
+    def _decay_lr(self):
+        """manual step-LR decay (trainer.py:120-128)"""
         for i, s in enumerate(cfg.SOLVER.STEPS):
             if i > 0 and self.step_count == s:
                 for group in self.optimizer.param_groups:
-                    group['lr'] *= cfg.SOLVER.GAMMA
-        out = self.model(in_dict)
+                    if torch.is_tensor(group['lr']):
+                        group['lr'].mul_(cfg.SOLVER.GAMMA)
+                    else:
+                        group['lr'] *= cfg.SOLVER.GAMMA
+
+    def train_step(self, in_dict):
+        self.model.train()
+        self._decay_lr()
+        BatchNorm2d.count_batches = False
+        try:
+            out = self.model(in_dict)
+        finally:
+            BatchNorm2d.count_batches = True
+        bump_batch_counters(self.model)
         losses = out['losses']
         loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
         self.optimizer.zero_grad(set_to_none=True)
@@ -88,3 +105,65 @@ class Trainer(object):
         self.optimizer.step()
         self.step_count += 1
         return out, losses
+
+    # ------------------------------------------------------------------------------------------
+    # hipGraph execution: the ~4k kernel launches of one step are captured once and replayed, which
+    # removes the host-side launch cost (the step is launch-bound in eager mode).
+    def capture(self, in_dict, warmup=2):
+        """Capture forward + backward (+ Adam when single-process) for batches shaped like `in_dict`.
+        With a GradReducer the gradient all-reduce and the optimizer run after the graph."""
+        from . import conv
+        if self.device.type != 'cuda':
+            raise RuntimeError('hipGraph capture needs a GPU')
+        self.model.train()
+        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in in_dict.items()}
+        fused_opt = self.reducer is None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_core(self._static, fused_opt)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        conv._PACK_CACHE.clear()              # weight packing must be part of the captured work
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_out = self._eager_core(self._static, fused_opt)
+        self._graph = graph
+        self._graph_fused_opt = fused_opt
+        return self
+
+    def _eager_core(self, batch, with_optimizer):
+        BatchNorm2d.count_batches = False
+        try:
+            out = self.model(batch)
+        finally:
+            BatchNorm2d.count_batches = True
+        bump_batch_counters(self.model)
+        losses = out['losses']
+        loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss_total.backward()
+        if with_optimizer:
+            self.optimizer.step()
+        return out, losses
+
+    def load_batch(self, in_dict):
+        """Copy a new batch into the captured graph's static input tensors."""
+        for k, v in in_dict.items():
+            if torch.is_tensor(v):
+                self._static[k].copy_(v, non_blocking=True)
+
+    def train_step_graphed(self, in_dict=None):
+        if self._graph is None:
+            raise RuntimeError('call capture(in_dict) first')
+        if in_dict is not None:
+            self.load_batch(in_dict)
+        self._decay_lr()
+        self._graph.replay()
+        if not self._graph_fused_opt:
+            self.reducer.reduce_now()
+            self.optimizer.step()
+        self.step_count += 1
+        return self._static_out
