@@ -27,7 +27,7 @@ _SIGNATURES = {
     'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'danet_conv_nt': (c_i, [c_i]),
     'danet_conv_kernel_id': (c_i, [c_i] * 6),
-    'danet_conv_wgrad_kernel_id': (c_i, [c_i] * 3),
+    'danet_conv_wgrad_kernel_id': (c_i, [c_i] * 4),
     'danet_conv_packed_elems': (c_sz, [c_i] * 6),
     'danet_conv_pack_weights': (c_i, [c_f, c_f] + [c_i] * 6 + [c_f]),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f]),

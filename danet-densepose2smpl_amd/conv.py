@@ -140,8 +140,8 @@ class Conv2dFunction(torch.autograd.Function):
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
             tok = None
             if PROFILER is not None:
-                kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups)
-                tok = PROFILER.begin('conv_wgrad_kernel<%d, %d>' % (kid // 10, kid % 10),
+                kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups, R * S)
+                tok = PROFILER.begin('conv_wgrad_kernel<%d, %d, %d>' % (kid // 100, (kid // 10) % 10, kid % 10),
                                      2.0 * B * OH * OW * Cout * Cin_g * R * S)
             check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
                                      B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, stream()),

@@ -229,9 +229,9 @@ extern "C" int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, in
     const int nt = danet_conv_nt(Cout_g);
     const int Cout_pad = (Cout_g + 16 * nt - 1) / (16 * nt) * (16 * nt);
     const long M = (long)B * OH * OW;
-    // pixel tiles per wave: fewer for small problems so that the grid still fills 256 CUs
-    const long blocks4 = (M + 255) / 256 * (Cout_pad / (16 * nt)) * groups;
-    const int mt = blocks4 < 512 ? 1 : 4;
+    // pixel tiles per wave: the largest of 4/2/1 that still gives the 256 CUs two workgroups each
+    const long nb = (long)(Cout_pad / (16 * nt)) * groups;
+    const int mt = (M + 255) / 256 * nb >= 512 ? 4 : ((M + 127) / 128 * nb >= 512 ? 2 : 1);
     const int vec8 = (Cin_g % 8 == 0) && (Cin % 8 == 0);
     return mt * 100 + nt * 10 + vec8;
 }
@@ -289,11 +289,12 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     const bool vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
-    const bool small = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100 == 1;
-    if (nt == 1) { if (small) launch_conv<1, 1>(p, vec8, st); else launch_conv<4, 1>(p, vec8, st); }
-    else if (nt == 2) { if (small) launch_conv<1, 2>(p, vec8, st); else launch_conv<4, 2>(p, vec8, st); }
-    else if (nt == 3) { if (small) launch_conv<1, 3>(p, vec8, st); else launch_conv<4, 3>(p, vec8, st); }
-    else { if (small) launch_conv<1, 4>(p, vec8, st); else launch_conv<4, 4>(p, vec8, st); }
+    const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
+#define CONV_CASE(M_, N_) if (mt == M_ && nt == N_) launch_conv<M_, N_>(p, vec8, st); else
+    CONV_CASE(1, 1) CONV_CASE(2, 1) CONV_CASE(4, 1) CONV_CASE(1, 2) CONV_CASE(2, 2) CONV_CASE(4, 2)
+    CONV_CASE(1, 3) CONV_CASE(2, 3) CONV_CASE(4, 3) CONV_CASE(1, 4) CONV_CASE(2, 4) CONV_CASE(4, 4)
+    return danet::fail(DANET_ERR_ARG, "conv_forward: no kernel for tiles %dx%d", mt, nt);
+#undef CONV_CASE
     DANET_CHECK_LAUNCH("conv_igemm_kernel");
     return DANET_OK;
 }

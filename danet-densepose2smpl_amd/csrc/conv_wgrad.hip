@@ -9,6 +9,7 @@
 // (cout-block, cin-block) stay in registers across the block's whole pixel range; the partial
 // results are added atomically into a packed fp32 buffer dWp[G][taps][Cout_g][Cin_g] (cin
 // contiguous -> 64-byte atomic segments), which conv_wgrad_unpack turns into the torch layout.
+#include <cstdlib>
 #include "common.h"
 #include "conv_common.h"
 
@@ -18,10 +19,9 @@ using namespace danet_conv;
 
 constexpr int CHUNK = 32;              // pixels per MFMA k-step
 constexpr int LDP = CHUNK + 8;         // padded pixel row (80 B: conflict-free ds_read_b128)
-constexpr int MAX_TG = 9;              // taps per block
 
 struct WgradP {
-    const bf16_t* x; const bf16_t* dy; float* dwp;
+    const bf16_t* x; const bf16_t* dy; float* dwp; const float* zero;
     int B, H, W, Cin, OH, OW, Cout;
     int R, S, stride, pad, dil, groups;
     int Cin_g, Cout_g;
@@ -29,31 +29,68 @@ struct WgradP {
     long M;
 };
 
-template <int CT, int NI>
+// raw[i] = 8 channels of pixel i (i = 0..3).  Writes row j (channel j) = {pix0, pix1, pix2, pix3} as one 8-byte
+// store to dst + j*LDP (dst points at [channel 0][pixel 0] of the 4-pixel group).
+__device__ inline void store_transposed(bf16_t* dst, const uint4* raw) {
+    const unsigned w[4][4] = {{raw[0].x, raw[0].y, raw[0].z, raw[0].w}, {raw[1].x, raw[1].y, raw[1].z, raw[1].w},
+                              {raw[2].x, raw[2].y, raw[2].z, raw[2].w}, {raw[3].x, raw[3].y, raw[3].z, raw[3].w}};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {           // channel pair (2jj, 2jj+1)
+        uint2 lo, hi;
+        lo.x = __builtin_amdgcn_perm(w[1][jj], w[0][jj], 0x05040100u);   // ch 2jj   : pix0 | pix1 << 16
+        lo.y = __builtin_amdgcn_perm(w[3][jj], w[2][jj], 0x05040100u);   //           pix2 | pix3 << 16
+        hi.x = __builtin_amdgcn_perm(w[1][jj], w[0][jj], 0x07060302u);   // ch 2jj+1
+        hi.y = __builtin_amdgcn_perm(w[3][jj], w[2][jj], 0x07060302u);
+        *reinterpret_cast<uint2*>(dst + (2 * jj) * LDP) = lo;
+        *reinterpret_cast<uint2*>(dst + (2 * jj + 1) * LDP) = hi;
+    }
+}
+
+// Channel counts must be multiples of 8 (the host pads; see conv.py): every staged run is one aligned
+// 16-byte load.  All loads are unconditional (clamped address + select) -- predicated loads compiled to
+// ~400 branches per chunk and made the kernel instruction-bound.
+template <int CT, int NI, int TG>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
 {
     constexpr int BCO = CT * 16, BCI = NI * 16;
-    __shared__ __attribute__((aligned(16))) bf16_t sA[BCO][LDP];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[MAX_TG][BCI][LDP];
+    constexpr int ROWS = BCO + TG * BCI;                       // LDS rows: dY^T channels, then X^T per tap
+    __shared__ __attribute__((aligned(16))) bf16_t sT[ROWS][LDP];
+    __shared__ int sTap[TG][3];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
     // grid.x = msplit, grid.y = cout-blocks * cin-blocks * tapgroups, grid.z = groups
-    const int nco = (p.Cout_g + BCO - 1) / BCO, nci = (p.Cin_g + BCI - 1) / BCI;
+    const int nci = (p.Cin_g + BCI - 1) / BCI;
     int by = blockIdx.y;
     const int tg = by % p.ntapgroups; by /= p.ntapgroups;
     const int cib = by % nci, cob = by / nci;
     const int g = blockIdx.z;
     const int taps = p.R * p.S;
-    const int tap0 = tg * MAX_TG;
-    const int ntap = min(MAX_TG, taps - tap0);
+    const int tap0 = tg * TG;
+    const int ntap = min(TG, taps - tap0);
     const int co0 = cob * BCO, ci0 = cib * BCI;
+    if (t < TG) {
+        const int tap = min(tap0 + t, taps - 1);
+        const int r = tap / p.S;
+        sTap[t][0] = r * p.dil; sTap[t][1] = (tap - r * p.S) * p.dil;
+        sTap[t][2] = (sTap[t][0] * p.W + sTap[t][1]) * p.Cin;
+    }
 
-    // this wave's accumulator tiles: indices tile = wave + 4*q over (tap, ct, ni)
-    constexpr int MAXQ = (MAX_TG * CT * NI + 3) / 4;
+    // accumulator tiles of this wave: tile = wave + 4*q over (tap, ct, ni); LDS fragment offsets are
+    // chunk-independent and precomputed
+    constexpr int NTILES = TG * CT * NI;
+    constexpr int MAXQ = (NTILES + 3) / 4;
     f32x4 acc[MAXQ];
+    int aoff[MAXQ], boff[MAXQ];
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < MAXQ; ++q) {
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tile = min(wave + 4 * q, NTILES - 1);
+        const int tl = tile / (CT * NI), rem = tile - tl * (CT * NI);
+        const int ct = rem / NI, ni = rem - ct * NI;
+        aoff[q] = (ct * 16 + li) * LDP + lg * 8;
+        boff[q] = (BCO + tl * BCI + ni * 16 + li) * LDP + lg * 8;
+    }
     const int ntiles = ntap * CT * NI;
 
     const long nchunks = (p.M + CHUNK - 1) / CHUNK;
@@ -61,71 +98,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
     const long c_begin = (long)blockIdx.x * per, c_end = min(nchunks, c_begin + per);
     const int ohw = p.OH * p.OW;
 
+    // Items of one chunk: one item = 4 consecutive pixels x 8 channels: four 16-byte loads, a 4x8 transpose
+    // in registers (v_perm_b32), eight 8-byte LDS stores.  X^T items (NIT_B of them, row block BCO/8 + itb/8)
+    // are spread over NITEM_B rounds of the 256 lanes; the dY^T items (NIT_A <= 64) take one extra round on
+    // wave 0.  A lane keeps the same pixel quad (t & 7) for all its items: the (b, oh, ow) decode and the
+    // 32-bit element offsets of its four pixels are computed once per chunk, an item then costs two adds
+    // and two unsigned compares per load.  Out-of-image / out-of-range runs read a 16-byte zero block behind
+    // the workspace instead of branching.  The loads of chunk i+1 are issued before the MFMAs of chunk i and
+    // committed to LDS after them (register double buffering).
+    constexpr int NIT_A = (BCO / 8) * (CHUNK / 4), NIT_B = TG * (BCI / 8) * (CHUNK / 4);
+    constexpr int NITEM_B = (NIT_B + 255) / 256;
+    static_assert(NIT_A <= 256, "dY items must fit one round");
+    const int pq = t & (CHUNK / 4 - 1);
+    const int nit_b = ntap * (BCI / 8) * (CHUNK / 4);
+    uint4 raw[NITEM_B + 1][4];
+    const bf16_t* const dyg = p.dy + (size_t)g * p.Cout_g;
+    const bf16_t* const xg = p.x + (size_t)g * p.Cin_g;
+    const bf16_t* const zero16 = reinterpret_cast<const bf16_t*>(p.zero);
+
+    auto fetch = [&](long chunk) {
+        const int mbase = (int)(chunk * CHUNK);
+        int offA[4], offB[4], pih[4], piw[4];
+        bool pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mbase + pq * 4 + i;
+            pv[i] = m < (int)p.M;
+            const int mm = pv[i] ? m : (int)p.M - 1;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            pih[i] = oh * p.stride - p.pad;
+            piw[i] = ow * p.stride - p.pad;
+            offA[i] = mm * p.Cout;
+            offB[i] = ((b * p.H + pih[i]) * p.W + piw[i]) * p.Cin;       // element offset of tap (0,0)
+        }
+#pragma unroll
+        for (int u = 0; u < NITEM_B; ++u) {
+            const int itb = t + u * 256;
+            const int rb = itb / (CHUNK / 4);
+            const int c8 = rb % (BCI / 8), tl = min(rb / (BCI / 8), TG - 1);
+            const int dh = sTap[tl][0], dw = sTap[tl][1], tapoff = sTap[tl][2];
+            const int cB = ci0 + c8 * 8;
+            const bool chan_ok = itb < nit_b && cB < p.Cin_g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = chan_ok && pv[i] && (unsigned)(pih[i] + dh) < (unsigned)p.H && (unsigned)(piw[i] + dw) < (unsigned)p.W;
+                const bf16_t* src = ok ? xg + (offB[i] + tapoff + cB) : zero16;
+                raw[u][i] = *reinterpret_cast<const uint4*>(src);
+            }
+        }
+        if (t < NIT_A) {                                   // dY^T items: wave 0 only
+            const int cA = co0 + (t / (CHUNK / 4)) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = pv[i] && cA < p.Cout_g;
+                const bf16_t* src = ok ? dyg + (offA[i] + cA) : zero16;
+                raw[NITEM_B][i] = *reinterpret_cast<const uint4*>(src);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NITEM_B; ++u) {
+            const int itb = t + u * 256;
+            if (itb < nit_b) store_transposed(&sT[BCO + (itb / (CHUNK / 4)) * 8][pq * 4], raw[u]);
+        }
+        if (t < NIT_A) store_transposed(&sT[(t / (CHUNK / 4)) * 8][pq * 4], raw[NITEM_B]);
+    };
+
+    __syncthreads();                       // tap table visible
+    if (c_begin < c_end) fetch(c_begin);
+    const bf16_t* const lds = &sT[0][0];
     for (long ch = c_begin; ch < c_end; ++ch) {
-        const long mbase = ch * CHUNK;
+        __syncthreads();                   // every wave finished reading the previous chunk
+        commit();
         __syncthreads();
-        // stage dY^T: items = (8-channel run, pixel), pixel fastest
-        for (int it = t; it < (BCO / 8) * CHUNK; it += 256) {
-            const int pix = it % CHUNK, c8 = it / CHUNK;
-            const long m = mbase + pix;
-            const int c = co0 + c8 * 8;
-            uint4 raw = {0u, 0u, 0u, 0u};
-            if (m < p.M && c < p.Cout_g) {
-                const bf16_t* src = p.dy + (size_t)m * p.Cout + (size_t)g * p.Cout_g + c;
-                if (c + 8 <= p.Cout_g && (p.Cout % 8 == 0) && (p.Cout_g % 8 == 0)) raw = *reinterpret_cast<const uint4*>(src);
-                else {
-                    unsigned short v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = c + j < p.Cout_g ? src[j] : (unsigned short)0;
-                    raw.x = v[0] | ((unsigned)v[1] << 16); raw.y = v[2] | ((unsigned)v[3] << 16);
-                    raw.z = v[4] | ((unsigned)v[5] << 16); raw.w = v[6] | ((unsigned)v[7] << 16);
-                }
-            }
-            const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sA[c8 * 8 + j][pix] = (bf16_t)((w4[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-        }
-        // stage X^T for every tap of the group
-        for (int it = t; it < ntap * (BCI / 8) * CHUNK; it += 256) {
-            const int pix = it % CHUNK;
-            const int rest = it / CHUNK;
-            const int c8 = rest % (BCI / 8), tl = rest / (BCI / 8);
-            const int tap = tap0 + tl;
-            const int r = tap / p.S, s = tap - r * p.S;
-            const long m = mbase + pix;
-            const int c = ci0 + c8 * 8;
-            uint4 raw = {0u, 0u, 0u, 0u};
-            if (m < p.M && c < p.Cin_g) {
-                const int b = (int)(m / ohw), rem = (int)(m - (long)b * ohw);
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                const int ih = oh * p.stride - p.pad + r * p.dil, iw = ow * p.stride - p.pad + s * p.dil;
-                if (ih >= 0 && iw >= 0 && ih < p.H && iw < p.W) {
-                    const bf16_t* src = p.x + (((size_t)b * p.H + ih) * p.W + iw) * p.Cin + (size_t)g * p.Cin_g + c;
-                    if (c + 8 <= p.Cin_g && (p.Cin % 8 == 0) && (p.Cin_g % 8 == 0)) raw = *reinterpret_cast<const uint4*>(src);
-                    else {
-                        unsigned short v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = c + j < p.Cin_g ? src[j] : (unsigned short)0;
-                        raw.x = v[0] | ((unsigned)v[1] << 16); raw.y = v[2] | ((unsigned)v[3] << 16);
-                        raw.z = v[4] | ((unsigned)v[5] << 16); raw.w = v[6] | ((unsigned)v[7] << 16);
-                    }
-                }
-            }
-            const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sB[tl][c8 * 8 + j][pix] = (bf16_t)((w4[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-        }
-        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int tile = wave + 4 * q;
-            if (tile < ntiles) {
-                const int tl = tile / (CT * NI), rem = tile - tl * (CT * NI);
-                const int ct = rem / NI, ni = rem - ct * NI;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sA[ct * 16 + li][lg * 8]);
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(&sB[tl][ni * 16 + li][lg * 8]);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[q], 0, 0, 0);
-            }
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + aoff[q]);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(lds + boff[q]);
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[q], 0, 0, 0);
         }
     }
     // D[i = cout][j = cin]: lane holds couts ct*16 + lg*4 + {0..3} for cin ni*16 + li
@@ -163,26 +216,27 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ dwp, float* __rest
     dw[idx] = beta != 0.f ? dw[idx] * beta + v : v;
 }
 
-template <int CT, int NI>
+template <int CT, int NI, int TG>
 void launch_wgrad(const WgradP& p, hipStream_t st) {
     const int nco = (p.Cout_g + CT * 16 - 1) / (CT * 16), nci = (p.Cin_g + NI * 16 - 1) / (NI * 16);
     const dim3 grid((unsigned)p.msplit, (unsigned)(nco * nci * p.ntapgroups), (unsigned)p.groups);
-    hipLaunchKernelGGL((conv_wgrad_kernel<CT, NI>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<CT, NI, TG>), grid, dim3(256), 0, st, p);
 }
 
 inline int tiles_for(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : ((c % 48 == 0 || c <= 48) ? 3 : 4)); }
 
 }  // namespace
 
-// Template instance of conv_wgrad_kernel<CT, NI>: CT*10 + NI.
-extern "C" int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups) {
+// Template instance conv_wgrad_kernel<CT, NI, TG>: returns CT*100 + NI*10 + (TG == 1 ? 1 : 9).
+// 1x1 convolutions (one tap) keep only CT*NI/4 accumulator tiles per wave, so they take 64x64 blocks.
+extern "C" int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups, int taps) {
     int ct = tiles_for(Cout / groups), ni = tiles_for(Cin / groups);
-    if (ct * ni > 9) { if (ct == 4) ct = 2; if (ni == 4 && ct * ni > 9) ni = 2; }
-    return ct * 10 + ni;
+    if (taps > 1 && ct * ni > 9) { if (ct == 4) ct = 2; if (ni == 4 && ct * ni > 9) ni = 2; }
+    return ct * 100 + ni * 10 + (taps == 1 ? 1 : 9);
 }
 
 extern "C" size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S) {
-    return (size_t)Cout * Cin_g * R * S;
+    return (size_t)Cout * Cin_g * R * S + 16;            // + a zero block the kernel reads for out-of-range runs
 }
 
 // dW[Cout][Cin_g][R][S] (fp32, torch layout) = beta * dW + conv_wgrad(x, dy).
@@ -195,8 +249,13 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
     DANET_CHECK_ARG(x && dy && dw && ws, "conv_wgrad: null pointer");
     DANET_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 &&
                     groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv_wgrad: bad sizes");
+    DANET_CHECK_ARG((Cin / groups) % 8 == 0 && (Cout / groups) % 8 == 0 && (long)B * OH * OW * Cout < 2147483647L &&
+                    (long)B * H * W * Cin < 2147483647L,
+                    "conv_wgrad: channels per group must be multiples of 8 (Cin_g=%d, Cout_g=%d); the host pads them",
+                    Cin / groups, Cout / groups);
     WgradP p;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dwp = ws;
+    p.zero = ws + (danet_conv_wgrad_ws_floats(Cout, Cin / groups, R, S) - 16);
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.dil = dil; p.groups = groups;
     p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
@@ -207,23 +266,31 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
     hipError_t e = hipMemsetAsync(ws, 0, need * sizeof(float), st);
     if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "conv_wgrad: memset: %s", hipGetErrorString(e));
     const int taps = R * S;
-    p.ntapgroups = (taps + MAX_TG - 1) / MAX_TG;
-    const int kid = danet_conv_wgrad_kernel_id(Cin, Cout, groups);                      // bounds registers
-    const int ct = kid / 10, ni = kid % 10;
+    const int kid = danet_conv_wgrad_kernel_id(Cin, Cout, groups, taps);               // bounds registers
+    const int ct = kid / 100, ni = (kid / 10) % 10, tgs = kid % 10;
+    p.ntapgroups = (taps + tgs - 1) / tgs;
     const int nco = (p.Cout_g + ct * 16 - 1) / (ct * 16), nci = (p.Cin_g + ni * 16 - 1) / (ni * 16);
     const long other = (long)nco * nci * p.ntapgroups * groups;
     const long nchunks = (p.M + CHUNK - 1) / CHUNK;
-    long msplit = (512 + other - 1) / other;
+    long target = 384;
+    if (const char* e = getenv("DANET_WGRAD_BLOCKS")) target = atol(e);       // tuning knob
+    long msplit = (target + other - 1) / other;
     if (msplit > nchunks / 2) msplit = nchunks / 2;
     if (msplit < 1) msplit = 1;
     p.msplit = (int)msplit;
-#define WG_CASE(a, b) if (ct == a && ni == b) launch_wgrad<a, b>(p, st); else
+#define WG_CASE(a, b) if (ct == a && ni == b && tgs == 9) launch_wgrad<a, b, 9>(p, st); else
+#define WG_CASE1(a, b) if (ct == a && ni == b && tgs == 1) launch_wgrad<a, b, 1>(p, st); else
     WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
     WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
     WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3)
     WG_CASE(4, 1) WG_CASE(4, 2)
+    WG_CASE1(1, 1) WG_CASE1(1, 2) WG_CASE1(1, 3) WG_CASE1(1, 4)
+    WG_CASE1(2, 1) WG_CASE1(2, 2) WG_CASE1(2, 3) WG_CASE1(2, 4)
+    WG_CASE1(3, 1) WG_CASE1(3, 2) WG_CASE1(3, 3) WG_CASE1(3, 4)
+    WG_CASE1(4, 1) WG_CASE1(4, 2) WG_CASE1(4, 3) WG_CASE1(4, 4)
     return danet::fail(DANET_ERR_ARG, "conv_wgrad: no kernel for tiles %dx%d", ct, ni);
 #undef WG_CASE
+#undef WG_CASE1
     DANET_CHECK_LAUNCH("conv_wgrad_kernel");
     const long total = (long)Cout * p.Cin_g * taps;
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, st, ws, dw, groups, p.Cout_g,

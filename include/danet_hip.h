@@ -122,7 +122,7 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  */
 int danet_conv_nt(int rows_per_group);
 int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, int groups);   /* MT*100 + NT*10 + vec8 */
-int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups);                      /* CT*10 + NI */
+int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups, int taps);            /* CT*100 + NI*10 + TG */
 size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode);
 int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
                             int mode, void* stream);
