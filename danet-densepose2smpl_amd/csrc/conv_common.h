@@ -21,7 +21,7 @@ struct ConvP {
     int B, H, W, Cin, OH, OW, Cout;
     int R, S, stride, pad, dil, groups, transposed;
     int Cin_g, Cout_g, Cout_pad, K, Kp;
-    int relu, out_fp32;
+    int relu, out_fp32, sshift;
     long M;
 };
 

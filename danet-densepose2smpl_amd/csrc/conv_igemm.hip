@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
         pw[mt] = p.transposed ? ow : ow * p.stride;
     }
     const int n0 = blockIdx.y * (16 * NT);
-    const bf16_t* wbase = p.w + ((size_t)g * p.Cout_pad + n0 + li) * p.Kp + lg * 8;
+    // packed weights are stored fragment-major: [group][16-row tile][k-step][lane][8] -- the 1 KB a wave
+    // loads for one (tile, k-step) is contiguous (8 fully used 128-byte lines instead of 16 half-used ones)
+    const bf16_t* wbase = p.w + ((size_t)g * (p.Cout_pad / 16) + n0 / 16) * (size_t)(p.Kp / 32) * 512 + lane * 8;
     const bf16_t* xg = p.x + (size_t)g * p.Cin_g;
 
     f32x4 acc[MT][NT];
@@ -75,31 +77,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nks = p.Kp / 32;
-    for (int ks = 0; ks < nks; ++ks) {
-        bf16x8 a[NT], bq[MT];
+
+    // fragment loads of one k-step (weights: A operand; gathered pixels: B operand)
+    auto load_step = [&](int ks, bf16x8* a, bf16x8* bq) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            a[nt] = *reinterpret_cast<const bf16x8*>(wbase + (size_t)nt * 16 * p.Kp + ks * 32);
+            a[nt] = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)nt * (p.Kp / 32) + ks) * 512);
         if (VEC8) {
             const int4 e = sTab[ks * 4 + lg];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 int ih = ph[mt] + e.x, iw = pw[mt] + e.y;
                 bool ok = e.w != 0;
-                if (p.transposed) {
-                    ok = ok && ih >= 0 && iw >= 0 && (ih % p.stride) == 0 && (iw % p.stride) == 0;
-                    ih /= p.stride; iw /= p.stride;
-                    ok = ok && ih < p.H && iw < p.W;
-                } else {
-                    ok = ok && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
+                if (p.transposed) {        // stride is a power of two (checked by the host): mask / shift
+                    ok = ok && ((ih | iw) & (p.stride - 1)) == 0;
+                    ih >>= p.sshift; iw >>= p.sshift;      // arithmetic shift keeps negatives negative
                 }
-                uint4 raw = {0u, 0u, 0u, 0u};
-                if (ok) raw = *reinterpret_cast<const uint4*>(xg + (((size_t)pb[mt] * p.H + ih) * p.W + iw) * p.Cin + e.z);
+                ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                // unconditional load from a clamped address + select (no branch around the load)
+                const bf16_t* src = ok ? xg + (((size_t)pb[mt] * p.H + ih) * p.W + iw) * p.Cin + e.z : xg;
+                const uint4 v = *reinterpret_cast<const uint4*>(src);
+                uint4 raw;
+                raw.x = ok ? v.x : 0u; raw.y = ok ? v.y : 0u; raw.z = ok ? v.z : 0u; raw.w = ok ? v.w : 0u;
                 bq[mt] = __builtin_bit_cast(bf16x8, raw);
             }
         } else {
-            // channel counts that are not a multiple of 8 (3-channel stem, 12-channel heads):
-            // element-wise gather; rare and tiny layers only
+            // channel counts that are not a multiple of 8: element-wise gather; the host pads channels to 8
+            // (conv.py), so this path only serves direct C-ABI callers with odd widths
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 unsigned short v[8];
@@ -131,12 +135,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                 bq[mt] = __builtin_bit_cast(bf16x8, raw);
             }
         }
+    };
+    auto mma_step = [&](const bf16x8* a, const bf16x8* bq) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bq[mt], acc[mt][nt], 0, 0, 0);
+    };
+
+    // Software pipeline: a ring of D register sets keeps the fragment loads of D k-steps in flight
+    // (statically indexed: the k-loop is unrolled by D).  The small-M layers (192 ch @16x16, 384 ch @8x8)
+    // run one wave per SIMD with 3 MFMAs per k-step, so a single k-step ahead still exposes almost a full
+    // L2 round trip per step; D = 8 / 4 / 2 for MT = 1 / 2 / 4.
+    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+    bf16x8 A[D][NT], Bq[D][MT];
+    // branch-free main loop (prefetch indices are clamped instead of guarded, so the compiler can use
+    // counted vmcnt waits); the last partial round is handled after it
+    const int last = nks - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_step(min(d, last), A[d], Bq[d]);
+    const int nfull = nks / D;
+    for (int r = 0; r < nfull; ++r) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            mma_step(A[d], Bq[d]);
+            load_step(min((r + 1) * D + d, last), A[d], Bq[d]);
+        }
     }
+    const int rem = nks - nfull * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < rem) mma_step(A[d], Bq[d]);
 
     // epilogue: lane holds couts n0 + nt*16 + lg*4 + {0..3} of pixel m0 + mt*16 + li
     const bool vec_ok = (p.Cout % 4 == 0) && (p.Cout_g % 4 == 0);
@@ -179,7 +209,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     }
 }
 
-// Weight packing: fp32 torch layout W[Cout][Cin_g][R][S] -> bf16 Wp[G][rows_pad][Kp].
+// Weight packing: fp32 torch layout W[Cout][Cin_g][R][S] -> bf16, logically Wp[G][rows_pad][Kp], stored
+// fragment-major (see the kernel).
 //  mode 0 (forward):  rows = cout within group, k = (r*S+s)*Cin_g + cin
 //  mode 1 (dgrad):    rows = cin  within group, k = (r*S+s)*Cout_g + cout   (used with the transposed gather)
 __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp,
@@ -200,7 +231,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
         const int cout = mode == 0 ? row : ch, cin = mode == 0 ? ch : row;
         v = w[(((size_t)(g * Cout_g + cout) * Cin_g + cin) * R + r) * S + s];
     }
-    wp[idx] = f2bf(v);
+    // fragment-major destination: [g][row/16][k/32][(k%32)/8][row%16][k%8]
+    const size_t dst = (((((size_t)g * (rows_pad / 16) + row / 16) * (Kp / 32) + k / 32) * 4 + (k % 32) / 8) * 16 + row % 16) * 8 + k % 8;
+    wp[dst] = f2bf(v);
 }
 
 template <int MT, int NT>
@@ -285,6 +318,9 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     const int nt = danet_conv_nt(p.Cout_g);
     p.Cout_pad = (p.Cout_g + 16 * nt - 1) / (16 * nt) * (16 * nt);
     p.relu = relu; p.out_fp32 = out_fp32;
+    DANET_CHECK_ARG((stride & (stride - 1)) == 0, "conv_forward: stride %d is not a power of two", stride);
+    p.sshift = 0;
+    while ((1 << p.sshift) < stride) ++p.sshift;
     p.M = (long)B * OH * OW;
     const bool vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
