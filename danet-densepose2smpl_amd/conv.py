@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import ptr, check, stream
 
 _PACK_CACHE = {}
+USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
 
 
@@ -136,6 +137,16 @@ class Conv2dFunction(torch.autograd.Function):
             gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
         if ctx.needs_input_grad[1]:
             gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
+            if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+                nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
+                ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+                tok = PROFILER.begin('conv_wgrad3x3_kernel', 2.0 * B * OH * OW * Cout * Cin_g * 9) if PROFILER is not None else None
+                check(L.danet_conv_wgrad3x3(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
+                                            B, H, W, Cin, Cout, groups, 0.0, stream()), 'danet_conv_wgrad3x3')
+                if tok is not None:
+                    PROFILER.end(tok)
+                gb = gy.float().sum(dim=(0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
+                return gx, gw, gb, None, None, None, None, None
             nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
             tok = None

@@ -21,6 +21,7 @@ UNITS = {
     'geometry.hip': [],
     'conv_igemm.hip': [],
     'conv_wgrad.hip': [],
+    'conv_wgrad3x3.hip': [],
     'norm_act.hip': [],
     'stn.hip': [],
 }

@@ -1,0 +1,269 @@
+// Weight gradient of 3x3 / stride-1 / pad-1 convolutions (89.6 % of the backbone's MACs) using the
+// gfx950 LDS transpose read.
+//
+//   dW[cout][tap][cin] = sum_pixels dY[pixel][cout] * X[pixel + tap][cin]
+//
+// The reduction (MFMA K) axis is the pixel index, but NHWC keeps channels contiguous.  Instead of
+// transposing while staging (conv_wgrad.hip: one gather per tap, i.e. X is read 9 times), this kernel
+//   * copies a 4x8-pixel tile of dY and the 6x10-pixel halo tile of X into LDS AS THEY ARE
+//     (plain coalesced 16-byte copies; every input pixel is loaded ~1.9x instead of 9x), and
+//   * reads MFMA fragments with ds_read_b64_tr_b16, which transposes on the fly: within a 16-lane
+//     group, lane j receives R[j][e] = S[4e + (j>>2)][j&3] where S[i][0..3] are the four bf16 at
+//     lane i's address (measured on MI355X, tools/experiments/tr_read.hip).  With lane i pointing
+//     at (pixel q0 + (i>>2), channels c0 + 4(i&3) ..+3), lane j ends up with channel c0 + j of the
+//     four pixels q0..q0+3 -- one half of an MFMA fragment (8 pixels of one channel row).
+// Any pixel <-> k assignment is valid as long as dY and X use the same one, so the tap shift is
+// just an address offset into the halo tile.
+// Partial sums of the blocks that share a dW tile go to a [split] workspace with plain coalesced
+// stores and are reduced (deterministically) by a second kernel that also writes the torch layout.
+#include <cstdlib>
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace danet_conv;
+
+constexpr int TH = 4, TW = 8;                 // output pixels per chunk (= one MFMA k-step of 32)
+constexpr int HH = TH + 2, HW = TW + 2;       // halo tile
+
+struct Wg3P {
+    const bf16_t* x; const bf16_t* dy; float* part;
+    int B, H, W, Cin, Cout, groups, Cin_g, Cout_g;
+    int tiles_h, tiles_w, msplit;
+    long nchunks;                              // B * tiles_h * tiles_w
+};
+
+typedef __attribute__((ext_vector_type(2))) unsigned v2u;
+
+__device__ inline v2u tr_read(unsigned lds_byte_addr) {
+    v2u r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_byte_addr) : "memory");
+    return r;
+}
+
+template <int CT, int NI>
+__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
+{
+    constexpr int BCO = CT * 16, BCI = NI * 16;
+    constexpr int PXY = BCO * 2, PXX = BCI * 2;                  // bytes per staged pixel
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [2 buffers][dY tile 32 px | X halo 60 px]
+    constexpr int YB = TH * TW * PXY, XB = HH * HW * PXX, BUF = YB + XB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nci = (p.Cin_g + BCI - 1) / BCI;
+    const int cib = blockIdx.y % nci, cob = blockIdx.y / nci;
+    const int g = blockIdx.z;
+    const int co0 = cob * BCO, ci0 = cib * BCI;
+    const bf16_t* const dyg = p.dy + (size_t)g * p.Cout_g + co0;
+    const bf16_t* const xg = p.x + (size_t)g * p.Cin_g + ci0;
+
+    // (tap, ni) pairs round-robin over the 4 waves; each pair carries CT accumulator tiles
+    constexpr int NPAIR = 9 * NI;
+    constexpr int MAXP = (NPAIR + 3) / 4;
+    f32x4 acc[MAXP][CT];
+    unsigned boff[MAXP];                     // byte offset of the pair's B fragment (h = 0) in the X tile
+#pragma unroll
+    for (int pi = 0; pi < MAXP; ++pi) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pi][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pair = min(wave + 4 * pi, NPAIR - 1);
+        const int tap = pair / NI, ni = pair - tap * NI;
+        const int r = tap / 3, s = tap - r * 3;
+        // lane i of 16-lane group lg supplies pixel (ty = lg, tx = 4h + (i>>2)), channels ni*16 + 4(i&3)
+        boff[pi] = (unsigned)(((lg + r) * HW + (li >> 2) + s) * PXX + (ni * 16 + 4 * (li & 3)) * 2);
+    }
+    const unsigned aoff = (unsigned)((lg * TW + (li >> 2)) * PXY + (4 * (li & 3)) * 2);   // dY fragment, h = 0, ct = 0
+
+    const long per = (p.nchunks + p.msplit - 1) / p.msplit;
+    const long c_begin = (long)blockIdx.x * per, c_end = min(p.nchunks, c_begin + per);
+
+    // staging: 16-byte pieces; dY tile = 32 px * (BCO/8) pieces, X halo = 60 px * (BCI/8) pieces
+    constexpr int NPY = TH * TW * (BCO / 8), NPX = HH * HW * (BCI / 8), NPIECE = NPY + NPX;
+    constexpr int NROUND = (NPIECE + 255) / 256;
+    uint4 stage[NROUND];
+
+    auto fetch = [&](long chunk) {
+        const int tw_i = (int)(chunk % p.tiles_w);
+        const long rest = chunk / p.tiles_w;
+        const int th_i = (int)(rest % p.tiles_h), b = (int)(rest / p.tiles_h);
+        const int oh0 = th_i * TH, ow0 = tw_i * TW;
+#pragma unroll
+        for (int u = 0; u < NROUND; ++u) {
+            const int pc = t + u * 256;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (pc < NPY) {
+                const int c8 = pc % (BCO / 8), q = pc / (BCO / 8);
+                const int oh = oh0 + q / TW, ow = ow0 + q % TW;
+                if (co0 + c8 * 8 < p.Cout_g)
+                    v = *reinterpret_cast<const uint4*>(dyg + (((size_t)b * p.H + oh) * p.W + ow) * p.Cout + c8 * 8);
+            } else if (pc < NPIECE) {
+                const int px = pc - NPY;
+                const int c8 = px % (BCI / 8), q = px / (BCI / 8);
+                const int ih = oh0 - 1 + q / HW, iw = ow0 - 1 + q % HW;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && ci0 + c8 * 8 < p.Cin_g)
+                    v = *reinterpret_cast<const uint4*>(xg + (((size_t)b * p.H + ih) * p.W + iw) * p.Cin + c8 * 8);
+            }
+            stage[u] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int u = 0; u < NROUND; ++u) {
+            const int pc = t + u * 256;
+            if (pc < NPIECE) *reinterpret_cast<uint4*>(base + (size_t)pc * 16) = stage[u];   // tiles are stored piece-linear
+        }
+    };
+
+    if (c_begin < c_end) fetch(c_begin);
+    int buf = 0;
+    for (long ch = c_begin; ch < c_end; ++ch) {
+        commit(buf);
+        __syncthreads();                       // tile `buf` complete; previous reads of `buf^1` also done
+        if (ch + 1 < c_end) fetch(ch + 1);
+        const unsigned ybase = (unsigned)(buf * BUF), xbase = ybase + YB;
+        // all transpose reads of the chunk are issued back to back, then ONE wait (the compiler does not
+        // count LDS operations issued from inline asm) and a scheduling barrier so that no MFMA is hoisted
+        // above the wait
+        v2u alo[CT], ahi[CT], blo[MAXP], bhi[MAXP];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            alo[ct] = tr_read(ybase + aoff + ct * 32);
+            ahi[ct] = tr_read(ybase + aoff + ct * 32 + 4 * PXY);
+        }
+#pragma unroll
+        for (int pi = 0; pi < MAXP; ++pi) {
+            blo[pi] = tr_read(xbase + boff[pi]);
+            bhi[pi] = tr_read(xbase + boff[pi] + 4 * PXX);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const uint4 raw = {alo[ct].x, alo[ct].y, ahi[ct].x, ahi[ct].y};
+            a[ct] = __builtin_bit_cast(bf16x8, raw);
+        }
+#pragma unroll
+        for (int pi = 0; pi < MAXP; ++pi) {
+            const uint4 raw = {blo[pi].x, blo[pi].y, bhi[pi].x, bhi[pi].y};
+            const bf16x8 bq = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                acc[pi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct], bq, acc[pi][ct], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // partial dW of this block: part[blockIdx.x][g][tap][cout][cin]
+    const size_t gsz = (size_t)9 * p.Cout_g * p.Cin_g;
+    float* dst = p.part + ((size_t)blockIdx.x * p.groups + g) * gsz;
+#pragma unroll
+    for (int pi = 0; pi < MAXP; ++pi) {
+        const int pair = wave + 4 * pi;
+        if (pair >= NPAIR) continue;
+        const int tap = pair / NI, ni = pair - tap * NI;
+        const int cin = ci0 + ni * 16 + li;
+        if (cin >= p.Cin_g) continue;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = co0 + ct * 16 + lg * 4 + r;
+                if (cout < p.Cout_g) dst[((size_t)tap * p.Cout_g + cout) * p.Cin_g + cin] = acc[pi][ct][r];
+            }
+    }
+}
+
+// dW[Cout][Cin_g][3][3] = beta*dW + sum_s part[s][g][tap][cout][cin]   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                               int G, int Cout_g, int Cin_g, int msplit, float beta)
+{
+    const long total = (long)G * Cout_g * Cin_g * 9;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // index in part layout: [g][tap][cout][cin]
+    if (idx >= total) return;
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= msplit; sp += 4) {
+        const float v0 = part[(size_t)sp * total + idx], v1 = part[(size_t)(sp + 1) * total + idx];
+        const float v2 = part[(size_t)(sp + 2) * total + idx], v3 = part[(size_t)(sp + 3) * total + idx];
+        s += (v0 + v1) + (v2 + v3);
+    }
+    for (; sp < msplit; ++sp) s += part[(size_t)sp * total + idx];
+    const int cin = (int)(idx % Cin_g);
+    long rest = idx / Cin_g;
+    const int cout = (int)(rest % Cout_g); rest /= Cout_g;
+    const int tap = (int)(rest % 9), g = (int)(rest / 9);
+    const size_t o = (((size_t)(g * Cout_g + cout)) * Cin_g + cin) * 9 + tap;
+    dw[o] = beta != 0.f ? dw[o] * beta + s : s;
+}
+
+template <int CT, int NI>
+int launch3(const Wg3P& p, hipStream_t st) {
+    const int nco = (p.Cout_g + CT * 16 - 1) / (CT * 16), nci = (p.Cin_g + NI * 16 - 1) / (NI * 16);
+    const size_t lds = 2 * (size_t)(TH * TW * CT * 32 + HH * HW * NI * 32);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CT, NI>), dim3(p.msplit, nco * nci, p.groups), dim3(256), lds, st, p);
+    return 0;
+}
+
+inline int tiles3(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : ((c % 48 == 0 || c <= 48) ? 3 : 4)); }
+
+}  // namespace
+
+// Applicability: 3x3, stride 1, pad 1, dilation 1, OW % 8 == 0, OH % 4 == 0, channels per group % 8 == 0.
+extern "C" int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups) {
+    return R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && H % TH == 0 && W % TW == 0 &&
+           (Cin / groups) % 8 == 0 && (Cout / groups) % 8 == 0;
+}
+
+static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, int* ni, int* msplit) {
+    const int Cout_g = Cout / groups, Cin_g = Cin / groups;
+    *ct = tiles3(Cout_g); *ni = tiles3(Cin_g);
+    if (*ct == 4) *ct = 2;                      // accumulators: ceil(9*NI/4)*CT tiles per wave
+    if (*ni == 4) *ni = 2;
+    const long other = (long)((Cout_g + *ct * 16 - 1) / (*ct * 16)) * ((Cin_g + *ni * 16 - 1) / (*ni * 16)) * groups;
+    const long nchunks = (long)B * (H / TH) * (W / TW);
+    long target = 256;
+    if (const char* e = getenv("DANET_WGRAD3_BLOCKS")) target = atol(e);
+    long ms = (target + other - 1) / other;
+    if (ms > nchunks / 4) ms = nchunks / 4;
+    if (ms < 1) ms = 1;
+    *msplit = (int)ms;
+}
+
+extern "C" size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups) {
+    int ct, ni, ms;
+    plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &ms);
+    return (size_t)ms * Cout * (Cin / groups) * 9;
+}
+
+extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
+                                   int B, int H, int W, int Cin, int Cout, int groups, float beta, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && dy && dw && ws && B > 0, "conv_wgrad3x3: bad arguments");
+    DANET_CHECK_ARG(danet_conv_wgrad3x3_ok(H, W, Cin, Cout, 3, 3, 1, 1, 1, groups), "conv_wgrad3x3: unsupported shape");
+    Wg3P p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.part = ws;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.groups = groups;
+    p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
+    p.tiles_h = H / TH; p.tiles_w = W / TW;
+    p.nchunks = (long)B * p.tiles_h * p.tiles_w;
+    int ct, ni;
+    plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &p.msplit);
+    if (ws_floats < danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups))
+        return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+#define W3(a, b) if (ct == a && ni == b) launch3<a, b>(p, st); else
+    W3(1, 1) W3(1, 2) W3(1, 3) W3(2, 1) W3(2, 2) W3(2, 3) W3(3, 1) W3(3, 2) W3(3, 3)
+    return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3: no kernel for tiles %dx%d", ct, ni);
+#undef W3
+    DANET_CHECK_LAUNCH("conv_wgrad3x3_kernel");
+    const long total = (long)Cout * p.Cin_g * 9;
+    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, st, ws, dw, groups, p.Cout_g,
+                       p.Cin_g, p.msplit, beta);
+    DANET_CHECK_LAUNCH("wgrad3x3_reduce_kernel");
+    return DANET_OK;
+}

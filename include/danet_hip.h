@@ -130,6 +130,12 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
                        int relu, int out_fp32, void* stream);
+/* 3x3 / stride 1 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
+ * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
+int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups);
+int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
+                        int B, int H, int W, int Cin, int Cout, int groups, float beta, void* stream);
 size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
 int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,

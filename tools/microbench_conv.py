@@ -54,6 +54,13 @@ def main():
         xp, gyp = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
         t = timeit(lambda: L.danet_conv_wgrad(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g, 0.0, stream()))
         res['wgrad_us'] = t * 1e6; res['wgrad_TF'] = flops / t / 1e12
+        if L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
+            n3 = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, g)
+            ws3 = torch.empty(n3, device='cuda')
+            gw3 = torch.empty_like(w)
+            t = timeit(lambda: L.danet_conv_wgrad3x3(ptr(xp), ptr(gyp), ptr(gw3), ptr(ws3), n3, B, H, W, Cin, Cout, g, 0.0, stream()))
+            res['wgrad3_us'] = t * 1e6; res['wgrad3_TF'] = flops / t / 1e12
+            res['wgrad3_vs_old_maxrel'] = float((gw3 - gw).abs().max() / (gw.abs().max() + 1e-9))
         if only != 'nomiopen':
             xb = x.detach().clone().requires_grad_(True)
             wb = w.bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
