@@ -50,6 +50,16 @@ struct FlatMap { long nvec; long M; int CV; int span; long gridspan; int ldv; in
     for (long row_ = ((long)blockIdx.x * (fm).span + (t)) / (fm).CV; row_ < (fm).M; row_ += rstep_)
 #define DANET_ROW_OFF(fm) (((size_t)row_ * (fm).ldv + (fm).coff + cv_) * VW)
 
+// Unrolled variant: UNR rows per trip with all their loads issued before any use (these streams run at
+// one or two workgroups per CU, so independent loads in flight are what hides the HBM latency).
+constexpr int UNR = 4;
+#define DANET_ROW_LOOP_U(fm, t)                                                                \
+    const int cv_ = (t) % (fm).CV;                                                             \
+    const long rstep_ = (fm).gridspan / (fm).CV;                                               \
+    for (long row0_ = ((long)blockIdx.x * (fm).span + (t)) / (fm).CV; row0_ < (fm).M; row0_ += rstep_ * UNR)
+#define DANET_ROW_U(fm, u) (row0_ + (long)(u) * rstep_)
+#define DANET_OFF_U(fm, u) (((size_t)(DANET_ROW_U(fm, u) < (fm).M ? DANET_ROW_U(fm, u) : row0_) * (fm).ldv + (fm).coff + cv_) * VW)
+
 __device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int CV, int span, float* dst /* [C] */) {
     // sm: [256][VW]; lanes with equal (t % CV) are summed in a fixed order, then one atomic per channel
     if (t < span) {
@@ -96,10 +106,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < VW; ++j) { s.v[j] = 0.f; q.v[j] = 0.f; }
     if (t < fm.span) {
-        DANET_ROW_LOOP(fm, t) {
-            const Vec a = load_bf(x + DANET_ROW_OFF(fm));
+        DANET_ROW_LOOP_U(fm, t) {
+            Vec a[UNR];
 #pragma unroll
-            for (int j = 0; j < VW; ++j) { s.v[j] += a.v[j]; q.v[j] += a.v[j] * a.v[j]; }
+            for (int u = 0; u < UNR; ++u) a[u] = load_bf(x + DANET_OFF_U(fm, u));
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const float m = DANET_ROW_U(fm, u) < fm.M ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < VW; ++j) { s.v[j] += m * a[u].v[j]; q.v[j] += m * a[u].v[j] * a[u].v[j]; }
+            }
         }
     }
     float* dst = sums + (size_t)(blockIdx.x % NCOPY) * 2 * Cst;
@@ -143,21 +159,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
             }
         }
     }
-    DANET_ROW_LOOP(fm, t) {
-        const size_t off = DANET_ROW_OFF(fm);
-        Vec a = load_bf(x + off);
+    DANET_ROW_LOOP_U(fm, t) {
+        Vec a[UNR], r[UNR];
+        size_t off[UNR];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) a.v[j] = a.v[j] * sc[j] + sh[j];
+        for (int u = 0; u < UNR; ++u) { off[u] = DANET_OFF_U(fm, u); a[u] = load_bf(x + off[u]); }
         if (res) {
-            const Vec r = load_bf(res + off);
 #pragma unroll
-            for (int j = 0; j < VW; ++j) a.v[j] += r.v[j];
+            for (int u = 0; u < UNR; ++u) r[u] = load_bf(res + off[u]);
         }
-        if (relu) {
 #pragma unroll
-            for (int j = 0; j < VW; ++j) a.v[j] = fmaxf(a.v[j], 0.f);
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                float v = a[u].v[j] * sc[j] + sh[j];
+                if (res) v += r[u].v[j];
+                a[u].v[j] = relu ? fmaxf(v, 0.f) : v;
+            }
+            if (DANET_ROW_U(fm, u) < fm.M) store_bf(y + off[u], a[u]);
         }
-        store_bf(y + off, a);
     }
 }
 
@@ -176,17 +196,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         float mean[VW], invstd[VW];
 #pragma unroll
         for (int j = 0; j < VW; ++j) { mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j]; }
-        DANET_ROW_LOOP(fm, t) {
-            const size_t off = DANET_ROW_OFF(fm);
-            Vec g = load_bf(dy + off);
-            const Vec a = load_bf(x + off);
-            if (relu) {
-                const Vec o = load_bf(y + off);
+        DANET_ROW_LOOP_U(fm, t) {
+            Vec g[UNR], a[UNR], o[UNR];
 #pragma unroll
-                for (int j = 0; j < VW; ++j) g.v[j] = o.v[j] > 0.f ? g.v[j] : 0.f;
+            for (int u = 0; u < UNR; ++u) {
+                const size_t off = DANET_OFF_U(fm, u);
+                g[u] = load_bf(dy + off);
+                a[u] = load_bf(x + off);
+                if (relu) o[u] = load_bf(y + off);
             }
 #pragma unroll
-            for (int j = 0; j < VW; ++j) { s1.v[j] += g.v[j]; s2.v[j] += g.v[j] * (a.v[j] - mean[j]) * invstd[j]; }
+            for (int u = 0; u < UNR; ++u) {
+                const bool live = DANET_ROW_U(fm, u) < fm.M;
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    const float gv = (live && (!relu || o[u].v[j] > 0.f)) ? g[u].v[j] : 0.f;
+                    s1.v[j] += gv; s2.v[j] += gv * (a[u].v[j] - mean[j]) * invstd[j];
+                }
+            }
         }
     }
     float* dst = red + (size_t)(blockIdx.x % NCOPY) * 2 * C;
@@ -214,20 +241,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         m1[j] = s0 * inv_count; m2[j] = s1 * inv_count;
         if (blockIdx.x == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
     }
-    DANET_ROW_LOOP(fm, t) {
-        const size_t off = DANET_ROW_OFF(fm);
-        Vec g = load_bf(dy + off);
-        const Vec a = load_bf(x + off);
-        if (relu) {
-            const Vec o = load_bf(y + off);
+    DANET_ROW_LOOP_U(fm, t) {
+        Vec g[UNR], a[UNR], o[UNR];
+        size_t off[UNR];
 #pragma unroll
-            for (int j = 0; j < VW; ++j) g.v[j] = o.v[j] > 0.f ? g.v[j] : 0.f;
+        for (int u = 0; u < UNR; ++u) {
+            off[u] = DANET_OFF_U(fm, u);
+            g[u] = load_bf(dy + off[u]);
+            a[u] = load_bf(x + off[u]);
+            if (relu) o[u] = load_bf(y + off[u]);
         }
-        if (dres) store_bf(dres + off, g);
-        Vec d;
 #pragma unroll
-        for (int j = 0; j < VW; ++j) d.v[j] = k0[j] * (g.v[j] - m1[j] - (a.v[j] - mean[j]) * invstd[j] * m2[j]);
-        store_bf(dx + off, d);
+        for (int u = 0; u < UNR; ++u) {
+            if (!(DANET_ROW_U(fm, u) < fm.M)) continue;
+            Vec d;
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                if (relu) g[u].v[j] = o[u].v[j] > 0.f ? g[u].v[j] : 0.f;
+                d.v[j] = k0[j] * (g[u].v[j] - m1[j] - (a[u].v[j] - mean[j]) * invstd[j] * m2[j]);
+            }
+            if (dres) store_bf(dres + off[u], g[u]);
+            store_bf(dx + off[u], d);
+        }
     }
 }
 
