@@ -35,10 +35,10 @@ _SIGNATURES = {
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
     'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 6 + [c_fl, c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
-    'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_f]),
-    'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_fl, c_fl, c_i, c_i, c_f]),
+    'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
+    'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),
-    'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f]),
+    'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f]),
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),

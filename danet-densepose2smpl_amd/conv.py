@@ -15,6 +15,46 @@ from . import _lib
 from ._lib import ptr, check, stream
 
 _PACK_CACHE = {}
+
+
+class ZeroArena(object):
+    """One fp32 buffer per device that is zeroed ONCE per step; kernels that need a zero-initialised
+    accumulator (BatchNorm statistics, atomically accumulated weight gradients) take slices of it
+    instead of each issuing its own memset (~800 per step otherwise).  `begin_step()` rewinds the bump
+    pointer and clears what the previous step used.  Inactive (capacity 0) unless a trainer enables it."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.high = 0
+
+    def enable(self, device, floats=160 * 1024 * 1024):
+        self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
+        self.off = 0
+        self.high = floats
+
+    def disable(self):
+        self.buf = None
+
+    def begin_step(self):
+        if self.buf is not None:
+            if self.high > 0:
+                self.buf[:self.high].zero_()
+            self.high = 0
+            self.off = 0
+
+    def alloc(self, n):
+        """-> (tensor, is_zero).  Falls back to a fresh (non-zeroed) tensor when inactive or full."""
+        n16 = (n + 15) // 16 * 16
+        if self.buf is None or self.off + n16 > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n16
+        self.high = max(self.high, self.off)
+        return t
+
+
+ARENA = ZeroArena()
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
 
@@ -148,14 +188,17 @@ class Conv2dFunction(torch.autograd.Function):
                 gb = gy.float().sum(dim=(0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
                 return gx, gw, gb, None, None, None, None, None
             nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
-            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            ws = ARENA.alloc(nws)
+            ws_zero = ws is not None
+            if ws is None:
+                ws = torch.empty(nws, dtype=torch.float32, device=x.device)
             tok = None
             if PROFILER is not None:
                 kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups, R * S)
                 tok = PROFILER.begin('conv_wgrad_kernel<%d, %d, %d>' % (kid // 100, (kid // 10) % 10, kid % 10),
                                      2.0 * B * OH * OW * Cout * Cin_g * R * S)
             check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
-                                     B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, stream()),
+                                     B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, int(ws_zero), stream()),
                   'danet_conv_wgrad')
             if tok is not None:
                 PROFILER.end(tok)

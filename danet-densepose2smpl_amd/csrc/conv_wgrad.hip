@@ -243,7 +243,7 @@ extern "C" size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S) 
 // ws: danet_conv_wgrad_ws_floats() floats of scratch (zeroed and filled here).
 extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                                 int B, int H, int W, int Cin, int OH, int OW, int Cout,
-                                int R, int S, int stride, int pad, int dil, int groups, float beta, void* stream)
+                                int R, int S, int stride, int pad, int dil, int groups, float beta, int ws_is_zero, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && dy && dw && ws, "conv_wgrad: null pointer");
@@ -263,8 +263,10 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
     const size_t need = danet_conv_wgrad_ws_floats(Cout, p.Cin_g, R, S);
     if (ws_floats < need) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu floats", ws_floats, need);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws, 0, need * sizeof(float), st);
-    if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "conv_wgrad: memset: %s", hipGetErrorString(e));
+    if (!ws_is_zero) {
+        hipError_t e = hipMemsetAsync(ws, 0, need * sizeof(float), st);
+        if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "conv_wgrad: memset: %s", hipGetErrorString(e));
+    }
     const int taps = R * S;
     const int kid = danet_conv_wgrad_kernel_id(Cin, Cout, groups, taps);               // bounds registers
     const int ct = kid / 100, ni = (kid / 10) % 10, tgs = kid % 10;

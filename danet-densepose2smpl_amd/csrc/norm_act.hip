@@ -354,14 +354,14 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
 
 extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                float* saved, float* sums_ws, float momentum, float eps, int training, int relu, void* stream)
+                                float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && y && M > 0 && C > 0, "bn_forward: bad arguments");
     DANET_CHECK_ARG(training ? (saved && sums_ws) : (running_mean && running_var), "bn_forward: missing buffers");
     DANET_CHECK_ARG(C % VW == 0, "bn_forward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
-    if (training) {
+    if (training && !ws_is_zero) {
         hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_forward: memset: %s", hipGetErrorString(e));
     }
@@ -389,14 +389,16 @@ extern "C" size_t danet_bn_ws_floats(int C) { return (size_t)NCOPY * 2 * C; }
 
 extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                                  const float* gamma, const float* saved, int relu,
-                                 void* dx, void* dres, float* dparam, float* red_ws, void* stream)
+                                 void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(dy && x && dx && saved && red_ws && M > 0 && C > 0 && (!relu || y), "bn_backward: bad arguments");
     DANET_CHECK_ARG(C % VW == 0, "bn_backward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
-    if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
+    if (!ws_is_zero) {
+        hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
+        if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
+    }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;

@@ -49,7 +49,7 @@ class ConvTranspose2dFunction(torch.autograd.Function):
             nws = L.danet_conv_wgrad_ws_floats(Cin, Cout, R, S)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
             check(L.danet_conv_wgrad(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
-                                     B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, 1, 1, 0.0, stream()), 'danet_conv_wgrad')
+                                     B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, 1, 1, 0.0, 0, stream()), 'danet_conv_wgrad')
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum(dim=(0, 2, 3))
         return gx, gw, gb, None, None, None

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import ptr, check, stream
-from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc  # noqa: F401
+from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc, ARENA  # noqa: F401
 
 
 class BatchNormActFunction(torch.autograd.Function):
@@ -25,12 +25,17 @@ class BatchNormActFunction(torch.autograd.Function):
                 raise ValueError('residual shape %s != %s' % (tuple(res.shape), tuple(x.shape)))
         y = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         saved = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
-        sums = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device) if training else None
+        sums, sums_zero = None, False
+        if training:
+            sums = ARENA.alloc(L.danet_bn_ws_floats(C))
+            sums_zero = sums is not None
+            if sums is None:
+                sums = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         g = None if gamma is None else gamma.detach().float().contiguous()
         b = None if beta is None else beta.detach().float().contiguous()
         check(L.danet_bn_forward(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
                                  ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(b), ptr(running_mean), ptr(running_var),
-                                 ptr(saved), ptr(sums), float(momentum), float(eps), int(training), int(relu), stream()),
+                                 ptr(saved), ptr(sums), int(sums_zero), float(momentum), float(eps), int(training), int(relu), stream()),
               'danet_bn_forward')
         if training:
             ctx.save_for_backward(x, y if relu else None, g, saved)
@@ -51,12 +56,15 @@ class BatchNormActFunction(torch.autograd.Function):
         M = B * H * W
         dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
-        red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+        red = ARENA.alloc(L.danet_bn_ws_floats(C))
+        red_zero = red is not None
+        if red is None:
+            red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)      # rows: d beta, d gamma
         check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
-                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), stream()),
+                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero), stream()),
               'danet_bn_backward')
         # unbind gives two independent-looking tensors that AccumulateGrad can keep without a clone
         dbeta, dgamma = (dparam[0], dparam[1]) if ctx.has_affine else (None, None)

@@ -14,6 +14,7 @@ from .config import cfg
 from .danet import DaNet
 from .distributed import GradReducer
 from .nn import BatchNorm2d, bump_batch_counters
+from . import conv as _conv
 from .geometry import perspective_projection
 
 
@@ -65,6 +66,8 @@ class Trainer(object):
                                           lr=torch.tensor(lr0, device=self.device) if on_gpu else lr0, weight_decay=0,
                                           **({'capturable': True, 'fused': True} if on_gpu else {}))
         self.step_count = 0
+        if on_gpu:
+            _conv.ARENA.enable(self.device)
         self._graph = None
         self._static = None
         self.reducer = None
@@ -88,6 +91,7 @@ class Trainer(object):
     def train_step(self, in_dict):
         self.model.train()
         self._decay_lr()
+        _conv.ARENA.begin_step()
         BatchNorm2d.count_batches = False
         try:
             out = self.model(in_dict)
@@ -135,6 +139,7 @@ class Trainer(object):
         return self
 
     def _eager_core(self, batch, with_optimizer):
+        _conv.ARENA.begin_step()
         BatchNorm2d.count_batches = False
         try:
             out = self.model(batch)

@@ -119,6 +119,8 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
  *      Cout := size / channels of dX) and also ConvTranspose2d.
  *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
+ *  Scratch buffers that must start zeroed (BN sums, wgrad accumulator) are cleared by the call unless
+ *  ws_is_zero != 0 (the host then zeroes one arena per step instead of ~800 small memsets).
  */
 int danet_conv_nt(int rows_per_group);
 int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, int groups);   /* MT*100 + NT*10 + vec8 */
@@ -139,7 +141,7 @@ int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, siz
 size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
 int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,
-                     int R, int S, int stride, int pad, int dil, int groups, float beta, void* stream);
+                     int R, int S, int stride, int pad, int dil, int groups, float beta, int ws_is_zero, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d (+ReLU, +residual add) and the HRNet fuse, NHWC bf16 viewed as [M = B*H*W, C].
@@ -158,11 +160,11 @@ int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
  */
 int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
-                     float* saved, float* sums_ws, float momentum, float eps, int training, int relu, void* stream);
+                     float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu, void* stream);
 size_t danet_bn_ws_floats(int C);
 int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                       const float* gamma, const float* saved, int relu,
-                      void* dx, void* dres, float* dparam, float* red_ws, void* stream);
+                      void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,
                            int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,

@@ -52,7 +52,7 @@ def main():
         nws = L.danet_conv_wgrad_ws_floats(Cout, Cin // g, k, k)
         ws = torch.empty(nws, device='cuda')
         xp, gyp = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
-        t = timeit(lambda: L.danet_conv_wgrad(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g, 0.0, stream()))
+        t = timeit(lambda: L.danet_conv_wgrad(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g, 0.0, 0, stream()))
         res['wgrad_us'] = t * 1e6; res['wgrad_TF'] = flops / t / 1e12
         if L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
             n3 = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, g)
