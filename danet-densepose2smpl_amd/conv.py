@@ -55,6 +55,7 @@ class ZeroArena(object):
 
 
 ARENA = ZeroArena()
+FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
 
@@ -130,7 +131,8 @@ def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32):
+def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32,
+                  bn_sums=None):
     L = _lib.lib()
     y = _empty_nhwc(B, Cout, OH, OW, torch.float32 if out_fp32 else torch.bfloat16, x.device)
     tok = None
@@ -140,7 +142,7 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
                              2.0 * B * OH * OW * Cout * (Cin // groups) * R * S)
     check(L.danet_conv_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(bias), ptr(y.permute(0, 2, 3, 1)),
                                B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed),
-                               int(relu), int(out_fp32), stream()), 'danet_conv_forward')
+                               int(relu), int(out_fp32), ptr(bn_sums), stream()), 'danet_conv_forward')
     if tok is not None:
         PROFILER.end(tok)
     return y
@@ -148,7 +150,7 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
 
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32):
+    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None):
         x = nhwc_bf16(x)
         B, Cin, H, W = x.shape
         Cout, Cin_g, R, S = weight.shape
@@ -157,7 +159,7 @@ class Conv2dFunction(torch.autograd.Function):
         OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         wp = pack_weight(weight, groups, 0)
         b = None if bias is None else bias.detach().float().contiguous()
-        y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32)
+        y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
         return y
@@ -186,7 +188,7 @@ class Conv2dFunction(torch.autograd.Function):
                 if tok is not None:
                     PROFILER.end(tok)
                 gb = gy.float().sum(dim=(0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
-                return gx, gw, gb, None, None, None, None, None
+                return gx, gw, gb, None, None, None, None, None, None
             nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
             ws = ARENA.alloc(nws)
             ws_zero = ws is not None
@@ -204,7 +206,7 @@ class Conv2dFunction(torch.autograd.Function):
                 PROFILER.end(tok)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum(dim=(0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 def _pad_channels_nhwc(x, mult=8):
@@ -217,7 +219,7 @@ def _pad_channels_nhwc(x, mult=8):
     return F.pad(x.permute(0, 2, 3, 1), (0, padc)).permute(0, 3, 1, 2)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False, want_stats=False):
     """Convolution on the MFMA kernels.  Channel counts that are not a multiple of 8 (3-channel image,
     21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
     forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
@@ -237,7 +239,16 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         B, _, OH, OW = y.shape
         y = y.permute(0, 2, 3, 1).reshape(B, OH, OW, groups, Cout_g + padn)[..., :Cout_g]
         return y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
-    return Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
+    sums = None
+    if FUSE_BN_STATS and want_stats and bias is None and not out_fp32:
+        n = _lib.lib().danet_bn_ws_floats(Cout)
+        sums = ARENA.alloc(n)
+        if sums is None:
+            sums = torch.zeros(n, dtype=torch.float32, device=x.device)
+    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums)
+    if sums is not None:
+        y._bn_sums = sums              # picked up by the BatchNorm2d that consumes y (nn.BatchNorm2d.forward)
+    return y
 
 
 class Conv2d(nn.Conv2d):
@@ -253,4 +264,6 @@ class Conv2d(nn.Conv2d):
         s, p, d = self.stride, self.padding, self.dilation
         if s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
             raise ValueError('danet Conv2d supports square stride/padding/dilation only')
-        return conv2d(x, self.weight, self.bias, s[0], p[0], d[0], self.groups, self.out_fp32)
+        # in training the epilogue also accumulates the BatchNorm statistics of the output (consumed by the
+        # following BatchNorm2d; ignored otherwise)
+        return conv2d(x, self.weight, self.bias, s[0], p[0], d[0], self.groups, self.out_fp32, want_stats=self.training)

@@ -16,12 +16,16 @@ __device__ inline bf16_t f2bf(float f) {                             // round to
 }
 __device__ inline float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 
+// replicas of per-channel BatchNorm accumulators: block b adds into replica b % BN_NCOPY
+constexpr int BN_NCOPY = 32;
+
 struct ConvP {
     const bf16_t* x; const bf16_t* w; const float* bias; void* y;
     int B, H, W, Cin, OH, OW, Cout;
     int R, S, stride, pad, dil, groups, transposed;
     int Cin_g, Cout_g, Cout_pad, K, Kp;
     int relu, out_fp32, sshift;
+    float* stats;      // optional [BN_NCOPY][2][Cout] (pre-zeroed): per-channel sum / sum of squares of the bf16 output
     long M;
 };
 

@@ -168,6 +168,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     for (int d = 0; d < D; ++d)
         if (d < rem) mma_step(A[d], Bq[d]);
 
+    // optional fused BatchNorm statistics of the (bf16-rounded) output: in-lane over the MT pixels, butterfly
+    // over the 16 pixel lanes, LDS over the 4 waves, then one atomic per channel into replica blockIdx.x % 32
+    if (p.stats) {
+        __shared__ float sStat[4][2][NT * 16];
+        float s1[NT][4], s2[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float v = (m0 + mt * 16 + li < p.M) ? bf2f(f2bf(acc[mt][nt][r])) : 0.f;
+                    a += v; b += v * v;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                s1[nt][r] = a; s2[nt][r] = b;
+            }
+        if (li == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sStat[wave][0][nt * 16 + lg * 4 + r] = s1[nt][r]; sStat[wave][1][nt * 16 + lg * 4 + r] = s2[nt][r]; }
+        }
+        __syncthreads();
+        if (t < 2 * NT * 16) {
+            const int which = t / (NT * 16), c = t - which * (NT * 16);
+            const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
+            const int cl = n0 + c;
+            if (cl < p.Cout_g)
+                atomicAdd(p.stats + ((size_t)(blockIdx.x % BN_NCOPY) * 2 + which) * p.Cout + g * p.Cout_g + cl, v);
+        }
+    }
+
     // epilogue: lane holds couts n0 + nt*16 + lg*4 + {0..3} of pixel m0 + mt*16 + li
     const bool vec_ok = (p.Cout % 4 == 0) && (p.Cout_g % 4 == 0);
 #pragma unroll
@@ -301,7 +336,7 @@ extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int C
 extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
                                   int B, int H, int W, int Cin, int OH, int OW, int Cout,
                                   int R, int S, int stride, int pad, int dil, int groups, int transposed,
-                                  int relu, int out_fp32, void* stream)
+                                  int relu, int out_fp32, float* bn_sums, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && wp && y, "conv_forward: null pointer");
@@ -317,7 +352,8 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     p.K = R * S * p.Cin_g; p.Kp = (p.K + 31) / 32 * 32;
     const int nt = danet_conv_nt(p.Cout_g);
     p.Cout_pad = (p.Cout_g + 16 * nt - 1) / (16 * nt) * (16 * nt);
-    p.relu = relu; p.out_fp32 = out_fp32;
+    p.relu = relu; p.out_fp32 = out_fp32; p.stats = bn_sums;
+    DANET_CHECK_ARG(!bn_sums || (!bias && !relu && !out_fp32), "conv_forward: fused BN statistics need a plain bf16 output");
     DANET_CHECK_ARG((stride & (stride - 1)) == 0, "conv_forward: stride %d is not a power of two", stride);
     p.sshift = 0;
     while ((1 << p.sshift) < stride) ++p.sshift;

@@ -20,7 +20,7 @@ namespace {
 
 using namespace danet_conv;
 
-constexpr int NCOPY = 32;   // replicas of the per-channel accumulators: block b adds into replica b % NCOPY (cuts same-address atomic contention)
+constexpr int NCOPY = danet_conv::BN_NCOPY;   // replicas of the per-channel accumulators: block b adds into replica b % NCOPY (cuts same-address atomic contention)
 constexpr int VW = 4;     // channels per lane (8-byte runs; every BN width on the path is a multiple of 4)
 
 struct Vec { float v[VW]; };
@@ -371,7 +371,7 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
         FlatMap fm; int grid;
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_forward: C=%d unsupported", C);
         // per-slab views of the per-channel buffers: [2][C] buffers are addressed as base+c0 with stride C
-        if (training) {
+        if (training && ws_is_zero != 2) {          // ws_is_zero == 2: the statistics were accumulated by the conv epilogue
             hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, fm, sums_ws + c0, C);
             DANET_CHECK_LAUNCH("bn_stats_kernel");
         }

@@ -14,7 +14,7 @@ class BatchNormActFunction(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ res]) on NHWC bf16; training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, fused_sums=None):
         L = _lib.lib()
         x = nhwc_bf16(x)
         B, C, H, W = x.shape
@@ -26,7 +26,9 @@ class BatchNormActFunction(torch.autograd.Function):
         y = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         saved = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
         sums, sums_zero = None, False
-        if training:
+        if training and fused_sums is not None:
+            sums, sums_zero = fused_sums, 2                   # accumulated by the producing conv's epilogue
+        elif training:
             sums = ARENA.alloc(L.danet_bn_ws_floats(C))
             sums_zero = sums is not None
             if sums is None:
@@ -68,7 +70,7 @@ class BatchNormActFunction(torch.autograd.Function):
               'danet_bn_backward')
         # unbind gives two independent-looking tensors that AccumulateGrad can keep without a clone
         dbeta, dgamma = (dparam[0], dparam[1]) if ctx.has_affine else (None, None)
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -83,10 +85,11 @@ class BatchNorm2d(nn.BatchNorm2d):
         if training and self.track_running_stats and self.num_batches_tracked is not None and BatchNorm2d.count_batches:
             self.num_batches_tracked.add_(1)
         momentum = 0.1 if self.momentum is None else self.momentum
+        fused = getattr(x, '_bn_sums', None) if training else None
         return BatchNormActFunction.apply(x, res, self.weight, self.bias,
                                           self.running_mean if self.track_running_stats else None,
                                           self.running_var if self.track_running_stats else None,
-                                          training, momentum, self.eps, relu)
+                                          training, momentum, self.eps, relu, fused)
 
 
 class SumReluFunction(torch.autograd.Function):

@@ -118,6 +118,9 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
  *      Cout := size / channels of dX) and also ConvTranspose2d.
+ *      bn_sums (optional, [32][2][Cout] fp32, zeroed by the caller): per-channel sum and sum of squares of the
+ *      bf16 output, accumulated by the epilogue; pass it to danet_bn_forward with ws_is_zero = 2 to skip
+ *      the separate statistics pass.
  *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
  *  Scratch buffers that must start zeroed (BN sums, wgrad accumulator) are cleared by the call unless
  *  ws_is_zero != 0 (the host then zeroes one arena per step instead of ~800 small memsets).
@@ -131,7 +134,7 @@ int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R
 int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
-                       int relu, int out_fp32, void* stream);
+                       int relu, int out_fp32, float* bn_sums, void* stream);
 /* 3x3 / stride 1 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);

@@ -19,7 +19,7 @@ import torch
 
 from conftest import golden, GOLDEN
 sys.path.insert(0, GOLDEN)
-from make_golden import formula_params, formula_input    # noqa: E402
+from make_golden import formula_params, formula_input, damp_residual_branches    # noqa: E402
 
 pytestmark = pytest.mark.gpu
 KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
@@ -52,13 +52,18 @@ def test_backbone_vs_reference_golden(name, cls):
     g = golden(name)
     net = (hrnet.PoseHighResolutionNet if cls == 'hrnet' else resnet.PoseResNet)(part_out_dim=7)
     formula_params(net)
+    if cls == 'resnet':
+        damp_residual_branches(net)               # as in make_golden.g6_backbones
     net = net.cuda().train()
     img = torch.from_numpy(g['img']).cuda().requires_grad_(True)
     out = net(img)
+    # bf16 convs vs the fp32 reference through a whole random-weight network: the bounds are what the
+    # fp32-vs-bf16-autocast comparison of the SAME torch network gives on CPU (x ~2 margin)
+    rms_max, cos_min = (0.35, 0.93) if cls == 'hrnet' else (0.2, 0.975)
     for k in KEYS:
         o = out[k] if (k != 'xd' or cls == 'hrnet') else out[k][:, ::4]
         rms, cos = _rms_cos(o, g[k])
-        assert rms < 0.35 and cos > 0.93, (k, rms, cos)
+        assert rms < rms_max and cos > cos_min, (k, rms, cos)
     loss = sum((out[k].float() * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32, device='cuda').view_as(out[k]) * 0.37)).sum() for k in KEYS[:5])
     loss.backward()
     assert torch.isfinite(img.grad).all()        # deep-net input gradients are chaotic: per-op backward tests pin them

@@ -108,3 +108,30 @@ def test_stn_gather_vs_torch_grid_sample(align):
     y.backward(gy.bfloat16())
     _close(y, yr, 1e-2, 'stn y')
     _close(xt.grad, xr.grad, 1e-2, 'stn dx')
+
+
+@pytest.mark.parametrize('Cin,Cout,H,B,k,stride,groups', [(48, 48, 64, 4, 3, 1, 1), (64, 256, 32, 2, 1, 1, 1), (96, 192, 32, 3, 3, 2, 1),
+                                                          (384, 384, 8, 2, 3, 1, 1), (40, 24, 17, 3, 3, 1, 1), (64, 64, 16, 2, 3, 1, 4)])
+def test_conv_epilogue_bn_statistics(Cin, Cout, H, B, k, stride, groups):
+    """BatchNorm statistics accumulated by the conv epilogue == the separate statistics pass on the
+    same bf16 conv output (fp32 sums, atomics: order differs, so 1e-4 relative)."""
+    from danet_densepose2smpl_amd import conv as dconv, nn as dnn
+    torch.manual_seed(0)
+    dev = 'cuda'
+    x = torch.randn(B, Cin, H, H, device=dev)
+    w = torch.randn(Cout, Cin // groups, k, k, device=dev) * 0.1
+    bn = dnn.BatchNorm2d(Cout).to(dev).train()
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.uniform_(-0.5, 0.5)
+    y_f = dconv.conv2d(x, w, None, stride, k // 2, 1, groups, want_stats=True)
+    assert getattr(y_f, '_bn_sums', None) is not None
+    out_f = bn(y_f, relu=True).float()
+    rm_f, rv_f = bn.running_mean.clone(), bn.running_var.clone()
+    bn.reset_running_stats()
+    y_u = dconv.conv2d(x, w, None, stride, k // 2, 1, groups)
+    assert getattr(y_u, '_bn_sums', None) is None
+    assert torch.equal(y_f, y_u)
+    out_u = bn(y_u, relu=True).float()
+    _close(rm_f, bn.running_mean, 1e-4, 'running_mean')
+    _close(rv_f, bn.running_var, 1e-4, 'running_var')
+    _close(out_f, out_u, 1e-2, 'bn output')          # bf16 outputs: one ulp where the mean differs in the last fp32 bits
