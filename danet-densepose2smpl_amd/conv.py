@@ -67,12 +67,12 @@ class KernelProfiler(object):
         self.only = only
         self.records = []
 
-    def begin(self, key, flops):
+    def begin(self, key, flops, shape=None):
         if self.only is not None and key != self.only:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        return (key, flops, e0, e1)
+        return (key, flops, e0, e1, shape)
 
     def end(self, tok):
         if tok is not None:
@@ -82,9 +82,17 @@ class KernelProfiler(object):
     def summary(self):
         """{key: (launches, total_seconds, total_flops)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for key, flops, e0, e1 in self.records:
+        for key, flops, e0, e1, _ in self.records:
             n, t, f = out.get(key, (0, 0.0, 0.0))
             out[key] = (n + 1, t + e0.elapsed_time(e1) * 1e-3, f + flops)
+        return out
+
+    def by_shape(self):
+        """{(key, shape): (launches, total_seconds, total_flops)} for tools/layer_profile.py."""
+        out = {}
+        for key, flops, e0, e1, shape in self.records:
+            n, t, f = out.get((key, shape), (0, 0.0, 0.0))
+            out[(key, shape)] = (n + 1, t + e0.elapsed_time(e1) * 1e-3, f + flops)
         return out
 
 
@@ -104,6 +112,75 @@ def _empty_nhwc(B, C, H, W, dtype, device):
     return torch.empty(B, H, W, C, dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
+class WeightBank(object):
+    """All packed weights of a model in ONE bf16 buffer, repacked by ONE launch per step.
+
+    A training step otherwise repacks every conv weight individually after each optimizer step
+    (~600 launches of a few microseconds).  Usage (see Trainer): `start_recording()`, run one step --
+    pack_weight() notes every (parameter, groups, mode) it is asked for --, `build()`, then
+    `refresh()` at the start of every following step: it launches the batched kernel and points
+    pack_weight's cache at the bank's views (tagged with the parameters' current versions, so a
+    weight modified later in the step simply misses and is packed individually)."""
+
+    def __init__(self):
+        self.requests = None
+        self.entries = []
+        self.jobs = None
+
+    def start_recording(self):
+        self.requests = {}
+
+    def note(self, weight, groups, mode):
+        if self.requests is not None:
+            self.requests[(id(weight), mode, groups)] = weight
+
+    def build(self):
+        global RECORDER
+        reqs, self.requests = self.requests or {}, None
+        if RECORDER is self:
+            RECORDER = None
+        if not reqs:
+            return self
+        L = _lib.lib()
+        dev = next(iter(reqs.values())).device
+        sizes = []
+        for (wid, mode, groups), w in reqs.items():
+            Cout, Cin_g, R, S = w.shape
+            sizes.append((int(L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode)) + 63) // 64 * 64)
+        self.flat = torch.empty(sum(sizes), dtype=torch.bfloat16, device=dev)
+        jb = int(L.danet_conv_pack_job_bytes())
+        import ctypes
+        host = (ctypes.c_uint8 * (jb * len(reqs)))()
+        off, start = 0, 0
+        self.entries = []
+        for ((wid, mode, groups), w), n in zip(reqs.items(), sizes):
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            view = self.flat[off:off + n]
+            Cout, Cin_g, R, S = w.shape
+            tot = L.danet_conv_pack_job_fill(ctypes.addressof(host) + jb * len(self.entries), w.data_ptr(), view.data_ptr(), start,
+                                             Cout, Cin_g, R, S, groups, mode)
+            assert 0 < tot <= n
+            self.entries.append(((wid, mode, groups), weakref.ref(w), view, w.data_ptr()))
+            off += n
+            start += tot
+        self.total = start
+        self.jobs = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
+        return self
+
+    def refresh(self):
+        if self.jobs is None:
+            return
+        check(_lib.lib().danet_conv_pack_weights_batched(ptr(self.jobs), len(self.entries), self.total, stream()),
+              'danet_conv_pack_weights_batched')
+        for key, wref, view, dptr in self.entries:
+            w = wref()
+            if w is not None and w.data_ptr() == dptr:
+                _PACK_CACHE[key] = (w._version, view, wref)
+
+
+RECORDER = None         # a WeightBank in its recording step
+
+
 def pack_weight(weight, groups, mode):
     """Packed bf16 copy of an fp32 conv weight.  Cached per nn.Parameter object and version (so a
     parameter is re-packed once per optimizer step); temporaries are never cached."""
@@ -111,6 +188,8 @@ def pack_weight(weight, groups, mode):
     key = (id(weight), mode, groups)
     ver = weight._version
     if cacheable:
+        if RECORDER is not None and weight.dtype == torch.float32 and weight.is_contiguous():
+            RECORDER.note(weight, groups, mode)
         hit = _PACK_CACHE.get(key)
         if hit is not None and hit[0] == ver and hit[2]() is weight:
             return hit[1]
@@ -139,7 +218,8 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     if PROFILER is not None:
         kid = L.danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups)
         tok = PROFILER.begin('conv_igemm_kernel<%d, %d, %s>' % (kid // 100, (kid // 10) % 10, 'true' if kid % 10 else 'false'),
-                             2.0 * B * OH * OW * Cout * (Cin // groups) * R * S)
+                             2.0 * B * OH * OW * Cout * (Cin // groups) * R * S,
+                             ('dgrad' if transposed else 'fwd', B, H, W, Cin, Cout, R, stride, groups))
     check(L.danet_conv_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(bias), ptr(y.permute(0, 2, 3, 1)),
                                B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed),
                                int(relu), int(out_fp32), ptr(bn_sums), stream()), 'danet_conv_forward')
@@ -182,7 +262,8 @@ class Conv2dFunction(torch.autograd.Function):
             if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
                 nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
                 ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-                tok = PROFILER.begin('conv_wgrad3x3_kernel', 2.0 * B * OH * OW * Cout * Cin_g * 9) if PROFILER is not None else None
+                tok = PROFILER.begin('conv_wgrad3x3_kernel', 2.0 * B * OH * OW * Cout * Cin_g * 9,
+                                     ('wgrad', B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
                 check(L.danet_conv_wgrad3x3(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
                                             B, H, W, Cin, Cout, groups, 0.0, stream()), 'danet_conv_wgrad3x3')
                 if tok is not None:
@@ -198,7 +279,8 @@ class Conv2dFunction(torch.autograd.Function):
             if PROFILER is not None:
                 kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups, R * S)
                 tok = PROFILER.begin('conv_wgrad_kernel<%d, %d, %d>' % (kid // 100, (kid // 10) % 10, kid % 10),
-                                     2.0 * B * OH * OW * Cout * Cin_g * R * S)
+                                     2.0 * B * OH * OW * Cout * Cin_g * R * S,
+                                     ('wgrad', B, H, W, Cin, Cout, R, stride, groups))
             check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
                                      B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, int(ws_zero), stream()),
                   'danet_conv_wgrad')

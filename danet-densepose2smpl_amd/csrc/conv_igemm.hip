@@ -271,6 +271,56 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
     wp[dst] = f2bf(v);
 }
 
+// One launch that (re)packs a whole table of weights: element i of the concatenated index space belongs to
+// the job whose [start, start + total) range holds it (binary search over the table).
+struct PackJob {
+    const float* w; bf16_t* wp; long start;
+    int Cout_g, Cin_g, R, S, G, rows_pad, Kp, mode;
+};
+
+__global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs, long total_all)
+{
+    // each thread packs 8 consecutive k of one row (one 16-byte store); the job of the block's first
+    // element is found once per block, threads past its end walk forward (jobs are >= 512 elements)
+    __shared__ int sJob;
+    const long base = (long)blockIdx.x * (blockDim.x * 8);
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].start <= base) lo = mid; else hi = mid - 1;
+        }
+        sJob = lo;
+    }
+    __syncthreads();
+    const long gidx = base + (long)threadIdx.x * 8;
+    if (gidx >= total_all) return;
+    int ji = sJob;
+    while (ji + 1 < njobs && jobs[ji + 1].start <= gidx) ++ji;
+    const PackJob j = jobs[ji];
+    const long idx = gidx - j.start;
+    const int k0 = (int)(idx % j.Kp);
+    const long rest = idx / j.Kp;
+    const int row = (int)(rest % j.rows_pad), g = (int)(rest / j.rows_pad);
+    const int inner = j.mode == 0 ? j.Cin_g : j.Cout_g;
+    const int rows = j.mode == 0 ? j.Cout_g : j.Cin_g;
+    const int RS = j.R * j.S, Kreal = RS * inner;
+    int tap = k0 / inner, ch = k0 - tap * inner;
+    union { bf16_t h[8]; int4 v; } o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+        if (row < rows && k0 + e < Kreal) {
+            const int cout = j.mode == 0 ? row : ch, cin = j.mode == 0 ? ch : row;
+            v = j.w[((size_t)(g * j.Cout_g + cout) * j.Cin_g + cin) * RS + tap];
+        }
+        o.h[e] = f2bf(v);
+        if (++ch == inner) { ch = 0; ++tap; }
+    }
+    const size_t dst = (((((size_t)g * (j.rows_pad / 16) + row / 16) * (j.Kp / 32) + k0 / 32) * 4 + (k0 % 32) / 8) * 16 + row % 16) * 8;
+    *reinterpret_cast<int4*>(j.wp + dst) = o.v;
+}
+
 template <int MT, int NT>
 int launch_conv(const ConvP& p, bool vec8, hipStream_t st) {
     const dim3 grid((unsigned)((p.M + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)p.groups);
@@ -327,6 +377,36 @@ extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int C
     hipLaunchKernelGGL(pack_weights_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (bf16_t*)wp, Cout_g, Cin_g, R, S, groups, rows_pad, Kp, mode);
     DANET_CHECK_LAUNCH("pack_weights_kernel");
+    return DANET_OK;
+}
+
+// Batched packing: the caller fills a host table of jobs with danet_conv_pack_job_fill (entry i at
+// byte offset i * danet_conv_pack_job_bytes(); `start` = running sum of the returned element counts),
+// copies it to the device and (re)packs every weight with one launch.
+extern "C" size_t danet_conv_pack_job_bytes(void) { return sizeof(PackJob); }
+
+extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
+                                         int Cout, int Cin_g, int R, int S, int groups, int mode)
+{
+    if (!job_host || groups <= 0 || Cout % groups != 0) return -1;
+    PackJob* j = (PackJob*)job_host;
+    const int Cout_g = Cout / groups;
+    const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
+    const int nt = danet_conv_nt(rows);
+    j->w = w; j->wp = (bf16_t*)wp; j->start = start;
+    j->Cout_g = Cout_g; j->Cin_g = Cin_g; j->R = R; j->S = S; j->G = groups; j->mode = mode;
+    j->rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
+    j->Kp = (R * S * inner + 31) / 32 * 32;
+    return (long)groups * j->rows_pad * j->Kp;
+}
+
+extern "C" int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(jobs_dev && njobs > 0 && total_elems > 0, "pack_weights_batched: empty job table");
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(danet::cdiv(total_elems, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs_dev, njobs, total_elems);
+    DANET_CHECK_LAUNCH("pack_weights_batched_kernel");
     return DANET_OK;
 }
 

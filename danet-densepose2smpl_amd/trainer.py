@@ -66,6 +66,7 @@ class Trainer(object):
                                           lr=torch.tensor(lr0, device=self.device) if on_gpu else lr0, weight_decay=0,
                                           **({'capturable': True, 'fused': True} if on_gpu else {}))
         self.step_count = 0
+        self.bank = None
         if on_gpu:
             _conv.ARENA.enable(self.device)
         self._graph = None
@@ -88,10 +89,23 @@ class Trainer(object):
                     else:
                         group['lr'] *= cfg.SOLVER.GAMMA
 
+    def _begin_step(self):
+        """Per-step device housekeeping: zero the accumulator arena, repack all conv weights (one launch).
+        The first GPU step records which packed weights the model asks for and builds the bank."""
+        _conv.ARENA.begin_step()
+        if self.device.type == 'cuda':
+            if self.bank is None:
+                self.bank = _conv.WeightBank()
+                self.bank.start_recording()
+                _conv.RECORDER = self.bank
+            elif self.bank.requests is not None:
+                self.bank.build()
+            self.bank.refresh()
+
     def train_step(self, in_dict):
         self.model.train()
         self._decay_lr()
-        _conv.ARENA.begin_step()
+        self._begin_step()
         BatchNorm2d.count_batches = False
         try:
             out = self.model(in_dict)
@@ -139,7 +153,7 @@ class Trainer(object):
         return self
 
     def _eager_core(self, batch, with_optimizer):
-        _conv.ARENA.begin_step()
+        self._begin_step()
         BatchNorm2d.count_batches = False
         try:
             out = self.model(batch)

@@ -118,6 +118,10 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
  *      Cout := size / channels of dX) and also ConvTranspose2d.
+ *  danet_conv_pack_job_* / danet_conv_pack_weights_batched   one launch that repacks a table of weights
+ *      (a training step repacks ~600 of them after every optimizer step): fill a host table with
+ *      danet_conv_pack_job_fill (entry i at byte i*danet_conv_pack_job_bytes(), start = running sum of
+ *      the returned element counts), copy it to the device, launch.
  *      bn_sums (optional, [32][2][Cout] fp32, zeroed by the caller): per-channel sum and sum of squares of the
  *      bf16 output, accumulated by the epilogue; pass it to danet_bn_forward with ws_is_zero = 2 to skip
  *      the separate statistics pass.
@@ -131,6 +135,10 @@ int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups, int taps);        
 size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode);
 int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
                             int mode, void* stream);
+size_t danet_conv_pack_job_bytes(void);
+long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
+                              int Cout, int Cin_g, int R, int S, int groups, int mode);
+int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream);
 int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
