@@ -32,6 +32,18 @@ class _Chain(nn.Module):
         return x
 
 
+BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, torch.cuda.current_stream(device).stream_id)
+    pool = _SIDE.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 class HighResolutionModule(nn.Module):
     def __init__(self, num_branches, block, num_blocks, num_inchannels, num_channels, fuse_method, multi_scale_output=True):
         super().__init__()
@@ -73,10 +85,30 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _branches_on_streams(self, x):
+        """The resolution branches of a module are independent until the fuse layers: branch 0 (the
+        chip-filling one) stays on the current stream, the low-resolution branches -- whose kernels
+        launch far fewer workgroups than there are CUs -- run beside it on side streams.  Autograd
+        replays each branch's backward on the stream its forward ran on."""
+        cur = torch.cuda.current_stream(x[0].device)
+        side = _side_streams(x[0].device, self.num_branches - 1)
+        out = [None] * self.num_branches
+        for i in range(1, self.num_branches):
+            side[i - 1].wait_stream(cur)
+            with torch.cuda.stream(side[i - 1]):
+                out[i] = self.branches[i](x[i])
+        out[0] = self.branches[0](x[0])
+        for i in range(1, self.num_branches):
+            cur.wait_stream(side[i - 1])
+        return out
+
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        if BRANCH_STREAMS and x[0].is_cuda:
+            x = self._branches_on_streams(x)
+        else:
+            x = [self.branches[i](x[i]) for i in range(self.num_branches)]
         out = []
         for i in range(len(self.fuse_layers)):
             terms, shifts = [], []

@@ -7,6 +7,9 @@ checkpoints are out of scope."""
 import types
 
 import numpy as np
+import contextlib
+import os
+
 import torch
 
 from . import ops
@@ -67,6 +70,10 @@ class Trainer(object):
                                           **({'capturable': True, 'fused': True} if on_gpu else {}))
         self.step_count = 0
         self.bank = None
+        # Every step (eager or captured) runs on ONE dedicated stream: autograd pins each parameter's
+        # gradient-accumulation node to the stream it was created on, and a node created on the default
+        # stream would pull that (non-capturing) stream into a later hipGraph capture.
+        self.stream = torch.cuda.Stream(device=self.device) if on_gpu else None
         if on_gpu:
             _conv.ARENA.enable(self.device)
         self._graph = None
@@ -102,25 +109,37 @@ class Trainer(object):
                 self.bank.build()
             self.bank.refresh()
 
+    @contextlib.contextmanager
+    def _on_stream(self):
+        if self.stream is None:
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            yield
+        cur.wait_stream(self.stream)
+
     def train_step(self, in_dict):
         self.model.train()
         self._decay_lr()
-        self._begin_step()
-        BatchNorm2d.count_batches = False
-        try:
-            out = self.model(in_dict)
-        finally:
-            BatchNorm2d.count_batches = True
-        bump_batch_counters(self.model)
-        losses = out['losses']
-        loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
-        self.optimizer.zero_grad(set_to_none=True)
-        if self.reducer is not None:
-            self.reducer.prepare()
-        loss_total.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        self.optimizer.step()
+        with self._on_stream():
+            self._begin_step()
+            BatchNorm2d.count_batches = False
+            try:
+                out = self.model(in_dict)
+            finally:
+                BatchNorm2d.count_batches = True
+            bump_batch_counters(self.model)
+            losses = out['losses']
+            loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
+            self.optimizer.zero_grad(set_to_none=True)
+            if self.reducer is not None:
+                self.reducer.prepare()
+            loss_total.backward()
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.optimizer.step()
         self.step_count += 1
         return out, losses
 
@@ -136,18 +155,20 @@ class Trainer(object):
         self.model.train()
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in in_dict.items()}
         fused_opt = self.reducer is None
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
+        with self._on_stream():
             for _ in range(warmup):
                 self._eager_core(self._static, fused_opt)
-        torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         conv._PACK_CACHE.clear()              # weight packing must be part of the captured work
         self.optimizer.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._static_out = self._eager_core(self._static, fused_opt)
+        from . import hrnet
+        hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
+        try:
+            with torch.cuda.graph(graph, stream=self.stream):
+                self._static_out = self._eager_core(self._static, fused_opt)
+        finally:
+            hrnet.BRANCH_STREAMS = False
         self._graph = graph
         self._graph_fused_opt = fused_opt
         return self

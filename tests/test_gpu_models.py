@@ -252,3 +252,30 @@ def test_danet_resnet50_inference_config2():
                               global_orient=para[:, 13:].reshape(2, 24, 3, 3)[:, :1], pose2rot=False)
     iuv = model.iuv_renderer.verts2uvimg(out.vertices, para[:, :3])
     assert iuv.shape == (2, 3, 64, 64)
+
+
+def test_graphed_step_matches_eager_step():
+    """hipGraph replay (side-stream branches, accumulator arena, weight bank) computes what plain eager
+    launches compute.  The learning rate is ~0 so that every step sees the same weights and the loss
+    terms can be compared directly; float atomics leave last-bit differences."""
+    _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
+            'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    tr = Trainer(default_options(2), device=dev, distributed=False, lr=1e-30)
+    batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
+    w0 = tr.model.img2iuv.iuv_est.conv1.weight.detach().clone() if hasattr(tr.model, 'img2iuv') else None
+    _, losses = tr.train_step(batch)
+    eager = {k: float(v.sum()) for k, v in losses.items()}
+    _, losses = tr.train_step(batch)
+    eager2 = {k: float(v.sum()) for k, v in losses.items()}
+    tr.capture(batch, warmup=2)
+    tr.train_step_graphed()
+    _, losses = tr.train_step_graphed()
+    torch.cuda.synchronize()
+    graphed = {k: float(v.sum()) for k, v in losses.items()}
+    for k in eager:
+        noise = abs(eager[k] - eager2[k])
+        assert abs(eager[k] - graphed[k]) <= 4 * noise + 2e-3 * max(abs(eager[k]), 1e-3), (k, eager[k], eager2[k], graphed[k])
+    assert tr.bank is not None and tr.bank.jobs is not None and len(tr.bank.entries) > 300
