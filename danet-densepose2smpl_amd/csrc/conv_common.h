@@ -24,7 +24,7 @@ struct ConvP {
     int B, H, W, Cin, OH, OW, Cout;
     int R, S, stride, pad, dil, groups, transposed;
     int Cin_g, Cout_g, Cout_pad, K, Kp;
-    int relu, out_fp32, sshift;
+    int relu, out_fp32, sshift, parity;
     float* stats;      // optional [BN_NCOPY][2][Cout] (pre-zeroed): per-channel sum / sum of squares of the bf16 output
     long M;
 };

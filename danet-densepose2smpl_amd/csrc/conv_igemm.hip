@@ -31,38 +31,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     extern __shared__ __attribute__((aligned(16))) int4 sTab[];     // [Kp/8] {dh, dw, cin, valid}
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int g = blockIdx.z;
+    // Parity classes (transposed gather with stride > 1): an output pixel (oy, ox) only sees the taps with
+    // r = (oy + pad) mod stride (same for s), so the launch is split into stride^2 classes (blockIdx.z), each
+    // visiting only its own pixels and only its own taps -- no multiply-by-zero k-steps.
+    const int nclass = p.parity ? p.stride * p.stride : 1;
+    const int g = blockIdx.z / nclass, cls = blockIdx.z - g * nclass;
+    const int py = p.parity ? cls / p.stride : 0, px = p.parity ? cls - py * p.stride : 0;
+    const int step = p.parity ? p.stride : 1;
+    const int OHc = (p.OH - py + step - 1) / step, OWc = (p.OW - px + step - 1) / step;   // pixels of this class
+    const long Mc = p.parity ? (long)p.B * OHc * OWc : p.M;
+    if ((long)blockIdx.x * (64 * MT) >= Mc) return;                                      // block-uniform
+    int nks = p.Kp / 32;
 
     if (VEC8) {
-        for (int e = t; e < p.Kp / 8; e += 256) {
-            const int k = e * 8;
-            int4 v = {0, 0, 0, 0};
-            if (k < p.K) {
-                const int tap = k / p.Cin_g, cin = k - tap * p.Cin_g;
-                const int r = tap / p.S, s = tap - r * p.S;
-                v.x = p.transposed ? p.pad - r * p.dil : r * p.dil - p.pad;
-                v.y = p.transposed ? p.pad - s * p.dil : s * p.dil - p.pad;
-                v.z = cin;
-                v.w = 1;
+        if (p.parity) {
+            const int r0 = (py + p.pad) % p.stride, s0 = (px + p.pad) % p.stride;
+            const int nr = r0 < p.R ? (p.R - r0 + p.stride - 1) / p.stride : 0;
+            const int ns = s0 < p.S ? (p.S - s0 + p.stride - 1) / p.stride : 0;
+            nks = nr * ns * p.Cin_g / 32;                        // host guarantees Cin_g % 32 == 0
+            for (int e = t; e < nks * 4; e += 256) {
+                const int k = e * 8;
+                const int ctap = k / p.Cin_g, cin = k - ctap * p.Cin_g;
+                const int ri = ctap / ns, si = ctap - ri * ns;
+                const int r = r0 + ri * p.stride, sx = s0 + si * p.stride;
+                int4 v;
+                v.x = p.pad - r; v.y = p.pad - sx; v.z = cin;
+                v.w = 1 + ((r * p.S + sx) * p.Cin_g + cin) / 32;  // k-step of the packed weights
+                sTab[e] = v;
             }
-            sTab[e] = v;
+        } else {
+            for (int e = t; e < p.Kp / 8; e += 256) {
+                const int k = e * 8;
+                int4 v = {0, 0, 0, 0};
+                if (k < p.K) {
+                    const int tap = k / p.Cin_g, cin = k - tap * p.Cin_g;
+                    const int r = tap / p.S, s = tap - r * p.S;
+                    v.x = p.transposed ? p.pad - r * p.dil : r * p.dil - p.pad;
+                    v.y = p.transposed ? p.pad - s * p.dil : s * p.dil - p.pad;
+                    v.z = cin;
+                    v.w = 1;
+                }
+                sTab[e] = v;
+            }
         }
         __syncthreads();
     }
 
-    // pixels of this wave: MT tiles of 16 consecutive output pixels
+    // pixels of this wave: MT tiles of 16 consecutive output pixels (of this parity class)
     const long m0 = (long)blockIdx.x * (64 * MT) + wave * (16 * MT);
     int pb[MT], ph[MT], pw[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         long m = m0 + mt * 16 + li;
-        if (m >= p.M) m = p.M - 1;
-        const int ohw = p.OH * p.OW;
+        if (m >= Mc) m = Mc - 1;
+        const int ohw = OHc * OWc;
         const int b = (int)(m / ohw), rem = (int)(m - (long)b * ohw);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int oh = rem / OWc, ow = rem - oh * OWc;
         pb[mt] = b;
-        ph[mt] = p.transposed ? oh : oh * p.stride;
-        pw[mt] = p.transposed ? ow : ow * p.stride;
+        ph[mt] = p.transposed ? oh * step + py : oh * p.stride;
+        pw[mt] = p.transposed ? ow * step + px : ow * p.stride;
     }
     const int n0 = blockIdx.y * (16 * NT);
     // packed weights are stored fragment-major: [group][16-row tile][k-step][lane][8] -- the 1 KB a wave
@@ -76,15 +103,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nks = p.Kp / 32;
-
     // fragment loads of one k-step (weights: A operand; gathered pixels: B operand)
     auto load_step = [&](int ks, bf16x8* a, bf16x8* bq) {
+        int4 e = {0, 0, 0, 0};
+        int wks = ks;
+        if (VEC8) {
+            e = sTab[ks * 4 + lg];
+            if (p.parity) wks = e.w - 1;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            a[nt] = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)nt * (p.Kp / 32) + ks) * 512);
+            a[nt] = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)nt * (p.Kp / 32) + wks) * 512);
         if (VEC8) {
-            const int4 e = sTab[ks * 4 + lg];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 int ih = ph[mt] + e.x, iw = pw[mt] + e.y;
@@ -153,8 +183,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     // branch-free main loop (prefetch indices are clamped instead of guarded, so the compiler can use
     // counted vmcnt waits); the last partial round is handled after it
     const int last = nks - 1;
+    if (nks > 0) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) load_step(min(d, last), A[d], Bq[d]);
+        for (int d = 0; d < D; ++d) load_step(min(d, last), A[d], Bq[d]);
+    }
     const int nfull = nks / D;
     for (int r = 0; r < nfull; ++r) {
 #pragma unroll
@@ -207,8 +239,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     const bool vec_ok = (p.Cout % 4 == 0) && (p.Cout_g % 4 == 0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const long m = m0 + mt * 16 + li;
-        if (m >= p.M) continue;
+        const long mc = m0 + mt * 16 + li;
+        if (mc >= Mc) continue;
+        const long m = p.parity ? ((long)pb[mt] * p.OH + ph[mt]) * p.OW + pw[mt] : mc;    // NHWC pixel index
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int cl = n0 + nt * 16 + lg * 4;          // channel within the group
@@ -321,9 +354,17 @@ __global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, in
     *reinterpret_cast<int4*>(j.wp + dst) = o.v;
 }
 
+bool g_no_parity = getenv("DANET_CONV_NO_PARITY") != nullptr;     // debugging / A-B timing knob
+
 template <int MT, int NT>
 int launch_conv(const ConvP& p, bool vec8, hipStream_t st) {
-    const dim3 grid((unsigned)((p.M + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)p.groups);
+    long mblk = p.M;
+    int nz = p.groups;
+    if (p.parity) {
+        mblk = (long)p.B * ((p.OH + p.stride - 1) / p.stride) * ((p.OW + p.stride - 1) / p.stride);    // largest class
+        nz *= p.stride * p.stride;
+    }
+    const dim3 grid((unsigned)((mblk + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)nz);
     const size_t lds = vec8 ? (size_t)(p.Kp / 8) * sizeof(int4) : 0;
     if (vec8) hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, false>), grid, dim3(256), lds, st, p);
@@ -439,6 +480,7 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     while ((1 << p.sshift) < stride) ++p.sshift;
     p.M = (long)B * OH * OW;
     const bool vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
+    p.parity = (transposed && stride > 1 && dil == 1 && vec8 && p.Cin_g % 32 == 0 && !g_no_parity) ? 1 : 0;
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;

@@ -29,6 +29,7 @@ SHAPES = [
     (256 * 24, 128 * 24, 1, 2, 0, 24, 4, 4, False),
     (128 * 24, 6 * 24, 1, 1, 0, 24, 1, 1, True),            # grouped 1x1 pose regressors
     (128, 256, 3, 2, 1, 1, 16, 16, False), (512, 512, 3, 1, 1, 1, 2, 2, False),
+    (96, 64, 3, 2, 1, 1, 17, 17, False), (64, 128, 1, 2, 0, 1, 15, 15, False),      # odd sizes: ragged parity classes of the strided dgrad
 ]
 
 
