@@ -28,10 +28,14 @@ _SIGNATURES = {
     'danet_conv_nt': (c_i, [c_i]),
     'danet_conv_kernel_id': (c_i, [c_i] * 6),
     'danet_conv_wgrad_kernel_id': (c_i, [c_i] * 4),
-    'danet_conv_packed_elems': (c_sz, [c_i] * 6),
-    'danet_conv_pack_weights': (c_i, [c_f, c_f] + [c_i] * 6 + [c_f]),
+    'danet_conv_packed_elems': (c_sz, [c_i] * 7),
+    'danet_conv_pack_weights': (c_i, [c_f, c_f] + [c_i] * 7 + [c_f]),
     'danet_conv_pack_job_bytes': (c_sz, []),
-    'danet_conv_pack_job_fill': (ctypes.c_long, [c_f, c_f, c_f, ctypes.c_long] + [c_i] * 6),
+    'danet_conv_pack_job_fill': (ctypes.c_long, [c_f, c_f, c_f, ctypes.c_long] + [c_i] * 7),
+    'danet_conv3x3_ok': (c_i, [c_i] * 10),
+    'danet_conv3x3_chunk': (c_i, [c_i] * 5),
+    'danet_conv3x3_kernel_id': (c_i, [c_i] * 5),
+    'danet_conv3x3_forward': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f, c_f]),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, c_f]),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f, c_f]),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),

@@ -5,6 +5,7 @@ in the torch layout (state-dict compatible with the reference) and are packed to
 parameter version.  Gradients: dX through the transposed gather of the same MFMA kernel, dW
 through the wgrad kernel (fp32), dbias as a channel sum.
 """
+import os
 import weakref
 
 import torch
@@ -56,6 +57,7 @@ class ZeroArena(object):
 
 ARENA = ZeroArena()
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
+USE_LDS3X3 = bool(int(os.environ.get('DANET_LDS3X3', '0')))         # 3x3/s1/p1 forward + data gradient through the LDS-staged kernel (conv3x3_lds.hip)
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
 
@@ -130,9 +132,9 @@ class WeightBank(object):
     def start_recording(self):
         self.requests = {}
 
-    def note(self, weight, groups, mode):
+    def note(self, weight, groups, mode, chunk):
         if self.requests is not None:
-            self.requests[(id(weight), mode, groups)] = weight
+            self.requests[(id(weight), mode, groups, chunk)] = weight
 
     def build(self):
         global RECORDER
@@ -144,23 +146,23 @@ class WeightBank(object):
         L = _lib.lib()
         dev = next(iter(reqs.values())).device
         sizes = []
-        for (wid, mode, groups), w in reqs.items():
+        for (wid, mode, groups, chunk), w in reqs.items():
             Cout, Cin_g, R, S = w.shape
-            sizes.append((int(L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode)) + 63) // 64 * 64)
+            sizes.append((int(L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode, chunk)) + 63) // 64 * 64)
         self.flat = torch.empty(sum(sizes), dtype=torch.bfloat16, device=dev)
         jb = int(L.danet_conv_pack_job_bytes())
         import ctypes
         host = (ctypes.c_uint8 * (jb * len(reqs)))()
         off, start = 0, 0
         self.entries = []
-        for ((wid, mode, groups), w), n in zip(reqs.items(), sizes):
+        for ((wid, mode, groups, chunk), w), n in zip(reqs.items(), sizes):
             assert w.dtype == torch.float32 and w.is_contiguous()
             view = self.flat[off:off + n]
             Cout, Cin_g, R, S = w.shape
             tot = L.danet_conv_pack_job_fill(ctypes.addressof(host) + jb * len(self.entries), w.data_ptr(), view.data_ptr(), start,
-                                             Cout, Cin_g, R, S, groups, mode)
+                                             Cout, Cin_g, R, S, groups, mode, chunk)
             assert 0 < tot <= n
-            self.entries.append(((wid, mode, groups), weakref.ref(w), view, w.data_ptr()))
+            self.entries.append(((wid, mode, groups, chunk), weakref.ref(w), view, w.data_ptr()))
             off += n
             start += tot
         self.total = start
@@ -181,15 +183,16 @@ class WeightBank(object):
 RECORDER = None         # a WeightBank in its recording step
 
 
-def pack_weight(weight, groups, mode):
-    """Packed bf16 copy of an fp32 conv weight.  Cached per nn.Parameter object and version (so a
+def pack_weight(weight, groups, mode, chunk=0):
+    """Packed bf16 copy of an fp32 conv weight (mode 0: forward operand, 1: data-gradient operand; chunk > 0:
+    the chunked K order of the LDS 3x3 kernel).  Cached per nn.Parameter object and version (so a
     parameter is re-packed once per optimizer step); temporaries are never cached."""
     cacheable = isinstance(weight, nn.Parameter)
-    key = (id(weight), mode, groups)
+    key = (id(weight), mode, groups, chunk)
     ver = weight._version
     if cacheable:
         if RECORDER is not None and weight.dtype == torch.float32 and weight.is_contiguous():
-            RECORDER.note(weight, groups, mode)
+            RECORDER.note(weight, groups, mode, chunk)
         hit = _PACK_CACHE.get(key)
         if hit is not None and hit[0] == ver and hit[2]() is weight:
             return hit[1]
@@ -198,9 +201,9 @@ def pack_weight(weight, groups, mode):
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
-    n = L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode)
+    n = L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode, chunk)
     wp = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
-    check(L.danet_conv_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, stream()), 'danet_conv_pack_weights')
+    check(L.danet_conv_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, chunk, stream()), 'danet_conv_pack_weights')
     if cacheable:
         _PACK_CACHE[key] = (ver, wp, weakref.ref(weight))
     return wp
@@ -228,6 +231,25 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     return y
 
 
+def _conv3x3_raw(x, weight, groups_unused, B, H, W, Cin, Cout, flip, bn_sums=None):
+    """3x3/s1/p1 through the LDS-staged kernel: forward (flip=False, x has the layer's Cin channels) or data
+    gradient (flip=True, x = dY with the layer's Cout channels; Cin/Cout here are the kernel's)."""
+    L = _lib.lib()
+    chunk = L.danet_conv3x3_chunk(B, H, W, Cin, Cout)
+    wp = pack_weight(weight, 1, 1 if flip else 0, chunk)
+    y = _empty_nhwc(B, Cout, H, W, torch.bfloat16, x.device)
+    tok = None
+    if PROFILER is not None:
+        kid = L.danet_conv3x3_kernel_id(B, H, W, Cin, Cout)
+        tok = PROFILER.begin('conv3x3_lds_kernel<%d, %d>' % (kid // 10, kid % 10), 2.0 * B * H * W * Cout * Cin * 9,
+                             ('dgrad' if flip else 'fwd', B, H, W, Cin, Cout, 3, 1, 1))
+    check(L.danet_conv3x3_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(y.permute(0, 2, 3, 1)), B, H, W, Cin, Cout,
+                                  int(flip), ptr(bn_sums), stream()), 'danet_conv3x3_forward')
+    if tok is not None:
+        PROFILER.end(tok)
+    return y
+
+
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None):
@@ -237,9 +259,13 @@ class Conv2dFunction(torch.autograd.Function):
         if Cin_g * groups != Cin:
             raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
         OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
-        wp = pack_weight(weight, groups, 0)
-        b = None if bias is None else bias.detach().float().contiguous()
-        y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
+        if USE_LDS3X3 and bias is None and not out_fp32 and \
+                _lib.lib().danet_conv3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+            y = _conv3x3_raw(x, weight, groups, B, H, W, Cin, Cout, False, bn_sums)
+        else:
+            wp = pack_weight(weight, groups, 0)
+            b = None if bias is None else bias.detach().float().contiguous()
+            y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
         return y
@@ -254,41 +280,83 @@ class Conv2dFunction(torch.autograd.Function):
         gy = nhwc_bf16(gy)
         OH, OW = gy.shape[2], gy.shape[3]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            wp1 = pack_weight(weight, groups, 1)
-            gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
         if ctx.needs_input_grad[1]:
+            # the weight gradient is off the critical path (only the optimizer consumes it): with
+            # WGRAD_STREAMS it is launched on a side stream, next to this layer's data gradient
             gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
-            if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
-                nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
-                ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-                tok = PROFILER.begin('conv_wgrad3x3_kernel', 2.0 * B * OH * OW * Cout * Cin_g * 9,
-                                     ('wgrad', B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
-                check(L.danet_conv_wgrad3x3(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
-                                            B, H, W, Cin, Cout, groups, 0.0, stream()), 'danet_conv_wgrad3x3')
-                if tok is not None:
-                    PROFILER.end(tok)
-                gb = gy.float().sum(dim=(0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
-                return gx, gw, gb, None, None, None, None, None, None
-            nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
-            ws = ARENA.alloc(nws)
-            ws_zero = ws is not None
-            if ws is None:
-                ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            tok = None
-            if PROFILER is not None:
-                kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups, R * S)
-                tok = PROFILER.begin('conv_wgrad_kernel<%d, %d, %d>' % (kid // 100, (kid // 10) % 10, kid % 10),
-                                     2.0 * B * OH * OW * Cout * Cin_g * R * S,
-                                     ('wgrad', B, H, W, Cin, Cout, R, stride, groups))
-            check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
-                                     B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, int(ws_zero), stream()),
-                  'danet_conv_wgrad')
-            if tok is not None:
-                PROFILER.end(tok)
+            side = _wgrad_stream(x.device) if WGRAD_STREAMS else None
+            if side is None:
+                _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups)
+            else:
+                with torch.cuda.stream(side):
+                    _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups)
+                _WG['keep'].append((x, gy))          # keep the operands' memory from being reused before the join
+        if ctx.needs_input_grad[0]:
+            if USE_LDS3X3 and L.danet_conv3x3_ok(H, W, Cout, Cin, R, S, stride, pad, dil, groups):
+                gx = _conv3x3_raw(gy, weight, groups, B, H, W, Cout, Cin, True)
+            else:
+                wp1 = pack_weight(weight, groups, 1)
+                gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum(dim=(0, 2, 3))
         return gx, gw, gb, None, None, None, None, None, None
+
+
+WGRAD_STREAMS = False    # weight gradients on side streams (set by the trainer's hipGraph capture; it joins them)
+_WG = {'streams': {}, 'keep': []}
+
+
+def _wgrad_stream(device):
+    """Side stream paired with the current stream; it first waits for everything queued on the current one."""
+    cur = torch.cuda.current_stream(device)
+    key = (device.index, cur.stream_id)
+    side = _WG['streams'].get(key)
+    if side is None:
+        side = _WG['streams'][key] = torch.cuda.Stream(device=device)
+    side.wait_stream(cur)
+    return side
+
+
+def join_wgrad_streams(device):
+    """Make the current stream wait for every side-stream weight gradient (call after backward, before the
+    optimizer / gradient all-reduce) and release the operands kept alive for them."""
+    if _WG['keep']:
+        cur = torch.cuda.current_stream(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        for (di, _), side in _WG['streams'].items():
+            if di == index:
+                cur.wait_stream(side)
+        _WG['keep'].clear()
+
+
+def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups):
+    L = _lib.lib()
+    if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+        nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        tok = PROFILER.begin('conv_wgrad3x3_kernel', 2.0 * B * OH * OW * Cout * Cin_g * 9,
+                             ('wgrad', B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
+        check(L.danet_conv_wgrad3x3(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
+                                    B, H, W, Cin, Cout, groups, 0.0, stream()), 'danet_conv_wgrad3x3')
+        if tok is not None:
+            PROFILER.end(tok)
+        return
+    nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
+    ws = ARENA.alloc(nws)
+    ws_zero = ws is not None
+    if ws is None:
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    tok = None
+    if PROFILER is not None:
+        kid = L.danet_conv_wgrad_kernel_id(Cin, Cout, groups, R * S)
+        tok = PROFILER.begin('conv_wgrad_kernel<%d, %d, %d>' % (kid // 100, (kid // 10) % 10, kid % 10),
+                             2.0 * B * OH * OW * Cout * Cin_g * R * S,
+                             ('wgrad', B, H, W, Cin, Cout, R, stride, groups))
+    check(L.danet_conv_wgrad(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
+                             B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, 0.0, int(ws_zero), stream()),
+          'danet_conv_wgrad')
+    if tok is not None:
+        PROFILER.end(tok)
 
 
 def _pad_channels_nhwc(x, mult=8):

@@ -22,6 +22,8 @@ UNITS = {
     'conv_igemm.hip': [],
     'conv_wgrad.hip': [],
     'conv_wgrad3x3.hip': [],
+    'conv3x3_lds.hip': [],
+    'conv_fast.hip': [],
     'norm_act.hip': [],
     'stn.hip': [],
 }

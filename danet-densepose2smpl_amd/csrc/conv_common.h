@@ -8,12 +8,13 @@ typedef unsigned short bf16_t;                                       // storage 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;           // MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;             // MFMA C/D fragment (16x16)
 
-__device__ inline bf16_t f2bf(float f) {                             // round to nearest even
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: one v_cvt_pk_bf16_f32 (gfx950) for two values
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+__device__ inline unsigned f2bf_pk(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
 }
+__device__ inline bf16_t f2bf(float f) { return (bf16_t)(f2bf_pk(f, 0.f) & 0xffffu); }
 __device__ inline float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 
 // replicas of per-channel BatchNorm accumulators: block b adds into replica b % BN_NCOPY
@@ -27,6 +28,11 @@ struct ConvP {
     int relu, out_fp32, sshift, parity;
     float* stats;      // optional [BN_NCOPY][2][Cout] (pre-zeroed): per-channel sum / sum of squares of the bf16 output
     long M;
+    long x_bytes, y_bytes;   // extents of the gathered / written tensors (buffer resources of conv_fast.hip)
 };
+
+// conv_fast.hip: the lean kernel for the common cases (conv_igemm.hip keeps the general one)
+bool conv_fast_ok(const ConvP& p, bool vec8);
+int conv_fast_launch(const ConvP& p, int mt, int nt, void* stream);
 
 }  // namespace danet_conv

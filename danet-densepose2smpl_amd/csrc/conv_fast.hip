@@ -1,0 +1,274 @@
+// Lean implicit-GEMM convolution: the same algorithm and operand layout as conv_igemm.hip, written for
+// instruction economy.  PMC counters on MI355X showed the generic kernel spending ~23 VALU instructions
+// per MFMA (64-bit address arithmetic, per-gather bounds logic, integer divisions in the prologue, a
+// software bf16 rounding in the epilogue): a 48-channel 3x3 layer issued ~3900 VALU + 1400 SALU
+// instructions per wave for 168 MFMAs and was bound by instruction issue, not by memory or the matrix
+// cores.  Here
+//   * every tensor is addressed through a buffer resource with a 32-bit byte offset; invalid gathers
+//     (padding, ragged tiles) get an out-of-range offset and the hardware returns zeros / drops the store,
+//   * a gather's offset is  pixel_base + tap_delta  (one add): tap deltas come from the LDS table, validity
+//     from per-pixel row / column bit masks built once in the prologue (two shifts, two ands),
+//   * weight fragment loads take the k-step as a scalar offset (no VALU),
+//   * divisions use a float reciprocal with a fix-up (operands < 2^24, checked by the host),
+//   * the epilogue converts with v_cvt_pk_bf16_f32 and the BatchNorm statistics reduce with DPP adds.
+// Handles: 8-channel granules (Cin % 8 == 0, Cin_g % 8 == 0), forward with any stride / dilation,
+// transposed gather with stride 1 or in parity-class mode; everything else stays on conv_igemm_kernel.
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace danet_conv;
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+__device__ inline unsigned udiv24(unsigned n, unsigned d, float rcp) {      // n < 2^24
+    unsigned q = (unsigned)((float)n * rcp);
+    const int r = (int)(n - q * d);
+    if (r < 0) --q; else if (r >= (int)d) ++q;
+    return q;
+}
+
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, o);
+}
+// sum over the 16 lanes of a DPP row, result in every lane (xor 1, xor 2, half-row mirror, row mirror)
+__device__ inline float row_sum16(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
+    return v;
+}
+
+constexpr int OOB = 0x7fffffff;      // beyond every buffer (sizes are checked to be < 2^31 bytes)
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
+{
+    extern __shared__ __attribute__((aligned(16))) i32x2 sTab[];     // per 8-channel k group: {byte delta, r | s<<5 | wks<<10}
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // parity classes of the strided transposed gather (see conv_igemm.hip)
+    const int nclass = p.parity ? p.stride * p.stride : 1;
+    const int g = blockIdx.z / nclass, cls = blockIdx.z - g * nclass;
+    const int py = p.parity ? cls / p.stride : 0, px = p.parity ? cls - py * p.stride : 0;
+    const int step = p.parity ? p.stride : 1;
+    const int OHc = (p.OH - py + step - 1) / step, OWc = (p.OW - px + step - 1) / step;
+    const int Mc = p.parity ? p.B * OHc * OWc : (int)p.M;
+    if (blockIdx.x * (64 * MT) >= Mc) return;
+
+    // tap geometry: tap row index i (0 .. nr-1) reads input row  ph + i*dh ; likewise columns
+    int nr = p.R, ns = p.S, r0 = 0, s0 = 0, rstep = 1, dh, orig_h = 0, orig_w = 0;
+    if (p.parity) {
+        r0 = (py + p.pad) % p.stride; s0 = (px + p.pad) % p.stride; rstep = p.stride;
+        nr = r0 < p.R ? (p.R - r0 + p.stride - 1) / p.stride : 0;
+        ns = s0 < p.S ? (p.S - s0 + p.stride - 1) / p.stride : 0;
+        dh = -1;
+        orig_h = (py + p.pad - r0) / p.stride; orig_w = (px + p.pad - s0) / p.stride;
+    } else if (p.transposed) {
+        dh = -p.dil; orig_h = p.pad; orig_w = p.pad;
+    } else {
+        dh = p.dil; orig_h = -p.pad; orig_w = -p.pad;
+    }
+    const int nks = p.parity ? nr * ns * p.Cin_g / 32 : p.Kp / 32;
+    const int Kreal = p.parity ? nks * 32 : p.K;
+
+    {
+        const float rc_c = 1.0f / (float)p.Cin_g, rc_s = 1.0f / (float)(ns > 0 ? ns : 1);
+        for (int e = t; e < nks * 4; e += 256) {
+            const int k = e * 8;
+            i32x2 v = {0, 31};                                          // row bit 31 is never set: invalid
+            if (k < Kreal) {
+                const int ctap = (int)udiv24((unsigned)k, (unsigned)p.Cin_g, rc_c), cin = k - ctap * p.Cin_g;
+                const int ri = (int)udiv24((unsigned)ctap, (unsigned)ns, rc_s), si = ctap - ri * ns;
+                const int wk = p.parity ? (((r0 + ri * rstep) * p.S + s0 + si * rstep) * p.Cin_g + cin) >> 5 : e >> 2;
+                v.x = ((ri * dh * p.W + si * dh) * p.Cin + cin) * 2;
+                v.y = ri | (si << 5) | (wk << 10);
+            } else {
+                v.y = 31 | ((e >> 2) << 10);
+            }
+            sTab[e] = v;
+        }
+    }
+
+    // pixels of this wave
+    const int m0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    int pixoff[MT], outoff[MT];
+    unsigned rowmask[MT], colmask[MT];
+    {
+        const int ohw = OHc * OWc;
+        const float rc_ohw = 1.0f / (float)ohw, rc_ow = 1.0f / (float)OWc;
+        const int osz = p.out_fp32 ? 4 : 2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mreal = m0 + mt * 16 + li;
+            const int m = mreal < Mc ? mreal : Mc - 1;
+            const int b = (int)udiv24((unsigned)m, (unsigned)ohw, rc_ohw), rem = m - b * ohw;
+            const int oh = (int)udiv24((unsigned)rem, (unsigned)OWc, rc_ow), ow = rem - oh * OWc;
+            const int ph = (p.transposed ? oh : oh * p.stride) + orig_h;
+            const int pw = (p.transposed ? ow : ow * p.stride) + orig_w;
+            pixoff[mt] = (((b * p.H + ph) * p.W + pw) * p.Cin + g * p.Cin_g) * 2;
+            unsigned rm = 0, cm = 0;
+            for (int i = 0; i < nr; ++i) rm |= ((unsigned)(ph + i * dh) < (unsigned)p.H ? 1u : 0u) << i;
+            for (int i = 0; i < ns; ++i) cm |= ((unsigned)(pw + i * dh) < (unsigned)p.W ? 1u : 0u) << i;
+            rowmask[mt] = rm; colmask[mt] = cm;
+            const int opix = p.parity ? (b * p.OH + oh * step + py) * p.OW + ow * step + px : m;
+            outoff[mt] = mreal < Mc ? (opix * p.Cout + g * p.Cout_g) * osz : OOB;
+        }
+    }
+    __syncthreads();
+
+    const int n0 = blockIdx.y * (16 * NT);
+    const int nks_w = p.Kp / 32;                                       // k-steps of the packed weights
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const bf16_t* wblk = p.w + ((size_t)g * (p.Cout_pad / 16) + n0 / 16) * (size_t)nks_w * 512;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wblk), 0, NT * nks_w * 1024, 0x00020000);
+    const int wlane = lane * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_step = [&](int ks, bf16x8* a, bf16x8* bq) {
+        const i32x2 e = sTab[ks * 4 + lg];
+        const int wks = p.parity ? __builtin_amdgcn_readfirstlane(e.y >> 10) : ks;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            a[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane, (nt * nks_w + wks) * 1024, 0));
+        const int rb = e.y & 31, sb = (e.y >> 5) & 31;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned ok = (rowmask[mt] >> rb) & (colmask[mt] >> sb) & 1u;
+            const int off = ok ? pixoff[mt] + e.x : OOB;
+            bq[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+    };
+    auto mma_step = [&](const bf16x8* a, const bf16x8* bq) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bq[mt], acc[mt][nt], 0, 0, 0);
+    };
+
+    // register ring of D k-steps in flight (see conv_igemm.hip)
+    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+    bf16x8 A[D][NT], Bq[D][MT];
+    const int last = nks - 1;
+    if (nks > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_step(min(d, last), A[d], Bq[d]);
+    }
+    const int nfull = nks / D;
+    for (int r = 0; r < nfull; ++r) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            mma_step(A[d], Bq[d]);
+            load_step(min((r + 1) * D + d, last), A[d], Bq[d]);
+        }
+    }
+    const int rem = nks - nfull * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < rem) mma_step(A[d], Bq[d]);
+
+    // fused BatchNorm statistics of the bf16-rounded output
+    if (p.stats) {
+        __shared__ float sStat[4][2][NT * 16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float v = outoff[mt] != OOB ? bf2f(f2bf(acc[mt][nt][r])) : 0.f;
+                    a += v; b += v * v;
+                }
+                a = row_sum16(a); b = row_sum16(b);
+                if (li == 0) { sStat[wave][0][nt * 16 + lg * 4 + r] = a; sStat[wave][1][nt * 16 + lg * 4 + r] = b; }
+            }
+        __syncthreads();
+        if (t < 2 * NT * 16) {
+            const int which = t / (NT * 16), c = t - which * (NT * 16);
+            const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
+            const int cl = n0 + c;
+            if (cl < p.Cout_g)
+                atomicAdd(p.stats + ((size_t)(blockIdx.x % BN_NCOPY) * 2 + which) * p.Cout + g * p.Cout_g + cl, v);
+        }
+    }
+
+    // epilogue: lane holds couts n0 + nt*16 + lg*4 + {0..3} of its MT pixels (Cout_g % 4 == 0, checked by the host)
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cl = n0 + nt * 16 + lg * 4;
+        const bool cok = cl < p.Cout_g;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.Cout * 4, 0x00020000);
+            bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(br, cok ? (g * p.Cout_g + cl) * 4 : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v = acc[mt][nt] + bv;
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            const bool ok = cok && outoff[mt] != OOB;
+            if (p.out_fp32) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, ok ? outoff[mt] + cl * 4 : OOB, 0, 0);
+            } else {
+                i32x2 pk = {(int)f2bf_pk(v[0], v[1]), (int)f2bf_pk(v[2], v[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, yr, ok ? outoff[mt] + cl * 2 : OOB, 0, 0);
+            }
+        }
+    }
+}
+
+template <int MT, int NT>
+void launch_fast(const ConvP& p, hipStream_t st) {
+    long mblk = p.M;
+    int nz = p.groups;
+    if (p.parity) {
+        mblk = (long)p.B * ((p.OH + p.stride - 1) / p.stride) * ((p.OW + p.stride - 1) / p.stride);
+        nz *= p.stride * p.stride;
+    }
+    const dim3 grid((unsigned)((mblk + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)nz);
+    const size_t lds = (size_t)(p.Kp / 8) * sizeof(i32x2);
+    hipLaunchKernelGGL((conv_fast_kernel<MT, NT>), grid, dim3(256), lds, st, p);
+}
+
+const bool g_no_fast = getenv("DANET_CONV_NO_FAST") != nullptr;     // A-B timing knob
+
+}  // namespace
+
+namespace danet_conv {
+
+// Can the lean kernel run this problem?  (p fully populated by danet_conv_forward.)
+bool conv_fast_ok(const ConvP& p, bool vec8) {
+    if (g_no_fast || !vec8) return false;
+    if (p.transposed && p.stride > 1 && !p.parity) return false;
+    if (p.R > 30 || p.S > 26 || p.Cout_g % 4 != 0 || p.Cout % 4 != 0) return false;
+    if (p.M >= (1L << 24) || p.Kp >= (1 << 24)) return false;
+    if (p.x_bytes >= (1L << 31) || p.y_bytes >= (1L << 31)) return false;
+    if ((long)p.groups * p.Cout_pad * p.Kp * 2 >= (1L << 31)) return false;
+    if ((size_t)(p.Kp / 8) * 8 > 60 * 1024) return false;
+    return true;
+}
+
+int conv_fast_launch(const ConvP& p, int mt, int nt, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+#define FAST_CASE(M_, N_) if (mt == M_ && nt == N_) { launch_fast<M_, N_>(p, st); return 0; }
+    FAST_CASE(1, 1) FAST_CASE(2, 1) FAST_CASE(4, 1) FAST_CASE(1, 2) FAST_CASE(2, 2) FAST_CASE(4, 2)
+    FAST_CASE(1, 3) FAST_CASE(2, 3) FAST_CASE(4, 3) FAST_CASE(1, 4) FAST_CASE(2, 4) FAST_CASE(4, 4)
+#undef FAST_CASE
+    return -1;
+}
+
+}  // namespace danet_conv

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                 bf16_t* y = reinterpret_cast<bf16_t*>(p.y) + off;
                 if (vec_ok) {
                     uint2 pk;
-                    pk.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    pk.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    pk.x = f2bf_pk(v[0], v[1]);
+                    pk.y = f2bf_pk(v[2], v[3]);
                     *reinterpret_cast<uint2*>(y) = pk;
                 } else
 #pragma unroll
@@ -281,8 +281,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 // fragment-major (see the kernel).
 //  mode 0 (forward):  rows = cout within group, k = (r*S+s)*Cin_g + cin
 //  mode 1 (dgrad):    rows = cin  within group, k = (r*S+s)*Cout_g + cout   (used with the transposed gather)
+// With chunk > 0 (conv3x3_lds.hip) the K order is (channel chunk, tap, channel within chunk) and every chunk is
+// zero-padded to KpC = roundup(R*S*chunk, 32).
+__device__ inline bool pack_decode(int k, int inner, int RS, int chunk, int& tap, int& ch) {
+    if (chunk <= 0) { tap = k / inner; ch = k - tap * inner; return k < RS * inner; }
+    const int KpC = (RS * chunk + 31) / 32 * 32;
+    const int ci = k / KpC, kk = k - ci * KpC;
+    tap = kk / chunk; ch = ci * chunk + (kk - tap * chunk);
+    return tap < RS;
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp,
-                                    int Cout_g, int Cin_g, int R, int S, int G, int rows_pad, int Kp, int mode)
+                                    int Cout_g, int Cin_g, int R, int S, int G, int rows_pad, int Kp, int mode, int chunk)
 {
     const long total = (long)G * rows_pad * Kp;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,8 +303,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
     const int inner = mode == 0 ? Cin_g : Cout_g;      // channels folded into K
     const int rows = mode == 0 ? Cout_g : Cin_g;
     float v = 0.f;
-    if (row < rows && k < R * S * inner) {
-        const int tap = k / inner, ch = k - tap * inner;
+    int tap, ch;
+    if (pack_decode(k, inner, R * S, chunk, tap, ch) && row < rows) {
         const int r = tap / S, s = tap - r * S;
         const int cout = mode == 0 ? row : ch, cin = mode == 0 ? ch : row;
         v = w[(((size_t)(g * Cout_g + cout) * Cin_g + cin) * R + r) * S + s];
@@ -308,7 +318,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
 // the job whose [start, start + total) range holds it (binary search over the table).
 struct PackJob {
     const float* w; bf16_t* wp; long start;
-    int Cout_g, Cin_g, R, S, G, rows_pad, Kp, mode;
+    int Cout_g, Cin_g, R, S, G, rows_pad, Kp, mode, chunk;
 };
 
 __global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs, long total_all)
@@ -337,18 +347,17 @@ __global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, in
     const int row = (int)(rest % j.rows_pad), g = (int)(rest / j.rows_pad);
     const int inner = j.mode == 0 ? j.Cin_g : j.Cout_g;
     const int rows = j.mode == 0 ? j.Cout_g : j.Cin_g;
-    const int RS = j.R * j.S, Kreal = RS * inner;
-    int tap = k0 / inner, ch = k0 - tap * inner;
+    const int RS = j.R * j.S;
     union { bf16_t h[8]; int4 v; } o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = 0.f;
-        if (row < rows && k0 + e < Kreal) {
+        int tap, ch;
+        if (pack_decode(k0 + e, inner, RS, j.chunk, tap, ch) && row < rows) {
             const int cout = j.mode == 0 ? row : ch, cin = j.mode == 0 ? ch : row;
             v = j.w[((size_t)(g * j.Cout_g + cout) * j.Cin_g + cin) * RS + tap];
         }
         o.h[e] = f2bf(v);
-        if (++ch == inner) { ch = 0; ++tap; }
     }
     const size_t dst = (((((size_t)g * (j.rows_pad / 16) + row / 16) * (j.Kp / 32) + k0 / 32) * 4 + (k0 % 32) / 8) * 16 + row % 16) * 8;
     *reinterpret_cast<int4*>(j.wp + dst) = o.v;
@@ -395,28 +404,34 @@ extern "C" int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, in
     return mt * 100 + nt * 10 + vec8;
 }
 
-extern "C" size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode) {
+// K extent of the packed operand: unchunked roundup(R*S*inner, 32); chunked (inner/chunk) * roundup(R*S*chunk, 32)
+static int packed_kp(int R, int S, int inner, int chunk) {
+    if (chunk <= 0) return (R * S * inner + 31) / 32 * 32;
+    return (inner / chunk) * ((R * S * chunk + 31) / 32 * 32);
+}
+
+extern "C" size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode, int chunk) {
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
     const int nt = danet_conv_nt(rows);
     const int rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
-    const int Kp = (R * S * inner + 31) / 32 * 32;
-    return (size_t)groups * rows_pad * Kp;
+    return (size_t)groups * rows_pad * packed_kp(R, S, inner, chunk);
 }
 
 extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
-                                       int mode, void* stream)
+                                       int mode, int chunk, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(w && wp && Cout > 0 && Cin_g > 0 && R > 0 && S > 0 && groups > 0 && Cout % groups == 0 && (mode == 0 || mode == 1),
                     "conv_pack_weights: bad arguments");
     const int Cout_g = Cout / groups;
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
+    DANET_CHECK_ARG(chunk >= 0 && (chunk == 0 || inner % chunk == 0), "conv_pack_weights: chunk %d does not divide %d channels", chunk, inner);
     const int nt = danet_conv_nt(rows);
     const int rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
-    const int Kp = (R * S * inner + 31) / 32 * 32;
+    const int Kp = packed_kp(R, S, inner, chunk);
     const long total = (long)groups * rows_pad * Kp;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       (bf16_t*)wp, Cout_g, Cin_g, R, S, groups, rows_pad, Kp, mode);
+                       (bf16_t*)wp, Cout_g, Cin_g, R, S, groups, rows_pad, Kp, mode, chunk);
     DANET_CHECK_LAUNCH("pack_weights_kernel");
     return DANET_OK;
 }
@@ -427,9 +442,9 @@ extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int C
 extern "C" size_t danet_conv_pack_job_bytes(void) { return sizeof(PackJob); }
 
 extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
-                                         int Cout, int Cin_g, int R, int S, int groups, int mode)
+                                         int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk)
 {
-    if (!job_host || groups <= 0 || Cout % groups != 0) return -1;
+    if (!job_host || groups <= 0 || Cout % groups != 0 || chunk < 0) return -1;
     PackJob* j = (PackJob*)job_host;
     const int Cout_g = Cout / groups;
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
@@ -437,7 +452,9 @@ extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* w
     j->w = w; j->wp = (bf16_t*)wp; j->start = start;
     j->Cout_g = Cout_g; j->Cin_g = Cin_g; j->R = R; j->S = S; j->G = groups; j->mode = mode;
     j->rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
-    j->Kp = (R * S * inner + 31) / 32 * 32;
+    if (chunk > 0 && inner % chunk != 0) return -1;
+    j->chunk = chunk;
+    j->Kp = packed_kp(R, S, inner, chunk);
     return (long)groups * j->rows_pad * j->Kp;
 }
 
@@ -484,6 +501,13 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
+    p.x_bytes = (long)B * H * W * Cin * 2;
+    p.y_bytes = p.M * Cout * (out_fp32 ? 4 : 2);
+    if (conv_fast_ok(p, vec8)) {
+        if (conv_fast_launch(p, mt, nt, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no fast kernel for tiles %dx%d", mt, nt);
+        DANET_CHECK_LAUNCH("conv_fast_kernel");
+        return DANET_OK;
+    }
 #define CONV_CASE(M_, N_) if (mt == M_ && nt == N_) launch_conv<M_, N_>(p, vec8, st); else
     CONV_CASE(1, 1) CONV_CASE(2, 1) CONV_CASE(4, 1) CONV_CASE(1, 2) CONV_CASE(2, 2) CONV_CASE(4, 2)
     CONV_CASE(1, 3) CONV_CASE(2, 3) CONV_CASE(4, 3) CONV_CASE(1, 4) CONV_CASE(2, 4) CONV_CASE(4, 4)

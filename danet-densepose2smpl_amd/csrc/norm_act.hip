@@ -34,8 +34,8 @@ __device__ inline Vec load_bf(const bf16_t* p) {
 }
 __device__ inline void store_bf(bf16_t* p, const Vec& a) {
     uint2 r;
-    r.x = f2bf(a.v[0]) | ((unsigned)f2bf(a.v[1]) << 16);
-    r.y = f2bf(a.v[2]) | ((unsigned)f2bf(a.v[3]) << 16);
+    r.x = f2bf_pk(a.v[0], a.v[1]);
+    r.y = f2bf_pk(a.v[2], a.v[3]);
     *reinterpret_cast<uint2*>(p) = r;
 }
 

@@ -35,8 +35,8 @@ __device__ inline V8 load8(const bf16_t* p) {
 }
 __device__ inline void store8(bf16_t* p, const V8& a) {
     uint4 r;
-    r.x = f2bf(a.v[0]) | ((unsigned)f2bf(a.v[1]) << 16); r.y = f2bf(a.v[2]) | ((unsigned)f2bf(a.v[3]) << 16);
-    r.z = f2bf(a.v[4]) | ((unsigned)f2bf(a.v[5]) << 16); r.w = f2bf(a.v[6]) | ((unsigned)f2bf(a.v[7]) << 16);
+    r.x = f2bf_pk(a.v[0], a.v[1]); r.y = f2bf_pk(a.v[2], a.v[3]);
+    r.z = f2bf_pk(a.v[4], a.v[5]); r.w = f2bf_pk(a.v[6], a.v[7]);
     *reinterpret_cast<uint4*>(p) = r;
 }
 

@@ -137,6 +137,7 @@ class Trainer(object):
             if self.reducer is not None:
                 self.reducer.prepare()
             loss_total.backward()
+            _conv.join_wgrad_streams(self.device)
             if self.reducer is not None:
                 self.reducer.finish()
             self.optimizer.step()
@@ -164,11 +165,13 @@ class Trainer(object):
         graph = torch.cuda.CUDAGraph()
         from . import hrnet
         hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
+        conv.WGRAD_STREAMS = bool(int(os.environ.get('DANET_WGRAD_STREAMS', '0')))
         try:
             with torch.cuda.graph(graph, stream=self.stream):
                 self._static_out = self._eager_core(self._static, fused_opt)
         finally:
             hrnet.BRANCH_STREAMS = False
+            conv.WGRAD_STREAMS = False
         self._graph = graph
         self._graph_fused_opt = fused_opt
         return self
@@ -185,6 +188,7 @@ class Trainer(object):
         loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
         self.optimizer.zero_grad(set_to_none=True)
         loss_total.backward()
+        _conv.join_wgrad_streams(self.device)
         if with_optimizer:
             self.optimizer.step()
         return out, losses

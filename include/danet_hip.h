@@ -114,6 +114,12 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  *      mode 0: forward operand      [G][rows_pad][Kp], rows = cout, k = (r*S+s)*Cin_g + cin
  *      mode 1: data-gradient operand [G][rows_pad][Kp], rows = cin,  k = (r*S+s)*Cout_g + cout
  *      (danet_conv_packed_elems gives the element count; rows_pad = roundup(rows, 16*danet_conv_nt(rows)))
+ *      chunk > 0 (danet_conv3x3_forward only): K ordered (channel chunk, tap, channel in chunk), every
+ *      chunk zero-padded to a multiple of 32; chunk = 0 everywhere else.
+ *  danet_conv3x3_*          3x3/stride-1/pad-1 forward and data gradient with both MFMA operands staged in
+ *      LDS (halo tile + weight slices).  danet_conv3x3_ok says whether a layer qualifies,
+ *      danet_conv3x3_chunk the chunk its weights must be packed with (mode 0 forward; mode 1 + flip = 1
+ *      for the data gradient, where x = dY and Cin/Cout are swapped).
  *  danet_conv_forward       y = conv(x, wp) (+bias[Cout])(ReLU); y is bf16 or fp32 NHWC.
  *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
@@ -132,13 +138,18 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
 int danet_conv_nt(int rows_per_group);
 int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, int groups);   /* MT*100 + NT*10 + vec8 */
 int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups, int taps);            /* CT*100 + NI*10 + TG */
-size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode);
+size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode, int chunk);
 int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
-                            int mode, void* stream);
+                            int mode, int chunk, void* stream);
 size_t danet_conv_pack_job_bytes(void);
 long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
-                              int Cout, int Cin_g, int R, int S, int groups, int mode);
+                              int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
 int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream);
+int danet_conv3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+int danet_conv3x3_chunk(int B, int H, int W, int Cin, int Cout);
+int danet_conv3x3_kernel_id(int B, int H, int W, int Cin, int Cout);                  /* MT*10 + NT */
+int danet_conv3x3_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int Cout,
+                          int flip, float* bn_sums, void* stream);
 int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,

@@ -14,7 +14,7 @@ from danet_densepose2smpl_amd._lib import ptr, stream   # noqa: E402
 PEAK = 2.5e15
 SHAPES = [
     (48, 48, 3, 1, 1, 1, 64, 64), (96, 96, 3, 1, 1, 1, 32, 32), (192, 192, 3, 1, 1, 1, 16, 16),
-    (384, 384, 3, 1, 1, 1, 8, 8), (64, 64, 3, 1, 1, 1, 64, 64), (256, 48, 3, 1, 1, 1, 64, 64),
+    (384, 384, 3, 1, 1, 1, 8, 8), (64, 64, 3, 1, 1, 1, 64, 64), (256, 48, 3, 1, 1, 1, 64, 64), (64, 64, 3, 1, 1, 1, 16, 16),
     (64, 256, 1, 1, 0, 1, 64, 64), (48, 96, 3, 2, 1, 1, 64, 64), (48 * 24, 21 * 24, 3, 1, 1, 24, 64, 64),
 ]
 
@@ -36,11 +36,13 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     L = _lib.lib()
     only = sys.argv[2] if len(sys.argv) > 2 else ''
-    for (Cin, Cout, k, s, p, g, H, W) in SHAPES:
+    sel = os.environ.get('DANET_MB_SHAPES')
+    shapes = SHAPES if not sel else [SHAPES[int(i)] for i in sel.split(',')]
+    for (Cin, Cout, k, s, p, g, H, W) in shapes:
         OH, OW = conv.conv_out_size(H, k, s, p, 1), conv.conv_out_size(W, k, s, p, 1)
         flops = 2.0 * B * OH * OW * Cout * (Cin // g) * k * k
         x = conv.nhwc_bf16(torch.randn(B, Cin, H, W, device='cuda'))
-        w = torch.randn(Cout, Cin // g, k, k, device='cuda') * 0.05
+        w = torch.nn.Parameter(torch.randn(Cout, Cin // g, k, k, device='cuda') * 0.05)      # Parameter: packed once (cached)
         gy = conv.nhwc_bf16(torch.randn(B, Cout, OH, OW, device='cuda'))
         wp0, wp1 = conv.pack_weight(w, g, 0), conv.pack_weight(w, g, 1)
         res = {'shape': [Cin, Cout, k, s, p, g, H, W], 'B': B, 'GFLOP': flops / 1e9}
@@ -48,7 +50,19 @@ def main():
         res['fwd_us'] = t * 1e6; res['fwd_TF'] = flops / t / 1e12
         t = timeit(lambda: conv._conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, k, k, s, p, 1, g, True, False, False))
         res['dgrad_us'] = t * 1e6; res['dgrad_TF'] = flops / t / 1e12
-        gw = torch.empty_like(w)
+        if L.danet_conv3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
+            y_old = conv._conv_fwd_raw(x, wp0, None, B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g, False, False, False)
+            y_new = conv._conv3x3_raw(x, w, 1, B, H, W, Cin, Cout, False)
+            res['lds_fwd_maxdiff'] = float((y_new.float() - y_old.float()).abs().max() / (y_old.float().abs().max() + 1e-9))
+            t = timeit(lambda: conv._conv3x3_raw(x, w, 1, B, H, W, Cin, Cout, False))
+            res['lds_fwd_us'] = t * 1e6; res['lds_fwd_TF'] = flops / t / 1e12
+            g_old = conv._conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, k, k, s, p, 1, g, True, False, False)
+            g_new = conv._conv3x3_raw(gy, w, 1, B, H, W, Cout, Cin, True)
+            res['lds_dgrad_maxdiff'] = float((g_new.float() - g_old.float()).abs().max() / (g_old.float().abs().max() + 1e-9))
+            t = timeit(lambda: conv._conv3x3_raw(gy, w, 1, B, H, W, Cout, Cin, True))
+            res['lds_dgrad_us'] = t * 1e6; res['lds_dgrad_TF'] = flops / t / 1e12
+            res['lds_plan'] = [L.danet_conv3x3_kernel_id(B, H, W, Cin, Cout), L.danet_conv3x3_chunk(B, H, W, Cin, Cout)]
+        gw = torch.empty_like(w.data)
         nws = L.danet_conv_wgrad_ws_floats(Cout, Cin // g, k, k)
         ws = torch.empty(nws, device='cuda')
         xp, gyp = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
@@ -57,13 +71,13 @@ def main():
         if L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
             n3 = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, g)
             ws3 = torch.empty(n3, device='cuda')
-            gw3 = torch.empty_like(w)
+            gw3 = torch.empty_like(w.data)
             t = timeit(lambda: L.danet_conv_wgrad3x3(ptr(xp), ptr(gyp), ptr(gw3), ptr(ws3), n3, B, H, W, Cin, Cout, g, 0.0, stream()))
             res['wgrad3_us'] = t * 1e6; res['wgrad3_TF'] = flops / t / 1e12
             res['wgrad3_vs_old_maxrel'] = float((gw3 - gw).abs().max() / (gw.abs().max() + 1e-9))
         if only != 'nomiopen':
             xb = x.detach().clone().requires_grad_(True)
-            wb = w.bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wb = w.detach().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
             t = timeit(lambda: F.conv2d(xb, wb, None, s, p, 1, g))
             res['miopen_fwd_us'] = t * 1e6
             y = F.conv2d(xb, wb, None, s, p, 1, g)
