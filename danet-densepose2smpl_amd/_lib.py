@@ -50,6 +50,10 @@ _SIGNATURES = {
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
     'danet_stn_gather_backward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
+    'danet_part_clean_forward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
+    'danet_part_clean_backward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
+    'danet_part_loss_forward': (c_i, [c_f] * 5 + [c_i] * 4 + [c_f, c_f]),
+    'danet_part_loss_backward': (c_i, [c_f] * 6 + [c_i] * 4 + [c_f, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),

@@ -374,6 +374,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
     forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
     Cout = weight.shape[0]
+    if groups == 1 and x.shape[1] != weight.shape[1] and x.shape[1] == weight.shape[1] + (-weight.shape[1]) % 8:
+        # the producer already zero-padded the channels to a multiple of 8 (part_ops.part_clean): pad the weight only
+        weight = F.pad(weight, (0, 0, 0, 0, 0, x.shape[1] - weight.shape[1]))
     if groups == 1 and x.shape[1] % 8 != 0:
         padc = (-x.shape[1]) % 8
         x = _pad_channels_nhwc(x)

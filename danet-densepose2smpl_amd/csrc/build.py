@@ -24,6 +24,7 @@ UNITS = {
     'conv_wgrad3x3.hip': [],
     'conv3x3_lds.hip': [],
     'conv_fast.hip': [],
+    'part_ops.hip': [],
     'norm_act.hip': [],
     'stn.hip': [],
 }

@@ -40,25 +40,43 @@ __device__ inline void store_bf(bf16_t* p, const Vec& a) {
 }
 
 // Flat mapping: vector id v = blockIdx.x*span + t + k*gridspan, span = RY*CV (CV = C/VW).
-// Requires t < span; then v % CV == t % CV for every k.
-struct FlatMap { long nvec; long M; int CV; int span; long gridspan; int ldv; int coff; };
+// Requires t < span; then v % CV == t % CV for every k: a lane keeps its channel vector cv = t % CV and
+// walks rows row0, row0 + rstep, ...  All offsets are 32-bit byte offsets into buffer resources (the
+// host checks the tensors are < 2 GB): rows past the end get an out-of-range offset, for which the
+// hardware returns zeros on loads and drops stores -- no bounds branches in the loops.
+struct FlatMap { int M; int CV; int span; int rstep; int ldv; int coff; int bytes; };
 
-// A lane's vectors: fixed channel-vector cv = t % CV, rows row0, row0 + rstep, ... (no division in the loop)
-#define DANET_ROW_LOOP(fm, t)                                                                  \
-    const int cv_ = (t) % (fm).CV;                                                             \
-    const long rstep_ = (fm).gridspan / (fm).CV;                                               \
-    for (long row_ = ((long)blockIdx.x * (fm).span + (t)) / (fm).CV; row_ < (fm).M; row_ += rstep_)
-#define DANET_ROW_OFF(fm) (((size_t)row_ * (fm).ldv + (fm).coff + cv_) * VW)
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+constexpr int OOB = 0x7fffffff;
+constexpr int UNR = 4;       // rows per trip; the next trip's loads are issued before the current trip's stores
 
-// Unrolled variant: UNR rows per trip with all their loads issued before any use (these streams run at
-// one or two workgroups per CU, so independent loads in flight are what hides the HBM latency).
-constexpr int UNR = 4;
-#define DANET_ROW_LOOP_U(fm, t)                                                                \
-    const int cv_ = (t) % (fm).CV;                                                             \
-    const long rstep_ = (fm).gridspan / (fm).CV;                                               \
-    for (long row0_ = ((long)blockIdx.x * (fm).span + (t)) / (fm).CV; row0_ < (fm).M; row0_ += rstep_ * UNR)
-#define DANET_ROW_U(fm, u) (row0_ + (long)(u) * rstep_)
-#define DANET_OFF_U(fm, u) (((size_t)(DANET_ROW_U(fm, u) < (fm).M ? DANET_ROW_U(fm, u) : row0_) * (fm).ldv + (fm).coff + cv_) * VW)
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ inline Vec ldv(__amdgpu_buffer_rsrc_t r, int off) {
+    const i32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    Vec o;
+    o.v[0] = __uint_as_float((unsigned)q.x << 16); o.v[1] = __uint_as_float((unsigned)q.x & 0xffff0000u);
+    o.v[2] = __uint_as_float((unsigned)q.y << 16); o.v[3] = __uint_as_float((unsigned)q.y & 0xffff0000u);
+    return o;
+}
+__device__ inline void stv(__amdgpu_buffer_rsrc_t r, int off, const Vec& a) {
+    const i32x2 q = {(int)f2bf_pk(a.v[0], a.v[1]), (int)f2bf_pk(a.v[2], a.v[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, off, 0, 0);
+}
+
+struct RowIter {
+    int row, off, rstep, ostride, M;
+    __device__ inline void init(const FlatMap& fm, int t, int& cv) {
+        cv = t % fm.CV;
+        row = (blockIdx.x * fm.span + t) / fm.CV;
+        off = ((row * fm.ldv + fm.coff + cv) * VW) * 2;
+        rstep = fm.rstep; ostride = fm.rstep * fm.ldv * VW * 2; M = fm.M;
+    }
+    __device__ inline int offset(int u) const { return row + u * rstep < M ? off + u * ostride : OOB; }
+    __device__ inline bool more() const { return row < M; }
+    __device__ inline void next() { row += rstep * UNR; off += ostride * UNR; }
+};
 
 __device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int CV, int span, float* dst /* [C] */) {
     // sm: [256][VW]; lanes with equal (t % CV) are summed in a fixed order, then one atomic per channel
@@ -86,7 +104,7 @@ constexpr int SLAB = 1024;   // channels per launch (wider tensors are processed
 // 2*Cs sums are spread over the block's lanes, each issuing NCOPY independent loads (fixed order).
 __device__ inline void reduce_replicas(const float* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
     for (int i = t; i < 2 * Cs; i += 256) {
-        const int which = i / Cs, c = i - which * Cs;
+        const int which = i >= Cs ? 1 : 0, c = i - which * Cs;
         float v[NCOPY];
 #pragma unroll
         for (int r = 0; r < NCOPY; ++r) v[r] = rep[(size_t)r * 2 * Cst + (size_t)which * Cst + c];
@@ -106,16 +124,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < VW; ++j) { s.v[j] = 0.f; q.v[j] = 0.f; }
     if (t < fm.span) {
-        DANET_ROW_LOOP_U(fm, t) {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes);
+        int cv; RowIter it; it.init(fm, t, cv);
+        for (; it.more(); it.next()) {
             Vec a[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) a[u] = load_bf(x + DANET_OFF_U(fm, u));
+            for (int u = 0; u < UNR; ++u) a[u] = ldv(xr, it.offset(u));
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const float m = DANET_ROW_U(fm, u) < fm.M ? 1.f : 0.f;
+            for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                for (int j = 0; j < VW; ++j) { s.v[j] += m * a[u].v[j]; q.v[j] += m * a[u].v[j] * a[u].v[j]; }
-            }
+                for (int j = 0; j < VW; ++j) { s.v[j] += a[u].v[j]; q.v[j] += a[u].v[j] * a[u].v[j]; }
         }
     }
     float* dst = sums + (size_t)(blockIdx.x % NCOPY) * 2 * Cst;
@@ -133,9 +151,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const int t = threadIdx.x;
     const int C = Cst;
     __shared__ float sStat[2][SLAB];
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes), rr = make_rsrc(res ? res : x, fm.bytes), yr = make_rsrc(y, fm.bytes);
+    int cv = 0; RowIter it; it.init(fm, t < fm.span ? t : 0, cv);
+    Vec a[UNR], r[UNR];
+    int o[UNR];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { o[u] = it.offset(u); a[u] = ldv(xr, o[u]); }
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) r[u] = ldv(rr, o[u]);
+        }
+    };
+    if (t < fm.span) fetch();                       // first rows are in flight while the statistics are reduced
     if (mode == 0) reduce_replicas(sums, C, fm.CV * VW, t, sStat);
     if (t >= fm.span) return;
-    const int c0 = (t % fm.CV) * VW;
+    const int c0 = cv * VW;
     float sc[VW], sh[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
@@ -159,25 +190,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
             }
         }
     }
-    DANET_ROW_LOOP_U(fm, t) {
-        Vec a[UNR], r[UNR];
-        size_t off[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) { off[u] = DANET_OFF_U(fm, u); a[u] = load_bf(x + off[u]); }
-        if (res) {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) r[u] = load_bf(res + off[u]);
-        }
+    while (it.more()) {
+        Vec outv[UNR];
+        int oo[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
+            oo[u] = o[u];
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
                 float v = a[u].v[j] * sc[j] + sh[j];
                 if (res) v += r[u].v[j];
-                a[u].v[j] = relu ? fmaxf(v, 0.f) : v;
+                outv[u].v[j] = relu ? fmaxf(v, 0.f) : v;
             }
-            if (DANET_ROW_U(fm, u) < fm.M) store_bf(y + off[u], a[u]);
         }
+        it.next();
+        if (it.more()) fetch();
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) stv(yr, oo[u], outv[u]);
     }
 }
 
@@ -192,28 +221,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
     for (int j = 0; j < VW; ++j) { s1.v[j] = 0.f; s2.v[j] = 0.f; }
     if (t < fm.span) {
-        const int c0 = (t % fm.CV) * VW;
+        const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(relu ? y : x, fm.bytes);
+        int cv; RowIter it; it.init(fm, t, cv);
+        const int c0 = cv * VW;
         float mean[VW], invstd[VW];
 #pragma unroll
         for (int j = 0; j < VW; ++j) { mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j]; }
-        DANET_ROW_LOOP_U(fm, t) {
+        for (; it.more(); it.next()) {
             Vec g[UNR], a[UNR], o[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const size_t off = DANET_OFF_U(fm, u);
-                g[u] = load_bf(dy + off);
-                a[u] = load_bf(x + off);
-                if (relu) o[u] = load_bf(y + off);
+                const int off = it.offset(u);
+                g[u] = ldv(gr, off);
+                a[u] = ldv(xr, off);
+                if (relu) o[u] = ldv(yr, off);
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const bool live = DANET_ROW_U(fm, u) < fm.M;
+            for (int u = 0; u < UNR; ++u)
 #pragma unroll
                 for (int j = 0; j < VW; ++j) {
-                    const float gv = (live && (!relu || o[u].v[j] > 0.f)) ? g[u].v[j] : 0.f;
+                    const float gv = (!relu || o[u].v[j] > 0.f) ? g[u].v[j] : 0.f;        // rows past the end load dy = 0
                     s1.v[j] += gv; s2.v[j] += gv * (a[u].v[j] - mean[j]) * invstd[j];
                 }
-            }
         }
     }
     float* dst = red + (size_t)(blockIdx.x % NCOPY) * 2 * C;
@@ -229,9 +258,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const int t = threadIdx.x;
     const int C = Cst;
     __shared__ float sStat[2][SLAB];
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(relu ? y : x, fm.bytes);
+    const __amdgpu_buffer_rsrc_t dxr = make_rsrc(dx, fm.bytes), drr = make_rsrc(dres ? dres : dx, fm.bytes);
+    int cv = 0; RowIter it; it.init(fm, t < fm.span ? t : 0, cv);
+    Vec g[UNR], a[UNR], o[UNR];
+    int of[UNR];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            of[u] = it.offset(u);
+            g[u] = ldv(gr, of[u]);
+            a[u] = ldv(xr, of[u]);
+            if (relu) o[u] = ldv(yr, of[u]);
+        }
+    };
+    if (t < fm.span) fetch();
     reduce_replicas(red, C, fm.CV * VW, t, sStat);
     if (t >= fm.span) return;
-    const int c0 = (t % fm.CV) * VW;
+    const int c0 = cv * VW;
     float mean[VW], invstd[VW], k0[VW], m1[VW], m2[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
@@ -241,27 +285,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         m1[j] = s0 * inv_count; m2[j] = s1 * inv_count;
         if (blockIdx.x == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
     }
-    DANET_ROW_LOOP_U(fm, t) {
-        Vec g[UNR], a[UNR], o[UNR];
-        size_t off[UNR];
+    while (it.more()) {
+        Vec d[UNR], gm[UNR];
+        int oo[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            off[u] = DANET_OFF_U(fm, u);
-            g[u] = load_bf(dy + off[u]);
-            a[u] = load_bf(x + off[u]);
-            if (relu) o[u] = load_bf(y + off[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (!(DANET_ROW_U(fm, u) < fm.M)) continue;
-            Vec d;
+            oo[u] = of[u];
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
-                if (relu) g[u].v[j] = o[u].v[j] > 0.f ? g[u].v[j] : 0.f;
-                d.v[j] = k0[j] * (g[u].v[j] - m1[j] - (a[u].v[j] - mean[j]) * invstd[j] * m2[j]);
+                const float gv = (!relu || o[u].v[j] > 0.f) ? g[u].v[j] : 0.f;
+                gm[u].v[j] = gv;
+                d[u].v[j] = k0[j] * (gv - m1[j] - (a[u].v[j] - mean[j]) * invstd[j] * m2[j]);
             }
-            if (dres) store_bf(dres + off[u], g[u]);
-            store_bf(dx + off[u], d);
+        }
+        it.next();
+        if (it.more()) fetch();
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (dres) stv(drr, oo[u], gm[u]);
+            stv(dxr, oo[u], d[u]);
         }
     }
 }
@@ -336,17 +378,19 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const bf16_t* __restr
 // slab [c_begin, c_begin + Cs) of a [M, C] tensor; Cs <= 1024
 inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* grid) {
     if (C % VW != 0 || Cs % VW != 0 || c_begin % VW != 0 || Cs / VW > 256) return -1;
+    if (M * C * 2 >= (1LL << 31) - (64 << 20)) return -1;          // 32-bit byte offsets
     fm->CV = Cs / VW;
     fm->ldv = C / VW;
     fm->coff = c_begin / VW;
-    fm->nvec = M * fm->CV;
-    fm->M = M;
+    fm->M = (int)M;
+    fm->bytes = (int)(M * C * 2);
     fm->span = (256 / fm->CV) * fm->CV;
-    long blocks = (fm->nvec + fm->span - 1) / fm->span;
+    const long nvec = M * fm->CV;
+    long blocks = (nvec + fm->span - 1) / fm->span;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     *grid = (int)blocks;
-    fm->gridspan = (long)fm->span * blocks;
+    fm->rstep = (int)((long)fm->span * blocks / fm->CV);
     return 0;
 }
 
@@ -369,7 +413,7 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;
-        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_forward: C=%d unsupported", C);
+        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_forward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         // per-slab views of the per-channel buffers: [2][C] buffers are addressed as base+c0 with stride C
         if (training && ws_is_zero != 2) {          // ws_is_zero == 2: the statistics were accumulated by the conv epilogue
             hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, fm, sums_ws + c0, C);
@@ -402,7 +446,7 @@ extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, i
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;
-        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d unsupported", C);
+        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
                            fm, saved + c0, C, relu, red_ws + c0);
         DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");

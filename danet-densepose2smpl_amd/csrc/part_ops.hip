@@ -1,0 +1,278 @@
+// Fused element-wise work of the partial-IUV ("limb") path: everything between the grouped
+// predict_partial_iuv convolution and the limb regressor's first convolution, and the three
+// partial-IUV losses.  The reference does this on [B,24,3,7,H,W] fp32 tensors with ~40 tensor ops
+// (/root/reference/models/danet/danet.py:264-283 part drop + iuvmap_clean per part;
+//  /root/reference/models/danet/iuv_estimator.py:206-246 part_iuv_simp + affine_grid + grid_sample of
+//  the ground truth + body_uv_losses per part): 264 MB per intermediate at the benchmark size.
+// Here one thread owns one (pixel, joint) pair -- 21 prediction channels -- and nothing but the
+// prediction itself (NHWC bf16 [B,H,W,24*21], channel = (joint*3 + {u,v,index})*7 + class) and the
+// 3-channel ground-truth IUV image is read.
+//
+//   part_clean        x24[b*24+j, h, w, 0:21] = iuvmap_clean(keep * pred) as bf16 NHWC, channels 21..23 = 0
+//                     (24-channel layout = the zero-padded operand the limb regressor's 1x1 conv reads)
+//   part_clean_bwd    d pred = onehot * keep * d x24 (U, V channels; the index channels get no gradient)
+//   part_loss         sums of: smooth-L1(U), smooth-L1(V) over foreground classes, index cross-entropy,
+//                     against the ground truth resampled by the joint's affine theta
+//   part_loss_bwd     d pred for the three sums, scaled by three device-side factors
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using namespace danet_conv;
+
+constexpr int NJ = 24, NC = 7, PCH = NJ * 3 * NC;     // joints, classes per joint map, prediction channels (504)
+constexpr int NREP = 32;
+
+__device__ inline float norm_coord(int o, int n, int align) {
+    return align ? (n > 1 ? -1.0f + 2.0f * (float)o / (float)(n - 1) : 0.0f) : (2.0f * (float)o + 1.0f) / (float)n - 1.0f;
+}
+__device__ inline float unnorm_coord(float g, int n, int align) {
+    return align ? (g + 1.0f) * 0.5f * (float)(n - 1) : ((g + 1.0f) * (float)n - 1.0f) * 0.5f;
+}
+
+struct Pred { float u[NC], v[NC], ix[NC]; };
+
+__device__ inline Pred load_pred(const bf16_t* __restrict__ src) {
+    Pred p;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { p.u[c] = bf2f(src[c]); p.v[c] = bf2f(src[NC + c]); p.ix[c] = bf2f(src[2 * NC + c]); }
+    return p;
+}
+
+__device__ inline int argmax7(const float* x) {          // first maximum, like torch.argmax
+    int am = 0; float best = x[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) if (x[c] > best) { best = x[c]; am = c; }
+    return am;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void part_clean_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ keep,
+                                                         int B, int HW, bf16_t* __restrict__ x24)
+{
+    const long total = (long)B * HW * NJ;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % NJ);
+    const long pix = i / NJ;
+    const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
+    Pred p = load_pred(pred + pix * PCH + j * 3 * NC);
+    float k[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) k[c] = keep ? keep[((size_t)b * NJ + j) * NC + c] : 1.f;
+    float sx[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sx[c] = p.ix[c] * k[c];
+    const int am = argmax7(sx);
+    float o[24];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        o[c] = c == am ? p.u[c] * k[c] : 0.f;
+        o[NC + c] = c == am ? p.v[c] * k[c] : 0.f;
+        o[2 * NC + c] = c == am ? 1.f : 0.f;
+    }
+    o[21] = o[22] = o[23] = 0.f;
+    uint4* dst = reinterpret_cast<uint4*>(x24 + (((size_t)b * NJ + j) * HW + hw) * 24);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint4 r;
+        r.x = f2bf_pk(o[q * 8 + 0], o[q * 8 + 1]); r.y = f2bf_pk(o[q * 8 + 2], o[q * 8 + 3]);
+        r.z = f2bf_pk(o[q * 8 + 4], o[q * 8 + 5]); r.w = f2bf_pk(o[q * 8 + 6], o[q * 8 + 7]);
+        dst[q] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void part_clean_bwd_kernel(const bf16_t* __restrict__ g24, const bf16_t* __restrict__ pred,
+                                                             const float* __restrict__ keep, int B, int HW, bf16_t* __restrict__ gpred)
+{
+    const long total = (long)B * HW * NJ;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % NJ);
+    const long pix = i / NJ;
+    const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
+    const bf16_t* src = pred + pix * PCH + j * 3 * NC;
+    float k[NC], sx[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { k[c] = keep ? keep[((size_t)b * NJ + j) * NC + c] : 1.f; sx[c] = bf2f(src[2 * NC + c]) * k[c]; }
+    const int am = argmax7(sx);
+    const bf16_t* g = g24 + (((size_t)b * NJ + j) * HW + hw) * 24;
+    const float gu = bf2f(g[am]) * k[am], gv = bf2f(g[NC + am]) * k[am];
+    bf16_t* dst = gpred + pix * PCH + j * 3 * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        dst[c] = c == am ? f2bf(gu) : (bf16_t)0;
+        dst[NC + c] = c == am ? f2bf(gv) : (bf16_t)0;
+        dst[2 * NC + c] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ground truth of joint j at output pixel (oh, ow): bilinear resampling (zero padding) of the 7-class
+// simplified maps built from the IUV image (class 0 = none of the joint's 6 DensePose parts).
+struct Gt { float I[NC], U[NC], V[NC]; };
+
+__device__ inline Gt part_gt(const float* __restrict__ img /* [3][H][W] of sample b */, const float* __restrict__ th /* [2][3] */,
+                             const int* __restrict__ sel /* [6] */, int H, int W, int oh, int ow, int align)
+{
+    Gt g;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { g.I[c] = 0.f; g.U[c] = 0.f; g.V[c] = 0.f; }
+    const float xn = norm_coord(ow, W, align), yn = norm_coord(oh, H, align);
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    const float ix = unnorm_coord(gx, W, align), iy = unnorm_coord(gy, H, align);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy;
+    int s[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s[c] = sel[c];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int xx = x0 + (n & 1), yy = y0 + (n >> 1);
+        if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H) continue;
+        const float wgt = ((n & 1) ? wx1 : 1.f - wx1) * ((n >> 1) ? wy1 : 1.f - wy1);
+        const size_t o = (size_t)yy * W + xx;
+        const float i0 = img[o];
+        int part = (int)rintf(i0 * 24.f);
+        part = part < 0 ? 0 : (part > 24 ? 24 : part);
+        const float uval = img[(size_t)H * W + o], vval = img[2 * (size_t)H * W + o];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (s[c] == part) { any = true; g.I[c + 1] += wgt; g.U[c + 1] += wgt * uval; g.V[c + 1] += wgt * vval; }
+        if (!any) g.I[0] += wgt;
+    }
+    return g;
+}
+
+__device__ inline float smooth_l1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
+
+__global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
+                                                        const float* __restrict__ theta, const float* __restrict__ wsample,
+                                                        const int* __restrict__ sel, int B, int H, int W, int align,
+                                                        float* __restrict__ sums /* [NREP][3] */)
+{
+    const int HW = H * W;
+    const long total = (long)B * HW * NJ;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float lu = 0.f, lv = 0.f, li = 0.f;
+    if (i < total) {
+        const int j = (int)(i % NJ);
+        const long pix = i / NJ;
+        const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
+        const float w = wsample ? wsample[b] : 1.f;
+        const Pred p = load_pred(pred + pix * PCH + j * 3 * NC);
+        const Gt g = part_gt(img + (size_t)b * 3 * HW, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float fg = g.I[c] > 0.f ? w : 0.f;
+            lu += smooth_l1(p.u[c] - g.U[c]) * fg;
+            lv += smooth_l1(p.v[c] - g.V[c]) * fg;
+        }
+        const int tgt = argmax7(g.I);
+        float mx = p.ix[0];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) mx = fmaxf(mx, p.ix[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) se += expf(p.ix[c] - mx);
+        li = (logf(se) + mx - p.ix[tgt]) * w;
+    }
+    __shared__ float red[3][4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lu += __shfl_xor(lu, o); lv += __shfl_xor(lv, o); li += __shfl_xor(li, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = lu; red[1][wave] = lv; red[2][wave] = li; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float s = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        atomicAdd(sums + (blockIdx.x % NREP) * 3 + threadIdx.x, s);
+    }
+}
+
+__global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
+                                                            const float* __restrict__ theta, const float* __restrict__ wsample,
+                                                            const int* __restrict__ sel, const float* __restrict__ scale /* [3] */,
+                                                            int B, int H, int W, int align, bf16_t* __restrict__ gpred)
+{
+    const int HW = H * W;
+    const long total = (long)B * HW * NJ;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % NJ);
+    const long pix = i / NJ;
+    const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
+    const float w = wsample ? wsample[b] : 1.f;
+    const float su = scale[0], sv = scale[1], si = scale[2];
+    const Pred p = load_pred(pred + pix * PCH + j * 3 * NC);
+    const Gt g = part_gt(img + (size_t)b * 3 * HW, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
+    const int tgt = argmax7(g.I);
+    float mx = p.ix[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, p.ix[c]);
+    float ex[NC], se = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ex[c] = expf(p.ix[c] - mx); se += ex[c]; }
+    const float inv = 1.f / se;
+    bf16_t* dst = gpred + pix * PCH + j * 3 * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float fg = g.I[c] > 0.f ? w : 0.f;
+        const float du = fminf(fmaxf(p.u[c] - g.U[c], -1.f), 1.f), dv = fminf(fmaxf(p.v[c] - g.V[c], -1.f), 1.f);
+        dst[c] = f2bf(su * fg * du);
+        dst[NC + c] = f2bf(sv * fg * dv);
+        dst[2 * NC + c] = f2bf(si * w * (ex[c] * inv - (c == tgt ? 1.f : 0.f)));
+    }
+}
+
+}  // namespace
+
+extern "C" int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, void* x24, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(pred && x24 && B > 0 && H > 0 && W > 0, "part_clean_forward: bad arguments");
+    const long total = (long)B * H * W * NJ;
+    hipLaunchKernelGGL(part_clean_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, keep, B, H * W, (bf16_t*)x24);
+    DANET_CHECK_LAUNCH("part_clean_kernel");
+    return DANET_OK;
+}
+
+extern "C" int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, void* gpred, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(g24 && pred && gpred && B > 0 && H > 0 && W > 0, "part_clean_backward: bad arguments");
+    const long total = (long)B * H * W * NJ;
+    hipLaunchKernelGGL(part_clean_bwd_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)g24, (const bf16_t*)pred, keep, B, H * W, (bf16_t*)gpred);
+    DANET_CHECK_LAUNCH("part_clean_bwd_kernel");
+    return DANET_OK;
+}
+
+// sums: [32][3] floats, zeroed by the caller; the loss terms are the column sums.
+extern "C" int danet_part_loss_forward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
+                                       const int* sel, int B, int H, int W, int align, float* sums, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(pred && iuv_img && theta && sel && sums && B > 0 && H > 0 && W > 0, "part_loss_forward: bad arguments");
+    const long total = (long)B * H * W * NJ;
+    hipLaunchKernelGGL(part_loss_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, B, H, W, align, sums);
+    DANET_CHECK_LAUNCH("part_loss_kernel");
+    return DANET_OK;
+}
+
+extern "C" int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
+                                        const int* sel, const float* scale, int B, int H, int W, int align, void* gpred, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(pred && iuv_img && theta && sel && scale && gpred && B > 0 && H > 0 && W > 0, "part_loss_backward: bad arguments");
+    const long total = (long)B * H * W * NJ;
+    hipLaunchKernelGGL(part_loss_bwd_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, (bf16_t*)gpred);
+    DANET_CHECK_LAUNCH("part_loss_bwd_kernel");
+    return DANET_OK;
+}

@@ -9,6 +9,9 @@ from .config import cfg
 from .geometry import batch_rodrigues
 from .iuv_estimator import IUV_Estimator, DP2SMPL_MAPPING
 from .iuvmap import iuvmap_clean
+from . import part_ops
+
+FUSED_PART_OPS = True       # part drop + per-part iuvmap_clean in one HIP kernel (False: the tensor-op formulation)
 from .renderer import IUV_Renderer
 from .smpl_regressor import SMPL_Regressor
 
@@ -105,11 +108,17 @@ class DaNet(nn.Module):
         if not in_dict.get('pretrain_mode', False):
             iuv_map = torch.cat([u_cl, v_cl, i_cl], dim=1)
             part_pred = uv['part_iuv_pred']
+            pk = None
             if keep is not None:                                              # danet.py:264-274
                 keep25f = torch.cat([torch.ones(B, 1, device=image.device), keep], dim=1)
                 pk = keep25f[:, self._partial_src]                           # [B,24,7]
-                part_pred = part_pred * pk.view(B, 24, 1, 7, 1, 1)
-            part_iuv_map = self._clean_partial(part_pred)
+            if FUSED_PART_OPS and part_pred.is_cuda:
+                part_iuv_map, x24 = part_ops.part_clean(part_pred, pk)        # one kernel; bf16 view of the padded operand
+                part_iuv_map._nhwc_padded = x24
+            else:
+                if pk is not None:
+                    part_pred = part_pred * pk.view(B, 24, 1, 7, 1, 1)
+                part_iuv_map = self._clean_partial(part_pred)
             rd['visualization']['part_iuv_pred'] = part_iuv_map
             smpl_rd = self.iuv2smpl({'iuv_map': iuv_map, 'part_iuv_map': part_iuv_map, 'target': target,
                                      'target_kps': target_kps, 'target_verts': target_verts, 'target_kps3d': target_kps3d,

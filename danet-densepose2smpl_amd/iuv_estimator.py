@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import cfg
+from . import part_ops
 from .geometry import softmax_integral_tensor
 from .hrnet import PoseHighResolutionNet
 from .iuvmap import iuv_img2map, iuvmap_clean
@@ -27,6 +28,8 @@ SMPL_CHILDREN = [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 10, 11, 15, 16, 17, 15, 18, 19
 SMPL2DP_PART = [[1, 2], [8, 10], [7, 9], [1, 2], [8, 10, 12, 14], [7, 9, 11, 13], [1, 2], [12, 14, 5], [11, 13, 6],
                 [1, 2], [12, 14, 5], [11, 13, 6], [1, 2, 23, 24], [15, 17], [16, 18], [23, 24], [15, 17], [16, 18],
                 [15, 17, 19, 21], [16, 18, 20, 22], [19, 21, 4], [20, 22, 3], [19, 21, 4], [20, 22, 3]]
+FUSED_PART_LOSSES = True    # partial-IUV losses through csrc/part_ops.hip (False: the tensor-op formulation)
+
 DP2SMPL_MAPPING = [[7, 8, 9, 10, 1, 2], [1, 2, 8, 10, 12, 14], [1, 2, 7, 9, 11, 13], [7, 8, 9, 10, 1, 2],
                    [1, 2, 8, 10, 12, 14], [1, 2, 7, 9, 11, 13], [7, 8, 9, 10, 1, 2], [8, 10, 12, 14, 5, 5],
                    [7, 9, 11, 13, 6, 6], [7, 8, 9, 10, 1, 2], [8, 10, 12, 14, 5, 5], [7, 9, 11, 13, 6, 6],
@@ -225,7 +228,19 @@ class IUV_Estimator(nn.Module):
         Sp = part_pred.size(-1)
         part_pred = part_pred.reshape(part_pred.size(0), 24, 3, -1, Sp, Sp)              # [B,24,3,7,H,W]
 
-        if self.training and iuv_image_gt is not None:
+        if self.training and iuv_image_gt is not None and FUSED_PART_LOSSES and part_pred.is_cuda and \
+                tuple(iuv_image_gt.shape[-2:]) == (Sp, Sp):
+            # one kernel: ground-truth resampling + the three losses (no [B,24,3,7,H,W] fp32 intermediates);
+            # rd['part_iuv_gt'] (visualisation only in the reference) is not materialised on this path
+            B = part_pred.shape[0]
+            w = None if has_iuv is None else has_iuv.to(torch.float32)
+            sums = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align)
+            wsum = torch.tensor(float(B), device=sums.device) if w is None else w.sum().clamp(min=1.0)
+            lU = sums[0] / B * cfg.DANET.POINT_REGRESSION_WEIGHTS
+            lV = sums[1] / B * cfg.DANET.POINT_REGRESSION_WEIGHTS
+            lI = sums[2] / (wsum * (24 * Sp * Sp))
+            rd['losses'].update({'loss_pU': lU / 24., 'loss_pV': lV / 24., 'loss_pIndexUV': lI})
+        elif self.training and iuv_image_gt is not None:
             simp = self.part_iuv_simp(*uvia_list[:3])                                    # [B,24,3,7,H,W]
             B = simp.shape[0]
             flat = simp.reshape(B * 24, 21, Sp, Sp)

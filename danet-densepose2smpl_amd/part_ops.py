@@ -1,0 +1,93 @@
+"""Fused partial-IUV ("limb") element-wise path on HIP kernels (csrc/part_ops.hip).
+
+`part_clean`  = part drop + iuvmap_clean of the 24 partial maps (/root/reference/models/danet/danet.py:264-283)
+                producing directly the zero-padded 24-channel NHWC bf16 operand of the limb regressor's first conv.
+`part_losses` = part_iuv_simp + affine_grid/grid_sample of the ground truth + body_uv_losses summed over the
+                24 joints (/root/reference/models/danet/iuv_estimator.py:206-246), as three raw sums.
+Both take the grouped conv's output [B, 24*21, H, W] (bf16, channels_last) as it is.
+"""
+import torch
+
+from . import _lib
+from ._lib import ptr, check, stream
+from .conv import nhwc_bf16, ARENA
+
+NJ, NC = 24, 7
+
+
+class PartCleanFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, keep):
+        pred = nhwc_bf16(pred)
+        B, C, H, W = pred.shape
+        if C != NJ * 3 * NC:
+            raise ValueError('part_clean: expected %d channels, got %d' % (NJ * 3 * NC, C))
+        k = None if keep is None else keep.detach().to(torch.float32).contiguous()
+        x24 = torch.empty(B * NJ, H, W, 24, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
+        check(_lib.lib().danet_part_clean_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, ptr(x24.permute(0, 2, 3, 1)), stream()),
+              'danet_part_clean_forward')
+        ctx.save_for_backward(pred, k)
+        return x24
+
+    @staticmethod
+    def backward(ctx, g24):
+        pred, k = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        g24 = nhwc_bf16(g24)
+        gp = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
+        check(_lib.lib().danet_part_clean_backward(ptr(g24.permute(0, 2, 3, 1)), ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W,
+                                                   ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_clean_backward')
+        return gp, None
+
+
+def part_clean(pred, keep=None):
+    """pred [B,504,H,W] (or its [B,24,3,7,H,W] view), keep [B,24,7] or None ->
+    (part_iuv_map [B,24,3,7,H,W] bf16 view, x24 [B*24,24,H,W] bf16 channels_last: channels 21..23 are zero)."""
+    if pred.dim() == 6:
+        B, J, T, K, H, W = pred.shape
+        pred = pred.reshape(B, J * T * K, H, W)
+    B, _, H, W = pred.shape
+    x24 = PartCleanFunction.apply(pred, keep)
+    view = x24[:, :21].reshape(B, NJ, 3, NC, H, W)          # strided view of the padded buffer, no copy
+    return view, x24
+
+
+class PartLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, iuv_img, theta, sample_w, sel, align):
+        pred = nhwc_bf16(pred)
+        B, C, H, W = pred.shape
+        img = iuv_img.detach().to(torch.float32).contiguous()
+        th = theta.detach().to(torch.float32).contiguous()
+        w = None if sample_w is None else sample_w.detach().to(torch.float32).contiguous()
+        sel = sel.to(torch.int32).contiguous()
+        if img.shape != (B, 3, H, W) or th.shape != (B, NJ, 2, 3) or sel.shape != (NJ, 6):
+            raise ValueError('part_losses: bad shapes %s %s %s' % (tuple(img.shape), tuple(th.shape), tuple(sel.shape)))
+        sums = ARENA.alloc(32 * 3)
+        if sums is None:
+            sums = torch.zeros(32 * 3, dtype=torch.float32, device=pred.device)
+        check(_lib.lib().danet_part_loss_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), B, H, W, int(align),
+                                                 ptr(sums), stream()), 'danet_part_loss_forward')
+        ctx.save_for_backward(pred, img, th, w, sel)
+        ctx.align = int(align)
+        return sums.view(32, 3).sum(dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, img, th, w, sel = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        gp = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
+        scale = g.detach().to(torch.float32).contiguous()
+        check(_lib.lib().danet_part_loss_backward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), ptr(scale),
+                                                  B, H, W, ctx.align, ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_loss_backward')
+        return gp, None, None, None, None, None
+
+
+def part_losses(pred, iuv_img, theta, sample_w, sel, align):
+    """-> tensor [3]: sum over (b, joint, class, pixel) of fg * smooth_l1(U), same for V, and the sum over
+    (b, joint, pixel) of w_b * cross-entropy of the index map; ground truth = the 3-channel IUV image
+    resampled per joint by `theta` [B,24,2,3] (sel [24,6]: DensePose parts of each joint)."""
+    if pred.dim() == 6:
+        B, J, T, K, H, W = pred.shape
+        pred = pred.reshape(B, J * T * K, H, W)
+    return PartLossFunction.apply(pred, iuv_img, theta, sample_w, sel, align)

@@ -280,7 +280,10 @@ class DecomposedPredictor(nn.Module):
         global_para, _ = self.body_net(body_iuv)
         global_para = global_para + self.mean_cam_shape
         nbs, S = limb_iuv.size(0), limb_iuv.size(-1)
-        stacked = limb_iuv.reshape(nbs * 24, -1, S, S)
+        # the fused part_clean op hands over the zero-padded 24-channel NHWC bf16 operand of the stem conv
+        stacked = getattr(limb_iuv, '_nhwc_padded', None)
+        if stacked is None:
+            stacked = limb_iuv.reshape(nbs * 24, -1, S, S)
         _, lf = self.limb_net(stacked)
         lf = lf['x4']
         lf = self.limb_reslayer(lf.reshape(nbs, -1, lf.size(-2), lf.size(-1)))      # [B,24*128,1,1]

@@ -106,6 +106,24 @@ int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream)
 int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Partial-IUV ("limb") path glue (replaces /root/reference/models/danet/danet.py:264-283 and
+ * /root/reference/models/danet/iuv_estimator.py:206-246, ~40 tensor ops on [B,24,3,7,H,W] fp32).
+ * pred: the grouped conv's output, NHWC bf16 [B,H,W,504], channel = (joint*3 + {u,v,index})*7 + class.
+ *  danet_part_clean_*   x24 [B*24,H,W,24] bf16 = iuvmap_clean(keep[B,24,7] * pred) (+3 zero channels);
+ *                       backward: d pred from d x24 (U,V channels only).
+ *  danet_part_loss_*    sums [32][3] (zeroed by the caller; column sums = smooth-L1 U, smooth-L1 V,
+ *                       index cross-entropy) against the [B,3,H,W] IUV image resampled per joint by
+ *                       theta [B,24,2,3]; sel [24][6] int; sample_w [B] (NULL = 1).  backward: d pred for
+ *                       scale[0..2] * the three sums (scale on the device).
+ */
+int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, void* x24, void* stream);
+int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, void* gpred, void* stream);
+int danet_part_loss_forward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
+                            const int* sel, int B, int H, int W, int align, float* sums, void* stream);
+int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
+                             const int* sel, const float* scale, int B, int H, int W, int align, void* gpred, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Convolution (replaces the cuDNN/ATen kernels behind every nn.Conv2d on the hot path:
  * /root/reference/models/module/hr_module.py:15-378, res_module.py:21-535; shapes SURVEY.md A.2).
  * Activations are NHWC bf16 (torch channels_last), accumulation fp32 on MFMA.
