@@ -32,6 +32,7 @@ struct Wg3P {
     int B, H, W, Cin, Cout, groups, Cin_g, Cout_g;
     int tiles_h, tiles_w, msplit;
     long nchunks;                              // B * tiles_h * tiles_w
+    long x_bytes, dy_bytes;                    // extents from the group / channel-block offset on (buffer resources)
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned v2u;
@@ -77,53 +78,69 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
     }
     const unsigned aoff = (unsigned)((lg * TW + (li >> 2)) * PXY + (4 * (li & 3)) * 2);   // dY fragment, h = 0, ct = 0
 
-    const long per = (p.nchunks + p.msplit - 1) / p.msplit;
-    const long c_begin = (long)blockIdx.x * per, c_end = min(p.nchunks, c_begin + per);
+    const int nchunks = (int)p.nchunks;
+    const int per = (nchunks + p.msplit - 1) / p.msplit;
+    const int c_begin = blockIdx.x * per, c_end = min(nchunks, c_begin + per);
 
-    // staging: 16-byte pieces; dY tile = 32 px * (BCO/8) pieces, X halo = 60 px * (BCI/8) pieces
-    constexpr int NPY = TH * TW * (BCO / 8), NPX = HH * HW * (BCI / 8), NPIECE = NPY + NPX;
-    constexpr int NROUND = (NPIECE + 255) / 256;
-    uint4 stage[NROUND];
-
-    auto fetch = [&](long chunk) {
-        const int tw_i = (int)(chunk % p.tiles_w);
-        const long rest = chunk / p.tiles_w;
-        const int th_i = (int)(rest % p.tiles_h), b = (int)(rest / p.tiles_h);
-        const int oh0 = th_i * TH, ow0 = tw_i * TW;
+    // staging: 16-byte pieces; dY tile = 32 px * (BCO/8) pieces, X halo = 60 px * (BCI/8) pieces.  What a thread
+    // copies does not depend on the chunk: its piece's offset relative to the tile origin and its halo
+    // coordinates are fixed, so a chunk costs one add and a bounds test per piece (32-bit buffer offsets;
+    // out-of-image halo pixels get an out-of-range offset and load zeros).
+    constexpr int NPY = TH * TW * (BCO / 8), NPX = HH * HW * (BCI / 8);
+    constexpr int NRY = (NPY + 255) / 256, NRX = (NPX + 255) / 256;
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dyg), 0, (int)p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg), 0, (int)p.x_bytes, 0x00020000);
+    int yrel[NRY], xrel[NRX], xhy[NRX], xhx[NRX];
 #pragma unroll
-        for (int u = 0; u < NROUND; ++u) {
-            const int pc = t + u * 256;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (pc < NPY) {
-                const int c8 = pc % (BCO / 8), q = pc / (BCO / 8);
-                const int oh = oh0 + q / TW, ow = ow0 + q % TW;
-                if (co0 + c8 * 8 < p.Cout_g)
-                    v = *reinterpret_cast<const uint4*>(dyg + (((size_t)b * p.H + oh) * p.W + ow) * p.Cout + c8 * 8);
-            } else if (pc < NPIECE) {
-                const int px = pc - NPY;
-                const int c8 = px % (BCI / 8), q = px / (BCI / 8);
-                const int ih = oh0 - 1 + q / HW, iw = ow0 - 1 + q % HW;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && ci0 + c8 * 8 < p.Cin_g)
-                    v = *reinterpret_cast<const uint4*>(xg + (((size_t)b * p.H + ih) * p.W + iw) * p.Cin + c8 * 8);
-            }
-            stage[u] = v;
+    for (int u = 0; u < NRY; ++u) {
+        const int pc = t + u * 256;
+        const int c8 = pc % (BCO / 8), q = pc / (BCO / 8);
+        yrel[u] = (pc < NPY && co0 + c8 * 8 < p.Cout_g) ? (((q / TW) * p.W + q % TW) * p.Cout + c8 * 8) * 2 : OOB;
+    }
+#pragma unroll
+    for (int u = 0; u < NRX; ++u) {
+        const int pc = t + u * 256;
+        const int c8 = pc % (BCI / 8), q = pc / (BCI / 8);
+        xrel[u] = (((q / HW - 1) * p.W + q % HW - 1) * p.Cin + c8 * 8) * 2;
+        const bool live = pc < NPX && ci0 + c8 * 8 < p.Cin_g;
+        xhy[u] = live ? q / HW : -100000;                                 // (-100000: never inside the image)
+        xhx[u] = q % HW;
+    }
+    // tile position of the current fetch (block-uniform), advanced chunk by chunk
+    int f_tw = c_begin % p.tiles_w, f_th = (c_begin / p.tiles_w) % p.tiles_h, f_b = c_begin / (p.tiles_w * p.tiles_h);
+    uint4 ystage[NRY], xstage[NRX];
+
+    auto fetch = [&]() {
+        const int oh0 = f_th * TH, ow0 = f_tw * TW;
+        const int pix0 = (f_b * p.H + oh0) * p.W + ow0;
+        const int by = pix0 * p.Cout * 2, bx = pix0 * p.Cin * 2;
+#pragma unroll
+        for (int u = 0; u < NRY; ++u)
+            ystage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yr, yrel[u] != OOB ? by + yrel[u] : OOB, 0, 0));
+#pragma unroll
+        for (int u = 0; u < NRX; ++u) {
+            const bool ok = (unsigned)(oh0 - 1 + xhy[u]) < (unsigned)p.H && (unsigned)(ow0 - 1 + xhx[u]) < (unsigned)p.W;
+            xstage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? bx + xrel[u] : OOB, 0, 0));
         }
+        if (++f_tw == p.tiles_w) { f_tw = 0; if (++f_th == p.tiles_h) { f_th = 0; ++f_b; } }
     };
     auto commit = [&](int buf) {
-        unsigned char* base = smem + buf * BUF;
+        unsigned char* base = smem + buf * BUF;                            // tiles are stored piece-linear: dY pieces, then X pieces
 #pragma unroll
-        for (int u = 0; u < NROUND; ++u) {
-            const int pc = t + u * 256;
-            if (pc < NPIECE) *reinterpret_cast<uint4*>(base + (size_t)pc * 16) = stage[u];   // tiles are stored piece-linear
-        }
+        for (int u = 0; u < NRY; ++u)
+            if (t + u * 256 < NPY) *reinterpret_cast<uint4*>(base + (size_t)(t + u * 256) * 16) = ystage[u];
+#pragma unroll
+        for (int u = 0; u < NRX; ++u)
+            if (t + u * 256 < NPX) *reinterpret_cast<uint4*>(base + (size_t)(NPY + t + u * 256) * 16) = xstage[u];
     };
 
-    if (c_begin < c_end) fetch(c_begin);
+    if (c_begin < c_end) fetch();
     int buf = 0;
-    for (long ch = c_begin; ch < c_end; ++ch) {
+    for (int ch = c_begin; ch < c_end; ++ch) {
         commit(buf);
         __syncthreads();                       // tile `buf` complete; previous reads of `buf^1` also done
-        if (ch + 1 < c_end) fetch(ch + 1);
+        if (ch + 1 < c_end) fetch();
         const unsigned ybase = (unsigned)(buf * BUF), xbase = ybase + YB;
         // all transpose reads of the chunk are issued back to back, then ONE wait (the compiler does not
         // count LDS operations issued from inline asm) and a scheduling barrier so that no MFMA is hoisted
@@ -157,23 +174,21 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
         }
         buf ^= 1;
     }
-    // partial dW of this block: part[blockIdx.x][g][tap][cout][cin]
-    const size_t gsz = (size_t)9 * p.Cout_g * p.Cin_g;
+    // partial dW of this block: part[blockIdx.x][g][tap][cout][cin] (32-bit index arithmetic, one add per store)
+    const int gsz = 9 * p.Cout_g * p.Cin_g;
     float* dst = p.part + ((size_t)blockIdx.x * p.groups + g) * gsz;
 #pragma unroll
     for (int pi = 0; pi < MAXP; ++pi) {
         const int pair = wave + 4 * pi;
-        if (pair >= NPAIR) continue;
         const int tap = pair / NI, ni = pair - tap * NI;
         const int cin = ci0 + ni * 16 + li;
-        if (cin >= p.Cin_g) continue;
+        if (pair >= NPAIR || cin >= p.Cin_g) continue;
+        float* row = dst + ((tap * p.Cout_g + co0 + lg * 4) * p.Cin_g + cin);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cout = co0 + ct * 16 + lg * 4 + r;
-                if (cout < p.Cout_g) dst[((size_t)tap * p.Cout_g + cout) * p.Cin_g + cin] = acc[pi][ct][r];
-            }
+            for (int r = 0; r < 4; ++r)
+                if (co0 + ct * 16 + lg * 4 + r < p.Cout_g) row[(ct * 16 + r) * p.Cin_g] = acc[pi][ct][r];
     }
 }
 
@@ -251,6 +266,8 @@ extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, flo
     p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
     p.tiles_h = H / TH; p.tiles_w = W / TW;
     p.nchunks = (long)B * p.tiles_h * p.tiles_w;
+    p.x_bytes = (long)B * H * W * Cin * 2; p.dy_bytes = (long)B * H * W * Cout * 2;
+    DANET_CHECK_ARG(p.x_bytes < (1L << 31) && p.dy_bytes < (1L << 31), "conv_wgrad3x3: tensors of 2 GB or more are not supported");
     int ct, ni;
     plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &p.msplit);
     if (ws_floats < danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups))
