@@ -37,7 +37,8 @@ _SIGNATURES = {
     'danet_conv3x3_kernel_id': (c_i, [c_i] * 5),
     'danet_conv3x3_forward': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f, c_f]),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, c_f]),
-    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f, c_f]),
+    'danet_conv_forward_kernel': (c_i, [c_i] * 15),
+    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
     'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 6 + [c_fl, c_f]),

@@ -56,6 +56,7 @@ class ZeroArena(object):
 
 
 ARENA = ZeroArena()
+FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '1')))   # dgrad epilogue reduces the producing BN's backward sums
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_LDS3X3 = bool(int(os.environ.get('DANET_LDS3X3', '0')))         # 3x3/s1/p1 forward + data gradient through the LDS-staged kernel (conv3x3_lds.hip)
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
@@ -214,18 +215,26 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32,
-                  bn_sums=None):
+                  bn_sums=None, bn_bwd=None):
+    """bn_bwd = (bn_x, bn_y or None, saved, red): data-gradient launches also reduce the BatchNorm-backward
+    sums of the BN that produced the conv's input (see include/danet_hip.h)."""
     L = _lib.lib()
     y = _empty_nhwc(B, Cout, OH, OW, torch.float32 if out_fp32 else torch.bfloat16, x.device)
     tok = None
     if PROFILER is not None:
-        kid = L.danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups)
-        tok = PROFILER.begin('conv_igemm_kernel<%d, %d, %s>' % (kid // 100, (kid // 10) % 10, 'true' if kid % 10 else 'false'),
+        kid = L.danet_conv_forward_kernel(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed), int(out_fp32))
+        name = 'conv_fast_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10) if kid % 10 else \
+            'conv_igemm_kernel<%d, %d, %s>' % (kid // 1000, (kid // 100) % 10, 'true' if (kid // 10) % 10 else 'false')
+        tok = PROFILER.begin(name,
                              2.0 * B * OH * OW * Cout * (Cin // groups) * R * S,
                              ('dgrad' if transposed else 'fwd', B, H, W, Cin, Cout, R, stride, groups))
     check(L.danet_conv_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(bias), ptr(y.permute(0, 2, 3, 1)),
                                B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed),
-                               int(relu), int(out_fp32), ptr(bn_sums), stream()), 'danet_conv_forward')
+                               int(relu), int(out_fp32), ptr(bn_sums),
+                               None if bn_bwd is None else ptr(bn_bwd[0].permute(0, 2, 3, 1)),
+                               None if bn_bwd is None or bn_bwd[1] is None else ptr(bn_bwd[1].permute(0, 2, 3, 1)),
+                               None if bn_bwd is None else ptr(bn_bwd[2]), None if bn_bwd is None else ptr(bn_bwd[3]),
+                               stream()), 'danet_conv_forward')
     if tok is not None:
         PROFILER.end(tok)
     return y
@@ -252,7 +261,7 @@ def _conv3x3_raw(x, weight, groups_unused, B, H, W, Cin, Cout, flip, bn_sums=Non
 
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None):
+    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None, bn_ctx=None):
         x = nhwc_bf16(x)
         B, Cin, H, W = x.shape
         Cout, Cin_g, R, S = weight.shape
@@ -268,6 +277,7 @@ class Conv2dFunction(torch.autograd.Function):
             y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
+        ctx.bn_ctx = bn_ctx
         return y
 
     @staticmethod
@@ -296,10 +306,24 @@ class Conv2dFunction(torch.autograd.Function):
                 gx = _conv3x3_raw(gy, weight, groups, B, H, W, Cout, Cin, True)
             else:
                 wp1 = pack_weight(weight, groups, 1)
-                gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
+                bn_bwd = None
+                if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
+                        L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 1:
+                    bn_x, bn_relu, saved = ctx.bn_ctx
+                    bn_y = x if bn_relu else None            # the conv's input IS that BatchNorm's output
+                    if bn_x.shape == x.shape:
+                        n = L.danet_bn_ws_floats(Cin)
+                        red = ARENA.alloc(n)
+                        if red is None:
+                            red = torch.zeros(n, dtype=torch.float32, device=x.device)
+                        bn_bwd = (bn_x, bn_y, saved, red)
+                gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
+                                   None, bn_bwd)
+                if bn_bwd is not None:
+                    gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum(dim=(0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 WGRAD_STREAMS = False    # weight gradients on side streams (set by the trainer's hipGraph capture; it joins them)
@@ -398,7 +422,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         sums = ARENA.alloc(n)
         if sums is None:
             sums = torch.zeros(n, dtype=torch.float32, device=x.device)
-    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums)
+    # the BatchNorm that produced x (if any) leaves its tensors on x: the data gradient then also reduces that
+    # BatchNorm's backward sums (saves one pass over dy, x, y per BatchNorm with a single consumer)
+    bn_ctx = getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and torch.is_grad_enabled()) else None
+    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums, bn_ctx)
     if sums is not None:
         y._bn_sums = sums              # picked up by the BatchNorm2d that consumes y (nn.BatchNorm2d.forward)
     return y

@@ -28,6 +28,10 @@ struct ConvP {
     int relu, out_fp32, sshift, parity;
     float* stats;      // optional [BN_NCOPY][2][Cout] (pre-zeroed): per-channel sum / sum of squares of the bf16 output
     long M;
+    // optional (data-gradient launches): reduce the BatchNorm-backward sums of the BN that produced this conv's
+    // input into bn_red [BN_NCOPY][2][Cout] while the gradient tile is still in registers: sum(dy') and
+    // sum(dy' * xhat) with dy' = dy * (bn_y > 0) under ReLU, xhat = (bn_x - mean) * invstd, bn_saved = [mean[Cout] | invstd[Cout]]
+    const bf16_t* bn_x; const bf16_t* bn_y; const float* bn_saved; float* bn_red;
     long x_bytes, y_bytes;   // extents of the gathered / written tensors (buffer resources of conv_fast.hip)
 };
 

@@ -46,6 +46,31 @@ __device__ inline float row_sum16(float v) {
 
 constexpr int OOB = 0x7fffffff;      // beyond every buffer (sizes are checked to be < 2^31 bytes)
 
+// Per-lane partial sums s1/s2[nt][r] of channels n0 + nt*16 + lg*4 + r (over the lane's pixels) -> summed over
+// the 16 pixel lanes (DPP), over the 4 waves (LDS), then one atomic per channel into replica blockIdx.x % 32 of
+// dst [32][2][Ctot].
+template <int NT>
+__device__ inline void channel_sums_to_replicas(float (*s1)[4], float (*s2)[4], float* __restrict__ dst, int Ctot, int cbase,
+                                                int n0, int Cg, int t, int li, int lg, int wave)
+{
+    __shared__ float sStat[4][2][NT * 16];
+    __syncthreads();                                   // a previous use of sStat by this block is finished
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = row_sum16(s1[nt][r]), b = row_sum16(s2[nt][r]);
+            if (li == 0) { sStat[wave][0][nt * 16 + lg * 4 + r] = a; sStat[wave][1][nt * 16 + lg * 4 + r] = b; }
+        }
+    __syncthreads();
+    if (t < 2 * NT * 16) {
+        const int which = t / (NT * 16), c = t - which * (NT * 16);
+        const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
+        const int cl = n0 + c;
+        if (cl < Cg) atomicAdd(dst + ((size_t)(blockIdx.x % BN_NCOPY) * 2 + which) * Ctot + cbase + cl, v);
+    }
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
 {
@@ -60,7 +85,10 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
     const int step = p.parity ? p.stride : 1;
     const int OHc = (p.OH - py + step - 1) / step, OWc = (p.OW - px + step - 1) / step;
     const int Mc = p.parity ? p.B * OHc * OWc : (int)p.M;
-    if (blockIdx.x * (64 * MT) >= Mc) return;
+    // (an XCD-contiguous tile order -- every XCD's L2 serving one contiguous pixel range -- was measured and did
+    // not help: the 256 MB infinity cache already absorbs the cross-XCD halo re-reads)
+    const int bx = blockIdx.x;
+    if (bx * (64 * MT) >= Mc) return;
 
     // tap geometry: tap row index i (0 .. nr-1) reads input row  ph + i*dh ; likewise columns
     int nr = p.R, ns = p.S, r0 = 0, s0 = 0, rstep = 1, dh, orig_h = 0, orig_w = 0;
@@ -97,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
     }
 
     // pixels of this wave
-    const int m0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int m0 = bx * (64 * MT) + wave * (16 * MT);
     int pixoff[MT], outoff[MT];
     unsigned rowmask[MT], colmask[MT];
     {
@@ -179,9 +207,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
     for (int d = 0; d < D; ++d)
         if (d < rem) mma_step(A[d], Bq[d]);
 
-    // fused BatchNorm statistics of the bf16-rounded output
+    // fused BatchNorm statistics of the bf16-rounded output (forward) ...
     if (p.stats) {
-        __shared__ float sStat[4][2][NT * 16];
+        float s1[NT][4], s2[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -192,17 +220,43 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
                     const float v = outoff[mt] != OOB ? bf2f(f2bf(acc[mt][nt][r])) : 0.f;
                     a += v; b += v * v;
                 }
-                a = row_sum16(a); b = row_sum16(b);
-                if (li == 0) { sStat[wave][0][nt * 16 + lg * 4 + r] = a; sStat[wave][1][nt * 16 + lg * 4 + r] = b; }
+                s1[nt][r] = a; s2[nt][r] = b;
             }
-        __syncthreads();
-        if (t < 2 * NT * 16) {
-            const int which = t / (NT * 16), c = t - which * (NT * 16);
-            const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
-            const int cl = n0 + c;
-            if (cl < p.Cout_g)
-                atomicAdd(p.stats + ((size_t)(blockIdx.x % BN_NCOPY) * 2 + which) * p.Cout + g * p.Cout_g + cl, v);
+        channel_sums_to_replicas<NT>(s1, s2, p.stats, p.Cout, g * p.Cout_g, n0, p.Cout_g, t, li, lg, wave);
+    }
+    // ... or (data gradient) the two BatchNorm-backward sums of the BN that produced this conv's input
+    if (p.bn_red) {
+        const __amdgpu_buffer_rsrc_t bxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bn_x), 0, (int)p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bn_y ? p.bn_y : p.bn_x), 0, (int)p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t svr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bn_saved), 0, p.Cout * 8, 0x00020000);
+        float s1[NT][4], s2[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cl = n0 + nt * 16 + lg * 4;
+            const int c = g * p.Cout_g + cl;
+            const bool cok = cl < p.Cout_g;
+            const f32x4 mean = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(svr, cok ? c * 4 : OOB, 0, 0));
+            const f32x4 invs = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(svr, cok ? (p.Cout + c) * 4 : OOB, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int off = (cok && outoff[mt] != OOB) ? outoff[mt] + cl * 2 : OOB;
+                const i32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(bxr, off, 0, 0);
+                i32x2 yq = {0x3f803f80, 0x3f803f80};                               // "positive" when there is no ReLU
+                if (p.bn_y) yq = __builtin_amdgcn_raw_buffer_load_b64(byr, off, 0, 0);
+                const float xv[4] = {__uint_as_float((unsigned)xq.x << 16), __uint_as_float((unsigned)xq.x & 0xffff0000u),
+                                     __uint_as_float((unsigned)xq.y << 16), __uint_as_float((unsigned)xq.y & 0xffff0000u)};
+                const float yv[4] = {__uint_as_float((unsigned)yq.x << 16), __uint_as_float((unsigned)yq.x & 0xffff0000u),
+                                     __uint_as_float((unsigned)yq.y << 16), __uint_as_float((unsigned)yq.y & 0xffff0000u)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gv = (off != OOB && yv[r] > 0.f) ? bf2f(f2bf(acc[mt][nt][r])) : 0.f;
+                    s1[nt][r] += gv; s2[nt][r] += gv * (xv[r] - mean[r]) * invs[r];
+                }
+            }
         }
+        channel_sums_to_replicas<NT>(s1, s2, p.bn_red, p.Cout, g * p.Cout_g, n0, p.Cout_g, t, li, lg, wave);
     }
 
     // epilogue: lane holds couts n0 + nt*16 + lg*4 + {0..3} of its MT pixels (Cout_g % 4 == 0, checked by the host)

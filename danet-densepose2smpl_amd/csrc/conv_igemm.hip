@@ -468,41 +468,67 @@ extern "C" int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, 
     return DANET_OK;
 }
 
-// y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], wp) (+bias)(ReLU).  `transposed` selects the
-// fractionally-strided gather (data gradient / ConvTranspose2d), in which case (H,W) is the size
-// of the tensor being gathered FROM and `Cin`/`Cout` are its / the result's channel counts.
-extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
-                                  int B, int H, int W, int Cin, int OH, int OW, int Cout,
-                                  int R, int S, int stride, int pad, int dil, int groups, int transposed,
-                                  int relu, int out_fp32, float* bn_sums, void* stream)
+// Problem description shared by danet_conv_forward and danet_conv_forward_kernel.
+static bool fill_conv_params(ConvP& p, bool& vec8, int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                             int R, int S, int stride, int pad, int dil, int groups, int transposed, int relu, int out_fp32)
 {
-    DANET_ENTER();
-    DANET_CHECK_ARG(x && wp && y, "conv_forward: null pointer");
-    DANET_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 &&
-                    pad >= 0 && dil > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0,
-                    "conv_forward: bad sizes B=%d H=%d W=%d Cin=%d OH=%d OW=%d Cout=%d R=%d S=%d stride=%d pad=%d groups=%d",
-                    B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, groups);
-    ConvP p;
-    p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.bias = bias; p.y = y;
+    if (!(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 &&
+          pad >= 0 && dil > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && (stride & (stride - 1)) == 0))
+        return false;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.dil = dil; p.groups = groups; p.transposed = transposed;
     p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
     p.K = R * S * p.Cin_g; p.Kp = (p.K + 31) / 32 * 32;
     const int nt = danet_conv_nt(p.Cout_g);
     p.Cout_pad = (p.Cout_g + 16 * nt - 1) / (16 * nt) * (16 * nt);
-    p.relu = relu; p.out_fp32 = out_fp32; p.stats = bn_sums;
-    DANET_CHECK_ARG(!bn_sums || (!bias && !relu && !out_fp32), "conv_forward: fused BN statistics need a plain bf16 output");
-    DANET_CHECK_ARG((stride & (stride - 1)) == 0, "conv_forward: stride %d is not a power of two", stride);
+    p.relu = relu; p.out_fp32 = out_fp32;
     p.sshift = 0;
     while ((1 << p.sshift) < stride) ++p.sshift;
     p.M = (long)B * OH * OW;
-    const bool vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
+    vec8 = (p.Cin_g % 8 == 0) && (Cin % 8 == 0);
     p.parity = (transposed && stride > 1 && dil == 1 && vec8 && p.Cin_g % 32 == 0 && !g_no_parity) ? 1 : 0;
+    p.x_bytes = (long)B * H * W * Cin * 2;
+    p.y_bytes = p.M * Cout * (out_fp32 ? 4 : 2);
+    return true;
+}
+
+// Which kernel danet_conv_forward launches for a problem: MT*1000 + NT*100 + vec8*10 + fast
+// (fast = 1: conv_fast_kernel<MT, NT>, 0: conv_igemm_kernel<MT, NT, vec8>); -1 for invalid sizes.
+extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
+                                         int stride, int pad, int dil, int groups, int transposed, int out_fp32)
+{
+    ConvP p{};
+    bool vec8;
+    if (!fill_conv_params(p, vec8, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, 0, out_fp32)) return -1;
+    const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
+    return mt * 1000 + danet_conv_nt(p.Cout_g) * 100 + (vec8 ? 10 : 0) + (conv_fast_ok(p, vec8) ? 1 : 0);
+}
+
+// y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], wp) (+bias)(ReLU).  `transposed` selects the
+// fractionally-strided gather (data gradient / ConvTranspose2d), in which case (H,W) is the size
+// of the tensor being gathered FROM and `Cin`/`Cout` are its / the result's channel counts.
+extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
+                                  int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                                  int R, int S, int stride, int pad, int dil, int groups, int transposed,
+                                  int relu, int out_fp32, float* bn_sums,
+                                  const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && wp && y, "conv_forward: null pointer");
+    ConvP p{};
+    bool vec8;
+    DANET_CHECK_ARG(fill_conv_params(p, vec8, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32),
+                    "conv_forward: bad sizes B=%d H=%d W=%d Cin=%d OH=%d OW=%d Cout=%d R=%d S=%d stride=%d (power of two) pad=%d groups=%d",
+                    B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, groups);
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.bias = bias; p.y = y; p.stats = bn_sums;
+    p.bn_x = (const bf16_t*)bn_x; p.bn_y = (const bf16_t*)bn_y; p.bn_saved = bn_saved; p.bn_red = bn_red;
+    DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && conv_fast_ok(p, vec8)),
+                    "conv_forward: the fused BatchNorm-backward reduction needs the fast kernel and a plain bf16 output (check danet_conv_forward_kernel)");
+    const int nt = danet_conv_nt(p.Cout_g);
+    DANET_CHECK_ARG(!bn_sums || (!bias && !relu && !out_fp32), "conv_forward: fused BN statistics need a plain bf16 output");
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
-    p.x_bytes = (long)B * H * W * Cin * 2;
-    p.y_bytes = p.M * Cout * (out_fp32 ? 4 : 2);
     if (conv_fast_ok(p, vec8)) {
         if (conv_fast_launch(p, mt, nt, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no fast kernel for tiles %dx%d", mt, nt);
         DANET_CHECK_LAUNCH("conv_fast_kernel");

@@ -447,9 +447,11 @@ extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, i
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
-                           fm, saved + c0, C, relu, red_ws + c0);
-        DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+        if (ws_is_zero != 2) {                     // ws_is_zero == 2: the sums were accumulated by the consumer conv's dgrad epilogue
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
+                               fm, saved + c0, C, relu, red_ws + c0);
+            DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+        }
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
                            fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (bf16_t*)dx, (bf16_t*)dres,
                            dparam ? dparam + c0 : nullptr);

@@ -45,6 +45,8 @@ class BatchNormActFunction(torch.autograd.Function):
             ctx.has_res = res is not None
             ctx.has_affine = gamma is not None
         ctx.training = training
+        if training:
+            y._bn_ctx = (x, bool(relu), saved)     # lets a consumer conv fuse this BN's backward reduction (no reference to y: no cycle)
         return y
 
     @staticmethod
@@ -53,15 +55,20 @@ class BatchNormActFunction(torch.autograd.Function):
             raise RuntimeError('BatchNorm backward in eval mode is not on the hot path')
         L = _lib.lib()
         x, y, g, saved = ctx.saved_tensors
+        gy_in = gy
         gy = nhwc_bf16(gy)
         B, C, H, W = x.shape
         M = B * H * W
         dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
-        red = ARENA.alloc(L.danet_bn_ws_floats(C))
-        red_zero = red is not None
-        if red is None:
-            red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+        red = getattr(gy_in, '_bn_red', None)        # reduced by the consumer conv's data-gradient epilogue (conv.py)
+        if red is not None:
+            red_zero = 2
+        else:
+            red = ARENA.alloc(L.danet_bn_ws_floats(C))
+            red_zero = red is not None
+            if red is None:
+                red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)      # rows: d beta, d gamma
         check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),

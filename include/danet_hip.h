@@ -149,6 +149,10 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      bn_sums (optional, [32][2][Cout] fp32, zeroed by the caller): per-channel sum and sum of squares of the
  *      bf16 output, accumulated by the epilogue; pass it to danet_bn_forward with ws_is_zero = 2 to skip
  *      the separate statistics pass.
+ *      bn_x / bn_y / bn_saved / bn_red (optional, data-gradient launches on the fast kernel only): the
+ *      BatchNorm that produced this conv's input -- its input bn_x, its output bn_y (NULL = no ReLU), its
+ *      saved [mean | invstd] -- for which the epilogue accumulates sum(dy') and sum(dy'*xhat) into bn_red
+ *      ([32][2][C], zeroed); danet_bn_backward with ws_is_zero = 2 then skips its reduction pass.
  *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
  *  Scratch buffers that must start zeroed (BN sums, wgrad accumulator) are cleared by the call unless
  *  ws_is_zero != 0 (the host then zeroes one arena per step instead of ~800 small memsets).
@@ -168,10 +172,14 @@ int danet_conv3x3_chunk(int B, int H, int W, int Cin, int Cout);
 int danet_conv3x3_kernel_id(int B, int H, int W, int Cin, int Cout);                  /* MT*10 + NT */
 int danet_conv3x3_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int Cout,
                           int flip, float* bn_sums, void* stream);
+int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
+                              int stride, int pad, int dil, int groups, int transposed, int out_fp32);
+                              /* MT*1000 + NT*100 + vec8*10 + fast: conv_fast_kernel<MT,NT> or conv_igemm_kernel<MT,NT,vec8> */
 int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
-                       int relu, int out_fp32, float* bn_sums, void* stream);
+                       int relu, int out_fp32, float* bn_sums,
+                       const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, void* stream);
 /* 3x3 / stride 1 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);

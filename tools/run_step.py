@@ -24,3 +24,11 @@ for s in range(steps):
     torch.cuda.synchronize(); dt = time.time() - t0
     print('step', s, '%.1f ms' % (dt * 1e3), {k: round(float(v.sum()), 4) for k, v in losses.items()})
 print('max mem GB', torch.cuda.max_memory_allocated() / 2**30)
+
+if os.environ.get('DANET_PMC_CALIB'):
+    # known-size traffic for calibrating the PMC byte counters (tools/pmc_traffic.sh): 512 MiB read + 512 MiB written
+    a = torch.ones(256 * 2**20, dtype=torch.bfloat16, device=dev)
+    b = torch.empty_like(a)
+    torch.cuda.synchronize()
+    b.copy_(a)
+    torch.cuda.synchronize()
