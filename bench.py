@@ -27,6 +27,18 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_DENSE_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (tools/pmc_traffic.sh), or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        d = json.load(open(path))['kernels'].get(kernel)
+        if d and 'fetch_bytes_per_launch' in d and 'write_bytes_per_launch' in d:
+            return int(d['fetch_bytes_per_launch'] + d['write_bytes_per_launch'])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,8 +156,10 @@ def main():
             n, secs, flops = summ[dominant]
             ach = flops / secs / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': None, 'kernel': dominant,
-                    'launches': n, 'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3)}
+                    'frac': round(ach / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': pmc_traffic(dominant), 'kernel': dominant,
+                    'launches': n, 'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3),
+                    'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
+                                      'calibrated on a 512 MiB copy; bytes per launch averaged over this kernel\'s launches of one step)'}
 
     if rank == 0:
         ips = world * B * args.steps / elapsed

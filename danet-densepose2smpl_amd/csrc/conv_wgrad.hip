@@ -46,6 +46,15 @@ __device__ inline void store_transposed(bf16_t* dst, const uint4* raw) {
     }
 }
 
+__device__ inline unsigned udiv24(unsigned n, unsigned d, float rcp) {      // n < 2^24 (checked by the host)
+    unsigned q = (unsigned)((float)n * rcp);
+    const int r = (int)(n - q * d);
+    if (r < 0) --q; else if (r >= (int)d) ++q;
+    return q;
+}
+__device__ inline int sTap_dh(const WgradP& p, int tap) { const int tt = min(tap, p.R * p.S - 1); return (tt / p.S) * p.dil; }
+__device__ inline int sTap_dw(const WgradP& p, int tap) { const int tt = min(tap, p.R * p.S - 1); return (tt - (tt / p.S) * p.S) * p.dil; }
+
 // Channel counts must be multiples of 8 (the host pads; see conv.py): every staged run is one aligned
 // 16-byte load.  All loads are unconditional (clamped address + select) -- predicated loads compiled to
 // ~400 branches per chunk and made the kernel instruction-bound.
@@ -112,49 +121,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
     const int pq = t & (CHUNK / 4 - 1);
     const int nit_b = ntap * (BCI / 8) * (CHUNK / 4);
     uint4 raw[NITEM_B + 1][4];
-    const bf16_t* const dyg = p.dy + (size_t)g * p.Cout_g;
-    const bf16_t* const xg = p.x + (size_t)g * p.Cin_g;
-    const bf16_t* const zero16 = reinterpret_cast<const bf16_t*>(p.zero);
+    // 32-bit byte offsets into buffer resources; out-of-image / out-of-range runs get an out-of-range offset and
+    // load zeros (no address selects, no branches)
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy + (size_t)g * p.Cout_g), 0, (int)(p.M * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x + (size_t)g * p.Cin_g), 0, (int)((long)p.B * p.H * p.W * p.Cin * 2), 0x00020000);
+    const float rc_ohw = 1.0f / (float)ohw, rc_ow = 1.0f / (float)p.OW;
+    // per item: channel offset (bytes) and tap geometry do not depend on the chunk
+    int it_dh[NITEM_B], it_dw[NITEM_B], it_off[NITEM_B];
+#pragma unroll
+    for (int u = 0; u < NITEM_B; ++u) {
+        const int itb = t + u * 256;
+        const int rb = itb / (CHUNK / 4);
+        const int c8 = rb % (BCI / 8), tl = min(rb / (BCI / 8), TG - 1);
+        const int cB = ci0 + c8 * 8;
+        const bool chan_ok = itb < nit_b && cB < p.Cin_g;
+        it_dh[u] = chan_ok ? sTap_dh(p, tap0 + tl) : -100000;                  // (-100000: never inside the image)
+        it_dw[u] = sTap_dw(p, tap0 + tl);
+        it_off[u] = (it_dh[u] * p.W + it_dw[u]) * p.Cin * 2 + cB * 2;
+    }
+    const int a_off = (co0 + (t / (CHUNK / 4)) * 8) * 2;
+    const bool a_ok = t < NIT_A && co0 + (t / (CHUNK / 4)) * 8 < p.Cout_g;
 
     auto fetch = [&](long chunk) {
         const int mbase = (int)(chunk * CHUNK);
         int offA[4], offB[4], pih[4], piw[4];
-        bool pv[4];
+        // decode the first pixel of the quad, step the other three
+        int m = mbase + pq * 4;
+        const int mc = m < (int)p.M ? m : (int)p.M - 1;
+        int b = (int)udiv24((unsigned)mc, (unsigned)ohw, rc_ohw);
+        const int rem = mc - b * ohw;
+        int oh = (int)udiv24((unsigned)rem, (unsigned)p.OW, rc_ow), ow = rem - oh * p.OW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = mbase + pq * 4 + i;
-            pv[i] = m < (int)p.M;
-            const int mm = pv[i] ? m : (int)p.M - 1;
-            const int b = mm / ohw, rem = mm - b * ohw;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            pih[i] = oh * p.stride - p.pad;
+            const bool pv = m + i < (int)p.M;
+            pih[i] = pv ? oh * p.stride - p.pad : -100000;
             piw[i] = ow * p.stride - p.pad;
-            offA[i] = mm * p.Cout;
-            offB[i] = ((b * p.H + pih[i]) * p.W + piw[i]) * p.Cin;       // element offset of tap (0,0)
+            offA[i] = pv ? (m + i) * p.Cout * 2 : OOB;
+            offB[i] = ((b * p.H + oh * p.stride - p.pad) * p.W + piw[i]) * p.Cin * 2;      // byte offset of tap (0,0)
+            if (++ow == p.OW) { ow = 0; if (++oh == p.OH) { oh = 0; ++b; } }
         }
 #pragma unroll
         for (int u = 0; u < NITEM_B; ++u) {
-            const int itb = t + u * 256;
-            const int rb = itb / (CHUNK / 4);
-            const int c8 = rb % (BCI / 8), tl = min(rb / (BCI / 8), TG - 1);
-            const int dh = sTap[tl][0], dw = sTap[tl][1], tapoff = sTap[tl][2];
-            const int cB = ci0 + c8 * 8;
-            const bool chan_ok = itb < nit_b && cB < p.Cin_g;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool ok = chan_ok && pv[i] && (unsigned)(pih[i] + dh) < (unsigned)p.H && (unsigned)(piw[i] + dw) < (unsigned)p.W;
-                const bf16_t* src = ok ? xg + (offB[i] + tapoff + cB) : zero16;
-                raw[u][i] = *reinterpret_cast<const uint4*>(src);
+                const bool ok = (unsigned)(pih[i] + it_dh[u]) < (unsigned)p.H && (unsigned)(piw[i] + it_dw[u]) < (unsigned)p.W;
+                raw[u][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? offB[i] + it_off[u] : OOB, 0, 0));
             }
         }
         if (t < NIT_A) {                                   // dY^T items: wave 0 only
-            const int cA = co0 + (t / (CHUNK / 4)) * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = pv[i] && cA < p.Cout_g;
-                const bf16_t* src = ok ? dyg + (offA[i] + cA) : zero16;
-                raw[NITEM_B][i] = *reinterpret_cast<const uint4*>(src);
-            }
+            for (int i = 0; i < 4; ++i)
+                raw[NITEM_B][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yr, (a_ok && offA[i] != OOB) ? offA[i] + a_off : OOB, 0, 0));
         }
     };
     auto commit = [&]() {
@@ -250,7 +268,7 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
     DANET_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 &&
                     groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv_wgrad: bad sizes");
     DANET_CHECK_ARG((Cin / groups) % 8 == 0 && (Cout / groups) % 8 == 0 && (long)B * OH * OW * Cout < 2147483647L &&
-                    (long)B * H * W * Cin < 2147483647L,
+                    (long)B * H * W * Cin < 1073741823L && (long)B * OH * OW * Cout < 1073741823L && (long)B * OH * OW < (1L << 24),
                     "conv_wgrad: channels per group must be multiples of 8 (Cin_g=%d, Cout_g=%d); the host pads them",
                     Cin / groups, Cout / groups);
     WgradP p;
