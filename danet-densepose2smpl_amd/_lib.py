@@ -41,7 +41,8 @@ _SIGNATURES = {
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
-    'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 6 + [c_fl, c_f]),
+    'danet_conv_wgrad3x3_kernel_id': (c_i, [c_i] * 6),
+    'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 6 + [c_fl, c_i, c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f]),

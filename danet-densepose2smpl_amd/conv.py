@@ -358,11 +358,17 @@ def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad,
     if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
         ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-        tok = PROFILER.begin('conv_wgrad3x3_kernel', 2.0 * B * OH * OW * Cout * Cin_g * 9,
-                             ('wgrad', B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
-        check(L.danet_conv_wgrad3x3(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
-                                    B, H, W, Cin, Cout, groups, 0.0, stream()), 'danet_conv_wgrad3x3')
-        if tok is not None:
+        args = (ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws, B, H, W, Cin, Cout, groups, 0.0)
+        if PROFILER is None:
+            check(L.danet_conv_wgrad3x3(*args, 0, stream()), 'danet_conv_wgrad3x3')
+        else:                                          # the MFMA kernel and the reduction bracketed separately
+            kid = L.danet_conv_wgrad3x3_kernel_id(B, H, W, Cin, Cout, groups)
+            tok = PROFILER.begin('conv_wgrad3x3_kernel<%d, %d>' % (kid // 10, kid % 10), 2.0 * B * OH * OW * Cout * Cin_g * 9,
+                                 ('wgrad', B, H, W, Cin, Cout, R, stride, groups))
+            check(L.danet_conv_wgrad3x3(*args, 1, stream()), 'danet_conv_wgrad3x3')
+            PROFILER.end(tok)
+            tok = PROFILER.begin('wgrad3x3_reduce_kernel', 0.0, ('wgrad-reduce', B, H, W, Cin, Cout, R, stride, groups))
+            check(L.danet_conv_wgrad3x3(*args, 2, stream()), 'danet_conv_wgrad3x3')
             PROFILER.end(tok)
         return
     nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)

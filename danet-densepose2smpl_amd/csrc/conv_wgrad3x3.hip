@@ -248,6 +248,13 @@ static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, i
     *msplit = (int)ms;
 }
 
+// CT*10 + NI of the conv_wgrad3x3_kernel<CT, NI> instance that runs (profiling attribution).
+extern "C" int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups) {
+    int ct, ni, ms;
+    plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &ms);
+    return ct * 10 + ni;
+}
+
 extern "C" size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups) {
     int ct, ni, ms;
     plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &ms);
@@ -255,10 +262,11 @@ extern "C" size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, in
 }
 
 extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
-                                   int B, int H, int W, int Cin, int Cout, int groups, float beta, void* stream)
+                                   int B, int H, int W, int Cin, int Cout, int groups, float beta, int phase, void* stream)
 {
+    // phase: 0 = both kernels; 1 = the MFMA kernel only (partials into ws); 2 = the reduction only (profiling brackets)
     DANET_ENTER();
-    DANET_CHECK_ARG(x && dy && dw && ws && B > 0, "conv_wgrad3x3: bad arguments");
+    DANET_CHECK_ARG(x && dy && dw && ws && B > 0 && phase >= 0 && phase <= 2, "conv_wgrad3x3: bad arguments");
     DANET_CHECK_ARG(danet_conv_wgrad3x3_ok(H, W, Cin, Cout, 3, 3, 1, 1, 1, groups), "conv_wgrad3x3: unsupported shape");
     Wg3P p;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.part = ws;
@@ -273,11 +281,14 @@ extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, flo
     if (ws_floats < danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups))
         return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (phase != 2) {
 #define W3(a, b) if (ct == a && ni == b) launch3<a, b>(p, st); else
-    W3(1, 1) W3(1, 2) W3(1, 3) W3(2, 1) W3(2, 2) W3(2, 3) W3(3, 1) W3(3, 2) W3(3, 3)
-    return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3: no kernel for tiles %dx%d", ct, ni);
+        W3(1, 1) W3(1, 2) W3(1, 3) W3(2, 1) W3(2, 2) W3(2, 3) W3(3, 1) W3(3, 2) W3(3, 3)
+        return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3: no kernel for tiles %dx%d", ct, ni);
 #undef W3
-    DANET_CHECK_LAUNCH("conv_wgrad3x3_kernel");
+        DANET_CHECK_LAUNCH("conv_wgrad3x3_kernel");
+    }
+    if (phase == 1) return DANET_OK;
     const long total = (long)Cout * p.Cin_g * 9;
     hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, st, ws, dw, groups, p.Cout_g,
                        p.Cin_g, p.msplit, beta);

@@ -184,8 +184,9 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
 size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups);
+int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups);   /* CT*10 + NI */
 int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
-                        int B, int H, int W, int Cin, int Cout, int groups, float beta, void* stream);
+                        int B, int H, int W, int Cin, int Cout, int groups, float beta, int phase /* 0 both kernels, 1 MFMA kernel only, 2 reduction only */, void* stream);
 size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
 int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,
