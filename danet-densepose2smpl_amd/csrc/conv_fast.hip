@@ -186,8 +186,63 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bq[mt], acc[mt][nt], 0, 0, 0);
     };
 
+    if constexpr (MT == 1) {
+        // Small-M layers (one pixel tile per wave: 192 ch @16x16, 384 ch @8x8, the regressor tails) are bound by
+        // streaming the weights: with private fragment loads every wave of a block pulls the block's whole
+        // (48..64 couts x K) weight slab through L1 -- 4x redundantly.  Here the four waves SHARE the A operand:
+        // per round of G k-steps each wave loads two k-steps' fragments, parks them in LDS (double-buffered), and all
+        // waves read every fragment from there (ds_read_b128, lane-linear, conflict-free).  The gathered B
+        // operands of the next round are loaded into a second register set while the current round's MFMAs run.
+        constexpr int G = 8;
+        unsigned char* const sA = reinterpret_cast<unsigned char*>(sTab) + p.Kp;      // [2][G][NT] KB behind the tap table
+        const int nrounds = (nks + G - 1) / G;
+        const int last = nks > 0 ? nks - 1 : 0;
+        bf16x8 Areg[2][NT], Bq2[2][G];
+        auto load_round = [&](int r, bf16x8* bq) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ks = __builtin_amdgcn_readfirstlane(r * G + 2 * wave + j);
+                const int kc = min(ks, last);
+                const int wks = p.parity ? __builtin_amdgcn_readfirstlane(sTab[kc * 4].y >> 10) : kc;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    Areg[j][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, ks < nks ? wlane : OOB, (nt * nks_w + wks) * 1024, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int ks = r * G + q;
+                const i32x2 e = sTab[min(ks, last) * 4 + lg];
+                const unsigned ok = (rowmask[0] >> (e.y & 31)) & (colmask[0] >> ((e.y >> 5) & 31)) & 1u;
+                bq[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && ks < nks) ? pixoff[0] + e.x : OOB, 0, 0));
+            }
+        };
+        auto round_body = [&](int r, bf16x8* bcur, bf16x8* bnxt) {
+            unsigned char* const buf = sA + (size_t)(r & 1) * (G * NT * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    *reinterpret_cast<bf16x8*>(buf + ((2 * wave + j) * NT + nt) * 1024 + lane * 16) = Areg[j][nt];
+            __syncthreads();                  // round r's fragments visible; everyone is done with round r-1 (other buffer)
+            if (r + 1 < nrounds) load_round(r + 1, bnxt);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                bf16x8 a[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const bf16x8*>(buf + (q * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bcur[q], acc[0][nt], 0, 0, 0);
+            }
+        };
+        if (nrounds > 0) load_round(0, Bq2[0]);
+        for (int r = 0; r < nrounds; r += 2) {
+            round_body(r, Bq2[0], Bq2[1]);
+            if (r + 1 < nrounds) round_body(r + 1, Bq2[1], Bq2[0]);
+        }
+    } else {
     // register ring of D k-steps in flight (see conv_igemm.hip)
-    constexpr int D = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+    constexpr int D = MT == 2 ? 4 : 2;
     bf16x8 A[D][NT], Bq[D][MT];
     const int last = nks - 1;
     if (nks > 0) {
@@ -206,6 +261,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < rem) mma_step(A[d], Bq[d]);
+    }
 
     // fused BatchNorm statistics of the bf16-rounded output (forward) ...
     if (p.stats) {
@@ -294,7 +350,14 @@ void launch_fast(const ConvP& p, hipStream_t st) {
         nz *= p.stride * p.stride;
     }
     const dim3 grid((unsigned)((mblk + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)nz);
-    const size_t lds = (size_t)(p.Kp / 8) * sizeof(i32x2);
+    const size_t lds = (size_t)(p.Kp / 8) * sizeof(i32x2) + (MT == 1 ? (size_t)2 * 8 * NT * 1024 : 0);
+    if (MT == 1) {
+        static bool attr_set = false;          // more than the default 64 KB of dynamic LDS
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fast_kernel<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_set = true;
+        }
+    }
     hipLaunchKernelGGL((conv_fast_kernel<MT, NT>), grid, dim3(256), lds, st, p);
 }
 
@@ -305,14 +368,15 @@ const bool g_no_fast = getenv("DANET_CONV_NO_FAST") != nullptr;     // A-B timin
 namespace danet_conv {
 
 // Can the lean kernel run this problem?  (p fully populated by danet_conv_forward.)
-bool conv_fast_ok(const ConvP& p, bool vec8) {
+bool conv_fast_ok(const ConvP& p, bool vec8, int mt) {
     if (g_no_fast || !vec8) return false;
     if (p.transposed && p.stride > 1 && !p.parity) return false;
     if (p.R > 30 || p.S > 26 || p.Cout_g % 4 != 0 || p.Cout % 4 != 0) return false;
     if (p.M >= (1L << 24) || p.Kp >= (1 << 24)) return false;
     if (p.x_bytes >= (1L << 31) || p.y_bytes >= (1L << 31)) return false;
     if ((long)p.groups * p.Cout_pad * p.Kp * 2 >= (1L << 31)) return false;
-    if ((size_t)(p.Kp / 8) * 8 > 60 * 1024) return false;
+    // LDS: tap table (Kp bytes) + for one-tile-per-wave launches up to 64 KB of shared weight fragments
+    if ((size_t)p.Kp > (size_t)(mt == 1 ? 28 : 60) * 1024) return false;
     return true;
 }
 

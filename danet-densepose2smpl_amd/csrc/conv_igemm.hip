@@ -501,7 +501,7 @@ extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, i
     bool vec8;
     if (!fill_conv_params(p, vec8, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, 0, out_fp32)) return -1;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
-    return mt * 1000 + danet_conv_nt(p.Cout_g) * 100 + (vec8 ? 10 : 0) + (conv_fast_ok(p, vec8) ? 1 : 0);
+    return mt * 1000 + danet_conv_nt(p.Cout_g) * 100 + (vec8 ? 10 : 0) + (conv_fast_ok(p, vec8, mt) ? 1 : 0);
 }
 
 // y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], wp) (+bias)(ReLU).  `transposed` selects the
@@ -522,14 +522,14 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
                     B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, groups);
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.bias = bias; p.y = y; p.stats = bn_sums;
     p.bn_x = (const bf16_t*)bn_x; p.bn_y = (const bf16_t*)bn_y; p.bn_saved = bn_saved; p.bn_red = bn_red;
-    DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && conv_fast_ok(p, vec8)),
+    const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
+    DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && conv_fast_ok(p, vec8, mt)),
                     "conv_forward: the fused BatchNorm-backward reduction needs the fast kernel and a plain bf16 output (check danet_conv_forward_kernel)");
     const int nt = danet_conv_nt(p.Cout_g);
     DANET_CHECK_ARG(!bn_sums || (!bias && !relu && !out_fp32), "conv_forward: fused BN statistics need a plain bf16 output");
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
-    const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
-    if (conv_fast_ok(p, vec8)) {
+    if (conv_fast_ok(p, vec8, mt)) {
         if (conv_fast_launch(p, mt, nt, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no fast kernel for tiles %dx%d", mt, nt);
         DANET_CHECK_LAUNCH("conv_fast_kernel");
         return DANET_OK;
