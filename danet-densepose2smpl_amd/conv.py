@@ -296,7 +296,7 @@ class Conv2dFunction(torch.autograd.Function):
             gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
             side = _wgrad_stream(x.device) if WGRAD_STREAMS else None
             if side is None:
-                _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups)
+                _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
             else:
                 with torch.cuda.stream(side):
                     _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups)
@@ -353,8 +353,44 @@ def join_wgrad_streams(device):
         _WG['keep'].clear()
 
 
-def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups):
+DEFER_WGRAD = False       # queue 3x3 weight gradients during backward; flush_wgrads() computes them in multi-problem launches
+_WQ = []
+
+
+def flush_wgrads():
+    """Compute every queued 3x3 weight gradient (call after backward, before anything reads parameter .grad)."""
+    if not _WQ:
+        return
     L = _lib.lib()
+    jobs = (_lib.Wg3Job * len(_WQ))()
+    for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups) in zip(jobs, _WQ):
+        # autograd must have kept the returned (still unwritten) gradient tensor itself as .grad -- a copy or an
+        # accumulation into an existing .grad (shared weights, gradient accumulation) would have read garbage
+        if isinstance(weight, nn.Parameter) and (weight.grad is None or weight.grad.data_ptr() != gptr):
+            _WQ.clear()
+            raise RuntimeError('deferred weight gradient of a %s parameter was copied or accumulated by autograd; '
+                               'set DANET_DEFER_WGRAD=0 for this model' % (tuple(weight.shape),))
+        j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
+        j.B, j.H, j.W, j.Cin, j.Cout, j.groups = B, H, W, Cin, Cout, groups
+    import ctypes
+    n = len(_WQ)
+    need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), n)
+    ws = torch.empty(need, dtype=torch.float32, device=_WQ[0][2].device)
+    tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * q[5] * q[6] * q[8] * (q[7] // q[9]) * 9 for q in _WQ),
+                         ('wgrad-multi', n)) if PROFILER is not None else None
+    check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
+    if tok is not None:
+        PROFILER.end(tok)
+    _WQ.clear()
+
+
+def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight=None):
+    L = _lib.lib()
+    if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None and USE_WGRAD3X3 and \
+            L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+        # only the ADDRESS of gw is kept: holding the tensor would make autograd clone it instead of adopting it as .grad
+        _WQ.append((gw.data_ptr(), weight, x, gy, B, H, W, Cin, Cout, groups))      # x, gy stay alive until the flush
+        return
     if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
         ws = torch.empty(nws, dtype=torch.float32, device=x.device)

@@ -43,8 +43,9 @@ __device__ inline v2u tr_read(unsigned lds_byte_addr) {
     return r;
 }
 
+// One workgroup's share of one problem: (bx of msplit pixel ranges, by = cout-block x cin-block, bz = group).
 template <int CT, int NI>
-__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
+__device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const int by, const int bz)
 {
     constexpr int BCO = CT * 16, BCI = NI * 16;
     constexpr int PXY = BCO * 2, PXX = BCI * 2;                  // bytes per staged pixel
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int nci = (p.Cin_g + BCI - 1) / BCI;
-    const int cib = blockIdx.y % nci, cob = blockIdx.y / nci;
-    const int g = blockIdx.z;
+    const int cib = by % nci, cob = by / nci;
+    const int g = bz;
     const int co0 = cob * BCO, ci0 = cib * BCI;
     const bf16_t* const dyg = p.dy + (size_t)g * p.Cout_g + co0;
     const bf16_t* const xg = p.x + (size_t)g * p.Cin_g + ci0;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
 
     const int nchunks = (int)p.nchunks;
     const int per = (nchunks + p.msplit - 1) / p.msplit;
-    const int c_begin = blockIdx.x * per, c_end = min(nchunks, c_begin + per);
+    const int c_begin = bx * per, c_end = min(nchunks, c_begin + per);
 
     // staging: 16-byte pieces; dY tile = 32 px * (BCO/8) pieces, X halo = 60 px * (BCI/8) pieces.  What a thread
     // copies does not depend on the chunk: its piece's offset relative to the tile origin and its halo
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
     }
     // partial dW of this block: part[blockIdx.x][g][tap][cout][cin] (32-bit index arithmetic, one add per store)
     const int gsz = 9 * p.Cout_g * p.Cin_g;
-    float* dst = p.part + ((size_t)blockIdx.x * p.groups + g) * gsz;
+    float* dst = p.part + ((size_t)bx * p.groups + g) * gsz;
 #pragma unroll
     for (int pi = 0; pi < MAXP; ++pi) {
         const int pair = wave + 4 * pi;
@@ -190,6 +191,58 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
             for (int r = 0; r < 4; ++r)
                 if (co0 + ct * 16 + lg * 4 + r < p.Cout_g) row[(ct * 16 + r) * p.Cin_g] = acc[pi][ct][r];
     }
+}
+
+template <int CT, int NI>
+__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
+{
+    wgrad3x3_body<CT, NI>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems in one launch (weight gradients are only needed by the optimizer, so a trainer
+// queues them during the backward pass and flushes the queue with a few of these): workgroup id -> problem by
+// the prefix table, then (bx, by, bz) within the problem.  Fewer, longer workgroups per problem amortise the
+// per-workgroup prologue / partial-sum traffic that dominates a single 17 us launch.
+constexpr int NPM = 20;
+struct Wg3Multi { Wg3P p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; };
+
+template <int CT, int NI>
+__global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
+{
+    int i = 0;
+    while (i + 1 < mp.n && (int)blockIdx.x >= mp.start[i + 1]) ++i;
+    const int l = blockIdx.x - mp.start[i];
+    const Wg3P& p = mp.p[i];
+    const int bx = l % p.msplit, rest = l / p.msplit;
+    wgrad3x3_body<CT, NI>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
+}
+
+struct Red3Multi { const float* part[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], msplit[NPM]; long start[NPM + 1]; int n; float beta; };
+
+__global__ __launch_bounds__(256) void wgrad3x3_reduce_multi_kernel(Red3Multi rp)
+{
+    const long gidx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= rp.start[rp.n]) return;
+    int i = 0;
+    while (i + 1 < rp.n && gidx >= rp.start[i + 1]) ++i;
+    const long idx = gidx - rp.start[i], total = rp.start[i + 1] - rp.start[i];
+    const float* part = rp.part[i];
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= rp.msplit[i]; sp += 4) {
+        const float v0 = part[(size_t)sp * total + idx], v1 = part[(size_t)(sp + 1) * total + idx];
+        const float v2 = part[(size_t)(sp + 2) * total + idx], v3 = part[(size_t)(sp + 3) * total + idx];
+        s += (v0 + v1) + (v2 + v3);
+    }
+    for (; sp < rp.msplit[i]; ++sp) s += part[(size_t)sp * total + idx];
+    const int Cin_g = rp.Cin_g[i], Cout_g = rp.Cout_g[i];
+    const int cin = (int)(idx % Cin_g);
+    long rest = idx / Cin_g;
+    const int cout = (int)(rest % Cout_g); rest /= Cout_g;
+    const int tap = (int)(rest % 9), g = (int)(rest / 9);
+    const size_t o = (((size_t)(g * Cout_g + cout)) * Cin_g + cin) * 9 + tap;
+    float* dw = rp.dw[i];
+    dw[o] = rp.beta != 0.f ? dw[o] * rp.beta + s : s;
 }
 
 // dW[Cout][Cin_g][3][3] = beta*dW + sum_s part[s][g][tap][cout][cin]   (fixed order -> deterministic)
@@ -294,4 +347,115 @@ extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, flo
                        p.Cin_g, p.msplit, beta);
     DANET_CHECK_LAUNCH("wgrad3x3_reduce_kernel");
     return DANET_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Batched form: n independent 3x3 weight-gradient problems (jobs[i] = {x, dy, dw, B, H, W, Cin, Cout, groups}),
+// grouped internally by kernel instance and launched NPM at a time.  ws must hold
+// danet_conv_wgrad3x3_multi_ws_floats(jobs, n) floats.
+struct Wg3Job { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups; };
+
+static long multi_target_blocks() {
+    if (const char* e = getenv("DANET_WGRAD3_MULTI_BLOCKS")) return atol(e);
+    return 512;
+}
+
+// msplit of every job when jobs [first, last) of one instance share a launch
+static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int ni, int* msplit) {
+    double tot = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const Wg3Job& j = jobs[idx[k]];
+        tot += (double)j.B * (j.H / TH) * (j.W / TW) * j.Cout * (j.Cin / j.groups);
+    }
+    const long target = multi_target_blocks();
+    for (int k = 0; k < cnt; ++k) {
+        const Wg3Job& j = jobs[idx[k]];
+        const int Cout_g = j.Cout / j.groups, Cin_g = j.Cin / j.groups;
+        const long other = (long)((Cout_g + ct * 16 - 1) / (ct * 16)) * ((Cin_g + ni * 16 - 1) / (ni * 16)) * j.groups;
+        const long nchunks = (long)j.B * (j.H / TH) * (j.W / TW);
+        const double w = (double)nchunks * j.Cout * Cin_g;
+        long ms = (long)(target * (w / tot) / other + 0.5);
+        if (ms > nchunks / 4) ms = nchunks / 4;
+        if (ms < 1) ms = 1;
+        msplit[k] = (int)ms;
+    }
+}
+
+static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_floats, float beta, hipStream_t st, size_t* need_out)
+{
+    size_t used = 0;
+    bool done[4096];
+    if (n > 4096) return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: too many jobs (%d)", n);
+    for (int i = 0; i < n; ++i) done[i] = false;
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        int ct, ni, dummy;
+        plan3(jobs[i].B, jobs[i].H, jobs[i].W, jobs[i].Cin, jobs[i].Cout, jobs[i].groups, &ct, &ni, &dummy);
+        int idx[NPM], cnt = 0;
+        for (int k = i; k < n && cnt < NPM; ++k) {
+            if (done[k]) continue;
+            int c2, n2;
+            plan3(jobs[k].B, jobs[k].H, jobs[k].W, jobs[k].Cin, jobs[k].Cout, jobs[k].groups, &c2, &n2, &dummy);
+            if (c2 == ct && n2 == ni) { idx[cnt++] = k; done[k] = true; }
+        }
+        int msplit[NPM];
+        plan_multi(jobs, idx, cnt, ct, ni, msplit);
+        Wg3Multi mp; Red3Multi rp;
+        mp.n = cnt; rp.n = cnt; rp.beta = beta;
+        mp.start[0] = 0; rp.start[0] = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const Wg3Job& j = jobs[idx[k]];
+            Wg3P& p = mp.p[k];
+            p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.part = ws ? ws + used : nullptr;
+            p.B = j.B; p.H = j.H; p.W = j.W; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
+            p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
+            p.tiles_h = j.H / TH; p.tiles_w = j.W / TW;
+            p.nchunks = (long)j.B * p.tiles_h * p.tiles_w;
+            p.x_bytes = (long)j.B * j.H * j.W * j.Cin * 2; p.dy_bytes = (long)j.B * j.H * j.W * j.Cout * 2;
+            p.msplit = msplit[k];
+            const int nyb = ((p.Cout_g + ct * 16 - 1) / (ct * 16)) * ((p.Cin_g + ni * 16 - 1) / (ni * 16));
+            mp.nyb[k] = nyb;
+            mp.start[k + 1] = mp.start[k] + msplit[k] * nyb * j.groups;
+            const long total = (long)j.Cout * p.Cin_g * 9;
+            rp.part[k] = p.part; rp.dw[k] = j.dw; rp.G[k] = j.groups; rp.Cout_g[k] = p.Cout_g; rp.Cin_g[k] = p.Cin_g; rp.msplit[k] = msplit[k];
+            rp.start[k + 1] = rp.start[k] + total;
+            used += (size_t)msplit[k] * total;
+            if (ws && !(p.x_bytes < (1L << 31) && p.dy_bytes < (1L << 31)))
+                return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: tensors of 2 GB or more are not supported");
+        }
+        if (!ws) continue;                                   // sizing pass
+        if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3_multi: workspace too small");
+        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + HH * HW * ni * 32);
+        const dim3 grid((unsigned)mp.start[cnt]);
+#define W3M(a, b) if (ct == a && ni == b) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b>), grid, dim3(256), lds, st, mp); else
+        W3M(1, 1) W3M(1, 2) W3M(1, 3) W3M(2, 1) W3M(2, 2) W3M(2, 3) W3M(3, 1) W3M(3, 2) W3M(3, 3)
+        return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: no kernel for tiles %dx%d", ct, ni);
+#undef W3M
+        DANET_CHECK_LAUNCH("conv_wgrad3x3_multi_kernel");
+        hipLaunchKernelGGL(wgrad3x3_reduce_multi_kernel, dim3((unsigned)danet::cdiv(rp.start[cnt], 256)), dim3(256), 0, st, rp);
+        DANET_CHECK_LAUNCH("wgrad3x3_reduce_multi_kernel");
+    }
+    if (need_out) *need_out = used;
+    return DANET_OK;
+}
+
+extern "C" size_t danet_conv_wgrad3x3_multi_ws_floats(const void* jobs, int n)
+{
+    size_t need = 0;
+    if (!jobs || n <= 0) return 0;
+    multi_foreach_launch((const Wg3Job*)jobs, n, nullptr, 0, 0.f, nullptr, &need);
+    return need;
+}
+
+extern "C" int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(jobs && n > 0 && ws, "conv_wgrad3x3_multi: bad arguments");
+    const Wg3Job* jb = (const Wg3Job*)jobs;
+    for (int i = 0; i < n; ++i)
+        DANET_CHECK_ARG(jb[i].x && jb[i].dy && jb[i].dw && jb[i].B > 0 &&
+                        danet_conv_wgrad3x3_ok(jb[i].H, jb[i].W, jb[i].Cin, jb[i].Cout, 3, 3, 1, 1, 1, jb[i].groups),
+                        "conv_wgrad3x3_multi: job %d is not a supported 3x3 problem", i);
+    return multi_foreach_launch(jb, n, ws, ws_floats, beta, (hipStream_t)stream, nullptr);
 }

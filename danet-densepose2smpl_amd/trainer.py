@@ -21,6 +21,9 @@ from . import conv as _conv
 from .geometry import perspective_projection
 
 
+DEFER_WGRAD = bool(int(os.environ.get('DANET_DEFER_WGRAD', '1')))
+
+
 def default_options(batch_size=32):
     return types.SimpleNamespace(batch_size=batch_size, openpose_train_weight=0., gt_train_weight=1.)
 
@@ -136,7 +139,14 @@ class Trainer(object):
             self.optimizer.zero_grad(set_to_none=True)
             if self.reducer is not None:
                 self.reducer.prepare()
-            loss_total.backward()
+            # without gradient hooks (single process) the 3x3 weight gradients are queued and computed in a few
+            # multi-problem launches after the backward pass
+            _conv.DEFER_WGRAD = self.reducer is None and DEFER_WGRAD
+            try:
+                loss_total.backward()
+            finally:
+                _conv.DEFER_WGRAD = False
+            _conv.flush_wgrads()
             _conv.join_wgrad_streams(self.device)
             if self.reducer is not None:
                 self.reducer.finish()
@@ -187,7 +197,12 @@ class Trainer(object):
         losses = out['losses']
         loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
         self.optimizer.zero_grad(set_to_none=True)
-        loss_total.backward()
+        _conv.DEFER_WGRAD = DEFER_WGRAD            # (graph capture / replay never uses gradient hooks)
+        try:
+            loss_total.backward()
+        finally:
+            _conv.DEFER_WGRAD = False
+        _conv.flush_wgrads()
         _conv.join_wgrad_streams(self.device)
         if with_optimizer:
             self.optimizer.step()

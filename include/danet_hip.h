@@ -184,6 +184,11 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
 size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups);
+/* Batched 3x3 weight gradients: weight gradients are only needed by the optimizer, so a trainer may queue them during the
+ * backward pass and compute them with a few multi-problem launches (up to 20 problems per launch, grouped by kernel instance).
+ * jobs: array of n { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups; } (host memory). */
+size_t danet_conv_wgrad3x3_multi_ws_floats(const void* jobs, int n);
+int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
 int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups);   /* CT*10 + NI */
 int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                         int B, int H, int W, int Cin, int Cout, int groups, float beta, int phase /* 0 both kernels, 1 MFMA kernel only, 2 reduction only */, void* stream);
