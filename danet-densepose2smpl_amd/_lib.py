@@ -41,6 +41,8 @@ _SIGNATURES = {
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
+    'danet_conv_wgrad_multi_ws_floats': (c_sz, [c_f, c_i]),
+    'danet_conv_wgrad_multi': (c_i, [c_f, c_i, c_f, c_sz, c_fl, c_f]),
     'danet_conv_wgrad3x3_multi_ws_floats': (c_sz, [c_f, c_i]),
     'danet_conv_wgrad3x3_multi': (c_i, [c_f, c_i, c_f, c_sz, c_fl, c_f]),
     'danet_conv_wgrad3x3_kernel_id': (c_i, [c_i] * 6),
@@ -69,6 +71,12 @@ class Wg3Job(ctypes.Structure):
     """One problem of danet_conv_wgrad3x3_multi (include/danet_hip.h)."""
     _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p),
                 ('B', c_i), ('H', c_i), ('W', c_i), ('Cin', c_i), ('Cout', c_i), ('groups', c_i)]
+
+
+class WgJob(ctypes.Structure):
+    """One problem of danet_conv_wgrad_multi (include/danet_hip.h)."""
+    _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p)] + \
+               [(k, c_i) for k in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'R', 'S', 'stride', 'pad', 'dil', 'groups')]
 
 
 def exported_symbols():

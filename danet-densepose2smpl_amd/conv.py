@@ -353,35 +353,59 @@ def join_wgrad_streams(device):
         _WG['keep'].clear()
 
 
-DEFER_WGRAD = False       # queue 3x3 weight gradients during backward; flush_wgrads() computes them in multi-problem launches
-_WQ = []
+DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches
+_WQ = []                  # 3x3 / stride-1 problems (conv_wgrad3x3.hip)
+_WQG = []                 # everything else (conv_wgrad.hip)
+
+
+def _check_adopted(queue):
+    """autograd must have kept the returned (still unwritten) gradient tensor itself as .grad -- a copy, or an
+    accumulation into an existing .grad (shared weights, gradient accumulation), would have read garbage."""
+    for q in queue:
+        gptr, weight = q[0], q[1]
+        if weight.grad is None or weight.grad.data_ptr() != gptr:
+            _WQ.clear()
+            _WQG.clear()
+            raise RuntimeError('deferred weight gradient of a %s parameter was copied or accumulated by autograd; '
+                               'set DANET_DEFER_WGRAD=0 for this model' % (tuple(weight.shape),))
 
 
 def flush_wgrads():
-    """Compute every queued 3x3 weight gradient (call after backward, before anything reads parameter .grad)."""
-    if not _WQ:
-        return
-    L = _lib.lib()
-    jobs = (_lib.Wg3Job * len(_WQ))()
-    for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups) in zip(jobs, _WQ):
-        # autograd must have kept the returned (still unwritten) gradient tensor itself as .grad -- a copy or an
-        # accumulation into an existing .grad (shared weights, gradient accumulation) would have read garbage
-        if isinstance(weight, nn.Parameter) and (weight.grad is None or weight.grad.data_ptr() != gptr):
-            _WQ.clear()
-            raise RuntimeError('deferred weight gradient of a %s parameter was copied or accumulated by autograd; '
-                               'set DANET_DEFER_WGRAD=0 for this model' % (tuple(weight.shape),))
-        j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
-        j.B, j.H, j.W, j.Cin, j.Cout, j.groups = B, H, W, Cin, Cout, groups
+    """Compute every queued weight gradient (call after backward, before anything reads parameter .grad)."""
     import ctypes
-    n = len(_WQ)
-    need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), n)
-    ws = torch.empty(need, dtype=torch.float32, device=_WQ[0][2].device)
-    tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * q[5] * q[6] * q[8] * (q[7] // q[9]) * 9 for q in _WQ),
-                         ('wgrad-multi', n)) if PROFILER is not None else None
-    check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
-    if tok is not None:
-        PROFILER.end(tok)
-    _WQ.clear()
+    L = _lib.lib()
+    if _WQ:
+        _check_adopted(_WQ)
+        jobs = (_lib.Wg3Job * len(_WQ))()
+        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups) in zip(jobs, _WQ):
+            j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
+            j.B, j.H, j.W, j.Cin, j.Cout, j.groups = B, H, W, Cin, Cout, groups
+        n = len(_WQ)
+        need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), n)
+        ws = torch.empty(need, dtype=torch.float32, device=_WQ[0][2].device)
+        tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * q[5] * q[6] * q[8] * (q[7] // q[9]) * 9 for q in _WQ),
+                             ('wgrad-multi', n)) if PROFILER is not None else None
+        check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
+        if tok is not None:
+            PROFILER.end(tok)
+        _WQ.clear()
+    if _WQG:
+        _check_adopted(_WQG)
+        jobs = (_lib.WgJob * len(_WQG))()
+        for j, (gptr, weight, x, gy, dims) in zip(jobs, _WQG):
+            j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
+            (j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups) = dims
+        n = len(_WQG)
+        need = L.danet_conv_wgrad_multi_ws_floats(ctypes.addressof(jobs), n)
+        ws = ARENA.alloc(need)
+        if ws is None:
+            ws = torch.zeros(need, dtype=torch.float32, device=_WQG[0][2].device)
+        tok = PROFILER.begin('conv_wgrad_multi', sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in (q[4] for q in _WQG)),
+                             ('wgrad-multi', n)) if PROFILER is not None else None
+        check(L.danet_conv_wgrad_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad_multi')
+        if tok is not None:
+            PROFILER.end(tok)
+        _WQG.clear()
 
 
 def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight=None):
@@ -390,6 +414,9 @@ def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad,
             L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         # only the ADDRESS of gw is kept: holding the tensor would make autograd clone it instead of adopting it as .grad
         _WQ.append((gw.data_ptr(), weight, x, gy, B, H, W, Cin, Cout, groups))      # x, gy stay alive until the flush
+        return
+    if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None:
+        _WQG.append((gw.data_ptr(), weight, x, gy, (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)))
         return
     if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)

@@ -59,7 +59,7 @@ __device__ inline int sTap_dw(const WgradP& p, int tap) { const int tt = min(tap
 // 16-byte load.  All loads are unconditional (clamped address + select) -- predicated loads compiled to
 // ~400 branches per chunk and made the kernel instruction-bound.
 template <int CT, int NI, int TG>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
+__device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const int by_in, const int bz)
 {
     constexpr int BCO = CT * 16, BCI = NI * 16;
     constexpr int ROWS = BCO + TG * BCI;                       // LDS rows: dY^T channels, then X^T per tap
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
     const int li = lane & 15, lg = lane >> 4;
     // grid.x = msplit, grid.y = cout-blocks * cin-blocks * tapgroups, grid.z = groups
     const int nci = (p.Cin_g + BCI - 1) / BCI;
-    int by = blockIdx.y;
+    int by = by_in;
     const int tg = by % p.ntapgroups; by /= p.ntapgroups;
     const int cib = by % nci, cob = by / nci;
-    const int g = blockIdx.z;
+    const int g = bz;
     const int taps = p.R * p.S;
     const int tap0 = tg * TG;
     const int ntap = min(TG, taps - tap0);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
 
     const long nchunks = (p.M + CHUNK - 1) / CHUNK;
     const long per = (nchunks + p.msplit - 1) / p.msplit;
-    const long c_begin = (long)blockIdx.x * per, c_end = min(nchunks, c_begin + per);
+    const long c_begin = (long)bx * per, c_end = min(nchunks, c_begin + per);
     const int ohw = p.OH * p.OW;
 
     // Items of one chunk: one item = 4 consecutive pixels x 8 channels: four 16-byte loads, a 4x8 transpose
@@ -218,6 +218,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
     }
 }
 
+template <int CT, int NI, int TG>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
+{
+    wgrad_body<CT, NI, TG>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems of one kernel instance in one launch (see conv_wgrad3x3.hip: weight gradients are
+// queued during the backward pass and flushed in batches).
+constexpr int NPM = 16;
+struct WgradMulti { WgradP p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; };
+
+template <int CT, int NI, int TG>
+__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradMulti mp)
+{
+    int i = 0;
+    while (i + 1 < mp.n && (int)blockIdx.x >= mp.start[i + 1]) ++i;
+    const int l = blockIdx.x - mp.start[i];
+    const WgradP& p = mp.p[i];
+    const int bx = l % p.msplit, rest = l / p.msplit;
+    wgrad_body<CT, NI, TG>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
+}
+
+struct UnpackMulti { const float* dwp[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], taps[NPM]; long start[NPM + 1]; int n; float beta; };
+
+__global__ __launch_bounds__(256) void wgrad_unpack_multi_kernel(UnpackMulti up)
+{
+    const long gidx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= up.start[up.n]) return;
+    int i = 0;
+    while (i + 1 < up.n && gidx >= up.start[i + 1]) ++i;
+    const long idx = gidx - up.start[i];
+    const int taps = up.taps[i], Cin_g = up.Cin_g[i], Cout_g = up.Cout_g[i];
+    const int tap = (int)(idx % taps);
+    long rest = idx / taps;
+    const int cin = (int)(rest % Cin_g); rest /= Cin_g;
+    const int cout = (int)(rest % Cout_g);
+    const int g = (int)(rest / Cout_g);
+    const float v = up.dwp[i][(((size_t)g * taps + tap) * Cout_g + cout) * Cin_g + cin];
+    float* dw = up.dw[i];
+    dw[idx] = up.beta != 0.f ? dw[idx] * up.beta + v : v;
+}
+
 // dWp[G][taps][Cout_g][Cin_g] -> dW[Cout][Cin_g][R][S]  (beta = 0: overwrite, 1: accumulate)
 __global__ void wgrad_unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
                                     int G, int Cout_g, int Cin_g, int taps, float beta)
@@ -317,4 +359,97 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
                        p.Cin_g, taps, beta);
     DANET_CHECK_LAUNCH("wgrad_unpack_kernel");
     return DANET_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Batched form: n independent problems, grouped by kernel instance, up to 16 per launch.  ws: zeroed by the
+// caller (danet_conv_wgrad_multi_ws_floats floats; every problem's packed accumulator lives there).
+struct WgJob { const void* x; const void* dy; float* dw; int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; };
+
+static bool wg_job_ok(const WgJob& j) {
+    return j.x && j.dy && j.dw && j.B > 0 && j.H > 0 && j.W > 0 && j.Cin > 0 && j.OH > 0 && j.OW > 0 && j.Cout > 0 && j.R > 0 && j.S > 0 &&
+           j.stride > 0 && j.groups > 0 && j.Cin % j.groups == 0 && j.Cout % j.groups == 0 && (j.Cin / j.groups) % 8 == 0 &&
+           (j.Cout / j.groups) % 8 == 0 && (long)j.B * j.H * j.W * j.Cin < 1073741823L && (long)j.B * j.OH * j.OW * j.Cout < 1073741823L &&
+           (long)j.B * j.OH * j.OW < (1L << 24);
+}
+
+static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float beta, hipStream_t st, size_t* need_out)
+{
+    if (n > 4096) return danet::fail(DANET_ERR_ARG, "conv_wgrad_multi: too many jobs (%d)", n);
+    bool done[4096];
+    for (int i = 0; i < n; ++i) done[i] = false;
+    size_t used = 0;
+    long target = 512;
+    if (const char* e = getenv("DANET_WGRAD_MULTI_BLOCKS")) target = atol(e);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        const int kid = danet_conv_wgrad_kernel_id(jobs[i].Cin, jobs[i].Cout, jobs[i].groups, jobs[i].R * jobs[i].S);
+        int idx[NPM], cnt = 0;
+        for (int k = i; k < n && cnt < NPM; ++k)
+            if (!done[k] && danet_conv_wgrad_kernel_id(jobs[k].Cin, jobs[k].Cout, jobs[k].groups, jobs[k].R * jobs[k].S) == kid) { idx[cnt++] = k; done[k] = true; }
+        const int ct = kid / 100, ni = (kid / 10) % 10, tgs = kid % 10;
+        double tot = 0;
+        for (int k = 0; k < cnt; ++k) { const WgJob& j = jobs[idx[k]]; tot += (double)j.B * j.OH * j.OW * j.Cout * (j.Cin / j.groups) * j.R * j.S; }
+        WgradMulti mp; UnpackMulti up;
+        mp.n = cnt; up.n = cnt; up.beta = beta; mp.start[0] = 0; up.start[0] = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const WgJob& j = jobs[idx[k]];
+            WgradP& p = mp.p[k];
+            const int taps = j.R * j.S;
+            p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.dwp = ws ? ws + used : nullptr; p.zero = nullptr;
+            p.B = j.B; p.H = j.H; p.W = j.W; p.Cin = j.Cin; p.OH = j.OH; p.OW = j.OW; p.Cout = j.Cout;
+            p.R = j.R; p.S = j.S; p.stride = j.stride; p.pad = j.pad; p.dil = j.dil; p.groups = j.groups;
+            p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
+            p.M = (long)j.B * j.OH * j.OW;
+            p.ntapgroups = (taps + tgs - 1) / tgs;
+            const int nco = (p.Cout_g + ct * 16 - 1) / (ct * 16), nci = (p.Cin_g + ni * 16 - 1) / (ni * 16);
+            const long other = (long)nco * nci * p.ntapgroups * j.groups;
+            const long nchunks = (p.M + CHUNK - 1) / CHUNK;
+            const double w = (double)p.M * j.Cout * p.Cin_g * taps;
+            long ms = (long)(target * (w / tot) / other + 0.5);
+            if (ms > nchunks / 2) ms = nchunks / 2;
+            if (ms < 1) ms = 1;
+            p.msplit = (int)ms;
+            mp.nyb[k] = nco * nci * p.ntapgroups;
+            mp.start[k + 1] = mp.start[k] + (int)(ms * other);
+            const long total = (long)j.Cout * p.Cin_g * taps;
+            up.dwp[k] = p.dwp; up.dw[k] = j.dw; up.G[k] = j.groups; up.Cout_g[k] = p.Cout_g; up.Cin_g[k] = p.Cin_g; up.taps[k] = taps;
+            up.start[k + 1] = up.start[k] + total;
+            used += (size_t)(total + 15) / 16 * 16;
+        }
+        if (!ws) continue;
+        if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad_multi: workspace too small");
+        const dim3 grid((unsigned)mp.start[cnt]);
+#define WGM(a, b) if (ct == a && ni == b && tgs == 9) hipLaunchKernelGGL((conv_wgrad_multi_kernel<a, b, 9>), grid, dim3(256), 0, st, mp); else
+#define WGM1(a, b) if (ct == a && ni == b && tgs == 1) hipLaunchKernelGGL((conv_wgrad_multi_kernel<a, b, 1>), grid, dim3(256), 0, st, mp); else
+        WGM(1, 1) WGM(1, 2) WGM(1, 3) WGM(1, 4) WGM(2, 1) WGM(2, 2) WGM(2, 3) WGM(2, 4) WGM(3, 1) WGM(3, 2) WGM(3, 3) WGM(4, 1) WGM(4, 2)
+        WGM1(1, 1) WGM1(1, 2) WGM1(1, 3) WGM1(1, 4) WGM1(2, 1) WGM1(2, 2) WGM1(2, 3) WGM1(2, 4)
+        WGM1(3, 1) WGM1(3, 2) WGM1(3, 3) WGM1(3, 4) WGM1(4, 1) WGM1(4, 2) WGM1(4, 3) WGM1(4, 4)
+        return danet::fail(DANET_ERR_ARG, "conv_wgrad_multi: no kernel for tiles %dx%d", ct, ni);
+#undef WGM
+#undef WGM1
+        DANET_CHECK_LAUNCH("conv_wgrad_multi_kernel");
+        hipLaunchKernelGGL(wgrad_unpack_multi_kernel, dim3((unsigned)danet::cdiv(up.start[cnt], 256)), dim3(256), 0, st, up);
+        DANET_CHECK_LAUNCH("wgrad_unpack_multi_kernel");
+    }
+    if (need_out) *need_out = used;
+    return DANET_OK;
+}
+
+extern "C" size_t danet_conv_wgrad_multi_ws_floats(const void* jobs, int n)
+{
+    size_t need = 0;
+    if (!jobs || n <= 0) return 0;
+    wg_multi((const WgJob*)jobs, n, nullptr, 0, 0.f, nullptr, &need);
+    return need;
+}
+
+extern "C" int danet_conv_wgrad_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(jobs && n > 0 && ws, "conv_wgrad_multi: bad arguments");
+    const WgJob* jb = (const WgJob*)jobs;
+    for (int i = 0; i < n; ++i) DANET_CHECK_ARG(wg_job_ok(jb[i]), "conv_wgrad_multi: job %d has unsupported sizes", i);
+    return wg_multi(jb, n, ws, ws_floats, beta, (hipStream_t)stream, nullptr);
 }

@@ -188,6 +188,10 @@ size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int
  * backward pass and compute them with a few multi-problem launches (up to 20 problems per launch, grouped by kernel instance).
  * jobs: array of n { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups; } (host memory). */
 size_t danet_conv_wgrad3x3_multi_ws_floats(const void* jobs, int n);
+/* the same for the general weight-gradient kernel; jobs: { const void* x; const void* dy; float* dw;
+ * int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; }; ws must be ZEROED by the caller. */
+size_t danet_conv_wgrad_multi_ws_floats(const void* jobs, int n);
+int danet_conv_wgrad_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
 int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
 int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups);   /* CT*10 + NI */
 int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,

@@ -149,3 +149,33 @@ def test_weight_bank_matches_individual_packing():
         ref = dconv.pack_weight(w, key[2], key[1])
         assert torch.equal(view[:ref.numel()].view(torch.int16), ref.view(torch.int16)), key
     dconv._PACK_CACHE.clear()
+
+
+def test_deferred_multi_problem_wgrad_matches_immediate():
+    """Weight gradients queued during backward and computed by the multi-problem launches (conv.flush_wgrads)
+    equal the per-layer launches (fp32; only the partial-sum order differs)."""
+    from danet_densepose2smpl_amd import conv as dconv
+    torch.manual_seed(0)
+    cfgs = [(48, 48, 3, 1, 1, 32), (96, 96, 3, 1, 1, 16), (192, 192, 3, 1, 1, 8), (48, 96, 3, 2, 1, 32), (64, 256, 1, 1, 0, 16),
+            (256, 64, 1, 1, 0, 16), (64, 64, 7, 2, 3, 32), (48, 24, 3, 1, 1, 32)]
+    convs = [dconv.Conv2d(ci, co, k, s, p, bias=False).cuda() for ci, co, k, s, p, _ in cfgs]
+    xs = [torch.randn(3, ci, h, h, device='cuda') for ci, _, _, _, _, h in cfgs]
+
+    def run(defer):
+        for c in convs:
+            c.weight.grad = None
+        dconv.DEFER_WGRAD = defer
+        try:
+            loss = sum((c(x).float() * torch.cos(torch.arange(c(x).numel(), device='cuda').view_as(c(x)) * 0.01)).sum() for c, x in zip(convs, xs))
+            loss.backward()
+        finally:
+            dconv.DEFER_WGRAD = False
+        if defer:
+            assert len(dconv._WQ) + len(dconv._WQG) == len(convs)
+        dconv.flush_wgrads()
+        torch.cuda.synchronize()
+        return [c.weight.grad.clone() for c in convs]
+    ref = run(False)
+    got = run(True)
+    for r, g, cfg in zip(ref, got, cfgs):
+        assert (g - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-6, cfg
