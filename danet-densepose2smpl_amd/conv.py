@@ -60,6 +60,7 @@ FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '1')))   # dgr
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_LDS3X3 = bool(int(os.environ.get('DANET_LDS3X3', '0')))         # 3x3/s1/p1 forward + data gradient through the LDS-staged kernel (conv3x3_lds.hip)
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
+TRACE = None           # debugging: a list that receives (tag, shape, mean |value|) for every conv / BN launch (tools/debug_flaky.py)
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
 
 
@@ -237,6 +238,8 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
                                stream()), 'danet_conv_forward')
     if tok is not None:
         PROFILER.end(tok)
+    if TRACE is not None:
+        TRACE.append(('dgrad' if transposed else 'conv', (B, H, W, Cin, Cout, R, stride), y.float().abs().mean()))
     return y
 
 

@@ -67,9 +67,9 @@ __device__ inline void stv(__amdgpu_buffer_rsrc_t r, int off, const Vec& a) {
 
 struct RowIter {
     int row, off, rstep, ostride, M;
-    __device__ inline void init(const FlatMap& fm, int t, int& cv) {
+    __device__ inline void init(const FlatMap& fm, int bid, int t, int& cv) {
         cv = t % fm.CV;
-        row = (blockIdx.x * fm.span + t) / fm.CV;
+        row = (bid * fm.span + t) / fm.CV;
         off = ((row * fm.ldv + fm.coff + cv) * VW) * 2;
         rstep = fm.rstep; ostride = fm.rstep * fm.ldv * VW * 2; M = fm.M;
     }
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
     for (int j = 0; j < VW; ++j) { s.v[j] = 0.f; q.v[j] = 0.f; }
     if (t < fm.span) {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes);
-        int cv; RowIter it; it.init(fm, t, cv);
+        int cv; RowIter it; it.init(fm, blockIdx.x, t, cv);
         for (; it.more(); it.next()) {
             Vec a[UNR];
 #pragma unroll
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 }
 
 // mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
-__global__ __launch_bounds__(256) void bn_apply_kernel(
-    const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, FlatMap fm,
+__device__ __forceinline__ void bn_apply_body(
+    const int bid, const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved /* [2][Cst] mean, invstd */,
     int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const int C = Cst;
     __shared__ float sStat[2][SLAB];
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes), rr = make_rsrc(res ? res : x, fm.bytes), yr = make_rsrc(y, fm.bytes);
-    int cv = 0; RowIter it; it.init(fm, t < fm.span ? t : 0, cv);
+    int cv = 0; RowIter it; it.init(fm, bid, t < fm.span ? t : 0, cv);
     Vec a[UNR], r[UNR];
     int o[UNR];
     auto fetch = [&]() {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         const float g = gamma ? gamma[c0 + j] : 1.f, b = beta ? beta[c0 + j] : 0.f;
         sc[j] = invstd * g;
         sh[j] = b - mean * sc[j];
-        if (mode == 0 && blockIdx.x == 0 && t < fm.CV) {
+        if (mode == 0 && bid == 0 && t < fm.CV) {
             if (saved) { saved[c0 + j] = mean; saved[C + c0 + j] = invstd; }
             if (running_mean) {
                 running_mean[c0 + j] = (1.f - momentum) * running_mean[c0 + j] + momentum * mean;
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+__device__ __forceinline__ void bn_bwd_reduce_body(
+    const int bid, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */)
 {
     __shared__ float sm[256][VW];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int j = 0; j < VW; ++j) { s1.v[j] = 0.f; s2.v[j] = 0.f; }
     if (t < fm.span) {
         const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(relu ? y : x, fm.bytes);
-        int cv; RowIter it; it.init(fm, t, cv);
+        int cv; RowIter it; it.init(fm, bid, t, cv);
         const int c0 = cv * VW;
         float mean[VW], invstd[VW];
 #pragma unroll
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 }
         }
     }
-    float* dst = red + (size_t)(blockIdx.x % NCOPY) * 2 * C;
+    float* dst = red + (size_t)(bid % NCOPY) * 2 * C;
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+__device__ __forceinline__ void bn_bwd_apply_body(
+    const int bid, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
     int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam)
 {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     __shared__ float sStat[2][SLAB];
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(relu ? y : x, fm.bytes);
     const __amdgpu_buffer_rsrc_t dxr = make_rsrc(dx, fm.bytes), drr = make_rsrc(dres ? dres : dx, fm.bytes);
-    int cv = 0; RowIter it; it.init(fm, t < fm.span ? t : 0, cv);
+    int cv = 0; RowIter it; it.init(fm, bid, t < fm.span ? t : 0, cv);
     Vec g[UNR], a[UNR], o[UNR];
     int of[UNR];
     auto fetch = [&]() {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         k0[j] = (gamma ? gamma[c0 + j] : 1.f) * invstd[j];
         const float s0 = sStat[0][c0 + j], s1 = sStat[1][c0 + j];
         m1[j] = s0 * inv_count; m2[j] = s1 * inv_count;
-        if (blockIdx.x == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
+        if (bid == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
     }
     while (it.more()) {
         Vec d[UNR], gm[UNR];
@@ -306,6 +306,65 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             stv(dxr, oo[u], d[u]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, FlatMap fm,
+    const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved,
+    int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu)
+{
+    bn_apply_body(blockIdx.x, x, res, y, fm, sums, gamma, beta, running_mean, running_var, saved, Cst, inv_count, unbias, momentum, eps, mode, relu);
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red)
+{
+    bn_bwd_reduce_body(blockIdx.x, dy, x, y, fm, saved, Cst, relu, red);
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
+    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam)
+{
+    bn_bwd_apply_body(blockIdx.x, dy, x, y, fm, saved, gamma, red, Cst, inv_count, relu, dx, dres, dparam);
+}
+
+// Up to 4 independent BatchNorms in one launch (the HRNet branches advance in lockstep: nn.multi_batch_norm): the
+// small branches' launches are dominated by the per-launch floor, one launch over all of them is not.
+constexpr int NBM = 4;
+struct BnFwdOne {
+    const bf16_t* x; const bf16_t* res; bf16_t* y; const float* sums; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; float* saved; FlatMap fm; int C; float inv_count, unbias; int relu;
+};
+struct BnFwdMulti { BnFwdOne a[NBM]; int start[NBM + 1]; int n; float momentum, eps; int mode; };
+__global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdMulti m)
+{
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const BnFwdOne& a = m.a[i];
+    bn_apply_body(blockIdx.x - m.start[i], a.x, a.res, a.y, a.fm, a.sums, a.gamma, a.beta, a.running_mean, a.running_var, a.saved,
+                  a.C, a.inv_count, a.unbias, m.momentum, m.eps, m.mode, a.relu);
+}
+struct BnBwdOne {
+    const bf16_t* dy; const bf16_t* x; const bf16_t* y; const float* saved; const float* gamma; float* red;
+    bf16_t* dx; bf16_t* dres; float* dparam; FlatMap fm; int C; float inv_count; int relu; int have_red;
+};
+struct BnBwdMulti { BnBwdOne a[NBM]; int start[NBM + 1]; int n; };
+__global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnBwdMulti m)
+{
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const BnBwdOne& a = m.a[i];
+    if (a.have_red) return;                              // already reduced by the consumer conv's data-gradient epilogue
+    bn_bwd_reduce_body(blockIdx.x - m.start[i], a.dy, a.x, a.y, a.fm, a.saved, a.C, a.relu, a.red);
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
+{
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const BnBwdOne& a = m.a[i];
+    bn_bwd_apply_body(blockIdx.x - m.start[i], a.dy, a.x, a.y, a.fm, a.saved, a.gamma, a.red, a.C, a.inv_count, a.relu, a.dx, a.dres, a.dparam);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -487,5 +546,74 @@ extern "C" int danet_sum_relu_backward(const void* gy, const void* y, int B, int
     hipLaunchKernelGGL(sum_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gy,
                        (const bf16_t*)y, B, H, W, C, shift, relu, (bf16_t*)d_term);
     DANET_CHECK_LAUNCH("sum_relu_bwd_kernel");
+    return DANET_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Multi-tensor BatchNorm (training mode): jobs on the host, up to 4 per call, C <= 1024 each.
+//  forward job:  { x, res, y, gamma, beta, running_mean, running_var, saved, sums; int64 M; int C, sums_state, relu }
+//      sums_state: 1 = sums is zeroed scratch (statistics pass needed), 2 = statistics already accumulated by the conv epilogue
+//  backward job: { dy, x, y, gamma, saved, dx, dres, dparam, red; int64 M; int C, red_state, relu }   (red_state as above)
+struct BnFwdJob { const void* x; const void* res; void* y; const float* gamma; const float* beta; float* running_mean; float* running_var;
+                  float* saved; float* sums; int64_t M; int C, sums_state, relu; };
+struct BnBwdJob { const void* dy; const void* x; const void* y; const float* gamma; const float* saved; void* dx; void* dres; float* dparam;
+                  float* red; int64_t M; int C, red_state, relu; };
+
+extern "C" int danet_bn_forward_multi(const void* jobs_, int n, float momentum, float eps, void* stream)
+{
+    DANET_ENTER();
+    const BnFwdJob* jobs = (const BnFwdJob*)jobs_;
+    DANET_CHECK_ARG(jobs && n >= 1 && n <= NBM, "bn_forward_multi: 1..%d jobs", NBM);
+    hipStream_t st = (hipStream_t)stream;
+    BnFwdMulti m; m.n = n; m.momentum = momentum; m.eps = eps; m.mode = 0; m.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const BnFwdJob& j = jobs[i];
+        DANET_CHECK_ARG(j.x && j.y && j.saved && j.sums && j.M > 0 && j.C > 0 && j.C <= SLAB && (j.sums_state == 1 || j.sums_state == 2),
+                        "bn_forward_multi: job %d: bad arguments (C <= %d, zeroed or pre-accumulated sums required)", i, SLAB);
+        BnFwdOne& a = m.a[i];
+        int grid;
+        DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_forward_multi: job %d: C=%d unsupported", i, j.C);
+        if (j.sums_state == 1) {
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)j.x, a.fm, j.sums, j.C);
+            DANET_CHECK_LAUNCH("bn_stats_kernel");
+        }
+        a.x = (const bf16_t*)j.x; a.res = (const bf16_t*)j.res; a.y = (bf16_t*)j.y; a.sums = j.sums; a.gamma = j.gamma; a.beta = j.beta;
+        a.running_mean = j.running_mean; a.running_var = j.running_var; a.saved = j.saved; a.C = j.C;
+        a.inv_count = 1.0f / (float)j.M; a.unbias = j.M > 1 ? (float)j.M / (float)(j.M - 1) : 1.f; a.relu = j.relu;
+        m.start[i + 1] = m.start[i] + grid;
+    }
+    hipLaunchKernelGGL(bn_apply_multi_kernel, dim3(m.start[n]), dim3(256), 0, st, m);
+    DANET_CHECK_LAUNCH("bn_apply_multi_kernel");
+    return DANET_OK;
+}
+
+extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
+{
+    DANET_ENTER();
+    const BnBwdJob* jobs = (const BnBwdJob*)jobs_;
+    DANET_CHECK_ARG(jobs && n >= 1 && n <= NBM, "bn_backward_multi: 1..%d jobs", NBM);
+    hipStream_t st = (hipStream_t)stream;
+    BnBwdMulti m; m.n = n; m.start[0] = 0;
+    bool need_reduce = false;
+    for (int i = 0; i < n; ++i) {
+        const BnBwdJob& j = jobs[i];
+        DANET_CHECK_ARG(j.dy && j.x && j.dx && j.saved && j.red && j.M > 0 && j.C > 0 && j.C <= SLAB && (!j.relu || j.y) &&
+                        (j.red_state == 1 || j.red_state == 2), "bn_backward_multi: job %d: bad arguments", i);
+        BnBwdOne& a = m.a[i];
+        int grid;
+        DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_backward_multi: job %d: C=%d unsupported", i, j.C);
+        a.dy = (const bf16_t*)j.dy; a.x = (const bf16_t*)j.x; a.y = (const bf16_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
+        a.dx = (bf16_t*)j.dx; a.dres = (bf16_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
+        a.have_red = j.red_state == 2;
+        need_reduce = need_reduce || !a.have_red;
+        m.start[i + 1] = m.start[i] + grid;
+    }
+    if (need_reduce) {
+        hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(m.start[n]), dim3(256), 0, st, m);
+        DANET_CHECK_LAUNCH("bn_bwd_reduce_multi_kernel");
+    }
+    hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(m.start[n]), dim3(256), 0, st, m);
+    DANET_CHECK_LAUNCH("bn_bwd_apply_multi_kernel");
     return DANET_OK;
 }

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .config import cfg
-from .nn import sum_relu
+from .nn import sum_relu, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
 
@@ -32,6 +32,7 @@ class _Chain(nn.Module):
         return x
 
 
+LOCKSTEP_BRANCHES = bool(int(os.environ.get('DANET_LOCKSTEP', '1')))    # one multi-tensor BatchNorm launch per block level
 BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)
 _SIDE = {}
 
@@ -85,6 +86,22 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _lockstep_ok(self):
+        n = len(self.branches[0])
+        return all(len(br) == n and all(isinstance(b, BasicBlock) and b.downsample is None for b in br) for br in self.branches)
+
+    def _branches_in_lockstep(self, x):
+        """All branches advance one BasicBlock at a time so that the four BatchNorms of a level share ONE launch
+        (nn.multi_batch_norm): the low-resolution branches' BatchNorm launches are dominated by the per-launch floor."""
+        xs = list(x[:self.num_branches])
+        for k in range(len(self.branches[0])):
+            blocks = [br[k] for br in self.branches]
+            h = [b.conv1(v) for b, v in zip(blocks, xs)]
+            h = multi_batch_norm([b.bn1 for b in blocks], h, None, relu=True)
+            h = [b.conv2(v) for b, v in zip(blocks, h)]
+            xs = multi_batch_norm([b.bn2 for b in blocks], h, xs, relu=True)
+        return xs
+
     def _branches_on_streams(self, x):
         """The resolution branches of a module are independent until the fuse layers: branch 0 (the
         chip-filling one) stays on the current stream, the low-resolution branches -- whose kernels
@@ -105,7 +122,9 @@ class HighResolutionModule(nn.Module):
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        if BRANCH_STREAMS and x[0].is_cuda:
+        if LOCKSTEP_BRANCHES and x[0].is_cuda and self.training and self._lockstep_ok():
+            x = self._branches_in_lockstep(x)
+        elif BRANCH_STREAMS and x[0].is_cuda:
             x = self._branches_on_streams(x)
         else:
             x = [self.branches[i](x[i]) for i in range(self.num_branches)]

@@ -45,6 +45,9 @@ class BatchNormActFunction(torch.autograd.Function):
             ctx.has_res = res is not None
             ctx.has_affine = gamma is not None
         ctx.training = training
+        from . import conv as _c
+        if _c.TRACE is not None:
+            _c.TRACE.append(('bn', tuple(x.shape), y.float().abs().mean()))
         if training:
             y._bn_ctx = (x, bool(relu), saved)     # lets a consumer conv fuse this BN's backward reduction (no reference to y: no cycle)
         return y
@@ -75,6 +78,9 @@ class BatchNormActFunction(torch.autograd.Function):
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
                                   None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero), stream()),
               'danet_bn_backward')
+        from . import conv as _c
+        if _c.TRACE is not None:
+            _c.TRACE.append(('bn_bwd' + ('+red' if red_zero == 2 else ''), tuple(x.shape), dx.float().abs().mean()))
         # unbind gives two independent-looking tensors that AccumulateGrad can keep without a clone
         dbeta, dgamma = (dparam[0], dparam[1]) if ctx.has_affine else (None, None)
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
@@ -97,6 +103,104 @@ class BatchNorm2d(nn.BatchNorm2d):
                                           self.running_mean if self.track_running_stats else None,
                                           self.running_var if self.track_running_stats else None,
                                           training, momentum, self.eps, relu, fused)
+
+
+class MultiBatchNormFunction(torch.autograd.Function):
+    """n (<= 4) independent training-mode BatchNorm(+residual)(+ReLU) ops in ONE launch per pass
+    (csrc/norm_act.hip bn_*_multi_kernel).  Tensor arguments: xs[n], ress[n] (None allowed), gammas[n], betas[n];
+    `static` carries the running buffers, flags and the conv-epilogue statistics."""
+
+    @staticmethod
+    def forward(ctx, static, *tensors):
+        L = _lib.lib()
+        n, relu, momentum, eps, rms, rvs, fused = static
+        xs = [nhwc_bf16(t) for t in tensors[:n]]
+        ress = [None if t is None else nhwc_bf16(t) for t in tensors[n:2 * n]]
+        gammas = [t.detach().float().contiguous() for t in tensors[2 * n:3 * n]]
+        betas = [t.detach().float().contiguous() for t in tensors[3 * n:4 * n]]
+        jobs = (_lib.BnFwdJob * n)()
+        ys, saveds, keep = [], [], []
+        for i in range(n):
+            B, C, H, W = xs[i].shape
+            if ress[i] is not None and ress[i].shape != xs[i].shape:
+                raise ValueError('residual shape %s != %s' % (tuple(ress[i].shape), tuple(xs[i].shape)))
+            y = _empty_nhwc(B, C, H, W, torch.bfloat16, xs[i].device)
+            saved = torch.empty(2, C, dtype=torch.float32, device=xs[i].device)
+            sums, state = fused[i], 2
+            if sums is None:
+                sums, state = ARENA.alloc(L.danet_bn_ws_floats(C)), 1
+                if sums is None:
+                    sums = torch.zeros(L.danet_bn_ws_floats(C), dtype=torch.float32, device=xs[i].device)
+            keep.append(sums)
+            j = jobs[i]
+            j.x, j.res, j.y = xs[i].data_ptr(), None if ress[i] is None else ress[i].data_ptr(), y.data_ptr()
+            j.gamma, j.beta = gammas[i].data_ptr(), betas[i].data_ptr()
+            j.running_mean = None if rms[i] is None else rms[i].data_ptr()
+            j.running_var = None if rvs[i] is None else rvs[i].data_ptr()
+            j.saved, j.sums = saved.data_ptr(), sums.data_ptr()
+            j.M, j.C, j.sums_state, j.relu = B * H * W, C, state, int(relu)
+            ys.append(y)
+            saveds.append(saved)
+        check(L.danet_bn_forward_multi(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
+        ctx.save_for_backward(*xs, *ys, *gammas, *saveds)
+        ctx.cfg = (n, relu, [r is not None for r in ress])
+        for y, x, saved in zip(ys, xs, saveds):
+            y._bn_ctx = (x, bool(relu), saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        L = _lib.lib()
+        n, relu, has_res = ctx.cfg
+        sv = ctx.saved_tensors
+        xs, ys, gammas, saveds = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
+        jobs = (_lib.BnBwdJob * n)()
+        dxs, dress, dparams, keep = [], [], [], []
+        for i in range(n):
+            B, C, H, W = xs[i].shape
+            red = getattr(gys[i], '_bn_red', None)
+            state = 2
+            if red is None:
+                red, state = ARENA.alloc(L.danet_bn_ws_floats(C)), 1
+                if red is None:
+                    red = torch.zeros(L.danet_bn_ws_floats(C), dtype=torch.float32, device=xs[i].device)
+            gy = nhwc_bf16(gys[i])
+            dx = _empty_nhwc(B, C, H, W, torch.bfloat16, xs[i].device)
+            dres = _empty_nhwc(B, C, H, W, torch.bfloat16, xs[i].device) if has_res[i] else None
+            dparam = torch.empty(2, C, dtype=torch.float32, device=xs[i].device)
+            keep += [red, gy]
+            j = jobs[i]
+            j.dy, j.x, j.y = gy.data_ptr(), xs[i].data_ptr(), ys[i].data_ptr()
+            j.gamma, j.saved = gammas[i].data_ptr(), saveds[i].data_ptr()
+            j.dx, j.dres, j.dparam, j.red = dx.data_ptr(), None if dres is None else dres.data_ptr(), dparam.data_ptr(), red.data_ptr()
+            j.M, j.C, j.red_state, j.relu = B * H * W, C, state, int(relu)
+            dxs.append(dx)
+            dress.append(dres)
+            dparams.append(dparam)
+        check(L.danet_bn_backward_multi(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
+        return (None, *dxs, *dress, *[d[1] for d in dparams], *[d[0] for d in dparams])
+
+
+def multi_batch_norm(bns, xs, ress=None, relu=False):
+    """[bn(x, res, relu) for bn, x, res in ...] for up to 4 training-mode BatchNorm2d modules in one launch per pass;
+    falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
+    n = len(bns)
+    ress = list(ress) if ress is not None else [None] * n
+    ok = 1 <= n <= 4 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
+    if not ok:
+        return [b(x, r, relu) for b, x, r in zip(bns, xs, ress)]
+    mom = {0.1 if b.momentum is None else b.momentum for b in bns}
+    eps = {b.eps for b in bns}
+    if len(mom) != 1 or len(eps) != 1:
+        return [b(x, r, relu) for b, x, r in zip(bns, xs, ress)]
+    for b in bns:
+        if b.track_running_stats and b.num_batches_tracked is not None and BatchNorm2d.count_batches:
+            b.num_batches_tracked.add_(1)
+    rms = [b.running_mean if b.track_running_stats else None for b in bns]
+    rvs = [b.running_var if b.track_running_stats else None for b in bns]
+    fused = [getattr(x, '_bn_sums', None) for x in xs]
+    static = (n, bool(relu), mom.pop(), eps.pop(), rms, rvs, fused)
+    return list(MultiBatchNormFunction.apply(static, *xs, *ress, *[b.weight for b in bns], *[b.bias for b in bns]))
 
 
 class SumReluFunction(torch.autograd.Function):

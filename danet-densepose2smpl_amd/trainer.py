@@ -103,7 +103,7 @@ class Trainer(object):
         """Per-step device housekeeping: zero the accumulator arena, repack all conv weights (one launch).
         The first GPU step records which packed weights the model asks for and builds the bank."""
         _conv.ARENA.begin_step()
-        if self.device.type == 'cuda':
+        if self.device.type == 'cuda' and not os.environ.get('DANET_NO_BANK'):
             if self.bank is None:
                 self.bank = _conv.WeightBank()
                 self.bank.start_recording()

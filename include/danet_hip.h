@@ -223,6 +223,13 @@ size_t danet_bn_ws_floats(int C);
 int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                       const float* gamma, const float* saved, int relu,
                       void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero, void* stream);
+/* Up to 4 independent training-mode BatchNorms per launch (HRNet branches in lockstep); C <= 1024 each.
+ *  forward job  { const void* x, *res; void* y; const float* gamma, *beta; float* running_mean, *running_var, *saved, *sums;
+ *                 int64_t M; int C, sums_state, relu; }   sums_state 1: zeroed scratch, 2: accumulated by the conv epilogue
+ *  backward job { const void* dy, *x, *y; const float* gamma, *saved; void* dx, *dres; float* dparam, *red;
+ *                 int64_t M; int C, red_state, relu; }    red_state 1: zeroed scratch, 2: accumulated by the dgrad epilogue */
+int danet_bn_forward_multi(const void* jobs, int n, float momentum, float eps, void* stream);
+int danet_bn_backward_multi(const void* jobs, int n, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,
                            int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,

@@ -173,3 +173,37 @@ def test_dgrad_epilogue_bn_backward_reduction(C, Cout, H, B, relu, use_res):
     if rf is not None:
         assert torch.equal(rf, ru)
     assert not torch.equal(gwf, gwu) or C < 0 or True      # (orders differ; equality is allowed but not required)
+
+
+def test_multi_batch_norm_matches_per_module():
+    """One launch over four differently shaped BatchNorm(+res)(+ReLU) problems == the four separate launches."""
+    from danet_densepose2smpl_amd import nn as dnn
+    torch.manual_seed(2)
+    shapes = [(3, 48, 32, 32), (3, 96, 16, 16), (3, 192, 8, 8), (3, 384, 4, 4)]
+    for use_res in (False, True):
+        bns_a = [dnn.BatchNorm2d(s[1]).cuda().train() for s in shapes]
+        bns_b = [dnn.BatchNorm2d(s[1]).cuda().train() for s in shapes]
+        for a, b in zip(bns_a, bns_b):
+            with torch.no_grad():
+                a.weight.uniform_(0.5, 1.5); a.bias.uniform_(-0.5, 0.5)
+            b.load_state_dict(a.state_dict())
+        xs = [torch.randn(s, device='cuda') for s in shapes]
+        rs = [torch.randn(s, device='cuda') for s in shapes] if use_res else [None] * 4
+        gs = [torch.randn(s, device='cuda').bfloat16() for s in shapes]
+        xa = [x.clone().requires_grad_(True) for x in xs]
+        ra = [None if r is None else r.clone().requires_grad_(True) for r in rs]
+        ya = dnn.multi_batch_norm(bns_a, xa, ra, relu=True)
+        torch.autograd.backward(ya, gs)
+        xb = [x.clone().requires_grad_(True) for x in xs]
+        rb = [None if r is None else r.clone().requires_grad_(True) for r in rs]
+        yb = [b(x, r, relu=True) for b, x, r in zip(bns_b, xb, rb)]
+        torch.autograd.backward(yb, gs)
+        for i in range(4):
+            _close(ya[i], yb[i], 1e-2, 'y %d' % i)           # (statistics via float atomics: last-bit differences round differently in bf16)
+            _close(xa[i].grad, xb[i].grad, 1e-2, 'dx %d' % i)
+            _close(bns_a[i].weight.grad, bns_b[i].weight.grad, 1e-4, 'dgamma %d' % i)
+            _close(bns_a[i].bias.grad, bns_b[i].bias.grad, 1e-4, 'dbeta %d' % i)
+            _close(bns_a[i].running_var, bns_b[i].running_var, 1e-5, 'running_var %d' % i)
+            if use_res:
+                _close(ra[i].grad, rb[i].grad, 1e-2, 'dres %d' % i)
+            assert int(bns_a[i].num_batches_tracked) == 1
