@@ -37,6 +37,8 @@ _SIGNATURES = {
     'danet_conv3x3_kernel_id': (c_i, [c_i] * 5),
     'danet_conv3x3_forward': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f, c_f]),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, c_f]),
+    'danet_conv_forward_multi_ok': (c_i, [c_f, c_i]),
+    'danet_conv_forward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_conv_forward_kernel': (c_i, [c_i] * 15),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
@@ -91,6 +93,12 @@ class BnBwdJob(ctypes.Structure):
     """One tensor of danet_bn_backward_multi."""
     _fields_ = [(k, ctypes.c_void_p) for k in ('dy', 'x', 'y', 'gamma', 'saved', 'dx', 'dres', 'dparam', 'red')] + \
                [('M', ctypes.c_int64), ('C', c_i), ('red_state', c_i), ('relu', c_i)]
+
+
+class ConvJob(ctypes.Structure):
+    """One problem of danet_conv_forward_multi (include/danet_hip.h)."""
+    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'wp', 'y', 'bn_sums', 'bn_x', 'bn_y', 'bn_saved', 'bn_red')] + \
+               [(k, c_i) for k in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'R', 'S', 'stride', 'pad', 'dil', 'groups', 'transposed')]
 
 
 def exported_symbols():

@@ -503,6 +503,141 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     return y
 
 
+def _conv_job(job, x, wp, y, dims, transposed, bn_sums=None, bn_bwd=None):
+    (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims
+    job.x, job.wp, job.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    job.bn_sums = None if bn_sums is None else bn_sums.data_ptr()
+    if bn_bwd is None:
+        job.bn_x = job.bn_y = job.bn_saved = job.bn_red = None
+    else:
+        job.bn_x, job.bn_y = bn_bwd[0].data_ptr(), None if bn_bwd[1] is None else bn_bwd[1].data_ptr()
+        job.bn_saved, job.bn_red = bn_bwd[2].data_ptr(), bn_bwd[3].data_ptr()
+    (job.B, job.H, job.W, job.Cin, job.OH, job.OW, job.Cout, job.R, job.S, job.stride, job.pad, job.dil, job.groups) = dims
+    job.transposed = int(transposed)
+
+
+class MultiConvFunction(torch.autograd.Function):
+    """n (<= 4) independent bias-free convolutions in ONE launch (forward) and one launch for their data gradients
+    (csrc/conv_fast.hip conv_fast_multi_kernel); weight gradients go through the usual (deferred) path.
+    Tensor arguments: xs[n], weights[n]; `static` = (n, [(stride, pad, dil, groups)], want_stats, bn_ctxs)."""
+
+    @staticmethod
+    def forward(ctx, static, *tensors):
+        import ctypes
+        L = _lib.lib()
+        n, cfgs, want_stats, bn_ctxs = static
+        xs = [nhwc_bf16(t) for t in tensors[:n]]
+        ws = tensors[n:2 * n]
+        jobs = (_lib.ConvJob * n)()
+        ys, sums_l, dims_l, keep = [], [], [], []
+        for i in range(n):
+            stride, pad, dil, groups = cfgs[i]
+            B, Cin, H, W = xs[i].shape
+            Cout, Cin_g, R, S = ws[i].shape
+            OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+            dims = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)
+            wp = pack_weight(ws[i], groups, 0)
+            y = _empty_nhwc(B, Cout, OH, OW, torch.bfloat16, xs[i].device)
+            sums = None
+            if want_stats and FUSE_BN_STATS:
+                nfl = L.danet_bn_ws_floats(Cout)
+                sums = ARENA.alloc(nfl)
+                if sums is None:
+                    sums = torch.zeros(nfl, dtype=torch.float32, device=y.device)
+            _conv_job(jobs[i], xs[i], wp, y, dims, False, sums)
+            ys.append(y); sums_l.append(sums); dims_l.append(dims); keep.append(wp)
+        check(L.danet_conv_forward_multi(ctypes.addressof(jobs), n, stream()), 'danet_conv_forward_multi')
+        if TRACE is not None:
+            for y, d in zip(ys, dims_l):
+                TRACE.append(('conv', (d[0], d[1], d[2], d[3], d[6], d[7], d[9]), y.float().abs().mean()))
+        ctx.save_for_backward(*xs, *ws)
+        ctx.cfg = (n, dims_l, bn_ctxs)
+        for y, sums in zip(ys, sums_l):
+            if sums is not None:
+                y._bn_sums = sums
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        import ctypes
+        L = _lib.lib()
+        n, dims_l, bn_ctxs = ctx.cfg
+        sv = ctx.saved_tensors
+        xs, ws = sv[:n], sv[n:2 * n]
+        gys = [nhwc_bf16(g) for g in gys]
+        gws = [None] * n
+        for i in range(n):                      # weight gradients first: queued (deferred) or launched per layer
+            if ctx.needs_input_grad[1 + n + i]:
+                (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
+                gws[i] = torch.empty(Cout, Cin // groups, R, S, dtype=torch.float32, device=xs[i].device)
+                _wgrad_into(gws[i], xs[i], gys[i], B, H, W, Cin, OH, OW, Cout, Cin // groups, R, S, stride, pad, dil, groups, ws[i])
+        gxs = [None] * n
+        need = [i for i in range(n) if ctx.needs_input_grad[1 + i]]
+        if need:
+            jobs = (_lib.ConvJob * len(need))()
+            keep, reds = [], []
+            for k, i in enumerate(need):
+                (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
+                wp1 = pack_weight(ws[i], groups, 1)
+                gx = _empty_nhwc(B, Cin, H, W, torch.bfloat16, xs[i].device)
+                bn_bwd = None
+                if FUSE_BN_BWD_REDUCE and bn_ctxs[i] is not None and bn_ctxs[i][0].shape == xs[i].shape:
+                    bn_x, bn_relu, saved = bn_ctxs[i]
+                    nfl = L.danet_bn_ws_floats(Cin)
+                    red = ARENA.alloc(nfl)
+                    if red is None:
+                        red = torch.zeros(nfl, dtype=torch.float32, device=gx.device)
+                    bn_bwd = (bn_x, xs[i] if bn_relu else None, saved, red)
+                # data gradient = the transposed gather: roles of (H, W, Cin) and (OH, OW, Cout) swap
+                _conv_job(jobs[k], gys[i], wp1, gx, (B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups), True, None, bn_bwd)
+                gxs[i] = gx
+                reds.append(None if bn_bwd is None else bn_bwd[3])
+                keep.append(wp1)
+            if L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), len(need)):
+                check(L.danet_conv_forward_multi(ctypes.addressof(jobs), len(need), stream()), 'danet_conv_forward_multi')
+                for k, i in enumerate(need):
+                    if reds[k] is not None:
+                        gxs[i]._bn_red = reds[k]
+            else:                                   # e.g. tile counts differ between the problems: per-layer launches
+                for k, i in enumerate(need):
+                    (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
+                    gxs[i] = _conv_fwd_raw(gys[i], keep[k], None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
+            if TRACE is not None:
+                for i in need:
+                    d = dims_l[i]
+                    TRACE.append(('dgrad', (d[0], d[4], d[5], d[6], d[3], d[7], d[9]), gxs[i].float().abs().mean()))
+        return (None, *gxs, *gws)
+
+
+def multi_conv(convs, xs):
+    """[conv(x) for conv, x in zip(convs, xs)] for up to 4 bias-free Conv2d modules in one launch per pass; falls back
+    to the per-module path when the set does not qualify (channel padding, bias, mixed tile counts, fp32 outputs)."""
+    import ctypes
+    n = len(convs)
+    L = _lib.lib()
+    ok = 1 <= n <= 4 and xs[0].is_cuda and all(c.bias is None and not c.out_fp32 and c.stride[0] == c.stride[1] and
+                                                c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1] for c in convs)
+    if ok:
+        jobs = (_lib.ConvJob * n)()
+        for j, c, x in zip(jobs, convs, xs):
+            B, Cin, H, W = x.shape
+            Cout, Cin_g, R, S = c.weight.shape
+            if Cin_g * c.groups != Cin or Cin % 8 or (Cout // c.groups) % 8:
+                ok = False
+                break
+            st, pd, dl = c.stride[0], c.padding[0], c.dilation[0]
+            (j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups, j.transposed) = \
+                (B, H, W, Cin, conv_out_size(H, R, st, pd, dl), conv_out_size(W, S, st, pd, dl), Cout, R, S, st, pd, dl, c.groups, 0)
+        ok = ok and bool(L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), n))
+    if not ok:
+        return [c(x) for c, x in zip(convs, xs)]
+    grad = torch.is_grad_enabled()
+    cfgs = [(c.stride[0], c.padding[0], c.dilation[0], c.groups) for c in convs]
+    bn_ctxs = [getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and grad) else None for x in xs]
+    static = (n, cfgs, all(c.training for c in convs), bn_ctxs)
+    return list(MultiConvFunction.apply(static, *xs, *[c.weight for c in convs]))
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d with the same parameters / state-dict keys, computed by the HIP MFMA kernels."""
 

@@ -38,5 +38,6 @@ struct ConvP {
 // conv_fast.hip: the lean kernel for the common cases (conv_igemm.hip keeps the general one)
 bool conv_fast_ok(const ConvP& p, bool vec8, int mt);
 int conv_fast_launch(const ConvP& p, int mt, int nt, void* stream);
+int conv_fast_launch_multi(const ConvP* ps, const int* mts, int n, int nt, void* stream);
 
 }  // namespace danet_conv

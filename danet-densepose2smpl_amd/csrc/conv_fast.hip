@@ -51,7 +51,7 @@ constexpr int OOB = 0x7fffffff;      // beyond every buffer (sizes are checked t
 // dst [32][2][Ctot].
 template <int NT>
 __device__ inline void channel_sums_to_replicas(float (*s1)[4], float (*s2)[4], float* __restrict__ dst, int Ctot, int cbase,
-                                                int n0, int Cg, int t, int li, int lg, int wave)
+                                                int n0, int Cg, int t, int li, int lg, int wave, int rep)
 {
     __shared__ float sStat[4][2][NT * 16];
     __syncthreads();                                   // a previous use of sStat by this block is finished
@@ -67,12 +67,12 @@ __device__ inline void channel_sums_to_replicas(float (*s1)[4], float (*s2)[4], 
         const int which = t / (NT * 16), c = t - which * (NT * 16);
         const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
         const int cl = n0 + c;
-        if (cl < Cg) atomicAdd(dst + ((size_t)(blockIdx.x % BN_NCOPY) * 2 + which) * Ctot + cbase + cl, v);
+        if (cl < Cg) atomicAdd(dst + ((size_t)(rep % BN_NCOPY) * 2 + which) * Ctot + cbase + cl, v);
     }
 }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
+__device__ __forceinline__ void conv_fast_body(const ConvP& p, const int bx_, const int by_, const int bz_)
 {
     extern __shared__ __attribute__((aligned(16))) i32x2 sTab[];     // per 8-channel k group: {byte delta, r | s<<5 | wks<<10}
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
 
     // parity classes of the strided transposed gather (see conv_igemm.hip)
     const int nclass = p.parity ? p.stride * p.stride : 1;
-    const int g = blockIdx.z / nclass, cls = blockIdx.z - g * nclass;
+    const int g = bz_ / nclass, cls = bz_ - g * nclass;
     const int py = p.parity ? cls / p.stride : 0, px = p.parity ? cls - py * p.stride : 0;
     const int step = p.parity ? p.stride : 1;
     const int OHc = (p.OH - py + step - 1) / step, OWc = (p.OW - px + step - 1) / step;
     const int Mc = p.parity ? p.B * OHc * OWc : (int)p.M;
     // (an XCD-contiguous tile order -- every XCD's L2 serving one contiguous pixel range -- was measured and did
     // not help: the 256 MB infinity cache already absorbs the cross-XCD halo re-reads)
-    const int bx = blockIdx.x;
+    const int bx = bx_;
     if (bx * (64 * MT) >= Mc) return;
 
     // tap geometry: tap row index i (0 .. nr-1) reads input row  ph + i*dh ; likewise columns
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
     }
     __syncthreads();
 
-    const int n0 = blockIdx.y * (16 * NT);
+    const int n0 = by_ * (16 * NT);
     const int nks_w = p.Kp / 32;                                       // k-steps of the packed weights
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const bf16_t* wblk = p.w + ((size_t)g * (p.Cout_pad / 16) + n0 / 16) * (size_t)nks_w * 512;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
                 }
                 s1[nt][r] = a; s2[nt][r] = b;
             }
-        channel_sums_to_replicas<NT>(s1, s2, p.stats, p.Cout, g * p.Cout_g, n0, p.Cout_g, t, li, lg, wave);
+        channel_sums_to_replicas<NT>(s1, s2, p.stats, p.Cout, g * p.Cout_g, n0, p.Cout_g, t, li, lg, wave, bx);
     }
     // ... or (data gradient) the two BatchNorm-backward sums of the BN that produced this conv's input
     if (p.bn_red) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
                 }
             }
         }
-        channel_sums_to_replicas<NT>(s1, s2, p.bn_red, p.Cout, g * p.Cout_g, n0, p.Cout_g, t, li, lg, wave);
+        channel_sums_to_replicas<NT>(s1, s2, p.bn_red, p.Cout, g * p.Cout_g, n0, p.Cout_g, t, li, lg, wave, bx);
     }
 
     // epilogue: lane holds couts n0 + nt*16 + lg*4 + {0..3} of its MT pixels (Cout_g % 4 == 0, checked by the host)
@@ -339,6 +339,31 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
             }
         }
     }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
+{
+    conv_fast_body<MT, NT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Up to 4 independent convolutions with the same NT in one launch (HRNet branches in lockstep): workgroup id ->
+// problem through the prefix table, then the problem's own (MT, grid).
+constexpr int NCM = 4;
+struct ConvMulti { ConvP p[NCM]; int start[NCM + 1]; int gx[NCM], gy[NCM], mt[NCM]; int n; };
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_fast_multi_kernel(ConvMulti m)
+{
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const int l = blockIdx.x - m.start[i];
+    const int bx = l % m.gx[i], rest = l / m.gx[i];
+    const int by = rest % m.gy[i], bz = rest / m.gy[i];
+    const ConvP& p = m.p[i];
+    if (m.mt[i] == 4) conv_fast_body<4, NT>(p, bx, by, bz);
+    else if (m.mt[i] == 2) conv_fast_body<2, NT>(p, bx, by, bz);
+    else conv_fast_body<1, NT>(p, bx, by, bz);
 }
 
 template <int MT, int NT>
@@ -386,6 +411,45 @@ int conv_fast_launch(const ConvP& p, int mt, int nt, void* stream) {
     FAST_CASE(1, 1) FAST_CASE(2, 1) FAST_CASE(4, 1) FAST_CASE(1, 2) FAST_CASE(2, 2) FAST_CASE(4, 2)
     FAST_CASE(1, 3) FAST_CASE(2, 3) FAST_CASE(4, 3) FAST_CASE(1, 4) FAST_CASE(2, 4) FAST_CASE(4, 4)
 #undef FAST_CASE
+    return -1;
+}
+
+// All problems must pass conv_fast_ok and share NT.  Returns 0 on launch, -1 if the set is not supported.
+int conv_fast_launch_multi(const ConvP* ps, const int* mts, int n, int nt, void* stream) {
+    if (n < 1 || n > NCM) return -1;
+    ConvMulti m;
+    m.n = n; m.start[0] = 0;
+    size_t lds = 0;
+    // longest k-loops first: workgroups are dispatched in id order, so the long-running ones (small-M, large-K
+    // problems) start at once and the short ones fill in behind them instead of leaving a tail
+    int order[NCM];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if ((long)ps[order[b]].Kp * mts[order[b]] > (long)ps[order[a]].Kp * mts[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+    for (int i = 0; i < n; ++i) {
+        const ConvP& p = ps[order[i]];
+        long mblk = p.M;
+        int nz = p.groups;
+        if (p.parity) {
+            mblk = (long)p.B * ((p.OH + p.stride - 1) / p.stride) * ((p.OW + p.stride - 1) / p.stride);
+            nz *= p.stride * p.stride;
+        }
+        const int mti = mts[order[i]];
+        m.p[i] = p; m.mt[i] = mti;
+        m.gx[i] = (int)((mblk + 64 * mti - 1) / (64 * mti));
+        m.gy[i] = p.Cout_pad / (16 * nt);
+        m.start[i + 1] = m.start[i] + m.gx[i] * m.gy[i] * nz;
+        const size_t l = (size_t)(p.Kp / 8) * sizeof(i32x2) + (mti == 1 ? (size_t)2 * 8 * nt * 1024 : 0);
+        if (l > lds) lds = l;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define MULTI_CASE(N_) if (nt == N_) { \
+        static bool attr_set = false; \
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fast_multi_kernel<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((conv_fast_multi_kernel<N_>), dim3((unsigned)m.start[n]), dim3(256), lds, st, m); return 0; }
+    MULTI_CASE(1) MULTI_CASE(2) MULTI_CASE(3) MULTI_CASE(4)
+#undef MULTI_CASE
     return -1;
 }
 

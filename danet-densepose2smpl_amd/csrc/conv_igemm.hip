@@ -542,3 +542,50 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     DANET_CHECK_LAUNCH("conv_igemm_kernel");
     return DANET_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Up to 4 independent convolutions in one launch (all on the fast kernel, same danet_conv_nt of their Cout_g).
+// job = { x, wp, y, bn_sums, bn_x, bn_y, bn_saved, bn_red; int B,H,W,Cin,OH,OW,Cout,R,S,stride,pad,dil,groups,transposed }
+// danet_conv_forward_multi_ok says whether a set qualifies (then the call cannot fail for shape reasons).
+struct ConvJob { const void* x; const void* wp; void* y; float* bn_sums; const void* bn_x; const void* bn_y; const float* bn_saved; float* bn_red;
+                 int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; };
+
+static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, int* nt_out) {
+    if (!jobs || n < 1 || n > 4) return -1;
+    int nt = -1;
+    for (int i = 0; i < n; ++i) {
+        const ConvJob& j = jobs[i];
+        bool vec8;
+        ps[i] = ConvP{};
+        if (!fill_conv_params(ps[i], vec8, j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups, j.transposed, 0, 0)) return -1;
+        const int nti = danet_conv_nt(ps[i].Cout_g);
+        if (nt < 0) nt = nti; else if (nt != nti) return -1;
+        mts[i] = danet_conv_kernel_id(j.B, j.OH, j.OW, j.Cin, j.Cout, j.groups) / 100;
+        if (!conv_fast_ok(ps[i], vec8, mts[i])) return -1;
+        ps[i].x = (const bf16_t*)j.x; ps[i].w = (const bf16_t*)j.wp; ps[i].bias = nullptr; ps[i].y = j.y; ps[i].stats = j.bn_sums;
+        ps[i].bn_x = (const bf16_t*)j.bn_x; ps[i].bn_y = (const bf16_t*)j.bn_y; ps[i].bn_saved = j.bn_saved; ps[i].bn_red = j.bn_red;
+    }
+    *nt_out = nt;
+    return 0;
+}
+
+extern "C" int danet_conv_forward_multi_ok(const void* jobs, int n)
+{
+    ConvP ps[4]; int mts[4], nt;
+    return conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt) == 0 ? 1 : 0;
+}
+
+extern "C" int danet_conv_forward_multi(const void* jobs, int n, void* stream)
+{
+    DANET_ENTER();
+    ConvP ps[4]; int mts[4], nt;
+    DANET_CHECK_ARG(conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt) == 0, "conv_forward_multi: unsupported set (see danet_conv_forward_multi_ok)");
+    for (int i = 0; i < n; ++i) {
+        DANET_CHECK_ARG(ps[i].x && ps[i].w && ps[i].y, "conv_forward_multi: job %d: null pointer", i);
+        DANET_CHECK_ARG(!ps[i].bn_red || (ps[i].bn_x && ps[i].bn_saved), "conv_forward_multi: job %d: incomplete BatchNorm-backward arguments", i);
+    }
+    DANET_CHECK_ARG(conv_fast_launch_multi(ps, mts, n, nt, stream) == 0, "conv_forward_multi: no kernel for %d tiles per block", nt);
+    DANET_CHECK_LAUNCH("conv_fast_multi_kernel");
+    return DANET_OK;
+}

@@ -14,6 +14,7 @@ from .config import cfg
 from .nn import sum_relu, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
+from .conv import multi_conv
 
 blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
 
@@ -33,6 +34,7 @@ class _Chain(nn.Module):
 
 
 LOCKSTEP_BRANCHES = bool(int(os.environ.get('DANET_LOCKSTEP', '1')))    # one multi-tensor BatchNorm launch per block level
+LOCKSTEP_CONVS = bool(int(os.environ.get('DANET_LOCKSTEP_CONVS', '1')))     # ... and one multi-problem conv launch
 BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)
 _SIDE = {}
 
@@ -96,9 +98,9 @@ class HighResolutionModule(nn.Module):
         xs = list(x[:self.num_branches])
         for k in range(len(self.branches[0])):
             blocks = [br[k] for br in self.branches]
-            h = [b.conv1(v) for b, v in zip(blocks, xs)]
+            h = multi_conv([b.conv1 for b in blocks], xs) if LOCKSTEP_CONVS else [b.conv1(v) for b, v in zip(blocks, xs)]
             h = multi_batch_norm([b.bn1 for b in blocks], h, None, relu=True)
-            h = [b.conv2(v) for b, v in zip(blocks, h)]
+            h = multi_conv([b.conv2 for b in blocks], h) if LOCKSTEP_CONVS else [b.conv2(v) for b, v in zip(blocks, h)]
             xs = multi_batch_norm([b.bn2 for b in blocks], h, xs, relu=True)
         return xs
 

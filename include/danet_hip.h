@@ -172,6 +172,12 @@ int danet_conv3x3_chunk(int B, int H, int W, int Cin, int Cout);
 int danet_conv3x3_kernel_id(int B, int H, int W, int Cin, int Cout);                  /* MT*10 + NT */
 int danet_conv3x3_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int Cout,
                           int flip, float* bn_sums, void* stream);
+/* Up to 4 independent convolutions (forward or data gradient) in one launch -- HRNet branches in lockstep.
+ * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red;
+ *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; }  (no bias / ReLU / fp32 output);
+ * all problems must run on the fast kernel with the same danet_conv_nt(Cout/groups): query danet_conv_forward_multi_ok. */
+int danet_conv_forward_multi_ok(const void* jobs, int n);
+int danet_conv_forward_multi(const void* jobs, int n, void* stream);
 int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
                               int stride, int pad, int dil, int groups, int transposed, int out_fp32);
                               /* MT*1000 + NT*100 + vec8*10 + fast: conv_fast_kernel<MT,NT> or conv_igemm_kernel<MT,NT,vec8> */
