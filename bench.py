@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--force-ddp', action='store_true', help='diagnostic: run the N > 1 code path (GradReducer + eager Adam) on a 1-rank group')
     return ap.parse_args()
 
 
@@ -94,8 +95,13 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     from danet_densepose2smpl_amd import conv
@@ -105,7 +111,7 @@ def main():
     cfg_from_dict({'DANET.INIMG_SIZE': args.size, 'DANET.HEATMAP_SIZE': args.size // 4})
     torch.manual_seed(1234)
     B = args.batch
-    tr = Trainer(default_options(B), device=dev, distributed=world > 1)
+    tr = Trainer(default_options(B), device=dev, distributed=world > 1 or args.force_ddp)
     batch = synthetic_in_dict(tr.model, B, dev, seed=1234 + rank)
 
     def sync():
@@ -188,7 +194,7 @@ def main():
             except Exception as e:                                   # the bench line must still be printed
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         dist.destroy_process_group()
 
 

@@ -63,13 +63,16 @@ class GradReducer(object):
                     dist.broadcast(t.data, src=src, group=self.group)
 
     def prepare(self):
-        """Call before backward()."""
+        """Call before backward(): arms the gradient hooks until finish()."""
         for b in self.buckets:
             b['ready'] = 0
             b['launched'] = False
         self._works = []
+        self._armed = True
 
     def _on_grad(self, p):
+        if not getattr(self, '_armed', False):      # e.g. a backward captured into a hipGraph: reduce_now() runs after the replay
+            return
         bi = self.param_bucket[id(p)]
         b = self.buckets[bi]
         b['ready'] += 1
@@ -91,14 +94,19 @@ class GradReducer(object):
         else:
             ctx = _Null()
         with ctx:
-            views = []
+            # pack with multi-tensor copies (a few launches per bucket instead of one per parameter)
+            dst, src, zero = [], [], []
             for p, o in zip(b['params'], b['offsets']):
                 v = flat[o:o + p.numel()]
                 if p.grad is None:
-                    v.zero_()
+                    zero.append(v)
                 else:
-                    v.copy_(p.grad.reshape(-1))
-                views.append(v)
+                    dst.append(v.view_as(p))
+                    src.append(p.grad)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if zero:
+                torch._foreach_zero_(zero)
             flat.div_(self.world)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append((bi, work))
@@ -114,13 +122,18 @@ class GradReducer(object):
         if self.use_cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         for b in self.buckets:
+            dst, src = [], []
             for p, o in zip(b['params'], b['offsets']):
                 g = b['flat'][o:o + p.numel()].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
-                    p.grad.copy_(g)
+                    dst.append(p.grad)
+                    src.append(g)
+            if dst:
+                torch._foreach_copy_(dst, src)
         self._works = []
+        self._armed = False
 
     def reduce_now(self):
         """Average all gradients after a backward that ran without hooks (hipGraph replay): every

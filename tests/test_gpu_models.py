@@ -365,3 +365,41 @@ def test_graphed_full_step_losses_match_eager():
     assert set(g) == set(e1) and len(g) == 17
     for k in e1:
         assert abs(e1[k] - g[k]) <= 6 * abs(e1[k] - e2[k]) + 3e-2 * abs(e1[k]) + 1e-4, (k, e1[k], e2[k], g[k])
+
+
+def test_data_parallel_graph_path_single_rank():
+    """The N > 1 execution path of bench.py (GradReducer: eager hooked steps, then hipGraph forward+backward followed by
+    the bucketed all-reduce and an eager Adam step) on a 1-rank RCCL group: it must run and agree with the
+    single-process trainer (the averaging over one rank is the identity)."""
+    import torch.distributed as dist
+    _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
+            'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    dev = torch.device('cuda', 0)
+    port = 29500 + (os.getpid() % 2000)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+    try:
+        res = {}
+        for mode in ('single', 'ddp'):
+            torch.manual_seed(0)
+            tr = Trainer(default_options(2), device=dev, distributed=(mode == 'ddp'), lr=1e-30)
+            assert (tr.reducer is not None) == (mode == 'ddp')
+            batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
+            batch['pretrain_mode'] = True
+            tr.train_step(batch)
+            _, l_eager = tr.train_step(batch)
+            tr.capture(batch, warmup=1)
+            tr.train_step_graphed()
+            _, l_graph = tr.train_step_graphed()
+            torch.cuda.synchronize()
+            named = [(n, p) for n, p in tr.model.named_parameters() if p.grad is not None and p.dim() == 4]
+            res[mode] = ({k: float(v.sum()) for k, v in l_eager.items()}, {k: float(v.sum()) for k, v in l_graph.items()},
+                         {n: p.grad.detach().clone() for n, p in named})      # (unused parameters get zero gradients in the ddp mode)
+        for k in res['single'][0]:
+            for a, b in ((res['ddp'][0][k], res['single'][0][k]), (res['ddp'][1][k], res['single'][1][k])):
+                assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
+        names = sorted(res['single'][2])[::max(1, len(res['single'][2]) // 20)]
+        rel = [((res['ddp'][2][n] - res['single'][2][n]).norm() / (res['single'][2][n].norm() + 1e-12)).item() for n in names]
+        assert max(rel) < 0.3 and sorted(rel)[len(rel) // 2] < 0.05, sorted(rel)[-3:]
+    finally:
+        dist.destroy_process_group()
