@@ -546,7 +546,13 @@ class MultiConvFunction(torch.autograd.Function):
                     sums = torch.zeros(nfl, dtype=torch.float32, device=y.device)
             _conv_job(jobs[i], xs[i], wp, y, dims, False, sums)
             ys.append(y); sums_l.append(sums); dims_l.append(dims); keep.append(wp)
+        tok = None
+        if PROFILER is not None:
+            tok = PROFILER.begin('conv_fast_multi_kernel<%d>' % L.danet_conv_nt(dims_l[0][6] // dims_l[0][12]),
+                                 sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in dims_l), ('fwd-multi', n))
         check(L.danet_conv_forward_multi(ctypes.addressof(jobs), n, stream()), 'danet_conv_forward_multi')
+        if tok is not None:
+            PROFILER.end(tok)
         if TRACE is not None:
             for y, d in zip(ys, dims_l):
                 TRACE.append(('conv', (d[0], d[1], d[2], d[3], d[6], d[7], d[9]), y.float().abs().mean()))
@@ -594,7 +600,14 @@ class MultiConvFunction(torch.autograd.Function):
                 reds.append(None if bn_bwd is None else bn_bwd[3])
                 keep.append(wp1)
             if L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), len(need)):
+                tok = None
+                if PROFILER is not None:
+                    dd = [dims_l[i] for i in need]
+                    tok = PROFILER.begin('conv_fast_multi_kernel<%d>' % L.danet_conv_nt(dd[0][3] // dd[0][12]),
+                                         sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in dd), ('dgrad-multi', len(need)))
                 check(L.danet_conv_forward_multi(ctypes.addressof(jobs), len(need), stream()), 'danet_conv_forward_multi')
+                if tok is not None:
+                    PROFILER.end(tok)
                 for k, i in enumerate(need):
                     if reds[k] is not None:
                         gxs[i]._bn_red = reds[k]

@@ -130,18 +130,44 @@ class HighResolutionModule(nn.Module):
             x = self._branches_on_streams(x)
         else:
             x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        if LOCKSTEP_BRANCHES and x[0].is_cuda and self.training:
+            fused = self._fuse_paths_in_lockstep(x)
+        else:
+            fused = {(i, j): self.fuse_layers[i][j](x[j]) for i in range(len(self.fuse_layers))
+                     for j in range(self.num_branches) if j != i}
         out = []
         for i in range(len(self.fuse_layers)):
-            terms, shifts = [], []
-            for j in range(self.num_branches):
-                if j == i:
-                    terms.append(x[j]); shifts.append(0)
-                elif j > i:
-                    terms.append(self.fuse_layers[i][j](x[j])); shifts.append(j - i)
-                else:
-                    terms.append(self.fuse_layers[i][j](x[j])); shifts.append(0)
+            terms = [x[j] if j == i else fused[(i, j)] for j in range(self.num_branches)]
+            shifts = [j - i if j > i else 0 for j in range(self.num_branches)]
             out.append(sum_relu(terms, shifts, relu=True))
         return out
+
+    def _fuse_paths_in_lockstep(self, x):
+        """Every (output i, input j) exchange path is a chain of 1..3 conv+BN stages; the paths are independent, so
+        stage k of all of them runs as a few multi-problem conv launches and multi-tensor BatchNorm launches
+        (groups of four) instead of one launch per stage."""
+        paths = {}
+        for i in range(len(self.fuse_layers)):
+            for j in range(self.num_branches):
+                if j != i:
+                    m = self.fuse_layers[i][j]
+                    paths[(i, j)] = [m] if isinstance(m, ConvBN) else list(m._modules.values())
+        cur = {key: x[key[1]] for key in paths}
+        depth = max(len(st) for st in paths.values())
+        for k in range(depth):
+            for relu in (False, True):
+                keys = [key for key, st in paths.items() if len(st) > k and bool(st[k].relu) == relu]
+                # same output-tile count first, so that a group of four qualifies for the multi-problem conv launch
+                keys.sort(key=lambda key: (paths[key][k]._modules['0'].out_channels % 48 == 0, paths[key][k]._modules['0'].out_channels))
+                for g0 in range(0, len(keys), 4):
+                    grp = keys[g0:g0 + 4]
+                    convs = [paths[key][k]._modules['0'] for key in grp]
+                    bns = [paths[key][k]._modules['1'] for key in grp]
+                    h = multi_conv(convs, [cur[key] for key in grp]) if LOCKSTEP_CONVS else [c(cur[key]) for c, key in zip(convs, grp)]
+                    h = multi_batch_norm(bns, h, None, relu=relu)
+                    for key, v in zip(grp, h):
+                        cur[key] = v
+        return cur
 
 
 class PoseHighResolutionNet(nn.Module):
