@@ -294,16 +294,10 @@ class Conv2dFunction(torch.autograd.Function):
         OH, OW = gy.shape[2], gy.shape[3]
         gx = gw = gb = None
         if ctx.needs_input_grad[1]:
-            # the weight gradient is off the critical path (only the optimizer consumes it): with
-            # WGRAD_STREAMS it is launched on a side stream, next to this layer's data gradient
+            # the weight gradient is off the critical path (only the optimizer consumes it): with DEFER_WGRAD it is
+            # only queued here and computed by flush_wgrads() in multi-problem launches after the backward pass
             gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
-            side = _wgrad_stream(x.device) if WGRAD_STREAMS else None
-            if side is None:
-                _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
-            else:
-                with torch.cuda.stream(side):
-                    _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups)
-                _WG['keep'].append((x, gy))          # keep the operands' memory from being reused before the join
+            _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
         if ctx.needs_input_grad[0]:
             if USE_LDS3X3 and L.danet_conv3x3_ok(H, W, Cout, Cin, R, S, stride, pad, dil, groups):
                 gx = _conv3x3_raw(gy, weight, groups, B, H, W, Cout, Cin, True)
@@ -327,33 +321,6 @@ class Conv2dFunction(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum(dim=(0, 2, 3))
         return gx, gw, gb, None, None, None, None, None, None, None
-
-
-WGRAD_STREAMS = False    # weight gradients on side streams (set by the trainer's hipGraph capture; it joins them)
-_WG = {'streams': {}, 'keep': []}
-
-
-def _wgrad_stream(device):
-    """Side stream paired with the current stream; it first waits for everything queued on the current one."""
-    cur = torch.cuda.current_stream(device)
-    key = (device.index, cur.stream_id)
-    side = _WG['streams'].get(key)
-    if side is None:
-        side = _WG['streams'][key] = torch.cuda.Stream(device=device)
-    side.wait_stream(cur)
-    return side
-
-
-def join_wgrad_streams(device):
-    """Make the current stream wait for every side-stream weight gradient (call after backward, before the
-    optimizer / gradient all-reduce) and release the operands kept alive for them."""
-    if _WG['keep']:
-        cur = torch.cuda.current_stream(device)
-        index = device.index if device.index is not None else torch.cuda.current_device()
-        for (di, _), side in _WG['streams'].items():
-            if di == index:
-                cur.wait_stream(side)
-        _WG['keep'].clear()
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches

@@ -24,7 +24,7 @@ struct C3P {
     int B, H, W, Cin, Cout, Cout_pad;
     int CK, CKpad, nchunk, nks_chunk, SK, nsl;          // channels per chunk (+8 pad in LDS), k-steps per chunk, slice
     int lTW, lTH, lTB, HH, HW;                          // log2 tile sizes; halo size
-    int nty, ntx, flip, ablate;
+    int nty, ntx, flip;
     long nks_total;
 };
 
@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(C3P p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWV = (NT * 9 * 64 + 255) / 256;           // weight-slice prefetch registers (SK <= 9)
-    if (p.ablate & 16) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int TW = 1 << p.lTW, TH = 1 << p.lTH;
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(C3P p)
 #pragma unroll
         for (int u = 0; u < NHV; ++u) {
             uint4 v = {0u, 0u, 0u, 0u};
-            if (hsrc[u] >= 0 && !(p.ablate & 1)) v = *reinterpret_cast<const uint4*>(p.x + hsrc[u] + (long)c * p.CK);
+            if (hsrc[u] >= 0) v = *reinterpret_cast<const uint4*>(p.x + hsrc[u] + (long)c * p.CK);
             hreg[u] = v;
         }
     };
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(C3P p)
 #pragma unroll
         for (int u = 0; u < NWV; ++u) {
             const int idx = t + u * 256;
-            if (idx < wpieces && !(p.ablate & 8)) {
+            if (idx < wpieces) {
                 const int nt = idx / (p.SK * 64), r = idx - nt * (p.SK * 64);
                 wreg[u] = *reinterpret_cast<const uint4*>(wrow + ((size_t)nt * p.nks_total + it * p.SK) * 512 + (size_t)r * 8);
             }
@@ -164,13 +163,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(C3P p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (p.ablate & 32) return;
     fetch_halo(0);
     fetch_w(0);
     commit_halo();
     commit_w();
     __syncthreads();
-    if (p.ablate & 64) return;
 
     const long total = (long)p.nchunk * p.nsl;
     int c = 0, s = 0;
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(C3P p)
         }
         const int* tab = sTab + s * p.SK * 4 + lg;
         const unsigned char* wl = sW + lane * 16;
-        for (int ks = 0; ks < ((p.ablate & 2) ? 0 : p.SK); ++ks) {
+        for (int ks = 0; ks < p.SK; ++ks) {
             const unsigned e = (unsigned)tab[ks * 4];
             bf16x8 a[NT], bq[MT];
 #pragma unroll
@@ -252,7 +249,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(C3P p)
     const bool vec_ok = p.Cout % 4 == 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if (!(ob[mt] < p.B && oy[mt] < p.H && ox[mt] < p.W) || ((p.ablate & 4) && acc[mt][0][0] != 12345.f)) continue;
+        if (!(ob[mt] < p.B && oy[mt] < p.H && ox[mt] < p.W)) continue;
         bf16_t* yp = p.y + (((size_t)ob[mt] * p.H + oy[mt]) * p.W + ox[mt]) * p.Cout;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -281,14 +278,12 @@ void launch3(const C3P& p, size_t lds, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_lds_kernel<MT, NT>), grid, dim3(256), lds, st, p);
 }
 
-bool g_no_lds3x3 = getenv("DANET_CONV_NO_LDS3X3") != nullptr;
 
 }  // namespace
 
 // Is the LDS 3x3 kernel applicable?  (square 3x3, stride 1, pad 1, no dilation, one group, 16-channel granules)
 extern "C" int danet_conv3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups)
 {
-    if (g_no_lds3x3) return 0;
     return (R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && groups == 1 && Cin % 16 == 0 && Cin >= 16 &&
             Cout % 4 == 0 && H > 0 && W > 0) ? 1 : 0;
 }
@@ -326,7 +321,6 @@ extern "C" int danet_conv3x3_forward(const void* x, const void* wp, void* y, int
     p.HH = (1 << pl.lTH) + 2; p.HW = (1 << pl.lTW) + 2;
     p.nty = (H + (1 << pl.lTH) - 1) >> pl.lTH; p.ntx = (W + (1 << pl.lTW) - 1) >> pl.lTW;
     p.flip = flip;
-    { const char* a = getenv("DANET_C3_ABLATE"); p.ablate = a ? atoi(a) : 0; }
     const int nbt = (B + (1 << pl.lTB) - 1) >> pl.lTB;
     const size_t npix = (size_t)(p.HH * p.HW) << pl.lTB;
     DANET_CHECK_ARG(npix * (pl.CK / 8) <= (size_t)NHV * 256, "conv3x3_forward: halo tile too large");

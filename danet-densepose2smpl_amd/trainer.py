@@ -147,7 +147,6 @@ class Trainer(object):
             finally:
                 _conv.DEFER_WGRAD = False
             _conv.flush_wgrads()
-            _conv.join_wgrad_streams(self.device)
             if self.reducer is not None:
                 self.reducer.finish()
             self.optimizer.step()
@@ -175,13 +174,11 @@ class Trainer(object):
         graph = torch.cuda.CUDAGraph()
         from . import hrnet
         hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
-        conv.WGRAD_STREAMS = bool(int(os.environ.get('DANET_WGRAD_STREAMS', '0')))
         try:
             with torch.cuda.graph(graph, stream=self.stream):
                 self._static_out = self._eager_core(self._static, fused_opt)
         finally:
             hrnet.BRANCH_STREAMS = False
-            conv.WGRAD_STREAMS = False
         self._graph = graph
         self._graph_fused_opt = fused_opt
         return self
@@ -203,7 +200,6 @@ class Trainer(object):
         finally:
             _conv.DEFER_WGRAD = False
         _conv.flush_wgrads()
-        _conv.join_wgrad_streams(self.device)
         if with_optimizer:
             self.optimizer.step()
         return out, losses

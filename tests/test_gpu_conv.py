@@ -179,3 +179,27 @@ def test_deferred_multi_problem_wgrad_matches_immediate():
     got = run(True)
     for r, g, cfg in zip(ref, got, cfgs):
         assert (g - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-6, cfg
+
+
+@pytest.mark.parametrize('shape', [(48, 48, 64), (96, 96, 32), (192, 48, 16), (384, 384, 8), (64, 64, 17)])
+def test_lds_staged_3x3_kernel_matches_default(shape):
+    """conv3x3_lds.hip (both MFMA operands staged through LDS; kept behind DANET_LDS3X3 because it is not faster,
+    DESIGN.md 3.1) computes the same forward and data gradient as the default kernel."""
+    from danet_densepose2smpl_amd import conv as dconv
+    Cin, Cout, H = shape
+    torch.manual_seed(0)
+    x = torch.randn(2, Cin, H, H, device='cuda')
+    w = torch.nn.Parameter(torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.05)
+    gy = torch.randn(2, Cout, H, H, device='cuda').bfloat16()
+    res = []
+    for lds in (False, True):
+        dconv.USE_LDS3X3 = lds
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = dconv.conv2d(xi, w, None, 1, 1)
+            y.backward(gy)
+            res.append((y.float(), xi.grad.float()))
+        finally:
+            dconv.USE_LDS3X3 = False
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() <= 1e-2 * a.abs().max().item()
