@@ -25,6 +25,7 @@ UNITS = {
     'conv3x3_lds.hip': [],
     'conv_fast.hip': [],
     'part_ops.hip': [],
+    'adam.hip': [],
     'norm_act.hip': [],
     'stn.hip': [],
 }

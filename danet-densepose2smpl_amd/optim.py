@@ -1,0 +1,88 @@
+"""Adam over all parameters in one HIP launch (csrc/adam.hip); same update as torch.optim.Adam(lr, betas=(0.9, 0.999),
+eps=1e-8) -- the reference's optimizer, /root/reference/train/trainer.py:42-44 -- without weight decay / amsgrad.
+
+The moments live in two flat fp32 buffers; a device table of <= 32768-element chunks {param, grad, moment offset, n}
+is rebuilt (host-side, then one pinned H2D copy) only when a gradient tensor's address changed -- every step in
+eager mode, never under hipGraph replay.  `param_groups[0]['lr']` is a device tensor, so a trainer can decay the
+rate between replays.  GPU only."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr, check, stream
+
+CHUNK = 32768
+
+
+class FusedAdam(object):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params or not self.params[0].is_cuda:
+            raise RuntimeError('FusedAdam runs on the GPU only')
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError('FusedAdam: parameters must be contiguous fp32 tensors')
+        self.betas, self.eps = betas, eps
+        lr_t = lr if torch.is_tensor(lr) else torch.tensor(float(lr), device=dev)
+        self.param_groups = [{'lr': lr_t.to(device=dev, dtype=torch.float32).reshape(()), 'params': self.params}]
+        self.offsets, tot = [], 0
+        for p in self.params:
+            self.offsets.append(tot)
+            tot += (p.numel() + 3) // 4 * 4                   # 16-byte aligned moment slices
+        self.exp_avg = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        cb = int(_lib.lib().danet_adam_chunk_bytes())
+        assert cb == 32
+        self._dtype = np.dtype([('p', np.uint64), ('g', np.uint64), ('off', np.int64), ('n', np.int32), ('pad', np.int32)])
+        rows = []
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            for c0 in range(0, p.numel(), CHUNK):
+                rows.append((i, c0, min(CHUNK, p.numel() - c0), o + c0))
+        self._rows = rows
+        self.nchunks = len(rows)
+        self._host = torch.empty(self.nchunks * cb, dtype=torch.uint8).pin_memory()
+        self._table = torch.empty(self.nchunks * cb, dtype=torch.uint8, device=dev)
+        self._np = self._host.numpy().view(self._dtype)
+        pidx = np.array([r[0] for r in rows], dtype=np.int64)
+        self._pidx = pidx
+        self._c0b = np.array([r[1] for r in rows], dtype=np.uint64) * 4
+        self._np['p'] = np.array([self.params[i].data_ptr() for i in pidx], dtype=np.uint64) + self._c0b
+        self._np['off'] = np.array([r[3] for r in rows], dtype=np.int64)
+        self._np['n'] = np.array([r[2] for r in rows], dtype=np.int32)
+        self._np['pad'] = 0
+        self._gptrs = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def _refresh_table(self):
+        g = np.fromiter((0 if p.grad is None else p.grad.data_ptr() for p in self.params), dtype=np.uint64, count=len(self.params))
+        if self._gptrs is not None and np.array_equal(g, self._gptrs):
+            return
+        for p in self.params:
+            if p.grad is not None and (p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.data_ptr() % 16):
+                raise ValueError('FusedAdam: gradients must be contiguous, 16-byte aligned fp32 tensors')
+        gp = g[self._pidx]
+        self._np['g'] = np.where(gp != 0, gp + self._c0b, 0).astype(np.uint64)
+        self._table.copy_(self._host, non_blocking=True)
+        self._gptrs = g
+
+    @torch.no_grad()
+    def step(self):
+        self._refresh_table()
+        self.step_t.add_(1.0)
+        check(_lib.lib().danet_adam_step(ptr(self._table), self.nchunks, ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                         ptr(self.param_groups[0]['lr']), ptr(self.step_t),
+                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), stream()), 'danet_adam_step')
+        # the kernel wrote the parameters through raw pointers: bump their version counters like an in-place op would
+        # (the conv weight-pack cache and autograd's saved-tensor checks key on them)
+        upd = [p for p in self.params if p.grad is not None]
+        torch._C._autograd._unsafe_set_version_counter(upd, [p._version + 1 for p in upd])

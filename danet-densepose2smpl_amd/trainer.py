@@ -22,6 +22,7 @@ from .geometry import perspective_projection
 
 
 DEFER_WGRAD = bool(int(os.environ.get('DANET_DEFER_WGRAD', '1')))
+USE_FUSED_ADAM = bool(int(os.environ.get('DANET_FUSED_ADAM', '1')))
 
 
 def default_options(batch_size=32):
@@ -68,9 +69,13 @@ class Trainer(object):
         on_gpu = self.device.type == 'cuda'
         lr0 = lr or cfg.SOLVER.BASE_LR
         # a tensor learning rate keeps the manual step decay (trainer.py:120-128) effective under hipGraph replay
-        self.optimizer = torch.optim.Adam(params=[p for p in self.model.parameters() if p.requires_grad],
-                                          lr=torch.tensor(lr0, device=self.device) if on_gpu else lr0, weight_decay=0,
-                                          **({'capturable': True, 'fused': True} if on_gpu else {}))
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if on_gpu and USE_FUSED_ADAM:
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(params, lr=lr0)            # one HIP launch per step (csrc/adam.hip)
+        else:
+            self.optimizer = torch.optim.Adam(params=params, lr=torch.tensor(lr0, device=self.device) if on_gpu else lr0,
+                                              weight_decay=0, **({'capturable': True, 'fused': True} if on_gpu else {}))
         self.step_count = 0
         self.bank = None
         # Every step (eager or captured) runs on ONE dedicated stream: autograd pins each parameter's

@@ -106,6 +106,14 @@ int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream)
 int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Optimizer (replaces torch.optim.Adam at /root/reference/train/trainer.py:42-44): one launch over a device table of
+ * <= 32768-element chunks { float* p; const float* g (NULL = skip); int64 off (into m, v); int32 n; int32 pad }.
+ * lr and step (1-based count, float) are read from device memory; p, g, m+off, v+off 16-byte aligned. */
+size_t danet_adam_chunk_bytes(void);
+int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
+                    float beta1, float beta2, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Partial-IUV ("limb") path glue (replaces /root/reference/models/danet/danet.py:264-283 and
  * /root/reference/models/danet/iuv_estimator.py:206-246, ~40 tensor ops on [B,24,3,7,H,W] fp32).
  * pred: the grouped conv's output, NHWC bf16 [B,H,W,504], channel = (joint*3 + {u,v,index})*7 + class.
