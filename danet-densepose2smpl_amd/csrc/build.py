@@ -14,16 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, 'libdanet_hip.so')
 ARCH = 'gfx950'
 
+MFMA_VGPR = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 UNITS = {
     'capi.hip': [],
     'smpl_lbs.hip': [],
     'iuv_raster.hip': ['-ffp-contract=off'],
     'geometry.hip': [],
-    'conv_igemm.hip': [],
-    'conv_wgrad.hip': [],
-    'conv_wgrad3x3.hip': [],
-    'conv3x3_lds.hip': [],
-    'conv_fast.hip': [],
+    # MFMA_VGPR: keep MFMA accumulators / operands in VGPRs; the default AGPR form made the compiler shuttle the
+    # register ring between the two files (196 v_accvgpr_* instructions in conv_fast_kernel<4,3>, ~1.4 per MFMA)
+    'conv_igemm.hip': MFMA_VGPR,
+    'conv_wgrad.hip': MFMA_VGPR,
+    'conv_wgrad3x3.hip': MFMA_VGPR,
+    'conv3x3_lds.hip': MFMA_VGPR,
+    'conv_fast.hip': MFMA_VGPR,
     'part_ops.hip': [],
     'adam.hip': [],
     'norm_act.hip': [],
