@@ -60,10 +60,10 @@ _SIGNATURES = {
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
     'danet_stn_gather_backward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
-    'danet_part_clean_forward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
-    'danet_part_clean_backward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
-    'danet_part_loss_forward': (c_i, [c_f] * 5 + [c_i] * 4 + [c_f, c_f]),
-    'danet_part_loss_backward': (c_i, [c_f] * 6 + [c_i] * 4 + [c_f, c_f]),
+    'danet_part_clean_forward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    'danet_part_clean_backward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    'danet_part_loss_forward': (c_i, [c_f] * 5 + [c_i] * 5 + [c_f, c_f]),
+    'danet_part_loss_backward': (c_i, [c_f] * 6 + [c_i] * 5 + [c_f, c_f]),
     'danet_adam_chunk_bytes': (c_sz, []),
     'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),

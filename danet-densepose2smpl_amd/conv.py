@@ -432,7 +432,8 @@ def _pad_channels_nhwc(x, mult=8):
     return F.pad(x.permute(0, 2, 3, 1), (0, padc)).permute(0, 3, 1, 2)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False, want_stats=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False, want_stats=False,
+           keep_group_padding=False):
     """Convolution on the MFMA kernels.  Channel counts that are not a multiple of 8 (3-channel image,
     21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
     forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
@@ -452,6 +453,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         if bias is not None:
             bias = F.pad(bias.view(groups, Cout_g), (0, padn)).reshape(-1)
         y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
+        if keep_group_padding:       # [B, groups*(Cout_g+padn), OH, OW]: the caller consumes the padded layout (part_ops)
+            return y
         B, _, OH, OW = y.shape
         y = y.permute(0, 2, 3, 1).reshape(B, OH, OW, groups, Cout_g + padn)[..., :Cout_g]
         return y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)

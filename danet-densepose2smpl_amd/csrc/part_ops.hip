@@ -21,7 +21,8 @@ namespace {
 
 using namespace danet_conv;
 
-constexpr int NJ = 24, NC = 7, PCH = NJ * 3 * NC;     // joints, classes per joint map, prediction channels (504)
+constexpr int NJ = 24, NC = 7;     // joints, classes per joint map; a joint's 21 channels sit at stride cpj (21, or 24 when
+                                   // the grouped conv's zero-padded output is consumed as it is): pixel stride NJ*cpj
 constexpr int NREP = 32;
 
 __device__ inline float norm_coord(int o, int n, int align) {
@@ -49,7 +50,7 @@ __device__ inline int argmax7(const float* x) {          // first maximum, like 
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void part_clean_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ keep,
-                                                         int B, int HW, bf16_t* __restrict__ x24)
+                                                         int B, int HW, int cpj, bf16_t* __restrict__ x24)
 {
     const long total = (long)B * HW * NJ;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void part_clean_kernel(const bf16_t* __restric
     const int j = (int)(i % NJ);
     const long pix = i / NJ;
     const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
-    Pred p = load_pred(pred + pix * PCH + j * 3 * NC);
+    Pred p = load_pred(pred + (pix * NJ + j) * cpj);
     float k[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) k[c] = keep ? keep[((size_t)b * NJ + j) * NC + c] : 1.f;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void part_clean_kernel(const bf16_t* __restric
 }
 
 __global__ __launch_bounds__(256) void part_clean_bwd_kernel(const bf16_t* __restrict__ g24, const bf16_t* __restrict__ pred,
-                                                             const float* __restrict__ keep, int B, int HW, bf16_t* __restrict__ gpred)
+                                                             const float* __restrict__ keep, int B, int HW, int cpj, bf16_t* __restrict__ gpred)
 {
     const long total = (long)B * HW * NJ;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -92,20 +93,21 @@ __global__ __launch_bounds__(256) void part_clean_bwd_kernel(const bf16_t* __res
     const int j = (int)(i % NJ);
     const long pix = i / NJ;
     const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
-    const bf16_t* src = pred + pix * PCH + j * 3 * NC;
+    const bf16_t* src = pred + (pix * NJ + j) * cpj;
     float k[NC], sx[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { k[c] = keep ? keep[((size_t)b * NJ + j) * NC + c] : 1.f; sx[c] = bf2f(src[2 * NC + c]) * k[c]; }
     const int am = argmax7(sx);
     const bf16_t* g = g24 + (((size_t)b * NJ + j) * HW + hw) * 24;
     const float gu = bf2f(g[am]) * k[am], gv = bf2f(g[NC + am]) * k[am];
-    bf16_t* dst = gpred + pix * PCH + j * 3 * NC;
+    bf16_t* dst = gpred + (pix * NJ + j) * cpj;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         dst[c] = c == am ? f2bf(gu) : (bf16_t)0;
         dst[NC + c] = c == am ? f2bf(gv) : (bf16_t)0;
         dst[2 * NC + c] = 0;
     }
+    for (int c = 3 * NC; c < cpj; ++c) dst[c] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -152,7 +154,7 @@ __device__ inline float smooth_l1(float d) { const float a = fabsf(d); return a 
 
 __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
                                                         const float* __restrict__ theta, const float* __restrict__ wsample,
-                                                        const int* __restrict__ sel, int B, int H, int W, int align,
+                                                        const int* __restrict__ sel, int B, int H, int W, int align, int cpj,
                                                         float* __restrict__ sums /* [NREP][3] */)
 {
     const int HW = H * W;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict
         const long pix = i / NJ;
         const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
         const float w = wsample ? wsample[b] : 1.f;
-        const Pred p = load_pred(pred + pix * PCH + j * 3 * NC);
+        const Pred p = load_pred(pred + (pix * NJ + j) * cpj);
         const Gt g = part_gt(img + (size_t)b * 3 * HW, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
                                                             const float* __restrict__ theta, const float* __restrict__ wsample,
                                                             const int* __restrict__ sel, const float* __restrict__ scale /* [3] */,
-                                                            int B, int H, int W, int align, bf16_t* __restrict__ gpred)
+                                                            int B, int H, int W, int align, int cpj, bf16_t* __restrict__ gpred)
 {
     const int HW = H * W;
     const long total = (long)B * HW * NJ;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __rest
     const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
     const float w = wsample ? wsample[b] : 1.f;
     const float su = scale[0], sv = scale[1], si = scale[2];
-    const Pred p = load_pred(pred + pix * PCH + j * 3 * NC);
+    const Pred p = load_pred(pred + (pix * NJ + j) * cpj);
     const Gt g = part_gt(img + (size_t)b * 3 * HW, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
     const int tgt = argmax7(g.I);
     float mx = p.ix[0];
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __rest
 #pragma unroll
     for (int c = 0; c < NC; ++c) { ex[c] = expf(p.ix[c] - mx); se += ex[c]; }
     const float inv = 1.f / se;
-    bf16_t* dst = gpred + pix * PCH + j * 3 * NC;
+    bf16_t* dst = gpred + (pix * NJ + j) * cpj;
+    for (int c = 3 * NC; c < cpj; ++c) dst[c] = 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const float fg = g.I[c] > 0.f ? w : 0.f;
@@ -230,49 +233,49 @@ __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __rest
 
 }  // namespace
 
-extern "C" int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, void* x24, void* stream)
+extern "C" int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, int cpj, void* x24, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(pred && x24 && B > 0 && H > 0 && W > 0, "part_clean_forward: bad arguments");
+    DANET_CHECK_ARG(pred && x24 && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_clean_forward: bad arguments");
     const long total = (long)B * H * W * NJ;
     hipLaunchKernelGGL(part_clean_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, keep, B, H * W, (bf16_t*)x24);
+                       (const bf16_t*)pred, keep, B, H * W, cpj, (bf16_t*)x24);
     DANET_CHECK_LAUNCH("part_clean_kernel");
     return DANET_OK;
 }
 
-extern "C" int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, void* gpred, void* stream)
+extern "C" int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, int cpj, void* gpred, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(g24 && pred && gpred && B > 0 && H > 0 && W > 0, "part_clean_backward: bad arguments");
+    DANET_CHECK_ARG(g24 && pred && gpred && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_clean_backward: bad arguments");
     const long total = (long)B * H * W * NJ;
     hipLaunchKernelGGL(part_clean_bwd_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)g24, (const bf16_t*)pred, keep, B, H * W, (bf16_t*)gpred);
+                       (const bf16_t*)g24, (const bf16_t*)pred, keep, B, H * W, cpj, (bf16_t*)gpred);
     DANET_CHECK_LAUNCH("part_clean_bwd_kernel");
     return DANET_OK;
 }
 
 // sums: [32][3] floats, zeroed by the caller; the loss terms are the column sums.
 extern "C" int danet_part_loss_forward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
-                                       const int* sel, int B, int H, int W, int align, float* sums, void* stream)
+                                       const int* sel, int B, int H, int W, int align, int cpj, float* sums, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(pred && iuv_img && theta && sel && sums && B > 0 && H > 0 && W > 0, "part_loss_forward: bad arguments");
+    DANET_CHECK_ARG(pred && iuv_img && theta && sel && sums && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_loss_forward: bad arguments");
     const long total = (long)B * H * W * NJ;
     hipLaunchKernelGGL(part_loss_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, B, H, W, align, sums);
+                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, B, H, W, align, cpj, sums);
     DANET_CHECK_LAUNCH("part_loss_kernel");
     return DANET_OK;
 }
 
 extern "C" int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
-                                        const int* sel, const float* scale, int B, int H, int W, int align, void* gpred, void* stream)
+                                        const int* sel, const float* scale, int B, int H, int W, int align, int cpj, void* gpred, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(pred && iuv_img && theta && sel && scale && gpred && B > 0 && H > 0 && W > 0, "part_loss_backward: bad arguments");
+    DANET_CHECK_ARG(pred && iuv_img && theta && sel && scale && gpred && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_loss_backward: bad arguments");
     const long total = (long)B * H * W * NJ;
     hipLaunchKernelGGL(part_loss_bwd_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, (bf16_t*)gpred);
+                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred);
     DANET_CHECK_LAUNCH("part_loss_bwd_kernel");
     return DANET_OK;
 }

@@ -224,9 +224,20 @@ class IUV_Estimator(nn.Module):
         thetas, _ = self.affine_para(centers, hidden)
         rd['stn_kps_pred'] = centers.detach()
         part_maps = stn_gather(feat, thetas, align_corners=align)                       # [B,24*C,H,W]
-        part_pred = self.iuv_est.final_pred.predict_partial_iuv(part_maps)
-        Sp = part_pred.size(-1)
-        part_pred = part_pred.reshape(part_pred.size(0), 24, 3, -1, Sp, Sp)              # [B,24,3,7,H,W]
+        ppi = self.iuv_est.final_pred.predict_partial_iuv
+        if FUSED_PART_LOSSES and self.training and part_maps.is_cuda and ppi.out_channels == 24 * 21 and ppi.groups == 24:
+            # keep the grouped conv's zero-padded output (24 channels per joint): the fused part ops read it as it is,
+            # the [B,24,3,7,H,W] tensor of the reference is a strided view of it
+            from .conv import conv2d
+            # (bf16 output: the part kernels read bf16 -- the same rounding the fp32 head output went through before)
+            pp = conv2d(part_maps, ppi.weight, ppi.bias, ppi.stride[0], ppi.padding[0], ppi.dilation[0], ppi.groups,
+                        False, keep_group_padding=True)
+            part_pred = part_ops.padded_view6(pp)
+            Sp = part_pred.size(-1)
+        else:
+            part_pred = ppi(part_maps)
+            Sp = part_pred.size(-1)
+            part_pred = part_pred.reshape(part_pred.size(0), 24, 3, -1, Sp, Sp)          # [B,24,3,7,H,W]
 
         if self.training and iuv_image_gt is not None and FUSED_PART_LOSSES and part_pred.is_cuda and \
                 tuple(iuv_image_gt.shape[-2:]) == (Sp, Sp):

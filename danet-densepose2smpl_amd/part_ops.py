@@ -15,16 +15,31 @@ from .conv import nhwc_bf16, ARENA
 NJ, NC = 24, 7
 
 
+def _cpj(C):
+    """channels per joint in memory: 21, or 24 for the grouped conv's zero-padded output"""
+    if C not in (NJ * 21, NJ * 24):
+        raise ValueError('partial IUV prediction must have %d or %d channels, got %d' % (NJ * 21, NJ * 24, C))
+    return C // NJ
+
+
+def padded_view6(pp):
+    """[B, 24*24, H, W] group-padded prediction -> its [B,24,3,7,H,W] view (no copy); the padded tensor rides along
+    as `._padded` so that part_clean / part_losses read it directly."""
+    B, C, H, W = pp.shape
+    v = pp.permute(0, 2, 3, 1).reshape(B, H, W, NJ, C // NJ)[..., :21].reshape(B, H, W, NJ, 3, NC).permute(0, 3, 4, 5, 1, 2)
+    v._padded = pp
+    return v
+
+
 class PartCleanFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, keep):
         pred = nhwc_bf16(pred)
         B, C, H, W = pred.shape
-        if C != NJ * 3 * NC:
-            raise ValueError('part_clean: expected %d channels, got %d' % (NJ * 3 * NC, C))
+        cpj = _cpj(C)
         k = None if keep is None else keep.detach().to(torch.float32).contiguous()
         x24 = torch.empty(B * NJ, H, W, 24, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
-        check(_lib.lib().danet_part_clean_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, ptr(x24.permute(0, 2, 3, 1)), stream()),
+        check(_lib.lib().danet_part_clean_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, cpj, ptr(x24.permute(0, 2, 3, 1)), stream()),
               'danet_part_clean_forward')
         ctx.save_for_backward(pred, k)
         return x24
@@ -35,7 +50,7 @@ class PartCleanFunction(torch.autograd.Function):
         B, C, H, W = pred.shape
         g24 = nhwc_bf16(g24)
         gp = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
-        check(_lib.lib().danet_part_clean_backward(ptr(g24.permute(0, 2, 3, 1)), ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W,
+        check(_lib.lib().danet_part_clean_backward(ptr(g24.permute(0, 2, 3, 1)), ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, _cpj(C),
                                                    ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_clean_backward')
         return gp, None
 
@@ -45,7 +60,7 @@ def part_clean(pred, keep=None):
     (part_iuv_map [B,24,3,7,H,W] bf16 view, x24 [B*24,24,H,W] bf16 channels_last: channels 21..23 are zero)."""
     if pred.dim() == 6:
         B, J, T, K, H, W = pred.shape
-        pred = pred.reshape(B, J * T * K, H, W)
+        pred = getattr(pred, '_padded', None) if getattr(pred, '_padded', None) is not None else pred.reshape(B, J * T * K, H, W)
     B, _, H, W = pred.shape
     x24 = PartCleanFunction.apply(pred, keep)
     view = x24[:, :21].reshape(B, NJ, 3, NC, H, W)          # strided view of the padded buffer, no copy
@@ -61,12 +76,13 @@ class PartLossFunction(torch.autograd.Function):
         th = theta.detach().to(torch.float32).contiguous()
         w = None if sample_w is None else sample_w.detach().to(torch.float32).contiguous()
         sel = sel.to(torch.int32).contiguous()
+        ctx.cpj = _cpj(C)
         if img.shape != (B, 3, H, W) or th.shape != (B, NJ, 2, 3) or sel.shape != (NJ, 6):
             raise ValueError('part_losses: bad shapes %s %s %s' % (tuple(img.shape), tuple(th.shape), tuple(sel.shape)))
         sums = ARENA.alloc(32 * 3)
         if sums is None:
             sums = torch.zeros(32 * 3, dtype=torch.float32, device=pred.device)
-        check(_lib.lib().danet_part_loss_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), B, H, W, int(align),
+        check(_lib.lib().danet_part_loss_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), B, H, W, int(align), ctx.cpj,
                                                  ptr(sums), stream()), 'danet_part_loss_forward')
         ctx.save_for_backward(pred, img, th, w, sel)
         ctx.align = int(align)
@@ -79,7 +95,7 @@ class PartLossFunction(torch.autograd.Function):
         gp = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
         scale = g.detach().to(torch.float32).contiguous()
         check(_lib.lib().danet_part_loss_backward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), ptr(scale),
-                                                  B, H, W, ctx.align, ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_loss_backward')
+                                                  B, H, W, ctx.align, ctx.cpj, ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_loss_backward')
         return gp, None, None, None, None, None
 
 
@@ -89,5 +105,5 @@ def part_losses(pred, iuv_img, theta, sample_w, sel, align):
     resampled per joint by `theta` [B,24,2,3] (sel [24,6]: DensePose parts of each joint)."""
     if pred.dim() == 6:
         B, J, T, K, H, W = pred.shape
-        pred = pred.reshape(B, J * T * K, H, W)
+        pred = getattr(pred, '_padded', None) if getattr(pred, '_padded', None) is not None else pred.reshape(B, J * T * K, H, W)
     return PartLossFunction.apply(pred, iuv_img, theta, sample_w, sel, align)

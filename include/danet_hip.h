@@ -116,7 +116,8 @@ int danet_adam_step(const void* table, int nchunks, float* m, float* v, const fl
 /* ---------------------------------------------------------------------------------------
  * Partial-IUV ("limb") path glue (replaces /root/reference/models/danet/danet.py:264-283 and
  * /root/reference/models/danet/iuv_estimator.py:206-246, ~40 tensor ops on [B,24,3,7,H,W] fp32).
- * pred: the grouped conv's output, NHWC bf16 [B,H,W,504], channel = (joint*3 + {u,v,index})*7 + class.
+ * pred: the grouped conv's output, NHWC bf16 [B,H,W,24*cpj], channel = joint*cpj + {u,v,index}*7 + class; cpj = 21, or 24
+ * when the conv's group-padded output is consumed as it is (the 3 padding channels per joint get zero gradients).
  *  danet_part_clean_*   x24 [B*24,H,W,24] bf16 = iuvmap_clean(keep[B,24,7] * pred) (+3 zero channels);
  *                       backward: d pred from d x24 (U,V channels only).
  *  danet_part_loss_*    sums [32][3] (zeroed by the caller; column sums = smooth-L1 U, smooth-L1 V,
@@ -124,12 +125,12 @@ int danet_adam_step(const void* table, int nchunks, float* m, float* v, const fl
  *                       theta [B,24,2,3]; sel [24][6] int; sample_w [B] (NULL = 1).  backward: d pred for
  *                       scale[0..2] * the three sums (scale on the device).
  */
-int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, void* x24, void* stream);
-int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, void* gpred, void* stream);
+int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, int cpj, void* x24, void* stream);
+int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, int cpj, void* gpred, void* stream);
 int danet_part_loss_forward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
-                            const int* sel, int B, int H, int W, int align, float* sums, void* stream);
+                            const int* sel, int B, int H, int W, int align, int cpj, float* sums, void* stream);
 int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
-                             const int* sel, const float* scale, int B, int H, int W, int align, void* gpred, void* stream);
+                             const int* sel, const float* scale, int B, int H, int W, int align, int cpj, void* gpred, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution (replaces the cuDNN/ATen kernels behind every nn.Conv2d on the hot path:

@@ -88,3 +88,36 @@ def test_part_losses_match_tensor_ops(align):
     assert torch.allclose(sums, ref, rtol=2e-4, atol=1e-2), (sums, ref)
     d = (p1.grad.float() - p2.grad.float()).abs().max().item()
     assert d <= 2e-2 * p2.grad.float().abs().max().item(), d        # bf16 gradients; a resampled weight exactly on the fg>0 edge may flip
+
+
+def test_group_padded_prediction_layout_matches_unpadded():
+    """The part ops on the grouped conv's zero-padded output (24 channels per joint) == on the 21-channel layout."""
+    from danet_densepose2smpl_amd import part_ops
+    from danet_densepose2smpl_amd.iuv_estimator import DP2SMPL_MAPPING
+    B, S = 2, 16
+    pred, keep = _inputs(B, S, 21, True)
+    pad = torch.zeros(B, S, S, 24, 24, dtype=torch.bfloat16, device='cuda')
+    pad[..., :21] = pred.permute(0, 2, 3, 1).reshape(B, S, S, 24, 21)
+    pad = pad.reshape(B, S, S, 576).permute(0, 3, 1, 2)
+    g = torch.Generator().manual_seed(3)
+    img = torch.stack([torch.randint(0, 25, (B, S, S), generator=g).float() / 24., torch.rand(B, S, S, generator=g),
+                       torch.rand(B, S, S, generator=g)], 1).cuda()
+    theta = torch.zeros(B, 24, 2, 3)
+    theta[:, :, 0, 0] = theta[:, :, 1, 1] = 0.6
+    theta[:, :, :, 2] = torch.rand(B, 24, 2, generator=g) - 0.5
+    theta = theta.cuda()
+    sel = torch.tensor(DP2SMPL_MAPPING, dtype=torch.long).cuda()
+    outs = []
+    for t in (pred, pad):
+        p = t.clone().requires_grad_(True)
+        v6 = part_ops.padded_view6(p) if p.shape[1] == 576 else p.reshape(B, 24, 3, 7, S, S)
+        view, x24 = part_ops.part_clean(v6, keep)
+        sums = part_ops.part_losses(v6, img, theta, None, sel, True)
+        (x24.float().square().sum() * 0.01 + sums.sum()).backward()
+        gr = p.grad.permute(0, 2, 3, 1).reshape(B, S, S, 24, -1)
+        if gr.shape[-1] == 24:
+            assert float(gr[..., 21:].abs().max()) == 0.0
+        outs.append((x24.float(), sums, gr[..., :21].float()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5)
+    assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-2 * outs[0][2].abs().max().item()
