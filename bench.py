@@ -39,6 +39,14 @@ def pmc_traffic(kernel):
     return None
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -156,6 +164,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    _flush_c_stdio()      # RCCL's start-up banner sits in the C stdio buffer of every rank: emit it now, not after the JSON line
     t0 = time.time()
     for _ in range(args.steps):
         step()
@@ -193,6 +202,7 @@ def main():
                 line['cpu_baseline'] = cpu_baseline(args.size, args.cpu_batch)
             except Exception as e:                                   # the bench line must still be printed
                 line['cpu_baseline'] = {'error': repr(e)}
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
     if world > 1 or args.force_ddp:
         dist.destroy_process_group()
