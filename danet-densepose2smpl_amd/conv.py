@@ -319,7 +319,7 @@ class Conv2dFunction(torch.autograd.Function):
                 if bn_bwd is not None:
                     gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gy.float().sum(dim=(0, 2, 3))
+            gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32)      # fp32 accumulation without a converted copy of gy
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
