@@ -627,7 +627,6 @@ class Conv2d(nn.Conv2d):
     def __init__(self, *args, out_fp32=False, **kwargs):
         super().__init__(*args, **kwargs)
         assert self.padding_mode == 'zeros'
-        assert self.kernel_size[0] == self.kernel_size[1] or True
         self.out_fp32 = out_fp32
 
     def forward(self, x):
