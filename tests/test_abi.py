@@ -56,3 +56,31 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(import|from)\s+oracle\b', txt, flags=re.M), f
                 assert 'liboracle' not in txt, f
+
+
+def test_new_ops_refuse_cpu_tensors_and_host_queries_work():
+    """The ops added later in the round keep the rule: CPU tensors raise, planning queries are host-side."""
+    import ctypes
+    from danet_densepose2smpl_amd import _lib, conv, nn as dnn, part_ops
+    from danet_densepose2smpl_amd.optim import FusedAdam
+    lib = _lib.lib()
+    with pytest.raises(RuntimeError, match='GPU only|no CPU'):
+        conv.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 3, 3), None, 1, 1)
+    with pytest.raises(RuntimeError, match='GPU only|no CPU'):
+        part_ops.part_clean(torch.zeros(1, 504, 4, 4))
+    with pytest.raises(RuntimeError, match='GPU'):
+        FusedAdam([torch.nn.Parameter(torch.zeros(4))])
+    # CPU tensors: the multi-tensor BatchNorm helper must fall back to the per-module path, which then refuses them
+    bn = dnn.BatchNorm2d(8).train()
+    with pytest.raises(RuntimeError, match='GPU only|no CPU'):
+        dnn.multi_batch_norm([bn], [torch.zeros(1, 8, 4, 4)])
+    # kernel-selection queries (no device needed)
+    assert lib.danet_conv_forward_kernel(32, 64, 64, 48, 64, 64, 48, 3, 3, 1, 1, 1, 1, 0, 0) == 4311      # <4,3>, vec8, fast kernel
+    assert lib.danet_conv_forward_kernel(32, 8, 8, 384, 8, 8, 384, 3, 3, 1, 1, 1, 1, 0, 0) % 10 == 1
+    assert lib.danet_conv_forward_kernel(2, 8, 8, 7, 8, 8, 8, 3, 3, 1, 1, 1, 1, 0, 0) % 10 == 0            # odd channels: general kernel
+    jobs = (_lib.Wg3Job * 2)()
+    for j, c in zip(jobs, (48, 96)):
+        j.x = j.dy = j.dw = 16
+        j.B, j.H, j.W, j.Cin, j.Cout, j.groups = 4, 32, 32, c, c, 1
+    assert lib.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), 2) >= 9 * (48 * 48 + 96 * 96)
+    assert lib.danet_adam_chunk_bytes() == 32 and lib.danet_conv_pack_job_bytes() >= 56
