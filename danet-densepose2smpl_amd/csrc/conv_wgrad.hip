@@ -380,7 +380,7 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
     bool done[4096];
     for (int i = 0; i < n; ++i) done[i] = false;
     size_t used = 0;
-    long target = 512;
+    long target = 1536;     // swept on MI355X: the one large 7x7 problem of a launch needs many workgroups to balance
     if (const char* e = getenv("DANET_WGRAD_MULTI_BLOCKS")) target = atol(e);
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;

@@ -358,7 +358,7 @@ struct Wg3Job { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout
 
 static long multi_target_blocks() {
     if (const char* e = getenv("DANET_WGRAD3_MULTI_BLOCKS")) return atol(e);
-    return 512;
+    return 768;          // swept on MI355X (384 / 512 / 768 / 1024): three workgroups per CU
 }
 
 // msplit of every job when jobs [first, last) of one instance share a launch
