@@ -177,6 +177,41 @@ class IUV_Estimator(nn.Module):
         loss_segAnn = None if ann_pred is None else ce(ann_pred, Annmap)
         return loss_U, loss_V, loss_IndexUV, loss_segAnn
 
+    @staticmethod
+    def dp_uvia_losses(u_pred, v_pred, index_pred, ann_pred, dp, has_dp=None, align=True):
+        """DensePose-COCO point supervision (iuv_estimator.py:343-419, called on the has_dp subset at :106-117), in
+        masked-weight form: every sample is evaluated and weighted by has_dp, so shapes stay static (hipGraph-capturable)
+        and an all-zero has_dp gives the zeros the reference returns at :118-121.
+        dp: the 9 blobs of datasets/base_dataset.py:228-232 -- X/Y/Ind/I points [B,196], U/V points and weights [B,25*196],
+        ann labels/weights [B,S*S].  Returns (loss_Udp, loss_Vdp, loss_IndexUVdp, loss_segAnndp)."""
+        B, K, S = u_pred.shape[0], cfg.DANET.NUM_PATCHES + 1, u_pred.shape[-1]
+        dev = u_pred.device
+        w = torch.ones(B, device=dev) if has_dp is None else (has_dp > 0).to(torch.float32)
+        n_on = w.sum().clamp(min=1.0)
+        # bilinear pooling of the predictions at the annotated points: pixel coordinates -> [-1, 1] as the reference does
+        xy = torch.stack([dp['body_uv_X_points'], dp['body_uv_Y_points']], dim=2).to(torch.float32)
+        grid = ((xy - S / 2.) * (2. / S)).unsqueeze(1)                                   # [B,1,196,2]
+
+        def pool(t):
+            return F.grid_sample(t.float(), grid, mode='bilinear', padding_mode='zeros', align_corners=align).squeeze(2).transpose(1, 2)
+        iu, iv, ii = pool(u_pred), pool(v_pred), pool(index_pred)                         # [B,196,K]
+        tu = dp['body_uv_U_points'].view(B, K, 196).transpose(1, 2).to(torch.float32)
+        tv = dp['body_uv_V_points'].view(B, K, 196).transpose(1, 2).to(torch.float32)
+        pw = dp['body_uv_point_weights'].view(B, K, 196).transpose(1, 2).to(torch.float32)
+        wb = w.view(B, 1, 1)
+        # utils/net.py:18-35 with inside = outside = point weights, N = 1: a plain sum
+        loss_U = (pw * F.smooth_l1_loss(pw * iu, pw * tu, reduction='none') * wb).sum() * cfg.DANET.POINT_REGRESSION_WEIGHTS
+        loss_V = (pw * F.smooth_l1_loss(pw * iv, pw * tv, reduction='none') * wb).sum() * cfg.DANET.POINT_REGRESSION_WEIGHTS
+        # patch-index cross-entropy over ALL 196 point slots of the labelled samples (mean), empty slots carry label 0
+        ce_i = F.cross_entropy(ii.reshape(B * 196, K), dp['body_uv_I_points'].reshape(-1).to(torch.int64), reduction='none')
+        loss_I = (ce_i.view(B, 196) * w.view(B, 1)).sum() / (n_on * 196) * cfg.DANET.PART_WEIGHTS
+        # dense 15-way body-part segmentation
+        na = ann_pred.shape[1]
+        ce_a = F.cross_entropy(ann_pred.float().reshape(B, na, S * S).transpose(1, 2).reshape(B * S * S, na),
+                               dp['body_uv_ann_labels'].reshape(-1).to(torch.int64), reduction='none')
+        loss_A = (ce_a.view(B, S * S) * w.view(B, 1)).sum() / (n_on * S * S) * cfg.DANET.INDEX_WEIGHTS
+        return loss_U, loss_V, loss_I, loss_A
+
     # --------------------------------------------------------------------------------------
     def forward(self, data, iuv_image_gt=None, smpl_kps_gt=None, kps3d_gt=None, uvia_dp_gt=None, has_iuv=None, has_dp=None):
         rd = {'losses': {}, 'metrics': {}, 'visualization': {}}
@@ -191,10 +226,16 @@ class IUV_Estimator(nn.Module):
             lU, lV, lI, lA = self.body_uv_losses(u_pred, v_pred, index_pred, ann_pred, uvia_list, has_iuv)
             rd['losses'].update({'loss_U': lU, 'loss_V': lV, 'loss_IndexUV': lI, 'loss_segAnn': lA})
         if self.training and uvia_dp_gt is not None:
-            # DensePose-COCO point supervision (iuv_estimator.py:106-121) is the next-row f3 of
-            # SURVEY.md 8f; with has_dp == 0 the reference itself reports zeros (:118-121).
-            z = torch.zeros(1, device=data.device)
-            rd['losses'].update({'loss_Udp': z, 'loss_Vdp': z.clone(), 'loss_IndexUVdp': z.clone(), 'loss_segAnndp': z.clone()})
+            # DensePose-COCO point supervision (iuv_estimator.py:106-121).  `dp_active` (host-side flag a data loader /
+            # trainer sets per batch) skips the work for batches without DensePose labels, as the reference's
+            # `torch.sum(has_dp) > 0` does, without a device sync inside the step.
+            if uvia_dp_gt.get('dp_active', True):
+                dp = {k: v for k, v in uvia_dp_gt.items() if torch.is_tensor(v)}
+                lU, lV, lI, lA = self.dp_uvia_losses(u_pred, v_pred, index_pred, ann_pred, dp, has_dp, align)
+                rd['losses'].update({'loss_Udp': lU, 'loss_Vdp': lV, 'loss_IndexUVdp': lI, 'loss_segAnndp': lA})
+            else:
+                z = torch.zeros(1, device=data.device)
+                rd['losses'].update({'loss_Udp': z, 'loss_Vdp': z.clone(), 'loss_IndexUVdp': z.clone(), 'loss_segAnndp': z.clone()})
         rd['uvia_pred'] = [u_pred, v_pred, index_pred, ann_pred]
         if not cfg.DANET.DECOMPOSED:
             return rd

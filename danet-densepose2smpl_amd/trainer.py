@@ -29,7 +29,7 @@ def default_options(batch_size=32):
     return types.SimpleNamespace(batch_size=batch_size, openpose_train_weight=0., gt_train_weight=1.)
 
 
-def synthetic_in_dict(model, B, device, seed=1234, img_size=None):
+def synthetic_in_dict(model, B, device, seed=1234, img_size=None, with_dp=False):
     """Seeded synthetic training batch with the reference's keys and shapes (trainer.py:184-212;
     datasets/base_dataset.py:228-298)."""
     g = torch.Generator(device='cpu').manual_seed(seed)
@@ -51,7 +51,17 @@ def synthetic_in_dict(model, B, device, seed=1234, img_size=None):
         skps = perspective_projection(out.smpl_joints, None, cam_t, 5000., zero_c) / (S / 2.)
         target_smpl_kps = torch.cat([skps, torch.ones(B, 24, 1, device=device)], dim=-1)
     ones = torch.ones(B, device=device)
-    return {'img': img, 'opt_pose': pose, 'opt_betas': betas, 'keypoints': keypoints, 'pose_3d': pose_3d,
+    extra = {}
+    if with_dp:
+        # the zero DensePose blobs every non-COCO sample carries (datasets/base_dataset.py:228-237); 'dp_active' is the
+        # host-side twin of the reference's `torch.sum(has_dp) > 0` test
+        Sh = S // 4
+        z = lambda n: torch.zeros(B, n, device=device)      # noqa: E731
+        extra['dp_dict'] = {'body_uv_ann_labels': torch.zeros(B, Sh * Sh, dtype=torch.int32, device=device),
+                            'body_uv_ann_weights': z(Sh * Sh), 'body_uv_X_points': z(196), 'body_uv_Y_points': z(196),
+                            'body_uv_Ind_points': z(196), 'body_uv_I_points': z(196), 'body_uv_U_points': z(4900),
+                            'body_uv_V_points': z(4900), 'body_uv_point_weights': z(4900), 'dp_active': False}
+    return {**extra, 'img': img, 'opt_pose': pose, 'opt_betas': betas, 'keypoints': keypoints, 'pose_3d': pose_3d,
             'has_pose_3d': ones.clone(), 'valid_fit': ones.clone(), 'has_iuv': ones.clone(), 'has_dp': torch.zeros(B, device=device),
             'target_smpl_kps': target_smpl_kps, 'target_verts': out.vertices.detach(), 'target_cam': cam,
             'vis_on': False, 'pretrain_mode': False}

@@ -316,7 +316,47 @@ def g10_losses():
          u=u, v=v, idx=idx, ann=ann, iuv_gt=gt, has_iuv=has_iuv, loss_U=lU, loss_V=lV, loss_I=lI, loss_A=lA)
 
 
-ALL.update({'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses})
+def g11_dp_losses():
+    """DensePose point supervision (iuv_estimator.py:343-419) on the has_dp subset, as the reference's forward calls it
+    (:106-117); gradients w.r.t. the FULL prediction batch (zero rows for samples without DensePose labels)."""
+    import torch.nn.functional as F
+    ag, gs = F.affine_grid, F.grid_sample
+    for align in (False, True):
+        ref_env({'DANET.HEATMAP_SIZE': 16})
+        if align:
+            F.grid_sample = lambda x, grid, mode='bilinear', padding_mode='zeros', align_corners=None: gs(x, grid, mode, padding_mode, align_corners=True)
+        else:
+            F.grid_sample = lambda x, grid, mode='bilinear', padding_mode='zeros', align_corners=None: gs(x, grid, mode, padding_mode, align_corners=False)
+        try:
+            from models.danet.iuv_estimator import IUV_Estimator
+            g = torch.Generator().manual_seed(11)
+            B, S = 4, 16
+            u, v, idx = (torch.randn(B, 25, S, S, generator=g).requires_grad_(True) for _ in range(3))
+            ann = torch.randn(B, 15, S, S, generator=g).requires_grad_(True)
+            has_dp = torch.tensor([1, 0, 1, 1])
+            I = torch.randint(0, 25, (B, 196), generator=g)
+            I[:, 150:] = 0                                          # unused point slots are zero-filled in the dataset
+            onehot = torch.nn.functional.one_hot(I, 25).permute(0, 2, 1).float()          # [B,25,196]
+            wts = onehot * (I > 0).float().unsqueeze(1)
+            dp = {'body_uv_X_points': torch.rand(B, 196, generator=g) * 15.0 + 0.3,
+                  'body_uv_Y_points': torch.rand(B, 196, generator=g) * 15.0 + 0.3,
+                  'body_uv_Ind_points': torch.zeros(B, 196), 'body_uv_I_points': I.float(),
+                  'body_uv_U_points': (torch.rand(B, 25, 196, generator=g) * wts).reshape(B, 4900),
+                  'body_uv_V_points': (torch.rand(B, 25, 196, generator=g) * wts).reshape(B, 4900),
+                  'body_uv_point_weights': wts.reshape(B, 4900),
+                  'body_uv_ann_labels': torch.randint(0, 15, (B, S * S), generator=g).to(torch.int32),
+                  'body_uv_ann_weights': torch.ones(B, S * S)}
+            on = has_dp == 1
+            lU, lV, lI, lA = IUV_Estimator.dp_uvia_losses(None, u[on], v[on], idx[on], ann[on], **{k: t[on] for k, t in dp.items()})
+            (lU * 1.0 + lV * 2.0 + lI * 3.0 + lA * 4.0).backward()
+            save('g11_dp_losses_align%d' % int(align), u=u.detach(), v=v.detach(), idx=idx.detach(), ann=ann.detach(), has_dp=has_dp,
+                 loss_Udp=lU.detach(), loss_Vdp=lV.detach(), loss_IndexUVdp=lI.detach(), loss_segAnndp=lA.detach(),
+                 gu=u.grad, gv=v.grad, gidx=idx.grad, gann=ann.grad, **{'dp__' + k: t for k, t in dp.items()})
+        finally:
+            F.affine_grid, F.grid_sample = ag, gs
+
+
+ALL.update({'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
 
 
 def _main():

@@ -403,3 +403,33 @@ def test_data_parallel_graph_path_single_rank():
         assert max(rel) < 0.3 and sorted(rel)[len(rel) // 2] < 0.05, sorted(rel)[-3:]
     finally:
         dist.destroy_process_group()
+
+
+def test_dp_point_losses_inside_the_estimator_and_train_step():
+    """DensePose point supervision wired into IUV_Estimator.forward (GPU tensors through the same
+    torch code that tests/test_host_logic.py pins against the reference) and into the train step."""
+    _cfg(**{'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16, 'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.,
+            'DANET.PARTDROP_RATE': 0.})
+    from danet_densepose2smpl_amd.iuv_estimator import IUV_Estimator
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    g = golden('g7_estimator_align1')
+    gd = golden('g11_dp_losses_align1')
+    est = IUV_Estimator(pretrained=False)
+    formula_params(est, skip=('learned_ratio', 'learned_offset', '_'))
+    est = est.cuda().train()
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    dp = {k[4:]: torch.from_numpy(gd[k])[:2].cuda() for k in gd.files if k.startswith('dp__')}
+    has_dp = torch.tensor([1., 0.], device='cuda')
+    rd = est(t('img'), t('iuv_gt'), t('kps'), uvia_dp_gt=dp, has_iuv=torch.ones(2, device='cuda'), has_dp=has_dp)
+    u, v, i, a = rd['uvia_pred']
+    ref = IUV_Estimator.dp_uvia_losses(u, v, i, a, dp, has_dp, True)
+    for k, r in zip(('loss_Udp', 'loss_Vdp', 'loss_IndexUVdp', 'loss_segAnndp'), ref):
+        assert torch.isfinite(rd['losses'][k]).all() and float(rd['losses'][k]) > 0
+        assert abs(float(rd['losses'][k]) - float(r)) <= 1e-5 * abs(float(r))
+    sum(v_.sum() for v_ in rd['losses'].values()).backward()
+    assert est.iuv_est.final_pred.predict_ann_index.weight.grad.abs().sum() > 0
+    # train step with the zero blobs of a non-COCO batch: four extra zero losses, like iuv_estimator.py:118-121
+    tr = Trainer(default_options(2), device=torch.device('cuda'), distributed=False)
+    batch = synthetic_in_dict(tr.model, 2, torch.device('cuda'), seed=1, with_dp=True)
+    _, losses = tr.train_step(batch)
+    assert len(losses) == 21 and all(float(losses[k].sum()) == 0.0 for k in ('loss_Udp', 'loss_Vdp', 'loss_IndexUVdp', 'loss_segAnndp'))

@@ -90,3 +90,29 @@ def test_config_overrides():
     cfg_from_dict({'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
     assert cfg.DANET.INIMG_SIZE == 256 and cfg.HR_MODEL.EXTRA.STAGE4.NUM_CHANNELS == [48, 96, 192, 384]
     reset_cfg()
+
+
+import pytest
+
+
+@pytest.mark.parametrize('align', [0, 1])
+def test_dp_point_losses_vs_reference(align):
+    """DensePose point supervision in masked-weight form == the reference evaluated on the has_dp subset
+    (golden g11: losses and the gradients w.r.t. all four prediction maps)."""
+    from danet_densepose2smpl_amd.config import reset_cfg, cfg_from_dict
+    from danet_densepose2smpl_amd.iuv_estimator import IUV_Estimator
+    reset_cfg()
+    cfg_from_dict({'DANET.HEATMAP_SIZE': 16})
+    g = golden('g11_dp_losses_align%d' % align)
+    u, v, idx, ann = (torch.from_numpy(g[k]).requires_grad_(True) for k in ('u', 'v', 'idx', 'ann'))
+    dp = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('dp__')}
+    has_dp = torch.from_numpy(g['has_dp'])
+    lU, lV, lI, lA = IUV_Estimator.dp_uvia_losses(u, v, idx, ann, dp, has_dp, bool(align))
+    for ours, k in ((lU, 'loss_Udp'), (lV, 'loss_Vdp'), (lI, 'loss_IndexUVdp'), (lA, 'loss_segAnndp')):
+        assert abs(float(ours) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+    (lU * 1.0 + lV * 2.0 + lI * 3.0 + lA * 4.0).backward()
+    for t, k in ((u, 'gu'), (v, 'gv'), (idx, 'gidx'), (ann, 'gann')):
+        np.testing.assert_allclose(t.grad.numpy(), g[k], atol=1e-6 + 1e-5 * np.abs(g[k]).max())
+    # no labelled sample at all: zeros, as iuv_estimator.py:118-121
+    z = IUV_Estimator.dp_uvia_losses(u.detach(), v.detach(), idx.detach(), ann.detach(), dp, torch.zeros(4), bool(align))
+    assert all(float(t) == 0.0 for t in z)
