@@ -56,6 +56,36 @@ class FusedAdam(object):
         self._np['pad'] = 0
         self._gptrs = None
 
+    def state_dict(self):
+        """torch.optim.Adam's layout (per-parameter step / exp_avg / exp_avg_sq + one param group), so the checkpoints of
+        utils/saver.py move between this optimizer and the reference's."""
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {'step': self.step_t.detach().clone(), 'exp_avg': self.exp_avg[o:o + n].view_as(p).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        group = {'lr': float(self.param_groups[0]['lr']), 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0,
+                 'amsgrad': False, 'maximize': False, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        ids = [i for g in groups for i in g['params']]
+        if len(ids) != len(self.params):
+            raise ValueError('FusedAdam.load_state_dict: %d parameters in the file, %d here' % (len(ids), len(self.params)))
+        step = 0.0
+        for pos, (i, p, o) in enumerate(zip(ids, self.params, self.offsets)):
+            st = sd['state'].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            step = max(step, float(st['step']))
+        self.step_t.fill_(step)             # one global step count (torch keeps one per parameter; they agree in training)
+        self.param_groups[0]['lr'].fill_(float(groups[0]['lr']))
+        self.betas, self.eps = tuple(groups[0].get('betas', self.betas)), groups[0].get('eps', self.eps)
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:

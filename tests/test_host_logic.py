@@ -116,3 +116,40 @@ def test_dp_point_losses_vs_reference(align):
     # no labelled sample at all: zeros, as iuv_estimator.py:118-121
     z = IUV_Estimator.dp_uvia_losses(u.detach(), v.detach(), idx.detach(), ann.detach(), dp, torch.zeros(4), bool(align))
     assert all(float(t) == 0.0 for t in z)
+
+
+def test_checkpoint_files_in_the_reference_format(tmp_path):
+    """saver.py-style training checkpoints and demo.py-style pretrained files round-trip."""
+    from danet_densepose2smpl_amd import checkpoint
+    from danet_densepose2smpl_amd.config import reset_cfg, cfg_from_dict
+    from danet_densepose2smpl_amd.danet import DaNet
+    from danet_densepose2smpl_amd.trainer import default_options
+    reset_cfg()
+    cfg_from_dict({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16})
+    torch.manual_seed(0)
+    a = DaNet(default_options(2), None, pretrained=False)
+    torch.manual_seed(1)
+    b = DaNet(default_options(2), None, pretrained=False)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.add_(0.01)
+    opt = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], lr=1e-4)
+    path = checkpoint.save_checkpoint(str(tmp_path / 'ck' / '00000010.pt'), {'model': a}, {'optimizer': opt}, epoch=3, batch_idx=7,
+                                      batch_size=2, dataset_perm=[1, 0], total_step_count=10)
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) >= {'model', 'optimizer', 'epoch', 'batch_idx', 'batch_size', 'dataset_perm', 'total_step_count'}
+    assert not any(k.startswith('iuv2smpl.smpl.') for k in raw['model']) and len(raw['model']) > 2000
+    book = checkpoint.load_checkpoint(path, {'model': b})
+    assert book == {'epoch': 3, 'batch_idx': 7, 'batch_size': 2, 'dataset_perm': [1, 0], 'total_step_count': 10}
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in raw['model'])
+    # a released-weights file: {'model': DataParallel-prefixed state dict}, loaded non-strictly
+    torch.save({'model': {'module.' + k: v for k, v in raw['model'].items() if 'predict_hm' not in k}}, str(tmp_path / 'rel.pt'))
+    torch.manual_seed(2)
+    c = DaNet(default_options(2), None, pretrained=False)
+    missing, unexpected = checkpoint.load_pretrained(c, str(tmp_path / 'rel.pt'))
+    assert unexpected == [] and all('predict_hm' in k or k.startswith('iuv2smpl.smpl.') for k in missing) and missing
+    k0 = 'img2iuv.iuv_est.conv1.weight'
+    assert torch.equal(c.state_dict()[k0], sa[k0])
+    with pytest.raises(ValueError):
+        checkpoint.load_pretrained(c, str(tmp_path / 'nope.pt'))
