@@ -18,7 +18,7 @@ from .danet import DaNet
 from .distributed import GradReducer
 from .nn import BatchNorm2d, bump_batch_counters
 from . import conv as _conv
-from .geometry import perspective_projection
+from .geometry import perspective_projection, label_prologue
 
 
 DEFER_WGRAD = bool(int(os.environ.get('DANET_DEFER_WGRAD', '1')))
@@ -103,6 +103,43 @@ class Trainer(object):
         if distributed:
             self.reducer = GradReducer(self.model, device=self.device)
             self.reducer.broadcast_parameters()
+
+    @torch.no_grad()
+    def prepare_batch(self, input_batch, opt_pose=None, opt_betas=None, img_res=None, focal_length=5000.):
+        """The reference's step prologue (train/trainer.py:134-212) on the device -- SURVEY.md 8 row f1.
+        input_batch: img, keypoints [B,49,3] (normalised to [-1,1], confidence), pose [B,72], betas [B,10], pose_3d [B,24,4],
+        has_smpl, has_pose_3d, has_dp, optional smpl_2dkps / dp_dict / has_iuv_dataset (the reference's
+        `dataset_name != 'dp_coco'`) / valid_fit.  opt_pose / opt_betas: the pseudo-label fits (FitsDict in the
+        reference; default: the ground truth).  Two SMPL forwards (HIP), one batched least-squares solve, no host
+        round trip.  Returns the in_dict `train_step` takes."""
+        dev = self.device
+        res = img_res or cfg.DANET.INIMG_SIZE
+        B = input_batch['img'].shape[0]
+        gt_pose, gt_betas = input_batch['pose'].to(dev), input_batch['betas'].to(dev)
+        has_smpl = input_batch['has_smpl'].to(dev) > 0
+        opt_pose = gt_pose.clone() if opt_pose is None else opt_pose.to(dev).clone()
+        opt_betas = gt_betas.clone() if opt_betas is None else opt_betas.to(dev).clone()
+        opt_betas = torch.where((opt_betas.abs() > 3).any(dim=-1, keepdim=True), torch.zeros_like(opt_betas), opt_betas)
+        opt_pose = torch.where(has_smpl.view(B, 1), gt_pose, opt_pose)
+        opt_betas = torch.where(has_smpl.view(B, 1), gt_betas, opt_betas)
+        opt = self.smpl(betas=opt_betas, body_pose=opt_pose[:, 3:], global_orient=opt_pose[:, :3])
+        valid_fit = input_batch['valid_fit'].to(dev) > 0 if 'valid_fit' in input_batch else has_smpl
+        has_iuv = valid_fit & (input_batch['has_iuv_dataset'].to(dev) > 0 if 'has_iuv_dataset' in input_batch
+                               else torch.ones(B, dtype=torch.bool, device=dev))
+        has_dp = input_batch.get('has_dp', torch.zeros(B, device=dev)).to(dev)
+        kps, cam, _ = label_prologue(opt.joints, opt.smpl_joints, input_batch['keypoints'].to(dev), has_iuv, has_dp,
+                                     input_batch.get('smpl_2dkps', None) if input_batch.get('smpl_2dkps', None) is None
+                                     else input_batch['smpl_2dkps'].to(dev), focal_length, res)
+        out = {'img': input_batch['img'].to(dev), 'opt_pose': opt_pose, 'opt_betas': opt_betas,
+               'keypoints': input_batch['keypoints'].to(dev), 'pose_3d': input_batch['pose_3d'].to(dev),
+               'has_pose_3d': input_batch['has_pose_3d'].to(dev).float(), 'valid_fit': valid_fit.float(),
+               'has_iuv': has_iuv.float(), 'has_dp': has_dp.float(), 'target_smpl_kps': kps,
+               'target_verts': opt.vertices.detach(), 'target_cam': cam,
+               'vis_on': bool(input_batch.get('vis_on', False)), 'pretrain_mode': bool(input_batch.get('pretrain_mode', False))}
+        if 'dp_dict' in input_batch:
+            out['dp_dict'] = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in input_batch['dp_dict'].items()}
+            out['dp_dict'].setdefault('dp_active', bool((has_dp > 0).any()))        # (one host read per batch, outside the step)
+        return out
 
     def _decay_lr(self):
         """manual step-LR decay (trainer.py:120-128)"""

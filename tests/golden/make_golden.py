@@ -356,7 +356,40 @@ def g11_dp_losses():
             F.affine_grid, F.grid_sample = ag, gs
 
 
-ALL.update({'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
+def g12_label_prologue():
+    """The geometry of the reference's step prologue (train/trainer.py:170-210): camera translation by weighted least
+    squares (utils/geometry.py:94-157), projected SMPL key-points, weak-perspective camera for the renderer."""
+    ref_env()
+    from utils.geometry import estimate_translation, perspective_projection
+    g = torch.Generator().manual_seed(12)
+    B, res, focal = 5, 224, 5000.
+    joints = torch.randn(B, 49, 3, generator=g) * 0.3
+    smpl_joints = torch.randn(B, 24, 3, generator=g) * 0.3
+    t_true = torch.stack([torch.randn(B, generator=g) * 0.1, torch.randn(B, generator=g) * 0.1, 8 + 4 * torch.rand(B, generator=g)], -1)
+    proj = perspective_projection(joints, rotation=torch.eye(3).unsqueeze(0).expand(B, -1, -1), translation=t_true, focal_length=focal,
+                                  camera_center=torch.zeros(B, 2) + 0.5 * res)
+    kp = torch.cat([proj / (0.5 * res) - 1 + 0.01 * torch.randn(B, 49, 2, generator=g), torch.rand(B, 49, 1, generator=g)], -1)
+    kp[0, 30:35, 2] = 0.0
+    kp_orig = kp.clone()
+    kp_orig[:, :, :-1] = 0.5 * res * (kp_orig[:, :, :-1] + 1)
+    cam_t = estimate_translation(joints, kp_orig, focal_length=focal, img_size=res)
+    has_iuv = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8)
+    has_dp = torch.tensor([0, 1, 0, 0, 0])
+    smpl_2dkps = torch.rand(B, 24, 3, generator=g)
+    tk = torch.zeros(B, 24, 3)
+    tk[:, :, :2] = perspective_projection(smpl_joints, rotation=torch.eye(3).unsqueeze(0).expand(B, -1, -1), translation=cam_t,
+                                          focal_length=focal, camera_center=torch.zeros(B, 2) + 0.5 * res)
+    tk[:, :, :2] = tk[:, :, :2] / (0.5 * res) - 1
+    tk[has_iuv == 1, :, 2] = 1
+    tk[has_dp == 1] = smpl_2dkps[has_dp == 1]
+    cam = torch.zeros(B, 3)
+    cam[:, 1:] = cam_t[:, :2]
+    cam[:, 0] = (2. * focal / res) / cam_t[:, 2]
+    save('g12_label_prologue', joints=joints, smpl_joints=smpl_joints, keypoints=kp, cam_t=cam_t, has_iuv=has_iuv, has_dp=has_dp,
+         smpl_2dkps=smpl_2dkps, target_smpl_kps=tk, target_cam=cam)
+
+
+ALL.update({'g12': g12_label_prologue, 'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
 
 
 def _main():

@@ -433,3 +433,24 @@ def test_dp_point_losses_inside_the_estimator_and_train_step():
     batch = synthetic_in_dict(tr.model, 2, torch.device('cuda'), seed=1, with_dp=True)
     _, losses = tr.train_step(batch)
     assert len(losses) == 21 and all(float(losses[k].sum()) == 0.0 for k in ('loss_Udp', 'loss_Vdp', 'loss_IndexUVdp', 'loss_segAnndp'))
+
+
+def test_prepare_batch_builds_a_trainable_in_dict():
+    """the step prologue on the device.  Labels rendered from a known camera must give that camera
+    back (least squares on exact projections), and the produced in_dict must train."""
+    _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32})
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    tr = Trainer(default_options(2), device=dev, distributed=False)
+    ref = synthetic_in_dict(tr.model, 2, dev, seed=3)
+    raw = {'img': ref['img'], 'keypoints': ref['keypoints'], 'pose': ref['opt_pose'], 'betas': ref['opt_betas'],
+           'pose_3d': ref['pose_3d'], 'has_smpl': torch.ones(2), 'has_pose_3d': torch.ones(2), 'has_dp': torch.zeros(2)}
+    batch = tr.prepare_batch(raw)
+    assert set(ref) <= set(batch)
+    # synthetic_in_dict projected the label joints with target_cam: the least-squares camera must reproduce it
+    assert (batch['target_cam'] - ref['target_cam']).abs().max() < 2e-3
+    assert (batch['target_smpl_kps'] - ref['target_smpl_kps']).abs().max() < 2e-3
+    assert torch.equal(batch['target_verts'], ref['target_verts'])
+    _, losses = tr.train_step(batch)
+    assert all(torch.isfinite(v).all() for v in losses.values()) and len(losses) == 17

@@ -153,3 +153,20 @@ def test_checkpoint_files_in_the_reference_format(tmp_path):
     assert torch.equal(c.state_dict()[k0], sa[k0])
     with pytest.raises(ValueError):
         checkpoint.load_pretrained(c, str(tmp_path / 'nope.pt'))
+
+
+def test_label_prologue_geometry_vs_reference():
+    """batched estimate_translation + projected key-points + renderer camera == the reference's
+    per-sample numpy loop and masked assignments (golden g12)."""
+    from danet_densepose2smpl_amd.geometry import estimate_translation, label_prologue
+    g = golden('g12_label_prologue')
+    t = lambda k: torch.from_numpy(g[k])
+    kp = t('keypoints').clone()
+    kp_px = kp.clone()
+    kp_px[:, :, :-1] = 0.5 * 224 * (kp_px[:, :, :-1] + 1)
+    cam_t = estimate_translation(t('joints'), kp_px, 5000., 224)
+    np.testing.assert_allclose(cam_t.numpy(), g['cam_t'], rtol=2e-5, atol=2e-5)
+    tk, cam, ct = label_prologue(t('joints'), t('smpl_joints'), kp, t('has_iuv'), t('has_dp'), t('smpl_2dkps'), 5000., 224)
+    np.testing.assert_allclose(ct.numpy(), g['cam_t'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tk.numpy(), g['target_smpl_kps'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(cam.numpy(), g['target_cam'], rtol=2e-5, atol=2e-5)
