@@ -389,7 +389,28 @@ def g12_label_prologue():
          smpl_2dkps=smpl_2dkps, target_smpl_kps=tk, target_cam=cam)
 
 
-ALL.update({'g12': g12_label_prologue, 'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
+def g13_eval_metrics():
+    """MPJPE and Procrustes-aligned reconstruction error (eval.py:183-216, utils/pose_utils.py:10-75)."""
+    ref_env()
+    from utils.pose_utils import reconstruction_error, compute_similarity_transform_batch
+    rng = np.random.default_rng(13)
+    B, J = 6, 14
+    gt = rng.normal(0, 0.3, (B, J, 3)).astype(np.float32)
+    pred = np.zeros_like(gt)
+    for i in range(B):                        # similarity-transformed + noisy copies (one reflected: det(R) < 0 branch)
+        A = rng.normal(size=(3, 3))
+        Q, _ = np.linalg.qr(A)
+        if i == 3:
+            Q[:, 0] *= -np.sign(np.linalg.det(Q))
+        pred[i] = (1.0 + 0.3 * rng.normal()) * gt[i] @ Q.T + rng.normal(0, 0.2, (1, 3)) + rng.normal(0, 0.02, (J, 3))
+    pred = pred.astype(np.float32)
+    mpjpe = np.sqrt(((pred - gt) ** 2).sum(-1)).mean(-1)
+    save('g13_eval_metrics', pred=pred, gt=gt, mpjpe=mpjpe.astype(np.float32),
+         aligned=compute_similarity_transform_batch(pred, gt).astype(np.float32),
+         recon=reconstruction_error(pred, gt, reduction=None).astype(np.float32))
+
+
+ALL.update({'g13': g13_eval_metrics, 'g12': g12_label_prologue, 'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
 
 
 def _main():

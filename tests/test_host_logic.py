@@ -170,3 +170,15 @@ def test_label_prologue_geometry_vs_reference():
     np.testing.assert_allclose(ct.numpy(), g['cam_t'], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(tk.numpy(), g['target_smpl_kps'], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(cam.numpy(), g['target_cam'], rtol=2e-5, atol=2e-5)
+
+
+def test_eval_metrics_vs_reference():
+    """batched MPJPE / Procrustes reconstruction error == the reference's numpy loop (golden g13,
+    including a reflected sample that exercises the det(R) = -1 correction)."""
+    from danet_densepose2smpl_amd import metrics
+    g = golden('g13_eval_metrics')
+    pred, gt = torch.from_numpy(g['pred']), torch.from_numpy(g['gt'])
+    np.testing.assert_allclose(metrics.mpjpe(pred, gt).numpy(), g['mpjpe'], rtol=1e-5)
+    np.testing.assert_allclose(metrics.similarity_transform(pred, gt).numpy(), g['aligned'], atol=2e-5)
+    np.testing.assert_allclose(metrics.reconstruction_error(pred, gt).numpy(), g['recon'], rtol=1e-4, atol=1e-6)
+    assert abs(float(metrics.reconstruction_error(pred, gt, 'mean')) - float(g['recon'].mean())) < 1e-6
