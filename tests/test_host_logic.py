@@ -4,7 +4,9 @@ weights instead of boolean-mask indexing, config, state-dict naming."""
 import numpy as np
 import torch
 
-from conftest import golden
+import os
+
+from conftest import golden, ROOT
 
 
 def test_iuvmap_glue_vs_reference():
@@ -182,3 +184,15 @@ def test_eval_metrics_vs_reference():
     np.testing.assert_allclose(metrics.similarity_transform(pred, gt).numpy(), g['aligned'], atol=2e-5)
     np.testing.assert_allclose(metrics.reconstruction_error(pred, gt).numpy(), g['recon'], rtol=1e-4, atol=1e-6)
     assert abs(float(metrics.reconstruction_error(pred, gt, 'mean')) - float(g['recon'].mean())) < 1e-6
+
+
+def test_bench_cpu_baseline_leg_runs_on_host_cores():
+    """bench.py's `cpu_baseline` (the oracle timed on the host; the only place outside tests / smoke that may use it)
+    produces the fields the bench line carries."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline(64, 1)
+    assert out['kind'] == 'port' and out['unit'] == 'images/sec' and out['value'] > 0 and out['cores'] >= 1 and 'sample' in out
+    assert bench.pmc_traffic('no_such_kernel') is None
