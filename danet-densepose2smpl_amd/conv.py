@@ -58,7 +58,6 @@ class ZeroArena(object):
 ARENA = ZeroArena()
 FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '1')))   # dgrad epilogue reduces the producing BN's backward sums
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
-USE_LDS3X3 = bool(int(os.environ.get('DANET_LDS3X3', '0')))         # 3x3/s1/p1 forward + data gradient through the LDS-staged kernel (conv3x3_lds.hip)
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 TRACE = None           # debugging: a list that receives (tag, shape, mean |value|) for every conv / BN launch (tools/debug_flaky.py)
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
@@ -211,6 +210,23 @@ def pack_weight(weight, groups, mode, chunk=0):
     return wp
 
 
+def _kernel_name(kid):
+    """Kernel symbol (as rocprofv3 prints it) for a danet_conv_forward_kernel id."""
+    if kid % 10 == 2:
+        return 'conv3x3_tile_kernel'
+    if kid % 10 == 1:
+        return 'conv_fast_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10)
+    return 'conv_igemm_kernel<%d, %d, %s>' % (kid // 1000, (kid // 100) % 10, 'true' if (kid // 10) % 10 else 'false')
+
+
+def _multi_kernel_name(jobs, n, cout_g):
+    import ctypes
+    L = _lib.lib()
+    if L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), n) == 2:
+        return 'conv3x3_tile_kernel'
+    return 'conv_fast_multi_kernel<%d>' % L.danet_conv_nt(cout_g)
+
+
 def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -224,8 +240,7 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     tok = None
     if PROFILER is not None:
         kid = L.danet_conv_forward_kernel(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed), int(out_fp32))
-        name = 'conv_fast_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10) if kid % 10 else \
-            'conv_igemm_kernel<%d, %d, %s>' % (kid // 1000, (kid // 100) % 10, 'true' if (kid // 10) % 10 else 'false')
+        name = _kernel_name(kid)
         tok = PROFILER.begin(name,
                              2.0 * B * OH * OW * Cout * (Cin // groups) * R * S,
                              ('dgrad' if transposed else 'fwd', B, H, W, Cin, Cout, R, stride, groups))
@@ -243,25 +258,6 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     return y
 
 
-def _conv3x3_raw(x, weight, groups_unused, B, H, W, Cin, Cout, flip, bn_sums=None):
-    """3x3/s1/p1 through the LDS-staged kernel: forward (flip=False, x has the layer's Cin channels) or data
-    gradient (flip=True, x = dY with the layer's Cout channels; Cin/Cout here are the kernel's)."""
-    L = _lib.lib()
-    chunk = L.danet_conv3x3_chunk(B, H, W, Cin, Cout)
-    wp = pack_weight(weight, 1, 1 if flip else 0, chunk)
-    y = _empty_nhwc(B, Cout, H, W, torch.bfloat16, x.device)
-    tok = None
-    if PROFILER is not None:
-        kid = L.danet_conv3x3_kernel_id(B, H, W, Cin, Cout)
-        tok = PROFILER.begin('conv3x3_lds_kernel<%d, %d>' % (kid // 10, kid % 10), 2.0 * B * H * W * Cout * Cin * 9,
-                             ('dgrad' if flip else 'fwd', B, H, W, Cin, Cout, 3, 1, 1))
-    check(L.danet_conv3x3_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp), ptr(y.permute(0, 2, 3, 1)), B, H, W, Cin, Cout,
-                                  int(flip), ptr(bn_sums), stream()), 'danet_conv3x3_forward')
-    if tok is not None:
-        PROFILER.end(tok)
-    return y
-
-
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None, bn_ctx=None):
@@ -271,13 +267,9 @@ class Conv2dFunction(torch.autograd.Function):
         if Cin_g * groups != Cin:
             raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
         OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
-        if USE_LDS3X3 and bias is None and not out_fp32 and \
-                _lib.lib().danet_conv3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
-            y = _conv3x3_raw(x, weight, groups, B, H, W, Cin, Cout, False, bn_sums)
-        else:
-            wp = pack_weight(weight, groups, 0)
-            b = None if bias is None else bias.detach().float().contiguous()
-            y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
+        wp = pack_weight(weight, groups, 0)
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
         ctx.bn_ctx = bn_ctx
@@ -299,25 +291,22 @@ class Conv2dFunction(torch.autograd.Function):
             gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
             _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
         if ctx.needs_input_grad[0]:
-            if USE_LDS3X3 and L.danet_conv3x3_ok(H, W, Cout, Cin, R, S, stride, pad, dil, groups):
-                gx = _conv3x3_raw(gy, weight, groups, B, H, W, Cout, Cin, True)
-            else:
-                wp1 = pack_weight(weight, groups, 1)
-                bn_bwd = None
-                if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
-                        L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 1:
-                    bn_x, bn_relu, saved = ctx.bn_ctx
-                    bn_y = x if bn_relu else None            # the conv's input IS that BatchNorm's output
-                    if bn_x.shape == x.shape:
-                        n = L.danet_bn_ws_floats(Cin)
-                        red = ARENA.alloc(n)
-                        if red is None:
-                            red = torch.zeros(n, dtype=torch.float32, device=x.device)
-                        bn_bwd = (bn_x, bn_y, saved, red)
-                gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
-                                   None, bn_bwd)
-                if bn_bwd is not None:
-                    gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
+            wp1 = pack_weight(weight, groups, 1)
+            bn_bwd = None
+            if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
+                    L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2):
+                bn_x, bn_relu, saved = ctx.bn_ctx
+                bn_y = x if bn_relu else None            # the conv's input IS that BatchNorm's output
+                if bn_x.shape == x.shape:
+                    n = L.danet_bn_ws_floats(Cin)
+                    red = ARENA.alloc(n)
+                    if red is None:
+                        red = torch.zeros(n, dtype=torch.float32, device=x.device)
+                    bn_bwd = (bn_x, bn_y, saved, red)
+            gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
+                               None, bn_bwd)
+            if bn_bwd is not None:
+                gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32)      # fp32 accumulation without a converted copy of gy
         return gx, gw, gb, None, None, None, None, None, None, None
@@ -518,7 +507,7 @@ class MultiConvFunction(torch.autograd.Function):
             ys.append(y); sums_l.append(sums); dims_l.append(dims); keep.append(wp)
         tok = None
         if PROFILER is not None:
-            tok = PROFILER.begin('conv_fast_multi_kernel<%d>' % L.danet_conv_nt(dims_l[0][6] // dims_l[0][12]),
+            tok = PROFILER.begin(_multi_kernel_name(jobs, n, dims_l[0][6] // dims_l[0][12]),
                                  sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in dims_l), ('fwd-multi', n))
         check(L.danet_conv_forward_multi(ctypes.addressof(jobs), n, stream()), 'danet_conv_forward_multi')
         if tok is not None:
@@ -573,7 +562,7 @@ class MultiConvFunction(torch.autograd.Function):
                 tok = None
                 if PROFILER is not None:
                     dd = [dims_l[i] for i in need]
-                    tok = PROFILER.begin('conv_fast_multi_kernel<%d>' % L.danet_conv_nt(dd[0][3] // dd[0][12]),
+                    tok = PROFILER.begin(_multi_kernel_name(jobs, len(need), dd[0][3] // dd[0][12]),
                                          sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in dd), ('dgrad-multi', len(need)))
                 check(L.danet_conv_forward_multi(ctypes.addressof(jobs), len(need), stream()), 'danet_conv_forward_multi')
                 if tok is not None:

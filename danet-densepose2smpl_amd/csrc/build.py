@@ -25,7 +25,7 @@ UNITS = {
     'conv_igemm.hip': MFMA_VGPR,
     'conv_wgrad.hip': MFMA_VGPR,
     'conv_wgrad3x3.hip': MFMA_VGPR,
-    'conv3x3_lds.hip': MFMA_VGPR,
+    'conv3x3.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
     'part_ops.hip': [],
     'adam.hip': [],

@@ -501,6 +501,7 @@ extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, i
     bool vec8;
     if (!fill_conv_params(p, vec8, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, 0, out_fp32)) return -1;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
+    if (conv3x3_ok(p, vec8)) { const int c = conv3x3_config(p, vec8, 1); return (c / 100) * 1000 + ((c / 10) % 10) * 100 + (c % 10) * 10 + 2; }
     return mt * 1000 + danet_conv_nt(p.Cout_g) * 100 + (vec8 ? 10 : 0) + (conv_fast_ok(p, vec8, mt) ? 1 : 0);
 }
 
@@ -523,12 +524,18 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.bias = bias; p.y = y; p.stats = bn_sums;
     p.bn_x = (const bf16_t*)bn_x; p.bn_y = (const bf16_t*)bn_y; p.bn_saved = bn_saved; p.bn_red = bn_red;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
-    DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && conv_fast_ok(p, vec8, mt)),
+    const bool c3 = conv3x3_ok(p, vec8);
+    DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && (c3 || conv_fast_ok(p, vec8, mt))),
                     "conv_forward: the fused BatchNorm-backward reduction needs the fast kernel and a plain bf16 output (check danet_conv_forward_kernel)");
     const int nt = danet_conv_nt(p.Cout_g);
     DANET_CHECK_ARG(!bn_sums || (!bias && !relu && !out_fp32), "conv_forward: fused BN statistics need a plain bf16 output");
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
+    if (c3) {
+        if (conv3x3_launch(&p, 1, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no 3x3 tiling");
+        DANET_CHECK_LAUNCH("conv3x3_tile_kernel");
+        return DANET_OK;
+    }
     if (conv_fast_ok(p, vec8, mt)) {
         if (conv_fast_launch(p, mt, nt, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no fast kernel for tiles %dx%d", mt, nt);
         DANET_CHECK_LAUNCH("conv_fast_kernel");
@@ -551,9 +558,21 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
 struct ConvJob { const void* x; const void* wp; void* y; float* bn_sums; const void* bn_x; const void* bn_y; const float* bn_saved; float* bn_red;
                  int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; };
 
-static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, int* nt_out) {
+// *all3 = every problem runs on the LDS-tile 3x3 kernel (then nt / mts are not needed)
+static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, int* nt_out, bool* all3) {
     if (!jobs || n < 1 || n > 4) return -1;
     int nt = -1;
+    *all3 = true;
+    for (int i = 0; i < n; ++i) {
+        const ConvJob& j = jobs[i];
+        bool vec8;
+        ps[i] = ConvP{};
+        if (!fill_conv_params(ps[i], vec8, j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups, j.transposed, 0, 0)) return -1;
+        if (!conv3x3_ok(ps[i], vec8)) { *all3 = false; break; }
+        ps[i].x = (const bf16_t*)j.x; ps[i].w = (const bf16_t*)j.wp; ps[i].bias = nullptr; ps[i].y = j.y; ps[i].stats = j.bn_sums;
+        ps[i].bn_x = (const bf16_t*)j.bn_x; ps[i].bn_y = (const bf16_t*)j.bn_y; ps[i].bn_saved = j.bn_saved; ps[i].bn_red = j.bn_red;
+    }
+    if (*all3) { *nt_out = 0; return 0; }
     for (int i = 0; i < n; ++i) {
         const ConvJob& j = jobs[i];
         bool vec8;
@@ -572,18 +591,24 @@ static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, i
 
 extern "C" int danet_conv_forward_multi_ok(const void* jobs, int n)
 {
-    ConvP ps[4]; int mts[4], nt;
-    return conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt) == 0 ? 1 : 0;
+    ConvP ps[4]; int mts[4], nt; bool all3;
+    if (conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt, &all3) != 0) return 0;
+    return all3 ? 2 : 1;                  // 2: one conv3x3_tile_kernel launch, 1: one conv_fast_multi_kernel launch
 }
 
 extern "C" int danet_conv_forward_multi(const void* jobs, int n, void* stream)
 {
     DANET_ENTER();
-    ConvP ps[4]; int mts[4], nt;
-    DANET_CHECK_ARG(conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt) == 0, "conv_forward_multi: unsupported set (see danet_conv_forward_multi_ok)");
+    ConvP ps[4]; int mts[4], nt; bool all3;
+    DANET_CHECK_ARG(conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt, &all3) == 0, "conv_forward_multi: unsupported set (see danet_conv_forward_multi_ok)");
     for (int i = 0; i < n; ++i) {
         DANET_CHECK_ARG(ps[i].x && ps[i].w && ps[i].y, "conv_forward_multi: job %d: null pointer", i);
         DANET_CHECK_ARG(!ps[i].bn_red || (ps[i].bn_x && ps[i].bn_saved), "conv_forward_multi: job %d: incomplete BatchNorm-backward arguments", i);
+    }
+    if (all3) {
+        DANET_CHECK_ARG(conv3x3_launch(ps, n, stream) == 0, "conv_forward_multi: no 3x3 tiling");
+        DANET_CHECK_LAUNCH("conv3x3_tile_kernel");
+        return DANET_OK;
     }
     DANET_CHECK_ARG(conv_fast_launch_multi(ps, mts, n, nt, stream) == 0, "conv_forward_multi: no kernel for %d tiles per block", nt);
     DANET_CHECK_LAUNCH("conv_fast_multi_kernel");

@@ -141,12 +141,11 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      mode 0: forward operand      [G][rows_pad][Kp], rows = cout, k = (r*S+s)*Cin_g + cin
  *      mode 1: data-gradient operand [G][rows_pad][Kp], rows = cin,  k = (r*S+s)*Cout_g + cout
  *      (danet_conv_packed_elems gives the element count; rows_pad = roundup(rows, 16*danet_conv_nt(rows)))
- *      chunk > 0 (danet_conv3x3_forward only): K ordered (channel chunk, tap, channel in chunk), every
- *      chunk zero-padded to a multiple of 32; chunk = 0 everywhere else.
- *  danet_conv3x3_*          3x3/stride-1/pad-1 forward and data gradient with both MFMA operands staged in
- *      LDS (halo tile + weight slices).  danet_conv3x3_ok says whether a layer qualifies,
- *      danet_conv3x3_chunk the chunk its weights must be packed with (mode 0 forward; mode 1 + flip = 1
- *      for the data gradient, where x = dY and Cin/Cout are swapped).
+ *      chunk must be 0 (reserved).
+ *  3x3 / stride-1 / pad-1 layers with groups = 1 and Cin % 16 == 0 (forward and data gradient) run on a persistent
+ *      LDS-tile kernel (csrc/conv3x3.hip: halo tile staged once in LDS, taps = LDS address offsets, K-split across
+ *      the waves of a workgroup for small-M layers); danet_conv_forward / danet_conv_forward_multi pick it by
+ *      themselves, danet_conv_forward_kernel reports it (last digit 2).
  *  danet_conv_forward       y = conv(x, wp) (+bias[Cout])(ReLU); y is bf16 or fp32 NHWC.
  *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
@@ -176,20 +175,19 @@ size_t danet_conv_pack_job_bytes(void);
 long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
                               int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
 int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream);
-int danet_conv3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
-int danet_conv3x3_chunk(int B, int H, int W, int Cin, int Cout);
-int danet_conv3x3_kernel_id(int B, int H, int W, int Cin, int Cout);                  /* MT*10 + NT */
-int danet_conv3x3_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int Cout,
-                          int flip, float* bn_sums, void* stream);
 /* Up to 4 independent convolutions (forward or data gradient) in one launch -- HRNet branches in lockstep.
  * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red;
  *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; }  (no bias / ReLU / fp32 output);
  * all problems must run on the fast kernel with the same danet_conv_nt(Cout/groups): query danet_conv_forward_multi_ok. */
-int danet_conv_forward_multi_ok(const void* jobs, int n);
+int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
+/* Run-time knobs of the LDS-tile 3x3 kernel (A-B timing, tests): enable 0/1 (-1 keeps); force_mt/force_kw = register
+ * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps). Returns the previous enable. */
+int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);
 int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
                               int stride, int pad, int dil, int groups, int transposed, int out_fp32);
-                              /* MT*1000 + NT*100 + vec8*10 + fast: conv_fast_kernel<MT,NT> or conv_igemm_kernel<MT,NT,vec8> */
+                              /* MT*1000 + NT*100 + vec8*10 + fast: conv_fast_kernel<MT,NT> or conv_igemm_kernel<MT,NT,vec8>;
+                                 MT*1000 + NT*100 + KW*10 + 2: conv3x3_tile_kernel with that register tiling */
 int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,

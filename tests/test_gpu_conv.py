@@ -181,25 +181,84 @@ def test_deferred_multi_problem_wgrad_matches_immediate():
         assert (g - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-6, cfg
 
 
-@pytest.mark.parametrize('shape', [(48, 48, 64), (96, 96, 32), (192, 48, 16), (384, 384, 8), (64, 64, 17)])
-def test_lds_staged_3x3_kernel_matches_default(shape):
-    """conv3x3_lds.hip (both MFMA operands staged through LDS; kept behind DANET_LDS3X3 because it is not faster,
-    DESIGN.md 3.1) computes the same forward and data gradient as the default kernel."""
+# (Cin, Cout, H, W, B): HRNet branch shapes at 256^2 and 224^2 inputs (row widths 64..8 and 56..7), the regressor
+# trunks (small images: several per tile), a non-square image, channel counts with 1..4 output tiles per block
+C3_SHAPES = [(48, 48, 64, 64, 4), (96, 96, 32, 32, 4), (192, 192, 16, 16, 8), (384, 384, 8, 8, 8),
+             (48, 48, 56, 56, 2), (96, 96, 28, 28, 3), (192, 192, 14, 14, 4), (384, 384, 7, 7, 6),
+             (64, 64, 16, 16, 24), (128, 128, 8, 8, 24), (256, 256, 4, 4, 48), (512, 512, 2, 2, 32),
+             (64, 64, 64, 64, 2), (48, 32, 20, 12, 3), (16, 16, 8, 8, 2), (48, 24, 64, 64, 2), (80, 48, 16, 16, 5)]
+
+
+@pytest.mark.parametrize('shape', C3_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('tiling', [(0, 0), (8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (4, 4)], ids=lambda t: 'mt%d_kw%d' % t)
+def test_lds_tile_3x3_kernel_vs_torch_fp32(shape, tiling):
+    """conv3x3.hip (persistent LDS-tile kernel) against F.conv2d in fp32 on the bf16-rounded operands: forward with the
+    fused BatchNorm statistics, data gradient, for the planner's tiling and every forced register tiling / K split
+    the shape admits (a tiling that cannot run falls back to the gather kernel, which must agree as well)."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    Cin, Cout, H, W, B = shape
+    g = torch.Generator().manual_seed(Cin * 7 + H)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float().cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)).bfloat16().float().cuda()
+    gy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float().cuda()
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, 1, 1)
+    yr.backward(gy)
+    L.danet_conv3x3_set(1, tiling[0], tiling[1], 0)
+    try:
+        xt = x.clone().requires_grad_(True)
+        wt = w.clone().requires_grad_(True)
+        y = dconv.conv2d(xt, wt, None, 1, 1, want_stats=True)
+        sums = getattr(y, '_bn_sums', None)
+        y.backward(gy.bfloat16())
+        torch.cuda.synchronize()
+    finally:
+        L.danet_conv3x3_set(1, 0, 0, 0)
+
+    def close(a, r, rel, what):
+        scale = r.abs().max().item() + 1e-6
+        err = (a.float() - r).abs().max().item()
+        assert err <= rel * scale, '%s: max err %g vs scale %g (%s, tiling %s)' % (what, err, scale, shape, tiling)
+    close(y, yr, 1e-2, 'forward')
+    close(xt.grad, xr.grad, 1e-2, 'dgrad')
+    close(wt.grad, _wgrad_ref(x, w, gy), 3e-3, 'wgrad')
+    if Cout % 8 == 0:
+        assert sums is not None
+        s = sums.view(32, 2, Cout).sum(0)
+        yb = y.float()
+        close(s[0], yb.sum(dim=(0, 2, 3)), 2e-3, 'statistics: sum')
+        close(s[1], (yb * yb).sum(dim=(0, 2, 3)), 1e-3, 'statistics: sum of squares')
+
+
+def _wgrad_ref(x, w, gy):
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, 1, 1).backward(gy)
+    return wr.grad
+
+
+def test_lds_tile_3x3_bias_fp32_relu_and_lockstep_launch():
+    """Head-style epilogue (bias, fp32 output) on the LDS-tile kernel, and the four HRNet branches in ONE launch
+    (forward and data gradient) against their separate launches."""
     from danet_densepose2smpl_amd import conv as dconv
-    Cin, Cout, H = shape
-    torch.manual_seed(0)
-    x = torch.randn(2, Cin, H, H, device='cuda')
-    w = torch.nn.Parameter(torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.05)
-    gy = torch.randn(2, Cout, H, H, device='cuda').bfloat16()
-    res = []
-    for lds in (False, True):
-        dconv.USE_LDS3X3 = lds
-        try:
-            xi = x.clone().requires_grad_(True)
-            y = dconv.conv2d(xi, w, None, 1, 1)
-            y.backward(gy)
-            res.append((y.float(), xi.grad.float()))
-        finally:
-            dconv.USE_LDS3X3 = False
-    for a, b in zip(res[0], res[1]):
-        assert (a - b).abs().max().item() <= 1e-2 * a.abs().max().item()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 48, 64, 64, generator=g).bfloat16().float().cuda()
+    w = (torch.randn(25, 48, 3, 3, generator=g) / 20).bfloat16().float().cuda()
+    b = torch.randn(25, generator=g).cuda()
+    y = dconv.conv2d(x, w, b, 1, 1, out_fp32=True)
+    yr = F.conv2d(x, w, b, 1, 1)
+    assert y.dtype == torch.float32 and (y - yr).abs().max().item() <= 2e-3 * yr.abs().max().item()
+
+    chans, sizes = (48, 96, 192, 384), (64, 32, 16, 8)
+    convs = [dconv.Conv2d(c, c, 3, 1, 1, bias=False).cuda() for c in chans]
+    xs = [torch.randn(4, c, s, s, device='cuda').bfloat16().float() for c, s in zip(chans, sizes)]
+    gys = [torch.randn(4, c, s, s, device='cuda').bfloat16() for c, s in zip(chans, sizes)]
+    xa = [t.clone().requires_grad_(True) for t in xs]
+    ys = dconv.multi_conv(convs, xa)
+    torch.autograd.backward(ys, gys)
+    for c, x0, xi, yi, gyi in zip(convs, xs, xa, ys, gys):
+        xr = x0.clone().requires_grad_(True)
+        yr = F.conv2d(xr, c.weight.detach().bfloat16().float(), None, 1, 1)
+        yr.backward(gyi.float())
+        assert (yi.float() - yr).abs().max().item() <= 1e-2 * yr.abs().max().item()
+        assert (xi.grad.float() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()

@@ -50,18 +50,6 @@ def main():
         res['fwd_us'] = t * 1e6; res['fwd_TF'] = flops / t / 1e12
         t = timeit(lambda: conv._conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, k, k, s, p, 1, g, True, False, False))
         res['dgrad_us'] = t * 1e6; res['dgrad_TF'] = flops / t / 1e12
-        if L.danet_conv3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
-            y_old = conv._conv_fwd_raw(x, wp0, None, B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g, False, False, False)
-            y_new = conv._conv3x3_raw(x, w, 1, B, H, W, Cin, Cout, False)
-            res['lds_fwd_maxdiff'] = float((y_new.float() - y_old.float()).abs().max() / (y_old.float().abs().max() + 1e-9))
-            t = timeit(lambda: conv._conv3x3_raw(x, w, 1, B, H, W, Cin, Cout, False))
-            res['lds_fwd_us'] = t * 1e6; res['lds_fwd_TF'] = flops / t / 1e12
-            g_old = conv._conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, k, k, s, p, 1, g, True, False, False)
-            g_new = conv._conv3x3_raw(gy, w, 1, B, H, W, Cout, Cin, True)
-            res['lds_dgrad_maxdiff'] = float((g_new.float() - g_old.float()).abs().max() / (g_old.float().abs().max() + 1e-9))
-            t = timeit(lambda: conv._conv3x3_raw(gy, w, 1, B, H, W, Cout, Cin, True))
-            res['lds_dgrad_us'] = t * 1e6; res['lds_dgrad_TF'] = flops / t / 1e12
-            res['lds_plan'] = [L.danet_conv3x3_kernel_id(B, H, W, Cin, Cout), L.danet_conv3x3_chunk(B, H, W, Cin, Cout)]
         gw = torch.empty_like(w.data)
         nws = L.danet_conv_wgrad_ws_floats(Cout, Cin // g, k, k)
         ws = torch.empty(nws, device='cuda')
