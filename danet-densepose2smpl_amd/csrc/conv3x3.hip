@@ -47,6 +47,7 @@ struct C3Prob {
     int tile0, ntiles;        // this problem's range in the launch's tile list
     int x_bytes, y_bytes;
     int swz;                  // tile order keeps the N-blocks of a pixel tile on one XCD
+    int* dbg;                 // optional [blocks][8] phase timestamps of each workgroup's last tile (tools/c3_bench.py)
 };
 
 struct C3Launch { C3Prob p[C3_MAXP]; int n; int total; };
@@ -56,6 +57,14 @@ __device__ inline unsigned udiv24(unsigned n, unsigned d, float rcp) {      // n
     const int r = (int)(n - q * d);
     if (r < 0) --q; else if (r >= (int)d) ++q;
     return q;
+}
+
+// Workgroup barrier that orders LDS traffic only: global stores of the epilogue keep draining across it
+// (__syncthreads() would wait for them: its fence covers every address space).
+__device__ inline void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 template <int CTRL>
@@ -77,7 +86,7 @@ template <int NT>
 __device__ inline void flush_channel_sums(float (*s1)[4], float (*s2)[4], float* sc, float* __restrict__ dst, int Ctot,
                                           int n0, int t, int li, int lg, int wave, int rep)
 {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -86,17 +95,14 @@ __device__ inline void flush_channel_sums(float (*s1)[4], float (*s2)[4], float*
             if (li == 0) { sc[(wave * 2 + 0) * (NT * 16) + nt * 16 + lg * 4 + r] = a; sc[(wave * 2 + 1) * (NT * 16) + nt * 16 + lg * 4 + r] = b; }
             s1[nt][r] = 0.f; s2[nt][r] = 0.f;
         }
-    __syncthreads();
+    lds_barrier();
     if (t < 2 * NT * 16) {
         const int which = t / (NT * 16), c = t - which * (NT * 16);
         const float v = (sc[(0 * 2 + which) * (NT * 16) + c] + sc[(1 * 2 + which) * (NT * 16) + c]) +
                         (sc[(2 * 2 + which) * (NT * 16) + c] + sc[(3 * 2 + which) * (NT * 16) + c]);
         if (n0 + c < Ctot) atomicAdd(dst + ((size_t)(rep % BN_NCOPY) * 2 + which) * Ctot + n0 + c, v);
     }
-    __syncthreads();
-    // the scratch overlays the tile's first cells, among them zero-padding cells that staging never rewrites
-    if (t < 4 * 2 * NT * 16 / 4) reinterpret_cast<i32x4*>(sc)[t] = i32x4{0, 0, 0, 0};
-    __syncthreads();
+    lds_barrier();                          // (the scratch overlays tile cells: the next staging pass rewrites them, pad columns included)
 }
 
 template <int MT, int NT, int KW>
@@ -105,6 +111,7 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
     constexpr int PW = 4 / KW;
     constexpr int MO = MT / KW;                    // accumulator tiles a wave finishes (stores, statistics) after the K-split reduction
     constexpr int D = 3;                           // weight-fragment ring: k-steps in flight
+    constexpr int RB = 10;                         // staging: rows whose loads are in flight together
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -117,24 +124,25 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
     const int rowB = Wp * Sp * 16;                 // LDS bytes of one slab row
     const int nrows = NI * (TH + 2);
 
+    if (p.dbg && t == 0) p.dbg[bid * 8 + 0] = (int)clock64();
     // ---- once per problem: tap table, zeroed tile, per-lane fragment / staging addresses --------------------------
-    __syncthreads();                               // a previous problem's readers of this LDS are done
-    for (int j = t; j < p.nks; j += 256) {
+    lds_barrier();                                 // a previous problem's readers of this LDS are done
+    if (t < p.nks) {
+        const float rc_n = 1.0f / (float)p.nc16;
         i32x2 e;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            int h = 2 * j + half;
+            int h = 2 * t + half;
             if (h > 9 * p.nc16 - 1) h = 9 * p.nc16 - 1;          // zero-weight tail of the last k-step: any valid cell
-            const int tap = h / p.nc16, c16 = h - tap * p.nc16;
-            const int r = tap / 3, s = tap - 3 * r;
+            const int tap = (int)udiv24((unsigned)h, (unsigned)p.nc16, rc_n), c16 = h - tap * p.nc16;
+            const int r = (tap * 11) >> 5, s = tap - 3 * r;      // tap / 3 for tap < 9
             int off = ((r - 1) * Wp + (s - 1)) * Sp * 16;
             if (p.flip) off = -off;
             off += c16 * 32;
             if (half == 0) e.x = off; else e.y = off;
         }
-        sTab[j] = e;
+        sTab[t] = e;
     }
-    for (int o = t * 16; o < nrows * rowB; o += 4096) *reinterpret_cast<i32x4*>(sX + o) = i32x4{0, 0, 0, 0};
 
     const int thw = TH * W, npix = NI * thw;
     const int osz = p.out_fp32 ? 4 : 2;
@@ -164,23 +172,26 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
             st_l[sub] = ok ? ((1 + pix) * Sp + c) * 16 : -1;
         }
     }
+    // zero padding: the two pad columns of every slab row are (re)zeroed per tile -- staging never writes them, the
+    // K-split reduction and the statistics scratch overlay them
     int padaddr[PADN];
-    if constexpr (KW > 1) {
-        // the K-split reduction reuses the tile's LDS for fp32 partial sums: pad columns are re-zeroed per tile
+    {
         const int npad = nrows * 2 * Sp;
+        const float rc_2s = 1.0f / (float)(2 * Sp);
 #pragma unroll
         for (int i = 0; i < PADN; ++i) {
             const int q = i * 256 + t;
             int a = -1;
             if (q < npad) {
-                const int row = q / (2 * Sp), rem = q - row * (2 * Sp);
-                const int side = rem / Sp, c = rem - side * Sp;
+                const int row = (int)udiv24((unsigned)q, (unsigned)(2 * Sp), rc_2s), rem = q - row * (2 * Sp);
+                const int side = rem >= Sp ? 1 : 0, c = rem - side * Sp;
                 a = row * rowB + (side ? (Wp - 1) : 0) * Sp * 16 + c * 16;
             }
             padaddr[i] = a;
         }
     }
-    __syncthreads();                               // table and zeroed tile are in place before the first staging pass
+    lds_barrier();                                 // the tap table is in place
+    if (p.dbg && t == 0) p.dbg[bid * 8 + 1] = (int)clock64();
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
@@ -221,48 +232,9 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
             stat_nb = nb;
         }
 
-        // ---- stage the tile: NI slabs of TH+2 rows, interior columns only (pad columns stay zero) -----------------
-        if constexpr (KW > 1) {
-#pragma unroll
-            for (int i = 0; i < PADN; ++i)
-                if (padaddr[i] >= 0) *reinterpret_cast<i32x4*>(sX + padaddr[i]) = i32x4{0, 0, 0, 0};
-        }
-        for (int sl = 0; sl < NI; ++sl) {
-            const int gimg = ((img0 + sl) * H) * W * p.Cin * 2;            // byte offset of the image (x_bytes < 2^31)
-#pragma unroll 2
-            for (int rr = 0; rr < TH + 2; rr += 2) {
-                i32x4 v[2][NSUB];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int yy = y0 - 1 + rr + u;
-                    const bool rok = yy >= 0 && yy < H && rr + u < TH + 2;
-                    const int grow = gimg + yy * W * p.Cin * 2;
-#pragma unroll
-                    for (int sub = 0; sub < NSUB; ++sub)
-                        v[u][sub] = rok ? __builtin_amdgcn_raw_buffer_load_b128(xr, st_g[sub], grow, 0) : i32x4{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (rr + u < TH + 2) {
-                        unsigned char* const lrow = sX + (sl * (TH + 2) + rr + u) * rowB;
-#pragma unroll
-                        for (int sub = 0; sub < NSUB; ++sub)
-                            if (st_l[sub] >= 0) *reinterpret_cast<i32x4*>(lrow + st_l[sub]) = v[u][sub];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- k-loop: weights through a register ring, pixels from the LDS tile ------------------------------------
+        // the first weight fragments travel while the tile is staged
         const bf16_t* wblk = p.w + (size_t)(n0 / 16) * (size_t)nks * 512;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wblk), 0, NT * nks * 1024, 0x00020000);
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
         bf16x8 A[D][NT];
         auto load_a = [&](int j, bf16x8* a) {
             const int jc = min(j, nks - 1);
@@ -272,6 +244,44 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) load_a(jbeg + d, A[d]);
+
+        // ---- stage the tile: NI slabs of TH+2 rows, interior columns only (pad columns stay zero) -----------------
+#pragma unroll
+        for (int i = 0; i < PADN; ++i)
+            if (padaddr[i] >= 0) *reinterpret_cast<i32x4*>(sX + padaddr[i]) = i32x4{0, 0, 0, 0};
+        for (int sl = 0; sl < NI; ++sl) {
+            const int gimg = ((img0 + sl) * H) * W * p.Cin * 2;            // byte offset of the image (x_bytes < 2^31)
+            for (int r0 = 0; r0 < TH + 2; r0 += RB) {                      // RB rows per batch: every load in flight at once
+                i32x4 v[RB][NSUB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int yy = y0 - 1 + r0 + u;
+                    const bool rok = yy >= 0 && yy < H && r0 + u < TH + 2;
+                    const int grow = gimg + yy * W * p.Cin * 2;
+#pragma unroll
+                    for (int sub = 0; sub < NSUB; ++sub)
+                        v[u][sub] = rok ? __builtin_amdgcn_raw_buffer_load_b128(xr, st_g[sub], grow, 0) : i32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (r0 + u < TH + 2) {
+                        unsigned char* const lrow = sX + (sl * (TH + 2) + r0 + u) * rowB;
+#pragma unroll
+                        for (int sub = 0; sub < NSUB; ++sub)
+                            if (st_l[sub] >= 0) *reinterpret_cast<i32x4*>(lrow + st_l[sub]) = v[u][sub];
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        if (p.dbg && t == 0) p.dbg[bid * 8 + 2] = (int)clock64();
+
+        // ---- k-loop: weights through a register ring, pixels from the LDS tile ------------------------------------
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         i32x2 e = sTab[min(jbeg, nks - 1)];
         for (int j = jbeg; j < jend; j += D) {
 #pragma unroll
@@ -292,9 +302,10 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
             }
         }
 
+        if (p.dbg && t == 0) p.dbg[bid * 8 + 3] = (int)clock64();
         // ---- K-split: partial sums meet in LDS; wave kw finishes accumulator tiles [kw*MO, (kw+1)*MO) --------------
         if constexpr (KW > 1) {
-            __syncthreads();                                        // every wave is done reading the tile
+            lds_barrier();                                          // every wave is done reading the tile
             // slot of (source wave, foreign tile f): wave * (MT - MO) * NT + f * NT + nt, 1 KB each
             unsigned char* const myred = sX + (size_t)wave * ((MT - MO) * NT * 1024) + lane * 16;
 #pragma unroll
@@ -310,7 +321,7 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int q = 0; q < KW; ++q) {
                 if (q != kw) {                                      // contributions of wave (pw, q) to my tiles
@@ -329,6 +340,7 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
             }
         }
 
+        if (p.dbg && t == 0) p.dbg[bid * 8 + 4] = (int)clock64();
         // ---- epilogue on the wave's own tiles ----------------------------------------------------------------------
         const int tile_out = ((img0 * H + y0) * W) * p.Cout * osz;  // byte offset of the tile's first output pixel
 #pragma unroll
@@ -391,10 +403,12 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
                 }
             }
         }
-        __syncthreads();                                            // the tile's LDS may be overwritten
+        lds_barrier();                                              // the tile's LDS may be overwritten (stores keep draining)
+        if (p.dbg && t == 0) p.dbg[bid * 8 + 5] = (int)clock64();
     }
     if (acc_stats && stat_nb >= 0)
         flush_channel_sums<NT>(s1, s2, reinterpret_cast<float*>(sX), stat_dst, p.Cout, stat_nb * (16 * NT), t, li, lg, wave, bid);
+    if (p.dbg && t == 0) p.dbg[bid * 8 + 6] = (int)clock64();
 }
 
 // One persistent launch over up to 4 problems (HRNet branches in lockstep): the register tilings the lockstep
@@ -407,13 +421,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(C3Launch L)
         const C3Prob& p = L.p[i];
         switch (p.cfg) {
 #define C3_CASE(M_, N_, K_) case M_ * 100 + N_ * 10 + K_: c3_body<M_, N_, K_>(p, bid, nblk, c3_smem); break;
-            C3_CASE(8, 3, 1) C3_CASE(8, 3, 2) C3_CASE(8, 3, 4) C3_CASE(4, 3, 4)
+            C3_CASE(4, 3, 1) C3_CASE(4, 3, 2) C3_CASE(4, 3, 4)
 #undef C3_CASE
             default: break;
         }
     }
 }
-inline bool multi_has(int cfg) { return cfg == 831 || cfg == 832 || cfg == 834 || cfg == 434; }
+inline bool multi_has(int cfg) { return cfg == 431 || cfg == 432 || cfg == 434; }
 
 // One problem, one register tiling per kernel (each instance gets its own register allocation).
 template <int MT, int NT, int KW>
@@ -442,7 +456,9 @@ Forced g_force = [] {
 }();
 bool g_c3_on = getenv("DANET_NO_C3") == nullptr;                  // off: everything back on conv_fast.hip
 int g_c3_blocks = getenv("DANET_C3_BLOCKS") ? atoi(getenv("DANET_C3_BLOCKS")) : 512;
+int g_c3_want = getenv("DANET_C3_WANT") ? atoi(getenv("DANET_C3_WANT")) : 0;     // tiles per problem the planner aims for (0: 512 / problems)
 Forced forced_cfg() { return g_force; }
+int* g_dbg = nullptr;
 
 constexpr int LDS_TWO = 81920;        // two workgroups per CU
 constexpr int LDS_ONE = 160 * 1024;
@@ -468,7 +484,7 @@ int plan_one(const ConvP& p, C3Prob& q, int NT, int MT, int KW) {
     if (nks > TAB_BYTES / 8 || nks < KW * 2) return -1;
     if (W * S > NSUB * 256) return -1;
     const int nrows = NI * (TH + 2);
-    if (KW > 1 && nrows * 2 * Sp > PADN * 256) return -1;
+    if (nrows * 2 * Sp > PADN * 256) return -1;
     const long tile = (long)nrows * (W + 2) * Sp * 16;
     const long red = KW > 1 ? (long)4 * (MT - MT / KW) * NT * 1024 : 0;
     const long scr = 4 * 2 * NT * 16 * 4;
@@ -500,14 +516,17 @@ bool shape_ok(const ConvP& p, bool vec8) {
 // candidate with the most tiles.
 int plan(const ConvP& p, C3Prob& q, int nprob) {
     const int NT = danet_conv_nt(p.Cout);
-    static const int cand[6][2] = {{8, 1}, {8, 2}, {8, 4}, {4, 1}, {4, 2}, {4, 4}};
+    // measured on MI355X (tools/c3_bench.py, B = 32): the 64-pixel x 48-channel wave tile beats the 128-pixel one at
+    // these sizes (more, shorter workgroups hide the serial load -> compute -> store chain of a tile better)
+    static const int cand[6][2] = {{4, 1}, {4, 2}, {4, 4}, {8, 1}, {8, 2}, {8, 4}};
     const Forced f = forced_cfg();
-    const int want = (2 * 256 + nprob - 1) / nprob;
+    const int want = g_c3_want > 0 ? g_c3_want : (2 * 256 + nprob - 1) / nprob;
     int best = -1, best_tiles = -1, best_lds = -1;
     C3Prob tmp = q;
     for (int c = 0; c < 6; ++c) {
         const int MT = cand[c][0], KW = cand[c][1];
         if (MT == 8 && NT != 3) continue;
+        if (nprob > 1 && !multi_has(MT * 100 + NT * 10 + KW)) continue;      // tilings compiled into the multi-problem kernel
         if (f.mt && (MT != f.mt || KW != f.kw)) continue;
         C3Prob t = q;
         const int lds = plan_one(p, t, NT, MT, KW);
@@ -515,7 +534,7 @@ int plan(const ConvP& p, C3Prob& q, int nprob) {
         if (f.mt) { q = t; return lds; }
         const bool two = lds <= LDS_TWO;
         if (two && t.ntiles >= want) { q = t; return lds; }
-        // keep the best fallback: prefer two-per-CU tiles, then more tiles, then the earlier (larger) tiling
+        // keep the best fallback: prefer two-per-CU tiles, then more tiles, then the earlier tiling
         const int score = (two ? 1 << 24 : 0) + t.ntiles;
         if (score > best_tiles) { best_tiles = score; best = c; best_lds = lds; tmp = t; }
     }
@@ -541,8 +560,9 @@ int conv3x3_config(const ConvP& p, bool vec8, int nprob) {
     return plan(p, q, nprob) > 0 ? q.cfg : 0;
 }
 
-// Launches n (<= 4) problems, all of which passed conv3x3_ok.  0 on launch, -1 otherwise.
-int conv3x3_launch(const ConvP* ps, int n, void* stream) {
+// Launches n (<= 4) problems in one launch.  0 on launch, -1 when the set cannot run on this kernel (nothing is
+// launched then); dry = true only answers that question.
+int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
     if (n < 1 || n > C3_MAXP) return -1;
     C3Launch L{};
     L.n = n;
@@ -555,6 +575,7 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream) {
         q.B = p.B; q.H = p.OH; q.W = p.OW; q.Cin = p.Cin; q.Cout = p.Cout; q.Cout_pad = p.Cout_pad;
         q.flip = p.transposed; q.relu = p.relu; q.out_fp32 = p.out_fp32;
         q.x_bytes = (int)p.x_bytes; q.y_bytes = (int)p.y_bytes;
+        q.dbg = g_dbg;
         const int lds = plan(p, q, n);
         if (lds < 0) return -1;
         q.tile0 = tile0;
@@ -562,6 +583,11 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream) {
         if (lds > lds_max) lds_max = lds;
     }
     L.total = tile0;
+    if (n > 1) for (int i = 0; i < n; ++i) if (!multi_has(L.p[i].cfg)) return -1;
+    if (dry) {
+        if (n == 1) { const int c = L.p[0].cfg, mt = c / 100, nt = (c / 10) % 10, kw = c % 10; return ((mt == 4 && nt >= 1 && nt <= 4) || (mt == 8 && nt == 3)) && (kw == 1 || kw == 2 || kw == 4) ? 0 : -1; }
+        return 0;
+    }
     const int cap = lds_max <= LDS_TWO ? g_c3_blocks : 256;
     const int grid = L.total < cap ? L.total : cap;
     hipStream_t st = (hipStream_t)stream;
@@ -577,7 +603,6 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream) {
             default: return -1;
         }
     }
-    for (int i = 0; i < n; ++i) if (!multi_has(L.p[i].cfg)) return -1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ONE);
@@ -590,11 +615,16 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream) {
 }  // namespace danet_conv
 
 // enable: 0/1 (-1 keeps); force_mt, force_kw: register tiling for every problem (0, 0 = planner's choice; -1 keeps);
-// blocks: workgroup cap of a launch (<= 0 keeps).  Returns the previous `enable`.
-extern "C" int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks) {
+// blocks: workgroup cap of a launch (<= 0 keeps); want_tiles: tiles per problem the planner aims for (0 = 512 / problems
+// of the launch; < 0 keeps).  Returns the previous `enable`.
+extern "C" int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks, int want_tiles) {
     const int prev = g_c3_on ? 1 : 0;
     if (enable >= 0) g_c3_on = enable != 0;
     if (force_mt >= 0 && force_kw >= 0) g_force = Forced{force_mt, force_kw};
     if (blocks > 0) g_c3_blocks = blocks;
+    if (want_tiles >= 0) g_c3_want = want_tiles;
     return prev;
 }
+// Profiling hook: device buffer of blocks*8 ints that receives every workgroup's phase timestamps (NULL: off).
+extern "C" void danet_conv3x3_debug(int* dev_buf) { g_dbg = dev_buf; }
+

@@ -43,6 +43,6 @@ int conv_fast_launch_multi(const ConvP* ps, const int* mts, int n, int nt, void*
 // conv3x3.hip: 3x3 / stride-1 / pad-1 forward and data gradient on an LDS-resident halo tile (persistent workgroups)
 bool conv3x3_ok(const ConvP& p, bool vec8);
 int conv3x3_config(const ConvP& p, bool vec8, int nprob);      // MT*100 + NT*10 + KW, 0 = not supported
-int conv3x3_launch(const ConvP* ps, int n, void* stream);      // n <= 4 problems in one launch
+int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry = false);      // n <= 4 problems in one launch; dry: only check
 
 }  // namespace danet_conv

@@ -572,6 +572,7 @@ static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, i
         ps[i].x = (const bf16_t*)j.x; ps[i].w = (const bf16_t*)j.wp; ps[i].bias = nullptr; ps[i].y = j.y; ps[i].stats = j.bn_sums;
         ps[i].bn_x = (const bf16_t*)j.bn_x; ps[i].bn_y = (const bf16_t*)j.bn_y; ps[i].bn_saved = j.bn_saved; ps[i].bn_red = j.bn_red;
     }
+    if (*all3 && conv3x3_launch(ps, n, nullptr, true) != 0) *all3 = false;      // e.g. a tiling the multi-problem kernel lacks
     if (*all3) { *nt_out = 0; return 0; }
     for (int i = 0; i < n; ++i) {
         const ConvJob& j = jobs[i];

@@ -181,8 +181,11 @@ int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_
  * all problems must run on the fast kernel with the same danet_conv_nt(Cout/groups): query danet_conv_forward_multi_ok. */
 int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
 /* Run-time knobs of the LDS-tile 3x3 kernel (A-B timing, tests): enable 0/1 (-1 keeps); force_mt/force_kw = register
- * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps). Returns the previous enable. */
-int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks);
+ * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps); want_tiles = tiles per
+ * problem the planner aims for (0 = 512 / problems of the launch; < 0 keeps). Returns the previous enable. */
+int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks, int want_tiles);
+/* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
+void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);
 int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
                               int stride, int pad, int dil, int groups, int transposed, int out_fp32);

@@ -75,13 +75,13 @@ def test_new_ops_refuse_cpu_tensors_and_host_queries_work():
     with pytest.raises(RuntimeError, match='GPU only|no CPU'):
         dnn.multi_batch_norm([bn], [torch.zeros(1, 8, 4, 4)])
     # kernel-selection queries (no device needed)
-    assert lib.danet_conv_forward_kernel(32, 64, 64, 48, 64, 64, 48, 3, 3, 1, 1, 1, 1, 0, 0) == 8322      # 3x3/s1: LDS-tile kernel, MT 8, NT 3, K-split 2
+    assert lib.danet_conv_forward_kernel(32, 64, 64, 48, 64, 64, 48, 3, 3, 1, 1, 1, 1, 0, 0) == 4312      # 3x3/s1: LDS-tile kernel, MT 4, NT 3, no K split
     assert lib.danet_conv_forward_kernel(32, 8, 8, 384, 8, 8, 384, 3, 3, 1, 1, 1, 1, 0, 0) == 4342         # small-M: 64-pixel tiles, K split four ways
-    prev = lib.danet_conv3x3_set(0, -1, -1, 0)
+    prev = lib.danet_conv3x3_set(0, -1, -1, 0, -1)
     assert prev == 1
     assert lib.danet_conv_forward_kernel(32, 64, 64, 48, 64, 64, 48, 3, 3, 1, 1, 1, 1, 0, 0) == 4311      # <4,3>, vec8, fast kernel
     assert lib.danet_conv_forward_kernel(32, 8, 8, 384, 8, 8, 384, 3, 3, 1, 1, 1, 1, 0, 0) % 10 == 1
-    lib.danet_conv3x3_set(1, -1, -1, 0)
+    lib.danet_conv3x3_set(1, -1, -1, 0, -1)
     assert lib.danet_conv_forward_kernel(32, 64, 64, 48, 64, 64, 96, 3, 3, 2, 1, 1, 1, 0, 0) % 10 == 1     # strided 3x3 stays on the gather kernel
     assert lib.danet_conv_forward_kernel(2, 8, 8, 7, 8, 8, 8, 3, 3, 1, 1, 1, 1, 0, 0) % 10 == 0            # odd channels: general kernel
     jobs = (_lib.Wg3Job * 2)()

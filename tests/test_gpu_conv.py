@@ -205,7 +205,7 @@ def test_lds_tile_3x3_kernel_vs_torch_fp32(shape, tiling):
     xr = x.clone().requires_grad_(True)
     yr = F.conv2d(xr, w, None, 1, 1)
     yr.backward(gy)
-    L.danet_conv3x3_set(1, tiling[0], tiling[1], 0)
+    L.danet_conv3x3_set(1, tiling[0], tiling[1], 0, -1)
     try:
         xt = x.clone().requires_grad_(True)
         wt = w.clone().requires_grad_(True)
@@ -214,7 +214,7 @@ def test_lds_tile_3x3_kernel_vs_torch_fp32(shape, tiling):
         y.backward(gy.bfloat16())
         torch.cuda.synchronize()
     finally:
-        L.danet_conv3x3_set(1, 0, 0, 0)
+        L.danet_conv3x3_set(1, 0, 0, 0, -1)
 
     def close(a, r, rel, what):
         scale = r.abs().max().item() + 1e-6
