@@ -50,7 +50,7 @@ struct C3Prob {
     int* dbg;                 // optional [blocks][8] phase timestamps of each workgroup's last tile (tools/c3_bench.py)
 };
 
-struct C3Launch { C3Prob p[C3_MAXP]; int n; int total; };
+struct C3Launch { C3Prob p[C3_MAXP]; int n; int total; int rotate; };
 
 __device__ inline unsigned udiv24(unsigned n, unsigned d, float rcp) {      // n < 2^24
     unsigned q = (unsigned)((float)n * rcp);
@@ -417,7 +417,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(C3Launch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
     const int bid = blockIdx.x, nblk = gridDim.x;
-    for (int i = 0; i < L.n; ++i) {
+    // every workgroup visits the problems in its own rotation: at any moment some CUs stream a large-image problem's
+    // tiles (memory phase) while others run a small-image problem's long k-loops, and the two workgroups of a CU
+    // (ids 256 apart) are one problem apart
+    const int rot = L.rotate ? (bid + bid / 256) % L.n : 0;
+    for (int ii = 0; ii < L.n; ++ii) {
+        const int i = (ii + rot) % L.n;
         const C3Prob& p = L.p[i];
         switch (p.cfg) {
 #define C3_CASE(M_, N_, K_) case M_ * 100 + N_ * 10 + K_: c3_body<M_, N_, K_>(p, bid, nblk, c3_smem); break;
@@ -459,6 +464,7 @@ int g_c3_blocks = getenv("DANET_C3_BLOCKS") ? atoi(getenv("DANET_C3_BLOCKS")) : 
 int g_c3_want = getenv("DANET_C3_WANT") ? atoi(getenv("DANET_C3_WANT")) : 0;     // tiles per problem the planner aims for (0: 512 / problems)
 Forced forced_cfg() { return g_force; }
 int* g_dbg = nullptr;
+int g_c3_rotate = getenv("DANET_C3_ROTATE") ? atoi(getenv("DANET_C3_ROTATE")) : 1;
 
 constexpr int LDS_TWO = 81920;        // two workgroups per CU
 constexpr int LDS_ONE = 160 * 1024;
@@ -583,6 +589,7 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
         if (lds > lds_max) lds_max = lds;
     }
     L.total = tile0;
+    L.rotate = g_c3_rotate;
     if (n > 1) for (int i = 0; i < n; ++i) if (!multi_has(L.p[i].cfg)) return -1;
     if (dry) {
         if (n == 1) { const int c = L.p[0].cfg, mt = c / 100, nt = (c / 10) % 10, kw = c % 10; return ((mt == 4 && nt >= 1 && nt <= 4) || (mt == 8 && nt == 3)) && (kw == 1 || kw == 2 || kw == 4) ? 0 : -1; }

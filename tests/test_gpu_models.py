@@ -315,32 +315,40 @@ def test_graphed_step_matches_eager_step():
     assert max(r_graph) < 0.3 and sorted(r_graph)[len(r_graph) // 2] < 0.05, ('graph vs eager', sorted(r_graph)[-3:])
 
 
-def test_lockstep_branches_match_per_branch_execution():
-    """HRNet with the branches advanced in lockstep (multi-tensor BatchNorm launches) == branch-by-branch execution:
-    same outputs (bit-identical forward) and the same parameter gradients up to atomics order."""
+@pytest.mark.parametrize('lds_tile', [False, True], ids=['gather_kernel', 'lds_tile_kernel'])
+def test_lockstep_branches_match_per_branch_execution(lds_tile):
+    """HRNet with the branches advanced in lockstep (multi-problem conv / multi-tensor BatchNorm launches) == branch-by-
+    branch execution.  With the 3x3 layers pinned to the gather kernel both orders run the same arithmetic (outputs
+    agree to bf16 rounding of a few reduction orders); with the LDS-tile kernel enabled a lockstep set may take a
+    different kernel / K split than its members alone (the 2x2-pixel branch of this 64x64 test does not tile), which
+    this ill-conditioned tiny net amplifies -- looser bound."""
     _cfg(**{'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16})
-    from danet_densepose2smpl_amd import hrnet
+    from danet_densepose2smpl_amd import hrnet, _lib
     torch.manual_seed(0)
     net = hrnet.PoseHighResolutionNet(part_out_dim=7)
     formula_params(net)
     net = net.cuda().train()
     img = torch.randn(4, 3, 64, 64, device='cuda')
     res = []
-    for lock in (False, True):
-        hrnet.LOCKSTEP_BRANCHES = lock
-        try:
-            net.zero_grad(set_to_none=True)
-            out = net(img)
-            loss = sum((out[k].float() * torch.cos(torch.arange(out[k].numel(), device='cuda').view_as(out[k]) * 0.37)).sum() for k in KEYS[:5])
-            loss.backward()
-        finally:
-            hrnet.LOCKSTEP_BRANCHES = True
-        res.append(({k: out[k].detach().float().clone() for k in KEYS}, {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    prev = _lib.lib().danet_conv3x3_set(int(lds_tile), -1, -1, 0, -1)
+    try:
+        for lock in (False, True):
+            hrnet.LOCKSTEP_BRANCHES = lock
+            try:
+                net.zero_grad(set_to_none=True)
+                out = net(img)
+                loss = sum((out[k].float() * torch.cos(torch.arange(out[k].numel(), device='cuda').view_as(out[k]) * 0.37)).sum() for k in KEYS[:5])
+                loss.backward()
+            finally:
+                hrnet.LOCKSTEP_BRANCHES = True
+            res.append(({k: out[k].detach().float().clone() for k in KEYS}, {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        _lib.lib().danet_conv3x3_set(prev, -1, -1, 0, -1)
     (o0, g0), (o1, g1) = res
     for k in KEYS:
-        assert _rms_cos(o1[k], o0[k].cpu().numpy())[0] < 2e-2, k
+        assert _rms_cos(o1[k], o0[k].cpu().numpy())[0] < (6e-2 if lds_tile else 2e-2), k
     worst = max(((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-12)).item() for n in g0 if g0[n].dim() == 4)
-    assert worst < 0.2, worst
+    assert worst < (0.6 if lds_tile else 0.2), worst      # (mixed kernels: chaotic at this size, measured 0.40; the strict check is the gather run)
 
 
 def test_graphed_full_step_losses_match_eager():
