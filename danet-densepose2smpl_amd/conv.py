@@ -288,7 +288,7 @@ class Conv2dFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # the weight gradient is off the critical path (only the optimizer consumes it): with DEFER_WGRAD it is
             # only queued here and computed by flush_wgrads() in multi-problem launches after the backward pass
-            gw = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
+            gw = new_wgrad(weight, (Cout, Cin_g, R, S), x.device)
             _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
         if ctx.needs_input_grad[0]:
             wp1 = pack_weight(weight, groups, 1)
@@ -315,6 +315,16 @@ class Conv2dFunction(torch.autograd.Function):
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches
 _WQ = []                  # 3x3 / stride-1 problems (conv_wgrad3x3.hip)
 _WQG = []                 # everything else (conv_wgrad.hip)
+GRAD_STORE = None         # distributed.GradStore of the running trainer: weight gradients are written into its views
+
+
+def new_wgrad(weight, shape, device):
+    """The tensor a weight-gradient kernel writes: the parameter's slot of the flat gradient storage (zero-copy for
+    the all-reduce and the optimizer) when there is one and the parameter has no gradient yet, else a new tensor."""
+    st = GRAD_STORE
+    if st is not None and isinstance(weight, nn.Parameter) and weight.grad is None and st.has(weight) and tuple(shape) == tuple(weight.shape):
+        return st.view(weight)
+    return torch.empty(*shape, dtype=torch.float32, device=device)
 
 
 def _check_adopted(queue):
@@ -329,42 +339,49 @@ def _check_adopted(queue):
                                'set DANET_DEFER_WGRAD=0 for this model' % (tuple(weight.shape),))
 
 
-def flush_wgrads():
-    """Compute every queued weight gradient (call after backward, before anything reads parameter .grad)."""
+def flush_wgrads(bucket=None):
+    """Compute every queued weight gradient (call after backward, before anything reads parameter .grad).  With
+    `bucket` = a bucket index of GRAD_STORE only that bucket's parameters are processed (the trainer walks the buckets
+    in order and all-reduces each one while the next one's launches run)."""
     import ctypes
     L = _lib.lib()
-    if _WQ:
-        _check_adopted(_WQ)
-        jobs = (_lib.Wg3Job * len(_WQ))()
-        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups) in zip(jobs, _WQ):
+
+    def mine(q):
+        return bucket is None or GRAD_STORE is None or GRAD_STORE.bucket_of.get(id(q[1]), -1) == bucket
+    wq = [q for q in _WQ if mine(q)]
+    if wq:
+        _check_adopted(wq)
+        jobs = (_lib.Wg3Job * len(wq))()
+        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups) in zip(jobs, wq):
             j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
             j.B, j.H, j.W, j.Cin, j.Cout, j.groups = B, H, W, Cin, Cout, groups
-        n = len(_WQ)
+        n = len(wq)
         need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), n)
-        ws = torch.empty(need, dtype=torch.float32, device=_WQ[0][2].device)
-        tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * q[5] * q[6] * q[8] * (q[7] // q[9]) * 9 for q in _WQ),
+        ws = torch.empty(need, dtype=torch.float32, device=wq[0][2].device)
+        tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * q[5] * q[6] * q[8] * (q[7] // q[9]) * 9 for q in wq),
                              ('wgrad-multi', n)) if PROFILER is not None else None
         check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
         if tok is not None:
             PROFILER.end(tok)
-        _WQ.clear()
-    if _WQG:
-        _check_adopted(_WQG)
-        jobs = (_lib.WgJob * len(_WQG))()
-        for j, (gptr, weight, x, gy, dims) in zip(jobs, _WQG):
+        _WQ[:] = [q for q in _WQ if not mine(q)]
+    wqg = [q for q in _WQG if mine(q)]
+    if wqg:
+        _check_adopted(wqg)
+        jobs = (_lib.WgJob * len(wqg))()
+        for j, (gptr, weight, x, gy, dims) in zip(jobs, wqg):
             j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
             (j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups) = dims
-        n = len(_WQG)
+        n = len(wqg)
         need = L.danet_conv_wgrad_multi_ws_floats(ctypes.addressof(jobs), n)
         ws = ARENA.alloc(need)
         if ws is None:
-            ws = torch.zeros(need, dtype=torch.float32, device=_WQG[0][2].device)
-        tok = PROFILER.begin('conv_wgrad_multi', sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in (q[4] for q in _WQG)),
+            ws = torch.zeros(need, dtype=torch.float32, device=wqg[0][2].device)
+        tok = PROFILER.begin('conv_wgrad_multi', sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in (q[4] for q in wqg)),
                              ('wgrad-multi', n)) if PROFILER is not None else None
         check(L.danet_conv_wgrad_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad_multi')
         if tok is not None:
             PROFILER.end(tok)
-        _WQG.clear()
+        _WQG[:] = [q for q in _WQG if not mine(q)]
 
 
 def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight=None):
@@ -534,7 +551,7 @@ class MultiConvFunction(torch.autograd.Function):
         for i in range(n):                      # weight gradients first: queued (deferred) or launched per layer
             if ctx.needs_input_grad[1 + n + i]:
                 (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
-                gws[i] = torch.empty(Cout, Cin // groups, R, S, dtype=torch.float32, device=xs[i].device)
+                gws[i] = new_wgrad(ws[i], (Cout, Cin // groups, R, S), xs[i].device)
                 _wgrad_into(gws[i], xs[i], gys[i], B, H, W, Cin, OH, OW, Cout, Cin // groups, R, S, stride, pad, dil, groups, ws[i])
         gxs = [None] * n
         need = [i for i in range(n) if ctx.needs_input_grad[1 + i]]

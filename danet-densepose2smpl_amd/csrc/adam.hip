@@ -14,7 +14,7 @@ struct AdamChunk { float* p; const float* g; long off; int n; int pad; };
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ lr_p, const float* __restrict__ step_p,
-                                                   float beta1, float beta2, float eps)
+                                                   float beta1, float beta2, float eps, float gscale)
 {
     const AdamChunk c = table[blockIdx.x];
     if (!c.g) return;                                              // parameter without a gradient this step
@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__
     float* __restrict__ vp = v + c.off;
     const int n4 = c.n >> 2;
     for (int i = threadIdx.x; i < n4; i += 256) {
-        const float4 g = reinterpret_cast<const float4*>(c.g)[i];
+        float4 g = reinterpret_cast<const float4*>(c.g)[i];
+        g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
         float4 p = reinterpret_cast<float4*>(c.p)[i];
         float4 mm = reinterpret_cast<float4*>(mp)[i];
         float4 vv = reinterpret_cast<float4*>(vp)[i];
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__
         reinterpret_cast<float4*>(vp)[i] = vv;
     }
     for (int i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
-        const float g = c.g[i];
+        const float g = c.g[i] * gscale;
         const float mm = beta1 * mp[i] + (1.f - beta1) * g, vv = beta2 * vp[i] + (1.f - beta2) * g * g;
         mp[i] = mm; vp[i] = vv;
         c.p[i] -= step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
@@ -51,13 +52,14 @@ extern "C" size_t danet_adam_chunk_bytes(void) { return sizeof(AdamChunk); }
 
 // table: nchunks entries { float* p; const float* g (NULL = skip); int64 off; int32 n; int32 pad } on the device; p, g and
 // the moment buffers m, v (+ off) must be 16-byte aligned for every chunk; lr and step (the 1-based step count, as a
-// float) live on the device.
+// float) live on the device.  grad_scale multiplies every gradient (1 / world size turns all-reduced sums into the
+// average without a pass of its own).
 extern "C" int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
-                               float beta1, float beta2, float eps, void* stream)
+                               float beta1, float beta2, float eps, float grad_scale, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(table && nchunks > 0 && m && v && lr && step, "adam_step: bad arguments");
-    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, beta1, beta2, eps, grad_scale);
     DANET_CHECK_LAUNCH("adam_kernel");
     return DANET_OK;
 }

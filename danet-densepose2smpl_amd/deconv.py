@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import ptr, check, stream
-from .conv import nhwc_bf16, pack_weight, _conv_fwd_raw
+from .conv import nhwc_bf16, pack_weight, _conv_fwd_raw, new_wgrad
 
 
 class ConvTranspose2dFunction(torch.autograd.Function):
@@ -45,7 +45,7 @@ class ConvTranspose2dFunction(torch.autograd.Function):
             wp0 = pack_weight(weight, 1, 0)
             gx = _conv_fwd_raw(gy, wp0, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, 1, 1, False, False, False)
         if ctx.needs_input_grad[1]:
-            gw = torch.empty(Cin, Cout, R, S, dtype=torch.float32, device=x.device)
+            gw = new_wgrad(weight, (Cin, Cout, R, S), x.device)
             nws = L.danet_conv_wgrad_ws_floats(Cin, Cout, R, S)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
             check(L.danet_conv_wgrad(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,

@@ -2,9 +2,13 @@
 eps=1e-8) -- the reference's optimizer, /root/reference/train/trainer.py:42-44 -- without weight decay / amsgrad.
 
 The moments live in two flat fp32 buffers; a device table of <= 32768-element chunks {param, grad, moment offset, n}
-is rebuilt (host-side, then one pinned H2D copy) only when a gradient tensor's address changed -- every step in
-eager mode, never under hipGraph replay.  `param_groups[0]['lr']` is a device tensor, so a trainer can decay the
-rate between replays.  GPU only."""
+drives the kernel.  With a `grad_store` (distributed.GradStore: every gradient is a view of one flat buffer) the
+table is written once and never changes -- parameters without a gradient in a step read their zeroed slot, which
+leaves parameter and moments of a never-used parameter untouched exactly like torch.optim.Adam's skip (a parameter
+that only sometimes receives gradients gets its moments decayed in the idle steps, torch would freeze them).
+Without a store the table is rebuilt (host side, double-buffered pinned copy) whenever a gradient tensor's address
+changed.  `param_groups[0]['lr']` is a device tensor, so a trainer can decay the rate between hipGraph replays.
+GPU only."""
 import ctypes
 
 import numpy as np
@@ -17,7 +21,7 @@ CHUNK = 32768
 
 
 class FusedAdam(object):
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_store=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params or not self.params[0].is_cuda:
             raise RuntimeError('FusedAdam runs on the GPU only')
@@ -44,17 +48,33 @@ class FusedAdam(object):
                 rows.append((i, c0, min(CHUNK, p.numel() - c0), o + c0))
         self._rows = rows
         self.nchunks = len(rows)
-        self._host = torch.empty(self.nchunks * cb, dtype=torch.uint8).pin_memory()
+        # two pinned host tables, used alternately: the asynchronous H2D copy of step N may still be reading one while
+        # the host fills the other for step N+1 (an event guards the reuse two steps later)
+        self._hosts = [torch.empty(self.nchunks * cb, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._events = [None, None]
+        self._turn = 0
         self._table = torch.empty(self.nchunks * cb, dtype=torch.uint8, device=dev)
-        self._np = self._host.numpy().view(self._dtype)
         pidx = np.array([r[0] for r in rows], dtype=np.int64)
         self._pidx = pidx
         self._c0b = np.array([r[1] for r in rows], dtype=np.uint64) * 4
-        self._np['p'] = np.array([self.params[i].data_ptr() for i in pidx], dtype=np.uint64) + self._c0b
-        self._np['off'] = np.array([r[3] for r in rows], dtype=np.int64)
-        self._np['n'] = np.array([r[2] for r in rows], dtype=np.int32)
-        self._np['pad'] = 0
+        for h in self._hosts:
+            a = h.numpy().view(self._dtype)
+            a['p'] = np.array([self.params[i].data_ptr() for i in pidx], dtype=np.uint64) + self._c0b
+            a['off'] = np.array([r[3] for r in rows], dtype=np.int64)
+            a['n'] = np.array([r[2] for r in rows], dtype=np.int32)
+            a['pad'] = 0
+            a['g'] = 0
         self._gptrs = None
+        self.grad_store = grad_store
+        self.grad_scale = 1.0 if grad_store is None else float(grad_store.grad_scale)
+        if grad_store is not None:
+            for p in self.params:
+                if not grad_store.has(p):
+                    raise ValueError('FusedAdam: a parameter is missing from the gradient store')
+            g = np.array([grad_store.grad_ptr(p) for p in self.params], dtype=np.uint64)
+            a = self._hosts[0].numpy().view(self._dtype)
+            a['g'] = g[pidx] + self._c0b
+            self._table.copy_(self._hosts[0])                 # synchronous, once
 
     def state_dict(self):
         """torch.optim.Adam's layout (per-parameter step / exp_avg / exp_avg_sq + one param group), so the checkpoints of
@@ -94,15 +114,24 @@ class FusedAdam(object):
                 p.grad.zero_()
 
     def _refresh_table(self):
+        if self.grad_store is not None:
+            return                                            # gradients live in the store: the table never changes
         g = np.fromiter((0 if p.grad is None else p.grad.data_ptr() for p in self.params), dtype=np.uint64, count=len(self.params))
         if self._gptrs is not None and np.array_equal(g, self._gptrs):
             return
         for p in self.params:
             if p.grad is not None and (p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.data_ptr() % 16):
                 raise ValueError('FusedAdam: gradients must be contiguous, 16-byte aligned fp32 tensors')
+        k = self._turn
+        self._turn ^= 1
+        if self._events[k] is not None:
+            self._events[k].synchronize()                     # the copy that last read this host table has finished
         gp = g[self._pidx]
-        self._np['g'] = np.where(gp != 0, gp + self._c0b, 0).astype(np.uint64)
-        self._table.copy_(self._host, non_blocking=True)
+        self._hosts[k].numpy().view(self._dtype)['g'] = np.where(gp != 0, gp + self._c0b, 0).astype(np.uint64)
+        self._table.copy_(self._hosts[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self._table.device))
+        self._events[k] = ev
         self._gptrs = g
 
     @torch.no_grad()
@@ -111,8 +140,8 @@ class FusedAdam(object):
         self.step_t.add_(1.0)
         check(_lib.lib().danet_adam_step(ptr(self._table), self.nchunks, ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                          ptr(self.param_groups[0]['lr']), ptr(self.step_t),
-                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), stream()), 'danet_adam_step')
+                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale), stream()), 'danet_adam_step')
         # the kernel wrote the parameters through raw pointers: bump their version counters like an in-place op would
         # (the conv weight-pack cache and autograd's saved-tensor checks key on them)
-        upd = [p for p in self.params if p.grad is not None]
+        upd = self.params if self.grad_store is not None else [p for p in self.params if p.grad is not None]
         torch._C._autograd._unsafe_set_version_counter(upd, [p._version + 1 for p in upd])

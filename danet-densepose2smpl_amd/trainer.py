@@ -15,7 +15,7 @@ import torch
 from . import ops
 from .config import cfg
 from .danet import DaNet
-from .distributed import GradReducer
+from .distributed import GradStore
 from .nn import BatchNorm2d, bump_batch_counters
 from . import conv as _conv
 from .geometry import perspective_projection, label_prologue
@@ -68,22 +68,32 @@ def synthetic_in_dict(model, B, device, seed=1234, img_size=None, with_dp=False)
 
 
 class Trainer(object):
-    """Single-process-per-GPU trainer; with world_size > 1 gradients are averaged by GradReducer
-    (bucketed RCCL all-reduce overlapped with backward)."""
+    """Single-process-per-GPU trainer.  Gradients live in one flat store (distributed.GradStore); with world_size > 1
+    its buckets are all-reduced (RCCL) while the remaining weight gradients of the step are still being computed."""
 
-    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None):
+    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None, bucket_mb=32.0):
         self.options = options or default_options()
         self.device = device or torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.model = (model or DaNet(self.options, None, pretrained=False, smpl_model=smpl_model)).to(self.device)
         self.smpl = self.model.iuv2smpl.smpl
         on_gpu = self.device.type == 'cuda'
         lr0 = lr or cfg.SOLVER.BASE_LR
+        if distributed is None:
+            distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1
+        self.distributed = bool(distributed)
         # a tensor learning rate keeps the manual step decay (trainer.py:120-128) effective under hipGraph replay
         params = [p for p in self.model.parameters() if p.requires_grad]
+        self.params = params
+        self.store = None
         if on_gpu and USE_FUSED_ADAM:
             from .optim import FusedAdam
-            self.optimizer = FusedAdam(params, lr=lr0)            # one HIP launch per step (csrc/adam.hip)
+            self.store = GradStore(params, bucket_mb=bucket_mb, device=self.device,
+                                   world=torch.distributed.get_world_size() if self.distributed else 1)
+            self.optimizer = FusedAdam(params, lr=lr0, grad_store=self.store)      # one HIP launch per step (csrc/adam.hip)
         else:
+            if self.distributed:
+                raise RuntimeError('data-parallel training needs the GPU path (FusedAdam + GradStore)')
             self.optimizer = torch.optim.Adam(params=params, lr=torch.tensor(lr0, device=self.device) if on_gpu else lr0,
                                               weight_decay=0, **({'capturable': True, 'fused': True} if on_gpu else {}))
         self.step_count = 0
@@ -96,13 +106,13 @@ class Trainer(object):
             _conv.ARENA.enable(self.device)
         self._graph = None
         self._static = None
-        self.reducer = None
-        if distributed is None:
-            distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1
-        if distributed:
-            self.reducer = GradReducer(self.model, device=self.device)
-            self.reducer.broadcast_parameters()
+        self._reduce_in_graph = True
+        if self.distributed:
+            self.store.broadcast_parameters(self.model)
+
+    @property
+    def reducer(self):          # (name kept for callers of the first version)
+        return self.store if self.distributed else None
 
     @torch.no_grad()
     def prepare_batch(self, input_batch, opt_pose=None, opt_betas=None, img_res=None, focal_length=5000.):
@@ -175,68 +185,14 @@ class Trainer(object):
             yield
         cur.wait_stream(self.stream)
 
-    def train_step(self, in_dict):
-        self.model.train()
-        self._decay_lr()
-        with self._on_stream():
-            self._begin_step()
-            BatchNorm2d.count_batches = False
-            try:
-                out = self.model(in_dict)
-            finally:
-                BatchNorm2d.count_batches = True
-            bump_batch_counters(self.model)
-            losses = out['losses']
-            loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
-            self.optimizer.zero_grad(set_to_none=True)
-            if self.reducer is not None:
-                self.reducer.prepare()
-            # without gradient hooks (single process) the 3x3 weight gradients are queued and computed in a few
-            # multi-problem launches after the backward pass
-            _conv.DEFER_WGRAD = self.reducer is None and DEFER_WGRAD
-            try:
-                loss_total.backward()
-            finally:
-                _conv.DEFER_WGRAD = False
-            _conv.flush_wgrads()
-            if self.reducer is not None:
-                self.reducer.finish()
-            self.optimizer.step()
-        self.step_count += 1
-        return out, losses
-
-    # ------------------------------------------------------------------------------------------
-    # hipGraph execution: the ~4k kernel launches of one step are captured once and replayed, which
-    # removes the host-side launch cost (the step is launch-bound in eager mode).
-    def capture(self, in_dict, warmup=2):
-        """Capture forward + backward (+ Adam when single-process) for batches shaped like `in_dict`.
-        With a GradReducer the gradient all-reduce and the optimizer run after the graph."""
-        from . import conv
-        if self.device.type != 'cuda':
-            raise RuntimeError('hipGraph capture needs a GPU')
-        self.model.train()
-        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in in_dict.items()}
-        fused_opt = self.reducer is None
-        with self._on_stream():
-            for _ in range(warmup):
-                self._eager_core(self._static, fused_opt)
-        torch.cuda.synchronize(self.device)
-        conv._PACK_CACHE.clear()              # weight packing must be part of the captured work
-        self.optimizer.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        from . import hrnet
-        hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
-        try:
-            with torch.cuda.graph(graph, stream=self.stream):
-                self._static_out = self._eager_core(self._static, fused_opt)
-        finally:
-            hrnet.BRANCH_STREAMS = False
-        self._graph = graph
-        self._graph_fused_opt = fused_opt
-        return self
-
-    def _eager_core(self, batch, with_optimizer):
+    def _core(self, batch, reduce=True, with_optimizer=True):
+        """One optimisation step on the current stream: forward, backward with the weight gradients queued, then bucket
+        by bucket: the bucket's weight-gradient launches, its small gradients copied into the store, its all-reduce
+        (N > 1, asynchronous: the next bucket's launches overlap it); Adam waits for the last all-reduce."""
+        st = self.store
         self._begin_step()
+        if st is not None:
+            st.begin_step()
         BatchNorm2d.count_batches = False
         try:
             out = self.model(batch)
@@ -246,21 +202,99 @@ class Trainer(object):
         losses = out['losses']
         loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
         self.optimizer.zero_grad(set_to_none=True)
-        _conv.DEFER_WGRAD = DEFER_WGRAD            # (graph capture / replay never uses gradient hooks)
+        _conv.GRAD_STORE = st
+        _conv.DEFER_WGRAD = DEFER_WGRAD
         try:
             loss_total.backward()
         finally:
             _conv.DEFER_WGRAD = False
-        _conv.flush_wgrads()
+            _conv.GRAD_STORE = None
+        if st is None:
+            _conv.flush_wgrads()
+        else:
+            _conv.GRAD_STORE = st
+            try:
+                for bi in range(len(st.buckets)):
+                    _conv.flush_wgrads(bucket=bi)
+                    st.collect(bi)
+                    if self.distributed and reduce:
+                        st.reduce_bucket(bi)
+                _conv.flush_wgrads()                     # (nothing left: every parameter belongs to a bucket)
+            finally:
+                _conv.GRAD_STORE = None
+            if self.distributed and reduce:
+                st.wait()
         if with_optimizer:
             self.optimizer.step()
         return out, losses
 
+    def train_step(self, in_dict):
+        self.model.train()
+        self._decay_lr()
+        with self._on_stream():
+            out, losses = self._core(in_dict)
+        self.step_count += 1
+        return out, losses
+
+    # ------------------------------------------------------------------------------------------
+    # hipGraph execution: the ~2.4k kernel launches of one step are captured once and replayed, which
+    # removes the host-side launch cost (the step is launch-bound in eager mode).
+    @staticmethod
+    def _clone_batch(d):
+        return {k: (v.clone() if torch.is_tensor(v) else Trainer._clone_batch(v) if isinstance(v, dict) else v) for k, v in d.items()}
+
+    def capture(self, in_dict, warmup=2):
+        """Capture the whole step -- forward, backward, the bucketed gradient all-reduces (N > 1) and Adam -- for batches
+        shaped like `in_dict`.  The host-side switches of a batch are frozen into the graph: `pretrain_mode` / `vis_on`
+        must not change between replays (checked by load_batch), and DensePose point supervision is captured as ACTIVE
+        whenever the batch carries a `dp_dict` (its losses are masked by `has_dp` per sample, so batches without
+        DensePose labels simply contribute zeros).  If the communication library cannot be captured the all-reduces
+        and the optimizer run right after each replay instead."""
+        from . import conv
+        if self.device.type != 'cuda':
+            raise RuntimeError('hipGraph capture needs a GPU')
+        self.model.train()
+        self._static = self._clone_batch(in_dict)
+        if isinstance(self._static.get('dp_dict'), dict):
+            self._static['dp_dict']['dp_active'] = True
+        with self._on_stream():
+            for _ in range(warmup):
+                self._core(self._static)
+        torch.cuda.synchronize(self.device)
+        from . import hrnet
+        for in_graph in ((True, False) if self.distributed else (True,)):
+            conv._PACK_CACHE.clear()              # weight packing must be part of the captured work
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
+            try:
+                # thread_local: the communication library's watchdog thread may poll events of earlier collectives while
+                # this thread captures (the default, global mode turns that into a capture error)
+                with torch.cuda.graph(graph, stream=self.stream, capture_error_mode='thread_local' if self.distributed else 'global'):
+                    self._static_out = self._core(self._static, reduce=in_graph, with_optimizer=in_graph)
+                self._reduce_in_graph = in_graph
+                break
+            except RuntimeError:
+                if not in_graph:
+                    raise
+                torch.cuda.synchronize(self.device)
+                self.store._works = []
+            finally:
+                hrnet.BRANCH_STREAMS = False
+        self._graph = graph
+        return self
+
     def load_batch(self, in_dict):
-        """Copy a new batch into the captured graph's static input tensors."""
-        for k, v in in_dict.items():
-            if torch.is_tensor(v):
-                self._static[k].copy_(v, non_blocking=True)
+        """Copy a new batch into the captured graph's static input tensors (nested dictionaries included)."""
+        def rec(dst, src, path):
+            for k, v in src.items():
+                if torch.is_tensor(v):
+                    dst[k].copy_(v, non_blocking=True)
+                elif isinstance(v, dict):
+                    rec(dst[k], v, path + k + '.')
+                elif k != 'dp_active' and dst.get(k) != v:
+                    raise ValueError('train_step_graphed: %s%s = %r differs from the captured %r; capture() again' % (path, k, v, dst.get(k)))
+        rec(self._static, in_dict, '')
 
     def train_step_graphed(self, in_dict=None):
         if self._graph is None:
@@ -269,8 +303,9 @@ class Trainer(object):
             self.load_batch(in_dict)
         self._decay_lr()
         self._graph.replay()
-        if not self._graph_fused_opt:
-            self.reducer.reduce_now()
-            self.optimizer.step()
+        if not self._reduce_in_graph:
+            with self._on_stream():
+                self.store.reduce_all()
+                self.optimizer.step()
         self.step_count += 1
         return self._static_out

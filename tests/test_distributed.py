@@ -1,6 +1,7 @@
-"""world_size-2 gloo tests (CPU) of the data-parallel gradient reducer: N-rank averaged gradients ==
-mean of the single-process gradients on the same shards; unused parameters keep the collective
-plan static; parameters/buffers are broadcast from rank 0."""
+"""world_size-2 gloo tests (CPU) of the flat gradient store / bucketed all-reduce (distributed.GradStore): N-rank
+averaged gradients == mean of the single-process gradients on the same shards (fp32, 1e-6); unused parameters are
+reduced as zeros, the collectives run in bucket order on every rank; parameters/buffers are broadcast from rank 0.
+The real Trainer path on two processes is tests/test_gpu_models.py::test_two_process_trainer_gradient_allreduce."""
 import os
 import socket
 import sys
@@ -39,28 +40,36 @@ def _worker(rank, world, port, tmp):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from danet_densepose2smpl_amd.distributed import GradReducer
+    from danet_densepose2smpl_amd.distributed import GradStore
     torch.manual_seed(100 + rank)                # different init per rank: broadcast must fix it
     net = _Net()
-    red = GradReducer(net, bucket_mb=0.0002, device=torch.device('cpu'))     # tiny buckets -> several collectives
-    assert len(red.buckets) > 2
-    red.broadcast_parameters()
+    st = GradStore(net.parameters(), bucket_mb=0.0002, device=torch.device('cpu'))     # tiny buckets -> several collectives
+    assert len(st.buckets) > 2 and st.world == world and st.grad_scale == 1.0 / world
+    st.broadcast_parameters(net)
     g = torch.Generator().manual_seed(7)
     data = torch.randn(world, 6, 8, generator=g)
     for step in range(2):
         net.zero_grad(set_to_none=True)
-        red.prepare()
+        st.begin_step()
         net(data[rank]).pow(2).mean().backward()
-        red.finish()
+        # bucket by bucket, in bucket order on every rank (the trainer interleaves the weight-gradient launches here)
+        for bi in range(len(st.buckets)):
+            st.collect(bi)
+            st.reduce_bucket(bi)
+        st.wait()
+        st.scale_()
+        st.attach_all()
+    for p in net.parameters():                   # every gradient is a view of the one flat buffer
+        assert p.grad.data_ptr() == st.grad_ptr(p)
     torch.save({'grads': {k: p.grad.clone() for k, p in net.named_parameters()},
                 'params': {k: p.detach().clone() for k, p in net.named_parameters()}}, os.path.join(tmp, 'r%d.pt' % rank))
-    # hook-free path used after a hipGraph replay
+    # the one-call form used after a hipGraph replay whose communication could not be captured
     net.zero_grad(set_to_none=True)
+    st.begin_step()
     net(data[rank]).pow(2).mean().backward()
-    red.remove()
-    red2 = GradReducer(net, bucket_mb=1.0, device=torch.device('cpu'))
-    red2.remove()                                 # no hooks: gradients already there
-    red2.reduce_now()
+    st.reduce_all()
+    st.scale_()
+    st.attach_all()
     torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(tmp, 'n%d.pt' % rank))
     dist.destroy_process_group()
 

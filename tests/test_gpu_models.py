@@ -376,9 +376,9 @@ def test_graphed_full_step_losses_match_eager():
 
 
 def test_data_parallel_graph_path_single_rank():
-    """The N > 1 execution path of bench.py (GradReducer: eager hooked steps, then hipGraph forward+backward followed by
-    the bucketed all-reduce and an eager Adam step) on a 1-rank RCCL group: it must run and agree with the
-    single-process trainer (the averaging over one rank is the identity)."""
+    """The N > 1 execution path of bench.py on a 1-rank RCCL group: eager steps with the bucketed all-reduces
+    interleaved with the weight-gradient launches, then the hipGraph capture with the all-reduces and Adam INSIDE the
+    graph.  It must run and agree with the single-process trainer (a sum over one rank is the identity)."""
     import torch.distributed as dist
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
@@ -390,19 +390,23 @@ def test_data_parallel_graph_path_single_rank():
         res = {}
         for mode in ('single', 'ddp'):
             torch.manual_seed(0)
-            tr = Trainer(default_options(2), device=dev, distributed=(mode == 'ddp'), lr=1e-30)
-            assert (tr.reducer is not None) == (mode == 'ddp')
+            tr = Trainer(default_options(2), device=dev, distributed=(mode == 'ddp'), lr=1e-30, bucket_mb=8.0)
+            assert (tr.reducer is not None) == (mode == 'ddp') and len(tr.store.buckets) > 8
             batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
             batch['pretrain_mode'] = True
             tr.train_step(batch)
             _, l_eager = tr.train_step(batch)
             tr.capture(batch, warmup=1)
+            if mode == 'ddp':
+                assert tr._reduce_in_graph, 'the RCCL all-reduces were not captured into the hipGraph'
             tr.train_step_graphed()
             _, l_graph = tr.train_step_graphed()
             torch.cuda.synchronize()
             named = [(n, p) for n, p in tr.model.named_parameters() if p.grad is not None and p.dim() == 4]
+            for n, p in named:
+                assert p.grad.data_ptr() == tr.store.grad_ptr(p), n      # zero-copy: .grad IS the bucket slot
             res[mode] = ({k: float(v.sum()) for k, v in l_eager.items()}, {k: float(v.sum()) for k, v in l_graph.items()},
-                         {n: p.grad.detach().clone() for n, p in named})      # (unused parameters get zero gradients in the ddp mode)
+                         {n: p.grad.detach().clone() for n, p in named})
         for k in res['single'][0]:
             for a, b in ((res['ddp'][0][k], res['single'][0][k]), (res['ddp'][1][k], res['single'][1][k])):
                 assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
@@ -411,6 +415,63 @@ def test_data_parallel_graph_path_single_rank():
         assert max(rel) < 0.3 and sorted(rel)[len(rel) // 2] < 0.05, sorted(rel)[-3:]
     finally:
         dist.destroy_process_group()
+
+
+def _two_proc_worker(rank, world, port, tmp):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)          # (both processes share GPU 0: RCCL needs one GPU per rank)
+    from danet_densepose2smpl_amd.config import reset_cfg, cfg_from_dict
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    reset_cfg()
+    cfg_from_dict({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16, 'DANET.PARTDROP_RATE': 0.,
+                   'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(10 + rank)                                         # different initial weights: the broadcast must fix them
+    tr = Trainer(default_options(2), device=dev, distributed=True, lr=1e-4, bucket_mb=4.0)
+    assert tr.store.world == world and len(tr.store.buckets) > 10
+    batch = synthetic_in_dict(tr.model, 2, dev, seed=100 + rank)         # every rank its own shard
+    p0 = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+    # one backward pass, local gradients kept aside, then the store's own reduction: reduced == sum of the local ones
+    with tr._on_stream():
+        tr._core(batch, reduce=False, with_optimizer=False)
+        local = tr.store.flat.clone()
+        for bi in range(len(tr.store.buckets)):
+            tr.store.reduce_bucket(bi)
+        tr.store.wait()
+        summed = tr.store.flat.clone()
+    torch.cuda.synchronize()
+    # the full pipelined step (bucket-wise all-reduce between the weight-gradient launches, Adam with grad_scale = 1/2)
+    tr.train_step(batch)
+    torch.cuda.synchronize()
+    p1 = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+    torch.save({'p0': p0, 'local': local.cpu(), 'summed': summed.cpu(), 'flat': tr.store.flat.cpu(), 'p1': p1}, os.path.join(tmp, 'r%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_two_process_trainer_gradient_allreduce(tmp_path):
+    """SURVEY 8e on the REAL trainer path: two processes (gloo backend, both on GPU 0), each with its own shard.  The
+    bucketed reduction of the flat gradient store returns, on both ranks, exactly the sum of the two ranks' local
+    gradients of the same backward pass (fp32; the average is that sum times grad_scale = 1/2, folded into Adam), for
+    every parameter incl. the never-used ones (zeros); after the full pipelined step both ranks hold the same gradients
+    and -- starting from the broadcast weights -- the same parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_proc_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
+    assert torch.equal(r0['p0'], r1['p0'])                                       # broadcast from rank 0
+    want = r0['local'] + r1['local']
+    scale = want.abs().max().item()
+    assert scale > 0
+    for r in (r0, r1):
+        assert (r['summed'] - want).abs().max().item() <= 1e-5 * scale          # fp32 sum of two terms
+    assert torch.equal(r0['summed'], r1['summed'])
+    assert (r0['local'] - r1['local']).abs().max().item() > 1e-3 * scale          # the shards really differ
+    assert torch.equal(r0['flat'], r1['flat']) and r0['flat'].abs().max().item() > 0
+    assert torch.equal(r0['p1'], r1['p1']) and not torch.equal(r0['p1'], r0['p0'])
 
 
 def test_dp_point_losses_inside_the_estimator_and_train_step():
