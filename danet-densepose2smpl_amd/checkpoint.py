@@ -35,12 +35,23 @@ def save_checkpoint(path, models, optimizers=None, epoch=0, batch_idx=0, batch_s
     return path
 
 
-def load_checkpoint(path, models, optimizers=None, map_location='cpu'):
+def _load_file(path, map_location, trusted):
+    """torch.load with weights_only=True (tensors and plain containers only); files that need full unpickling (numpy
+    permutation arrays of utils/saver.py, old torch versions) are read only when the caller vouches for them."""
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception:
+        if not trusted:
+            raise RuntimeError('%s needs full unpickling (arbitrary code may run): pass trusted=True for files you trust' % path)
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def load_checkpoint(path, models, optimizers=None, map_location='cpu', trusted=False):
     """saver.load_checkpoint: every model takes the keys it shares with the file (shape mismatches are an error, as
     in the reference's load_state_dict); optimizers load theirs if present.  Returns the bookkeeping values."""
     if not os.path.isfile(path):
         raise ValueError('checkpoint does not exist: %s' % path)
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    ckpt = _load_file(path, map_location, trusted)
     for name, m in models.items():
         if name in ckpt:
             own = m.state_dict()
@@ -52,12 +63,12 @@ def load_checkpoint(path, models, optimizers=None, map_location='cpu'):
     return {k: ckpt.get(k) for k in BOOKKEEPING}
 
 
-def load_pretrained(model, path, key='model', map_location='cpu'):
+def load_pretrained(model, path, key='model', map_location='cpu', trusted=False):
     """demo.py:92-97 / eval.py: `model.load_state_dict(checkpoint['model'], strict=False)`; a bare state dict and
     DataParallel's 'module.' prefix are accepted too.  Returns (missing_keys, unexpected_keys)."""
     if not os.path.isfile(path):
         raise ValueError('pretrained model does not exist: %s' % path)
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    ckpt = _load_file(path, map_location, trusted)
     sd = ckpt[key] if isinstance(ckpt, dict) and key in ckpt and isinstance(ckpt[key], dict) else ckpt
     res = model.load_state_dict(_strip_module(sd), strict=False)
     return list(res.missing_keys), list(res.unexpected_keys)

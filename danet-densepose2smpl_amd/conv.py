@@ -461,6 +461,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
         if keep_group_padding:       # [B, groups*(Cout_g+padn), OH, OW]: the caller consumes the padded layout (part_ops)
             return y
+        if groups == 1:              # a view: channels stay at the epilogue's padded pixel stride (iuv_ops reads it as it is)
+            return y[:, :Cout]
         B, _, OH, OW = y.shape
         y = y.permute(0, 2, 3, 1).reshape(B, OH, OW, groups, Cout_g + padn)[..., :Cout_g]
         return y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)

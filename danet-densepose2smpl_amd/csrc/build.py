@@ -28,6 +28,7 @@ UNITS = {
     'conv3x3.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
     'part_ops.hip': [],
+    'iuv_ops.hip': [],
     'adam.hip': [],
     'norm_act.hip': [],
     'stn.hip': [],

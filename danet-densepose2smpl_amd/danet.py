@@ -89,16 +89,28 @@ class DaNet(nn.Module):
             uv_image_gt = uv_image_gt * (has_iuv > 0).to(uv_image_gt.dtype).view(B, 1, 1, 1)
 
         rd = {'losses': {}, 'metrics': {}, 'visualization': {}, 'prediction': {}}
-        uv = self.img2iuv(image, uv_image_gt, target_smpl_kps, uvia_dp_gt=in_dict.get('dp_dict'), has_iuv=has_iuv, has_dp=has_dp)
-        u_pred, v_pred, index_pred, ann_pred = uv['uvia_pred']
-
-        keep = None
+        keep = keep25 = None
         if self.training and D.PARTDROP_RATE > 0:                            # danet.py:194-203
             keep = (torch.rand(B, 24, device=image.device) >= D.PARTDROP_RATE).to(torch.float32)
-            keep25 = torch.cat([torch.ones(B, 1, device=image.device), keep], dim=1).view(B, 25, 1, 1)
-            u_pred, v_pred, index_pred = u_pred * keep25, v_pred * keep25, index_pred * keep25
-        u_cl, v_cl, i_cl, a_cl = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
-        rd['visualization']['iuv_pred'] = [u_cl.detach(), v_cl.detach(), i_cl.detach(), a_cl.detach()]
+            keep25 = torch.cat([torch.ones(B, 1, device=image.device), keep], dim=1)
+        uv = self.img2iuv(image, uv_image_gt, target_smpl_kps, uvia_dp_gt=in_dict.get('dp_dict'), has_iuv=has_iuv, has_dp=has_dp,
+                          keep25=keep25)
+        u_pred, v_pred, index_pred, ann_pred = uv['uvia_pred']
+
+        if 'iuv_map' in uv:
+            # the fused global-IUV op (csrc/iuv_ops.hip) already dropped, cleaned and concatenated: [U | V | I | 5 zeros] bf16
+            iuv_map = uv['iuv_map']
+            vis = [iuv_map[:, :25].detach(), iuv_map[:, 25:50].detach(), iuv_map[:, 50:75].detach(), None]
+            if in_dict.get('vis_on', False):
+                vis[3] = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)[3].detach()
+            rd['visualization']['iuv_pred'] = vis
+        else:
+            if keep25 is not None:
+                k4 = keep25.view(B, 25, 1, 1)
+                u_pred, v_pred, index_pred = u_pred * k4, v_pred * k4, index_pred * k4
+            u_cl, v_cl, i_cl, a_cl = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
+            rd['visualization']['iuv_pred'] = [u_cl.detach(), v_cl.detach(), i_cl.detach(), a_cl.detach()]
+            iuv_map = torch.cat([u_cl, v_cl, i_cl], dim=1)
         if in_dict.get('vis_on', False):
             rd['visualization']['gt_uv'] = uv_image_gt
             if 'stn_kps_pred' in uv:
@@ -106,12 +118,10 @@ class DaNet(nn.Module):
 
         smpl_rd = None
         if not in_dict.get('pretrain_mode', False):
-            iuv_map = torch.cat([u_cl, v_cl, i_cl], dim=1)
             part_pred = uv['part_iuv_pred']
             pk = None
             if keep is not None:                                              # danet.py:264-274
-                keep25f = torch.cat([torch.ones(B, 1, device=image.device), keep], dim=1)
-                pk = keep25f[:, self._partial_src]                           # [B,24,7]
+                pk = keep25[:, self._partial_src]                            # [B,24,7]
             if FUSED_PART_OPS and part_pred.is_cuda:
                 part_iuv_map, x24 = part_ops.part_clean(part_pred, pk)        # one kernel; bf16 view of the padded operand
                 part_iuv_map._nhwc_padded = x24

@@ -29,6 +29,7 @@ SMPL2DP_PART = [[1, 2], [8, 10], [7, 9], [1, 2], [8, 10, 12, 14], [7, 9, 11, 13]
                 [1, 2], [12, 14, 5], [11, 13, 6], [1, 2, 23, 24], [15, 17], [16, 18], [23, 24], [15, 17], [16, 18],
                 [15, 17, 19, 21], [16, 18, 20, 22], [19, 21, 4], [20, 22, 3], [19, 21, 4], [20, 22, 3]]
 FUSED_PART_LOSSES = True    # partial-IUV losses through csrc/part_ops.hip (False: the tensor-op formulation)
+FUSED_GLOBAL_IUV = True     # global IUV losses / clean / soft-argmax through csrc/iuv_ops.hip (False: the tensor-op formulation)
 
 DP2SMPL_MAPPING = [[7, 8, 9, 10, 1, 2], [1, 2, 8, 10, 12, 14], [1, 2, 7, 9, 11, 13], [7, 8, 9, 10, 1, 2],
                    [1, 2, 8, 10, 12, 14], [1, 2, 7, 9, 11, 13], [7, 8, 9, 10, 1, 2], [8, 10, 12, 14, 5, 5],
@@ -213,15 +214,31 @@ class IUV_Estimator(nn.Module):
         return loss_U, loss_V, loss_I, loss_A
 
     # --------------------------------------------------------------------------------------
-    def forward(self, data, iuv_image_gt=None, smpl_kps_gt=None, kps3d_gt=None, uvia_dp_gt=None, has_iuv=None, has_dp=None):
+    def forward(self, data, iuv_image_gt=None, smpl_kps_gt=None, kps3d_gt=None, uvia_dp_gt=None, has_iuv=None, has_dp=None,
+                keep25=None):
+        """keep25 [B,25] (optional): DaNet's part-drop mask; with it the fused global-IUV op also produces the cleaned,
+        concatenated regressor input (rd['iuv_map'], rd['iuv_argmax']) in the same launch."""
         rd = {'losses': {}, 'metrics': {}, 'visualization': {}}
         align = bool(cfg.DANET.get('ALIGN_CORNERS', True))
         est = self.iuv_est(data)
         u_pred, v_pred = est['predict_u'], est['predict_v']
         index_pred, ann_pred = est['predict_uv_index'], est['predict_ann_index']
+        fused = FUSED_GLOBAL_IUV and u_pred.is_cuda
 
         uvia_list = None
-        if self.training and iuv_image_gt is not None:
+        am_raw = None
+        if fused:
+            from . import iuv_ops
+            want = self.training and iuv_image_gt is not None
+            w = None if has_iuv is None else has_iuv.to(torch.float32)
+            sums, rd['iuv_map'], am_raw = iuv_ops.iuv_global(u_pred, v_pred, index_pred, ann_pred, iuv_image_gt if want else None, w, keep25)
+            rd['iuv_argmax'] = am_raw
+            if want:
+                B, S2 = u_pred.shape[0], u_pred.shape[-1] * u_pred.shape[-2]
+                wsum = float(B) if w is None else w.sum().clamp(min=1.0)
+                rd['losses'].update({'loss_U': sums[0] * (cfg.DANET.POINT_REGRESSION_WEIGHTS / B), 'loss_V': sums[1] * (cfg.DANET.POINT_REGRESSION_WEIGHTS / B),
+                                     'loss_IndexUV': sums[2] / (wsum * S2), 'loss_segAnn': sums[3] / (wsum * S2)})
+        elif self.training and iuv_image_gt is not None:
             uvia_list = iuv_img2map(iuv_image_gt)
             lU, lV, lI, lA = self.body_uv_losses(u_pred, v_pred, index_pred, ann_pred, uvia_list, has_iuv)
             rd['losses'].update({'loss_U': lU, 'loss_V': lV, 'loss_IndexUV': lI, 'loss_segAnn': lA})
@@ -240,12 +257,15 @@ class IUV_Estimator(nn.Module):
         if not cfg.DANET.DECOMPOSED:
             return rd
 
-        _, _, index_cl, _ = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
         feat = est['xd']
         hm = est['predict_hm']
         S = hm.size(-1)
         rd['skps_hm_pred'] = hm.detach()
-        centers = softmax_integral_tensor(10 * hm, hm.size(1), hm.size(-2), hm.size(-1))
+        if fused:
+            from . import iuv_ops
+            centers = iuv_ops.softargmax(hm, 10.0)
+        else:
+            centers = softmax_integral_tensor(10 * hm, hm.size(1), hm.size(-2), hm.size(-1))
         centers = centers / (0.5 * S) - 1
 
         if self.training and smpl_kps_gt is not None:
@@ -258,7 +278,11 @@ class IUV_Estimator(nn.Module):
 
         hidden = None
         if cfg.DANET.STN_PART_VIS_SCORE > 0:
-            score_maps = torch.einsum('jc,bchw->bjhw', self._vis_membership, index_cl.detach())
+            if am_raw is not None:        # membership of the winning part, looked up per pixel
+                score_maps = self._vis_membership.t()[am_raw.long()].permute(0, 3, 1, 2)
+            else:
+                _, _, index_cl, _ = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
+                score_maps = torch.einsum('jc,bchw->bjhw', self._vis_membership, index_cl.detach())
             score = _sample_points(score_maps, centers.detach(), align)
             hidden = score < cfg.DANET.STN_PART_VIS_SCORE
 
@@ -293,6 +317,8 @@ class IUV_Estimator(nn.Module):
             lI = sums[2] / (wsum * (24 * Sp * Sp))
             rd['losses'].update({'loss_pU': lU / 24., 'loss_pV': lV / 24., 'loss_pIndexUV': lI})
         elif self.training and iuv_image_gt is not None:
+            if uvia_list is None:
+                uvia_list = iuv_img2map(iuv_image_gt)
             simp = self.part_iuv_simp(*uvia_list[:3])                                    # [B,24,3,7,H,W]
             B = simp.shape[0]
             flat = simp.reshape(B * 24, 21, Sp, Sp)

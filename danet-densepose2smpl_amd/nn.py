@@ -92,11 +92,19 @@ class BatchNorm2d(nn.BatchNorm2d):
     # per-module `num_batches_tracked += 1` is one tiny launch per layer (353 per step); a trainer may
     # switch it off and bump all counters with one multi-tensor op (bump_batch_counters)
     count_batches = True
+    _ran = []                 # counters of the modules that ran in training mode while count_batches was off
+
+    def _count(self):
+        if self.track_running_stats and self.num_batches_tracked is not None:
+            if BatchNorm2d.count_batches:
+                self.num_batches_tracked.add_(1)
+            else:
+                BatchNorm2d._ran.append(self.num_batches_tracked)
 
     def forward(self, x, res=None, relu=False):
         training = self.training or not self.track_running_stats
-        if training and self.track_running_stats and self.num_batches_tracked is not None and BatchNorm2d.count_batches:
-            self.num_batches_tracked.add_(1)
+        if training:
+            self._count()
         momentum = 0.1 if self.momentum is None else self.momentum
         fused = getattr(x, '_bn_sums', None) if training else None
         return BatchNormActFunction.apply(x, res, self.weight, self.bias,
@@ -194,8 +202,7 @@ def multi_batch_norm(bns, xs, ress=None, relu=False):
     if len(mom) != 1 or len(eps) != 1:
         return [b(x, r, relu) for b, x, r in zip(bns, xs, ress)]
     for b in bns:
-        if b.track_running_stats and b.num_batches_tracked is not None and BatchNorm2d.count_batches:
-            b.num_batches_tracked.add_(1)
+        b._count()
     rms = [b.running_mean if b.track_running_stats else None for b in bns]
     rvs = [b.running_var if b.track_running_stats else None for b in bns]
     fused = [getattr(x, '_bn_sums', None) for x in xs]
@@ -293,12 +300,10 @@ def stn_gather(x, theta, out_hw=None, align_corners=True):
     return StnGatherFunction.apply(x, theta, out_hw, align_corners)
 
 
-def bump_batch_counters(module):
-    """num_batches_tracked += 1 for every BatchNorm of `module`, as ONE multi-tensor launch."""
-    counters = getattr(module, '_bn_counters', None)
-    if counters is None:
-        counters = [m.num_batches_tracked for m in module.modules()
-                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
-        module._bn_counters = counters
+def bump_batch_counters(module=None):
+    """num_batches_tracked += 1 for every BatchNorm2d that ran in training mode since the last call (with
+    BatchNorm2d.count_batches switched off), as ONE multi-tensor launch -- the modules torch would have counted
+    (/root/reference's nn.BatchNorm2d.forward): not the never-used stacks, not eval-mode layers, not a skipped regressor."""
+    counters, BatchNorm2d._ran = BatchNorm2d._ran, []
     if counters:
         torch._foreach_add_(counters, 1)

@@ -106,6 +106,29 @@ int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream)
 int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Global (25-class) IUV glue (csrc/iuv_ops.hip).  Replaces utils/iuvmap.py:6-38,103-147 (iuvmap_clean, iuv_img2map),
+ * models/danet/iuv_estimator.py:304-341 (body_uv_losses) and danet.py:194-205,247 (part drop, clean, concat), and
+ * utils/keypoints.py:334-394 (soft-argmax of the joint heat-maps).
+ *  u, v, ix: fp32 [B*H*W][ld] (25 valid channels, 28 <= ld <= 32, ld % 4 == 0); an: [B*H*W][lda = 16] (15 valid);
+ *  gt: rendered IUV image [B,3,H,W] fp32 NCHW (want_loss only); w: [B] per-sample weights or NULL; keep: [B,25] part-drop
+ *  mask or NULL.  forward: map = bf16 [B*H*W][80] (U*onehot | V*onehot | onehot | 5 zeros; one-hot of argmax(ix*keep)),
+ *  am_raw / am_drop = uint8 argmax of ix / ix*keep, sums[4] += (sum smooth-L1 U, V at the ground-truth part's channel,
+ *  sum CE of the 25-way index, sum CE of the 15-way Ann logits), weighted by w.  backward: coef[4] = dL/dsums (device),
+ *  dmap = gradient of map or NULL; du, dv, di ([..][ld]) and da ([..][lda]) are fully written.
+ *  softargmax: hm fp32 [B*H*W][ld] (J valid) -> out [B,J,2] = E[(x, y)] under softmax(scale*hm); saved [B,J,4] feeds the
+ *  backward, which writes dhm as dense [B*H*W][J]. */
+int danet_iuv_global_forward(const float* u, const float* v, const float* ix, const float* an, int ld, int lda,
+                             const float* gt, const float* w, const float* keep, int B, int H, int W, int want_loss,
+                             void* map, unsigned char* am_raw, unsigned char* am_drop, float* sums, void* stream);
+int danet_iuv_global_backward(const float* u, const float* v, const float* ix, const float* an, int ld, int lda,
+                              const float* gt, const float* w, const float* keep, const unsigned char* am_drop,
+                              const void* dmap, const float* coef, int B, int H, int W, int want_loss,
+                              float* du, float* dv, float* di, float* da, void* stream);
+int danet_softargmax_forward(const float* hm, int ld, int B, int J, int H, int W, float scale, float* out, float* saved, void* stream);
+int danet_softargmax_backward(const float* hm, int ld, int B, int J, int H, int W, float scale, const float* saved,
+                              const float* gout, float* dhm, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimizer (replaces torch.optim.Adam at /root/reference/train/trainer.py:42-44): one launch over a device table of
  * <= 32768-element chunks { float* p; const float* g (NULL = skip); int64 off (into m, v); int32 n; int32 pad }.
  * lr and step (1-based count, float) are read from device memory; p, g, m+off, v+off 16-byte aligned.  grad_scale
