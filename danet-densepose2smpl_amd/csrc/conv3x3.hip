@@ -23,6 +23,7 @@
 // the data gradient only mirrors the tap offsets.
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
     constexpr int PW = 4 / KW;
     constexpr int MO = MT / KW;                    // accumulator tiles a wave finishes (stores, statistics) after the K-split reduction
     constexpr int D = 3;                           // weight-fragment ring: k-steps in flight
-    constexpr int RB = 10;                         // staging: rows whose loads are in flight together
+    constexpr int RB = 6;                          // staging: rows whose loads are in flight together (a TH = 4 tile is one batch)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -125,7 +126,48 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
     const int nrows = NI * (TH + 2);
 
     if (p.dbg && t == 0) p.dbg[bid * 8 + 0] = (int)clock64();
-    // ---- once per problem: tap table, zeroed tile, per-lane fragment / staging addresses --------------------------
+    // ---- the first tile's input rows are requested before anything else: they travel during the prologue -----------
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    int st_g[NSUB];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) st_g[sub] = sub * 256 + t < W * S ? (sub * 256 + t) * 16 : OOB;
+    // first tile of this problem owned by this workgroup: ids congruent to bid modulo nblk over the launch's list
+    int tau = bid - p.tile0 % nblk;
+    if (tau < 0) tau += nblk;
+    auto tile_coords = [&](int tt, int& img0_, int& y0_, int& nb_) {
+        int pt;
+        if (p.swz) {                               // tt = (pt_hi * nnb + nb) * 8 + pt_lo
+            const int lo = tt & 7, rest = tt >> 3;
+            const int hi = rest / p.nnb;
+            nb_ = rest - hi * p.nnb; pt = hi * 8 + lo;
+        } else {
+            pt = tt / p.nnb; nb_ = tt - pt * p.nnb;
+        }
+        const int bi = pt / p.tiles_h, tb = pt - bi * p.tiles_h;
+        img0_ = bi * NI; y0_ = tb * TH;
+    };
+    // rows [r0, r0 + RB) of slab sl of the tile at (img0, y0): loads into registers / registers into the LDS tile
+    auto issue_rows = [&](int img0_, int y0_, int sl, int r0, i32x4 (*v)[NSUB], bool live) {
+        const int gimg = ((img0_ + sl) * H) * W * p.Cin * 2;               // byte offset of the image (x_bytes < 2^31)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int yy = y0_ - 1 + r0 + u;
+            const bool rok = live && yy >= 0 && yy < H && r0 + u < TH + 2;
+            const int grow = gimg + yy * W * p.Cin * 2;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+                v[u][sub] = rok ? __builtin_amdgcn_raw_buffer_load_b128(xr, st_g[sub], grow, 0) : i32x4{0, 0, 0, 0};
+        }
+    };
+    const bool pre = NI == 1 && TH + 2 <= RB && tau < p.ntiles;        // (one batch of rows: the common case)
+    i32x4 xv0[RB][NSUB];
+    {
+        int i0, y0_, nb_;
+        tile_coords(min(tau, p.ntiles - 1), i0, y0_, nb_);
+        issue_rows(i0, y0_, 0, 0, xv0, pre);
+    }
+
+    // ---- once per problem: tap table, per-lane fragment / staging addresses ----------------------------------------
     lds_barrier();                                 // a previous problem's readers of this LDS are done
     if (t < p.nks) {
         const float rc_n = 1.0f / (float)p.nc16;
@@ -160,7 +202,7 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
             outoff[mt] = valid ? (((sl * H + r) * W + xx) * p.Cout + lg * 4) * osz : OOB;
         }
     }
-    int st_g[NSUB], st_l[NSUB];
+    int st_l[NSUB];
     {
         const float rc_s = 1.0f / (float)S;
 #pragma unroll
@@ -168,10 +210,20 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
             const int q = sub * 256 + t;
             const bool ok = q < W * S;
             const int pix = (int)udiv24((unsigned)(ok ? q : 0), (unsigned)S, rc_s), c = (ok ? q : 0) - pix * S;
-            st_g[sub] = ok ? q * 16 : OOB;
             st_l[sub] = ok ? ((1 + pix) * Sp + c) * 16 : -1;
         }
     }
+    auto write_rows = [&](int sl, int r0, i32x4 (*v)[NSUB]) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            if (r0 + u < TH + 2) {
+                unsigned char* const lrow = sX + (sl * (TH + 2) + r0 + u) * rowB;
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub)
+                    if (st_l[sub] >= 0) *reinterpret_cast<i32x4*>(lrow + st_l[sub]) = v[u][sub];
+            }
+        }
+    };
     // zero padding: the two pad columns of every slab row are (re)zeroed per tile -- staging never writes them, the
     // K-split reduction and the statistics scratch overlay them
     int padaddr[PADN];
@@ -193,7 +245,6 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
     lds_barrier();                                 // the tap table is in place
     if (p.dbg && t == 0) p.dbg[bid * 8 + 1] = (int)clock64();
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const int nks = p.nks;
     const int nks_w = (nks + KW - 1) / KW;
@@ -209,21 +260,10 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
     const bool acc_stats = p.stats != nullptr || p.bn_red != nullptr;
     float* const stat_dst = p.stats ? p.stats : p.bn_red;
 
-    // first tile of this problem owned by this workgroup: ids congruent to bid modulo nblk over the launch's list
-    int tau = bid - p.tile0 % nblk;
-    if (tau < 0) tau += nblk;
-
-    for (; tau < p.ntiles; tau += nblk) {
-        int pt, nb;
-        if (p.swz) {                               // tau = (pt_hi * nnb + nb) * 8 + pt_lo
-            const int lo = tau & 7, rest = tau >> 3;
-            const int hi = rest / p.nnb;
-            nb = rest - hi * p.nnb; pt = hi * 8 + lo;
-        } else {
-            pt = tau / p.nnb; nb = tau - pt * p.nnb;
-        }
-        const int bi = pt / p.tiles_h, tb = pt - bi * p.tiles_h;
-        const int img0 = bi * NI, y0 = tb * TH;
+    auto do_tile = [&](const int tau, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int img0, y0, nb;
+        tile_coords(tau, img0, y0, nb);
         const int n0 = nb * (16 * NT);
 
         if (acc_stats && stat_nb != nb) {
@@ -249,29 +289,17 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
 #pragma unroll
         for (int i = 0; i < PADN; ++i)
             if (padaddr[i] >= 0) *reinterpret_cast<i32x4*>(sX + padaddr[i]) = i32x4{0, 0, 0, 0};
-        for (int sl = 0; sl < NI; ++sl) {
-            const int gimg = ((img0 + sl) * H) * W * p.Cin * 2;            // byte offset of the image (x_bytes < 2^31)
-            for (int r0 = 0; r0 < TH + 2; r0 += RB) {                      // RB rows per batch: every load in flight at once
-                i32x4 v[RB][NSUB];
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    const int yy = y0 - 1 + r0 + u;
-                    const bool rok = yy >= 0 && yy < H && r0 + u < TH + 2;
-                    const int grow = gimg + yy * W * p.Cin * 2;
-#pragma unroll
-                    for (int sub = 0; sub < NSUB; ++sub)
-                        v[u][sub] = rok ? __builtin_amdgcn_raw_buffer_load_b128(xr, st_g[sub], grow, 0) : i32x4{0, 0, 0, 0};
+        bool staged = false;
+        if constexpr (FIRST) {
+            if (pre) { write_rows(0, 0, xv0); staged = true; }
+        }
+        if (!staged) {
+            for (int sl = 0; sl < NI; ++sl)
+                for (int r0 = 0; r0 < TH + 2; r0 += RB) {                  // RB rows per batch: every load in flight at once
+                    i32x4 v[RB][NSUB];
+                    issue_rows(img0, y0, sl, r0, v, true);
+                    write_rows(sl, r0, v);
                 }
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    if (r0 + u < TH + 2) {
-                        unsigned char* const lrow = sX + (sl * (TH + 2) + r0 + u) * rowB;
-#pragma unroll
-                        for (int sub = 0; sub < NSUB; ++sub)
-                            if (st_l[sub] >= 0) *reinterpret_cast<i32x4*>(lrow + st_l[sub]) = v[u][sub];
-                    }
-                }
-            }
         }
         lds_barrier();
         if (p.dbg && t == 0) p.dbg[bid * 8 + 2] = (int)clock64();
@@ -405,6 +433,10 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
         }
         lds_barrier();                                              // the tile's LDS may be overwritten (stores keep draining)
         if (p.dbg && t == 0) p.dbg[bid * 8 + 5] = (int)clock64();
+    };
+    if (tau < p.ntiles) {
+        do_tile(tau, std::true_type{});
+        for (tau += nblk; tau < p.ntiles; tau += nblk) do_tile(tau, std::false_type{});
     }
     if (acc_stats && stat_nb >= 0)
         flush_channel_sums<NT>(s1, s2, reinterpret_cast<float*>(sX), stat_dst, p.Cout, stat_nb * (16 * NT), t, li, lg, wave, bid);
