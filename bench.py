@@ -28,15 +28,20 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: 
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (tools/pmc_traffic.sh), or None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        d = json.load(open(path))['kernels'].get(kernel)
-        if d and 'fetch_bytes_per_launch' in d and 'write_bytes_per_launch' in d:
-            return int(d['fetch_bytes_per_launch'] + d['write_bytes_per_launch'])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch of `kernel`, source description) from this round's committed PMC summary
+    (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a 512 MiB copy
+    in the same run), or (None, reason).  The file records the commit it was measured at."""
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            f = json.load(open(path))
+            d = f['kernels'].get(kernel)
+            if d and 'fetch_bytes_per_launch' in d and 'write_bytes_per_launch' in d:
+                return int(d['fetch_bytes_per_launch'] + d['write_bytes_per_launch']), \
+                    'profiles/%s (commit %s; bytes per launch averaged over this kernel\'s launches of one step)' % (name, f.get('commit', 'n/a'))
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, 'no PMC summary for this kernel under profiles/'
 
 
 def _flush_c_stdio():
@@ -62,34 +67,86 @@ def parse():
 
 
 def cpu_baseline(size, cpu_batch):
-    """The oracle timed on the host cores on a bounded sample of the same workload."""
+    """The oracle timed on the host cores on a bounded sample of the same workload: every convolutional net of the step
+    (oracle/torch_ref.StepNets: HRNet-W48 + global and partial IUV heads + body / limb regressor nets) forward + backward
+    + Adam in fp32, plus the C restatements of the SMPL layer (2 forward, 1 backward -- what the timed GPU step holds)
+    and of the IUV raster."""
     import numpy as np
     import oracle
     from oracle import torch_ref
     from danet_densepose2smpl_amd import assets
-    torch.manual_seed(0)
-    net = torch_ref.HRNet(part_out_dim=7)
-    img = torch.randn(cpu_batch, 3, size, size)
-    torch_ref.hrnet_step_cpu(net, img, 1)                                   # warm-up
-    t_net = torch_ref.hrnet_step_cpu(net, img, 1)
+    t_net, nparam = torch_ref.train_step_cpu(cpu_batch, size, 1)
     model = assets.make_synthetic_smpl(0)
     vm, faces, tex = assets.densepose_render_tables(assets.make_synthetic_densepose(model, 0))
     rng = np.random.default_rng(0)
     betas = rng.normal(0, 1, (cpu_batch, 10)).astype(np.float32)
     pose = rng.normal(0, 0.2, (cpu_batch, 72)).astype(np.float32)
     t0 = time.time()
-    for _ in range(4):                                                       # 4 SMPL forwards per train step
+    for _ in range(2):
         verts, _ = oracle.lbs_forward(model, betas, pose, False, np.float32)
     rot = np.tile(np.eye(3, dtype=np.float32), (cpu_batch, 24, 1, 1))
-    oracle.lbs_backward(model, betas, rot, verts, None, np.float32)          # 1 SMPL backward
+    oracle.lbs_backward(model, betas, rot, verts, None, np.float32)
     cam = np.tile(np.array([[0.9, 0.0, 0.0]], np.float32), (cpu_batch, 1))
     oracle.raster_forward(verts, cam, vm, faces, tex, 5000.0, float(size), size // 4)
     t_geo = time.time() - t0
     return {'value': round(cpu_batch / (t_net + t_geo), 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port',
-            'sample': 'B=%d of the B=32 step: oracle/torch_ref.HRNet-W48 + global IUV heads fwd+bwd fp32 (%.2fs) + '
-                      '4x C SMPL fwd, 1x C SMPL bwd, 1x C IUV raster (%.2fs); partial-IUV head, regressor nets and Adam not included'
-                      % (cpu_batch, t_net, t_geo)}
+            'sample': 'B=%d of the B=32 step: oracle/torch_ref.StepNets fwd+bwd+Adam fp32 (%.2fs; %.1f M parameters; 30.06 of the '
+                      'step\'s 30.07 GMAC/img = 99.9 %% of its 5.77 TFLOP: only the GCN / 1x1 regressors and the loss glue are '
+                      'left out) + 2x C SMPL fwd, 1x C SMPL bwd, 1x C IUV raster (%.2fs)' % (cpu_batch, t_net, nparam / 1e6, t_geo)}
+
+
+def geometry_rooflines(tr, B, size, dev):
+    """HIP-event timings of the SMPL layer and the IUV raster at the bench batch, as achieved HBM GB/s against their
+    algorithmic bytes (LBS 19.6 MB of constants once + 83.6 kB per item; backward reads the constants and
+    dL/dverts again; raster ~5.0 MB at B = 32)."""
+    smpl, rend = tr.model.iuv2smpl.smpl, tr.model.iuv_renderer
+    g = torch.Generator(device='cpu').manual_seed(7)
+    betas = torch.randn(B, 10, generator=g).to(dev).requires_grad_(True)
+    rot = torch.eye(3).repeat(B, 24, 1, 1).to(dev).requires_grad_(True)
+    cam = torch.tensor([[0.9, 0.0, 0.0]]).repeat(B, 1).to(dev)
+
+    def fwd():
+        return smpl(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+
+    def timed(fn, n=20):
+        # replayed from a hipGraph: an event pair then brackets device time, not the host's launch latency
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                fn()
+            for _ in range(2):
+                gr.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                gr.replay()
+            e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3 / n
+    t_f = timed(fwd)
+
+    def fb():
+        out = fwd()
+        (out.vertices.sum() + out.joints.sum()).backward()
+        betas.grad = None
+        rot.grad = None
+    t_fb = timed(fb)
+    verts = fwd().vertices.detach()
+    t_r = timed(lambda: rend.verts2uvimg(verts, cam))
+    const, per = 19.6e6, 83.6e3
+    by_f, by_b, by_r = const + per * B, const + (82.7e3 + per) * B, 5.0e6 * B / 32.0
+    peak = 8000.0
+    mk = lambda name, by, t: {'kernel': name, 'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': peak, 'unit': 'GB/s',   # noqa: E731
+                              'frac': round(by / t / 1e9 / peak, 4), 'us': round(t * 1e6, 1), 'alg_bytes': int(by)}
+    return [mk('smpl_lbs forward (prep+main+finalize)', by_f, t_f), mk('smpl_lbs backward', by_b, max(t_fb - t_f, 1e-9)),
+            mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 
 def main():
@@ -180,11 +237,17 @@ def main():
         if dominant in summ:
             n, secs, flops = summ[dominant]
             ach = flops / secs / 1e12
+            traffic, tsrc = pmc_traffic(dominant)
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': pmc_traffic(dominant), 'kernel': dominant,
+                    'frac': round(ach / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': traffic, 'kernel': dominant,
                     'launches': n, 'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3),
-                    'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
-                                      'calibrated on a 512 MiB copy; bytes per launch averaged over this kernel\'s launches of one step)'}
+                    'traffic_source': tsrc}
+    extra = None
+    if rank == 0:
+        try:
+            extra = geometry_rooflines(tr, B, args.size, dev)
+        except Exception as e:                                       # secondary figures must not take the bench line down
+            extra = [{'error': repr(e)}]
 
     if rank == 0:
         ips = world * B * args.steps / elapsed
@@ -192,11 +255,14 @@ def main():
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                 'exec': 'hipgraph' if use_graph else 'eager',
-                'config': {'workload': 'full DaNet train step (HRNet-W48 + part-wise IUV heads + SMPL LBS x4 + IUV render + '
-                                       'regressor + losses, fwd+bwd+Adam), %dx%d, %d img/GPU; convs bf16 MFMA fp32-acc, '
+                'allreduce': ('in-graph, per bucket between the weight-gradient launches' if (use_graph and tr._reduce_in_graph) else
+                              'after the graph replay' if use_graph else 'eager, per bucket') if world > 1 or args.force_ddp else None,
+                'config': {'workload': 'full DaNet train step (HRNet-W48 + global and part-wise IUV heads + regressor nets + SMPL LBS '
+                                       '(2 forward + 1 backward; the 2 label-side forwards belong to the untimed batch prologue) + IUV '
+                                       'render + losses, fwd+bwd+Adam), %dx%d, %d img/GPU; convs bf16 MFMA fp32-acc, '
                                        'LBS/raster/losses fp32' % (args.size, args.size, B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world},
-                'roofline': roof}
+                'roofline': roof, 'roofline_extra': extra}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.size, args.cpu_batch)

@@ -288,3 +288,53 @@ def hrnet_step_cpu(net, img, reps=1):
         loss = sum(out[k].float().mean() for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm'))
         loss.backward()
     return (time.time() - t0) / reps
+
+
+class StepNets(nn.Module):
+    """Every convolutional net of one DaNet optimisation step (models/danet/danet.py:133-366) in plain torch: HRNet-W48 +
+    global heads + grouped partial-IUV head (iuv_estimator.py:193-211) + body_net / limb_net / grouped limb layer4
+    (smpl_regressor.py:470-520).  Used by bench.py's cpu_baseline leg: 30.0 of the step's 30.07 GMAC per image
+    (21.151 + 0.892 + 0.364 + 7.584; the GCN and the 1x1 regressors, < 0.01, are left out)."""
+
+    def __init__(self):
+        super().__init__()
+        self.iuv_est = HRNet(part_out_dim=7)
+        self.body_net = nn.Sequential(nn.Conv2d(75, 64, 1, bias=False), nn.BatchNorm2d(64), nn.ReLU(), SmplResNet(18, 64, 13))
+        self.limb_net = nn.Sequential(nn.Conv2d(21, 64, 1, bias=False), nn.BatchNorm2d(64), nn.ReLU(), SmplResNet(18, 64, 0, truncate=1))
+        self.limb_reslayer = LimbResLayers(256, 128, 24)
+
+    def forward(self, img):
+        out = self.iuv_est(img)
+        B = img.shape[0]
+        xd = out['xd']
+        S = xd.shape[-1]
+        theta = torch.tensor([[0.5, 0., 0.], [0., 0.5, 0.]]).repeat(B, 24, 1, 1)
+        part = self.iuv_est.final_pred.predict_partial_iuv(stn_part_maps(xd, theta, True))          # [B,504,S,S]
+        idx = out['predict_uv_index']
+        onehot = F.one_hot(idx.argmax(1), 25).permute(0, 3, 1, 2).float()
+        iuv_map = torch.cat([out['predict_u'] * onehot, out['predict_v'] * onehot, onehot], 1)
+        cam_shape, _ = self.body_net(iuv_map)
+        _, x4 = self.limb_net(part.reshape(B * 24, 21, S, S))
+        rot = self.limb_reslayer(x4.reshape(B, 24 * 256, x4.shape[-2], x4.shape[-1]))
+        return out, part, cam_shape, rot
+
+
+def train_step_cpu(B, size, reps=1):
+    """Seconds per fwd + bwd + Adam step of StepNets on the host cores (fp32, stock torch)."""
+    import time
+    torch.manual_seed(0)
+    net = StepNets().train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    img = torch.randn(B, 3, size, size)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, part, cam_shape, rot = net(img)
+        loss = sum(out[k].float().mean() for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm'))
+        (loss + part.mean() + cam_shape.mean() + rot.mean()).backward()
+        opt.step()
+    step()                                                                               # warm-up (allocator, thread pool)
+    t0 = time.time()
+    for _ in range(reps):
+        step()
+    return (time.time() - t0) / reps, sum(p.numel() for p in net.parameters())

@@ -242,24 +242,60 @@ def test_danet_train_step_and_inference():
         tr.model.infer_net(batch['img'])
 
 
-def test_danet_resnet50_inference_config2():
-    """BASELINE.json configs[1]: DaNet inference, ResNet-50 backbone (reduced batch here)."""
+@pytest.mark.parametrize('B', [2, 16])
+def test_danet_resnet50_inference_config2(B):
+    """BASELINE.json configs[1]: DaNet inference, ResNet-50 backbone, 256x256 (B = 16 is the configuration's batch)."""
     _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64, 'DANET.IUV_REGRESSOR': 'resnet'})
     from danet_densepose2smpl_amd.danet import DaNet
     from danet_densepose2smpl_amd.trainer import default_options
     torch.manual_seed(0)
-    model = DaNet(default_options(2), None, pretrained=False).cuda().eval()
-    img = torch.randn(2, 3, 256, 256, device='cuda')
+    model = DaNet(default_options(B), None, pretrained=False).cuda().eval()
+    img = torch.randn(B, 3, 256, 256, device='cuda')
     pred = model.infer_net(img)
     para = pred['para']
-    assert para.shape == (2, 229) and torch.isfinite(para).all()
+    assert para.shape == (B, 229) and torch.isfinite(para).all()
     rot = para[:, 13:].reshape(-1, 3, 3)
     eye = torch.eye(3, device='cuda').expand_as(rot)
     assert (torch.bmm(rot, rot.transpose(1, 2)) - eye).abs().max() < 1e-4      # rot6d -> valid rotations
-    out = model.iuv2smpl.smpl(betas=para[:, 3:13], body_pose=para[:, 13:].reshape(2, 24, 3, 3)[:, 1:],
-                              global_orient=para[:, 13:].reshape(2, 24, 3, 3)[:, :1], pose2rot=False)
+    out = model.iuv2smpl.smpl(betas=para[:, 3:13], body_pose=para[:, 13:].reshape(B, 24, 3, 3)[:, 1:],
+                              global_orient=para[:, 13:].reshape(B, 24, 3, 3)[:, :1], pose2rot=False)
     iuv = model.iuv_renderer.verts2uvimg(out.vertices, para[:, :3])
-    assert iuv.shape == (2, 3, 64, 64)
+    assert iuv.shape == (B, 3, 64, 64)
+    part = torch.round(iuv[:, 0] * 24)
+    assert (part == iuv[:, 0] * 24).all() and part.min() >= 0 and part.max() <= 24        # integer-valued part-index plane
+
+
+def test_full_size_graphed_step_properties():
+    """The bench configuration itself (B = 32, 256x256, hipGraph replay): the losses of a replay are finite and equal to
+    the eager step's on the same batch and weights (learning rate ~0) within the bf16 noise of the atomics' summation
+    order; every parameter that takes part in the step has a finite gradient living in the flat gradient store; the
+    rendered ground-truth part plane is integer-valued; a second replay on the same batch reproduces the first."""
+    _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64, 'DANET.PARTDROP_RATE': 0.,
+            'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    tr = Trainer(default_options(32), device=dev, distributed=False, lr=1e-30)
+    batch = synthetic_in_dict(tr.model, 32, dev, seed=3)
+    _, le = tr.train_step(batch)
+    e = {k: float(v.sum()) for k, v in le.items()}
+    tr.capture(batch, warmup=1)
+    _, l1 = tr.train_step_graphed()
+    g1 = {k: float(v.sum()) for k, v in l1.items()}
+    _, l2 = tr.train_step_graphed()
+    g2 = {k: float(v.sum()) for k, v in l2.items()}
+    torch.cuda.synchronize()
+    assert set(g1) == set(e) and len(g1) == 17
+    for k in e:
+        assert np.isfinite(g1[k]) and abs(g1[k] - e[k]) <= 5e-2 * abs(e[k]) + 1e-4, (k, e[k], g1[k])
+        assert abs(g2[k] - g1[k]) <= 5e-2 * abs(g1[k]) + 1e-4, (k, g1[k], g2[k])
+    flat = tr.store.flat
+    assert torch.isfinite(flat).all() and float(flat.abs().max()) > 0
+    for n, p in tr.model.named_parameters():
+        if p.grad is not None:
+            assert p.grad.data_ptr() == tr.store.grad_ptr(p), n
+    uv = tr.model.iuv_renderer.verts2uvimg(batch['target_verts'], batch['target_cam'])
+    assert uv.shape == (32, 3, 64, 64) and (torch.round(uv[:, 0] * 24) == uv[:, 0] * 24).all()
 
 
 def test_graphed_step_matches_eager_step():

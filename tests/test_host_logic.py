@@ -193,6 +193,7 @@ def test_bench_cpu_baseline_leg_runs_on_host_cores():
     spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    out = bench.cpu_baseline(64, 1)
+    out = bench.cpu_baseline(64, 2)                  # (B >= 2: train-mode BatchNorm on the regressor's 1x1 feature maps)
     assert out['kind'] == 'port' and out['unit'] == 'images/sec' and out['value'] > 0 and out['cores'] >= 1 and 'sample' in out
-    assert bench.pmc_traffic('no_such_kernel') is None
+    assert 'StepNets' in out['sample'] and '99.9' in out['sample']
+    assert bench.pmc_traffic('no_such_kernel')[0] is None
