@@ -100,6 +100,73 @@ class KernelProfiler(object):
 
 
 
+PRECISION = 'bf16'     # 'fp32': verification mode (BASELINE config C4's arithmetic): convolutions on the fp32 HIP kernels of
+                       # csrc/conv_f32.hip, normalisation / activation / resampling glue as fp32 tensor ops.  Slow; used by the parity tests.
+
+
+class precision(object):
+    """`with conv.precision('fp32'):` -- run the enclosed forward / backward passes in the fp32 verification mode."""
+
+    def __init__(self, mode):
+        if mode not in ('bf16', 'fp32'):
+            raise ValueError('precision must be bf16 or fp32')
+        self.mode = mode
+
+    def __enter__(self):
+        global PRECISION
+        self.prev, PRECISION = PRECISION, self.mode
+        return self
+
+    def __exit__(self, *a):
+        global PRECISION
+        PRECISION = self.prev
+        return False
+
+
+def fp32_mode():
+    return PRECISION == 'fp32'
+
+
+class Conv2dF32Function(torch.autograd.Function):
+    """fp32 convolution on the verification kernels (csrc/conv_f32.hip): forward, data and weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, groups):
+        L = _lib.lib()
+        B, Cin, H, W = x.shape
+        Cout, Cin_g, R, S = weight.shape
+        if Cin_g * groups != Cin:
+            raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
+        OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+        xh = x.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        y = torch.empty(B, OH, OW, Cout, dtype=torch.float32, device=x.device)
+        check(L.danet_conv_f32(0, ptr(xh), ptr(w), ptr(b), ptr(y), B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, stream()), 'danet_conv_f32')
+        ctx.save_for_backward(xh, w)
+        ctx.cfg = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, bias is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xh, w = ctx.saved_tensors
+        (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, has_bias) = ctx.cfg
+        g = gy.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        gx = gw = gb = None
+        dims = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=g.device)
+            check(L.danet_conv_f32(1, ptr(g), ptr(w), None, ptr(gx), *dims, stream()), 'danet_conv_f32')
+            gx = gx.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            check(L.danet_conv_f32(2, ptr(xh), ptr(g), None, ptr(gw), *dims, stream()), 'danet_conv_f32')
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=(0, 1, 2))
+        return gx, gw, gb, None, None, None, None
+
+
 def nhwc_bf16(x):
     """bf16, channels_last-contiguous view/copy of a [B,C,H,W] tensor."""
     if x.dtype != torch.bfloat16:
@@ -443,6 +510,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     """Convolution on the MFMA kernels.  Channel counts that are not a multiple of 8 (3-channel image,
     21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
     forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
+    if PRECISION == 'fp32':
+        if x.shape[1] != weight.shape[1] * groups:           # a producer's zero-padded channels: drop them
+            x = x[:, :weight.shape[1] * groups]
+        return Conv2dF32Function.apply(x, weight, bias, stride, padding, dilation, groups)
     Cout = weight.shape[0]
     if groups == 1 and x.shape[1] != weight.shape[1] and x.shape[1] == weight.shape[1] + (-weight.shape[1]) % 8:
         # the producer already zero-padded the channels to a multiple of 8 (part_ops.part_clean): pad the weight only
@@ -606,7 +677,7 @@ def multi_conv(convs, xs):
     import ctypes
     n = len(convs)
     L = _lib.lib()
-    ok = 1 <= n <= 4 and xs[0].is_cuda and all(c.bias is None and not c.out_fp32 and c.stride[0] == c.stride[1] and
+    ok = PRECISION != 'fp32' and 1 <= n <= 4 and xs[0].is_cuda and all(c.bias is None and not c.out_fp32 and c.stride[0] == c.stride[1] and
                                                 c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1] for c in convs)
     if ok:
         jobs = (_lib.ConvJob * n)()

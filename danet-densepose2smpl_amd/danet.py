@@ -122,7 +122,8 @@ class DaNet(nn.Module):
             pk = None
             if keep is not None:                                              # danet.py:264-274
                 pk = keep25[:, self._partial_src]                            # [B,24,7]
-            if FUSED_PART_OPS and part_pred.is_cuda:
+            from . import conv as _conv
+            if FUSED_PART_OPS and part_pred.is_cuda and _conv.PRECISION != 'fp32':
                 part_iuv_map, x24 = part_ops.part_clean(part_pred, pk)        # one kernel; bf16 view of the padded operand
                 part_iuv_map._nhwc_padded = x24
             else:

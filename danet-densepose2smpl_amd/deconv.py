@@ -60,4 +60,8 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         super().__init__(cin, cout, kernel, stride, padding, output_padding, bias=bias)
 
     def forward(self, x):
+        from . import conv as _conv
+        if _conv.PRECISION == 'fp32':                       # verification mode: the transposed conv as an fp32 tensor op
+            import torch.nn.functional as F
+            return F.conv_transpose2d(x.float(), self.weight, self.bias, self.stride, self.padding, self.output_padding)
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], self.output_padding[0])

@@ -223,7 +223,9 @@ class IUV_Estimator(nn.Module):
         est = self.iuv_est(data)
         u_pred, v_pred = est['predict_u'], est['predict_v']
         index_pred, ann_pred = est['predict_uv_index'], est['predict_ann_index']
-        fused = FUSED_GLOBAL_IUV and u_pred.is_cuda
+        from . import conv as _conv
+        fp32 = _conv.PRECISION == 'fp32'                     # verification mode: the tensor-op formulations throughout
+        fused = FUSED_GLOBAL_IUV and u_pred.is_cuda and not fp32
 
         uvia_list = None
         am_raw = None
@@ -290,7 +292,7 @@ class IUV_Estimator(nn.Module):
         rd['stn_kps_pred'] = centers.detach()
         part_maps = stn_gather(feat, thetas, align_corners=align)                       # [B,24*C,H,W]
         ppi = self.iuv_est.final_pred.predict_partial_iuv
-        if FUSED_PART_LOSSES and self.training and part_maps.is_cuda and ppi.out_channels == 24 * 21 and ppi.groups == 24:
+        if FUSED_PART_LOSSES and not fp32 and self.training and part_maps.is_cuda and ppi.out_channels == 24 * 21 and ppi.groups == 24:
             # keep the grouped conv's zero-padded output (24 channels per joint): the fused part ops read it as it is,
             # the [B,24,3,7,H,W] tensor of the reference is a strided view of it
             from .conv import conv2d
@@ -304,7 +306,7 @@ class IUV_Estimator(nn.Module):
             Sp = part_pred.size(-1)
             part_pred = part_pred.reshape(part_pred.size(0), 24, 3, -1, Sp, Sp)          # [B,24,3,7,H,W]
 
-        if self.training and iuv_image_gt is not None and FUSED_PART_LOSSES and part_pred.is_cuda and \
+        if self.training and iuv_image_gt is not None and FUSED_PART_LOSSES and not fp32 and part_pred.is_cuda and \
                 tuple(iuv_image_gt.shape[-2:]) == (Sp, Sp):
             # one kernel: ground-truth resampling + the three losses (no [B,24,3,7,H,W] fp32 intermediates);
             # rd['part_iuv_gt'] (visualisation only in the reference) is not materialised on this path

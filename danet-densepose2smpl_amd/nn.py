@@ -4,8 +4,10 @@ import ctypes
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
+from . import conv as _conv
 from ._lib import ptr, check, stream
 from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc, ARENA  # noqa: F401
 
@@ -105,6 +107,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         training = self.training or not self.track_running_stats
         if training:
             self._count()
+        if _conv.PRECISION == 'fp32':                       # verification mode: fp32 tensor ops
+            y = F.batch_norm(x.float(), self.running_mean if self.track_running_stats else None,
+                             self.running_var if self.track_running_stats else None, self.weight, self.bias, training,
+                             0.1 if self.momentum is None else self.momentum, self.eps)
+            if res is not None:
+                y = y + res.float()
+            return F.relu(y) if relu else y
         momentum = 0.1 if self.momentum is None else self.momentum
         fused = getattr(x, '_bn_sums', None) if training else None
         return BatchNormActFunction.apply(x, res, self.weight, self.bias,
@@ -194,7 +203,7 @@ def multi_batch_norm(bns, xs, ress=None, relu=False):
     falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
     n = len(bns)
     ress = list(ress) if ress is not None else [None] * n
-    ok = 1 <= n <= 4 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
+    ok = _conv.PRECISION != 'fp32' and 1 <= n <= 4 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
     if not ok:
         return [b(x, r, relu) for b, x, r in zip(bns, xs, ress)]
     mom = {0.1 if b.momentum is None else b.momentum for b in bns}
@@ -257,6 +266,12 @@ class SumReluFunction(torch.autograd.Function):
 
 def sum_relu(terms, shifts=None, relu=True):
     shifts = [0] * len(terms) if shifts is None else list(shifts)
+    if _conv.PRECISION == 'fp32':                           # verification mode: fp32 tensor ops
+        y = None
+        for t, sh in zip(terms, shifts):
+            t = t.float() if sh == 0 else F.interpolate(t.float(), scale_factor=2 ** sh, mode='nearest')
+            y = t if y is None else y + t
+        return F.relu(y) if relu else y
     return SumReluFunction.apply(relu, shifts, *terms)
 
 
@@ -297,6 +312,13 @@ class StnGatherFunction(torch.autograd.Function):
 
 def stn_gather(x, theta, out_hw=None, align_corners=True):
     out_hw = (x.shape[2], x.shape[3]) if out_hw is None else out_hw
+    if _conv.PRECISION == 'fp32':                           # verification mode: the reference's own op sequence (iuv_estimator.py:193-204)
+        B, C = x.shape[0], x.shape[1]
+        outs = []
+        for i in range(theta.shape[1]):
+            grid = F.affine_grid(theta[:, i].detach().float(), [B, C, out_hw[0], out_hw[1]], align_corners=align_corners)
+            outs.append(F.grid_sample(x.float(), grid, mode='bilinear', padding_mode='zeros', align_corners=align_corners))
+        return torch.cat(outs, dim=1)
     return StnGatherFunction.apply(x, theta, out_hw, align_corners)
 
 

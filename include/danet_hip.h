@@ -203,6 +203,12 @@ int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_
  * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red;
  *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; }  (no bias / ReLU / fp32 output);
  * all problems must run on the fast kernel with the same danet_conv_nt(Cout/groups): query danet_conv_forward_multi_ok. */
+/* fp32 verification convolution (csrc/conv_f32.hip; BASELINE config C4's arithmetic type, slow by design): NHWC fp32
+ * tensors, weights in torch's [Cout][Cin/groups][R][S] layout.  mode 0: out = conv(a = x, b = w) + bias; mode 1: out = dX
+ * from a = dY, b = w; mode 2: out = dW from a = x, b = dY.  (H, W, Cin) / (OH, OW, Cout) always describe x / y. */
+int danet_conv_f32(int mode, const float* a, const float* b, const float* bias, float* out,
+                   int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups,
+                   void* stream);
 int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
 /* Run-time knobs of the LDS-tile 3x3 kernel (A-B timing, tests): enable 0/1 (-1 keeps); force_mt/force_kw = register
  * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps); want_tiles = tiles per

@@ -1,0 +1,140 @@
+"""The fp32 verification mode (conv.precision('fp32'): convolutions on csrc/conv_f32.hip, glue as fp32 tensor ops --
+BASELINE config C4's arithmetic type) against the reference's own fp32 golden vectors (tests/golden/g6, g7, g9: produced
+by importing /root/reference, see make_golden.py).  What the bf16 path can only show within its rounding noise
+(tests/test_gpu_models.py: relative RMS < 0.35 through ~90 layers) is pinned here at fp32 tolerance: every structural
+claim -- layer wiring, padding / stride / group arithmetic, BatchNorm modes, fuse layers, STN decomposition, losses,
+the regressor and its GCN -- to <= 1e-3 of the output scale, losses to <= 1e-4 relative, gradients to <= 1e-2."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, GOLDEN
+sys.path.insert(0, GOLDEN)
+from make_golden import formula_params, formula_input, damp_residual_branches    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
+
+
+def _cfg(**kw):
+    from danet_densepose2smpl_amd.config import reset_cfg, cfg_from_dict
+    reset_cfg()
+    cfg_from_dict(kw)
+
+
+def _rel(a, ref):
+    ref = np.asarray(ref, np.float32)
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-6))
+
+
+@pytest.mark.parametrize('shape', [(48, 48, 3, 1, 1, 1, 20, 12), (64, 128, 3, 2, 1, 1, 17, 17), (3, 64, 7, 2, 3, 1, 32, 32),
+                                   (48 * 4, 21 * 4, 3, 1, 1, 4, 8, 8), (96, 48, 1, 1, 0, 1, 8, 8), (16, 16, 3, 1, 2, 1, 9, 9)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_fp32_conv_kernels_vs_torch(shape):
+    """forward, data gradient, weight gradient and bias gradient of csrc/conv_f32.hip vs F.conv2d in fp32
+    (the last shape uses dilation 2 through the low-level call)."""
+    from danet_densepose2smpl_amd import conv
+    Cin, Cout, k, stride, pad, groups, H, W = shape
+    dil = 2 if (Cin, pad) == (16, 2) else 1
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(3, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin // groups, k, k, generator=g) / np.sqrt(k * k * Cin / groups)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride, pad, dil, groups)
+    gy = torch.randn(yr.shape, generator=g).cuda()
+    yr.backward(gy)
+    xt, wt, bt = (t.clone().requires_grad_(True) for t in (x, w, b))
+    with conv.precision('fp32'):
+        y = conv.conv2d(xt, wt, bt, stride, pad, dil, groups)
+        y.backward(gy)
+    assert y.dtype == torch.float32
+    for a, r, name in ((y, yr, 'y'), (xt.grad, xr.grad, 'dx'), (wt.grad, wr.grad, 'dw'), (bt.grad, br.grad, 'db')):
+        assert _rel(a, r.detach().cpu().numpy()) < 2e-5, name
+
+
+@pytest.mark.parametrize('name,cls', [('g6_hrnet', 'hrnet'), ('g6_poseresnet', 'resnet')])
+def test_backbones_fp32_vs_reference_golden(name, cls):
+    _cfg(**{'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16})
+    from danet_densepose2smpl_amd import hrnet, resnet, conv
+    g = golden(name)
+    net = (hrnet.PoseHighResolutionNet if cls == 'hrnet' else resnet.PoseResNet)(part_out_dim=7)
+    formula_params(net)
+    if cls == 'resnet':
+        damp_residual_branches(net)
+    net = net.cuda().train()
+    img = torch.from_numpy(g['img']).cuda().requires_grad_(True)
+    with conv.precision('fp32'):
+        out = net(img)
+        for k in KEYS:
+            o = out[k] if (k != 'xd' or cls == 'hrnet') else out[k][:, ::4]
+            assert o.dtype == torch.float32 and _rel(o, g[k]) < 1e-3, (k, _rel(o, g[k]))
+        loss = sum((out[k].float() * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32, device='cuda').view_as(out[k]) * 0.37)).sum() for k in KEYS[:5])
+        loss.backward()
+    gw = {k: p.grad for k, p in net.named_parameters()}
+    checked = 0
+    for k in g.files:
+        if k.startswith('grad__'):
+            nm = k[len('grad__'):].replace('__', '.')
+            if nm in gw and gw[nm] is not None:
+                assert _rel(gw[nm], g[k]) < 1e-2, (nm, _rel(gw[nm], g[k]))
+                checked += 1
+    assert checked >= 3
+    assert _rel(net.bn1.running_mean, g['bn1_running_mean']) < 1e-4
+
+
+@pytest.mark.parametrize('align', [0, 1])
+def test_iuv_estimator_fp32_vs_reference_golden(align):
+    _cfg(**{'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16, 'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.,
+            'DANET.PARTDROP_RATE': 0., 'DANET.ALIGN_CORNERS': bool(align)})
+    from danet_densepose2smpl_amd.iuv_estimator import IUV_Estimator
+    from danet_densepose2smpl_amd import conv
+    g = golden('g7_estimator_align%d' % align)
+    est = IUV_Estimator(pretrained=False)
+    formula_params(est, skip=('learned_ratio', 'learned_offset', '_'))
+    with torch.no_grad():
+        est.learned_ratio.copy_(torch.from_numpy(g['learned_ratio']))
+        est.learned_offset.copy_(torch.from_numpy(g['learned_offset']))
+    est = est.cuda().train()
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    with conv.precision('fp32'):
+        rd = est(t('img'), t('iuv_gt'), t('kps'), has_iuv=torch.ones(2, device='cuda'))
+    for a, k in zip(rd['uvia_pred'], ('u', 'v', 'index', 'ann')):
+        assert _rel(a, g[k]) < 1e-3, (k, _rel(a, g[k]))
+    assert np.abs(rd['stn_kps_pred'].cpu().numpy() - g['stn_kps_pred']).max() < 1e-4
+    assert _rel(rd['part_iuv_pred'], g['part_iuv_pred']) < 1e-3
+    assert np.abs(rd['part_iuv_gt'].cpu().numpy() - g['part_iuv_gt']).max() < 1e-4
+    n = 0
+    for k in g.files:
+        if k.startswith('loss__'):
+            ours, ref = float(rd['losses'][k[6:]].detach().sum()), float(g[k].sum())
+            assert abs(ours - ref) <= 1e-4 * abs(ref) + 1e-6, (k, ours, ref)
+            n += 1
+    assert n >= 8
+
+
+def test_decomposed_predictor_fp32_vs_reference_golden():
+    _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from danet_densepose2smpl_amd.smpl_regressor import DecomposedPredictor
+    from danet_densepose2smpl_amd import conv
+    g = golden('g9_predictor')
+    pose6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(24).unsqueeze(0)
+    net = DecomposedPredictor(None, (torch.tensor([[0.9, 0., 0.]]), torch.zeros(1, 10), pose6), pretrained=False)
+    formula_params(net, skip=('mean_', 'I_n', 'A_link', 'A_mask', 'A', 'r2p_A', 'p2r_A'))
+    net = net.cuda()
+    iuv = formula_input('g9.iuv', (4, 75, 64, 64)).cuda()
+    part = formula_input('g9.part', (4, 24, 3, 7, 64, 64)).cuda()
+    with conv.precision('fp32'):
+        net.train()
+        rd = net(iuv, part)
+        assert np.abs(rd['para'].detach().cpu().numpy() - g['para_train']).max() < 1e-3
+        assert _rel(rd['joint_position'][0], g['jp0']) < 1e-3 and _rel(rd['joint_position'][1], g['jp1']) < 1e-3
+        assert np.abs(rd['joint_rotation'][0].detach().cpu().numpy() - g['jr0']).max() < 1e-3
+        net.eval()
+        with torch.no_grad():
+            pe = net(iuv, part)['para']
+    assert np.abs(pe.cpu().numpy() - g['para_eval']).max() < 1e-3
