@@ -188,7 +188,78 @@ def g3_graph():
     save('g3_graph', A_smpl=g1, A_smpl2=g2, Ar=Ar, und=und, dig_da=dig0, dig_ad=dig1, hm=hm, softint=si)
 
 
-ALL = {'g1': g1_geometry, 'g2': g2_iuvmap, 'g3': g3_graph}
+
+def g4_gcn():
+    """models/module/GCN.py GCN(128, 256, 128, 3, 24) -- output, input gradient and weight
+    gradients, with the refinement adjacency of DecomposedPredictor (utils/graph.py:232-261)."""
+    ref_env()
+    from models.module.GCN import GCN
+    net = GCN(128, 256, 128, 3, 24)
+    formula_params(net)
+    net.train()
+    x = formula_input('g4.x', (4, 24, 128), -1.0, 1.0).requires_grad_(True)
+    A = torch.from_numpy(np.load(os.path.join(HERE, 'g3_graph.npz'))['und'])
+    y = net(x, A)
+    w = formula_input('g4.w', tuple(y.shape), -1.0, 1.0)
+    (y * w).sum().backward()
+    grads = {('grad__' + k.replace('.', '__')): p.grad for k, p in net.named_parameters()}
+    save('g4_gcn', A=A, y=y, x_grad=x.grad, **grads)
+
+
+def g5_layers():
+    """single layers / blocks of the reference's own modules (res_module.py:27-97,
+    hr_module.py:15-179), train-mode BatchNorm, B = 2: output, input gradient, sentinel weight gradients, BatchNorm
+    running statistics after the step."""
+    ref_env({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16})
+    from models.module.res_module import BasicBlock, Bottleneck
+    from models.module.hr_module import HighResolutionModule
+    import torch.nn as nn
+    out = {}
+
+    def run(tag, mod, xs):
+        formula_params(mod)
+        mod.train()
+        xs = [x.clone().requires_grad_(True) for x in xs]
+        ys = mod(list(xs) if len(xs) > 1 else xs[0])
+        ys = ys if isinstance(ys, (list, tuple)) else [ys]
+        loss = 0
+        for i, y in enumerate(ys):
+            loss = loss + (y * formula_input('%s.w%d' % (tag, i), tuple(y.shape), -1.0, 1.0)).sum()
+        loss.backward()
+        for i, y in enumerate(ys):
+            out['%s__y%d' % (tag, i)] = y.detach()
+        for i, x in enumerate(xs):
+            out['%s__dx%d' % (tag, i)] = x.grad
+        for k, p in mod.named_parameters():
+            if p.grad is not None and p.dim() in (1, 4):
+                out['%s__grad__%s' % (tag, k.replace('.', '__'))] = p.grad
+        for k, b in mod.named_buffers():
+            if k.endswith('running_mean') or k.endswith('running_var'):
+                out['%s__buf__%s' % (tag, k.replace('.', '__'))] = b.detach().clone()
+
+    run('basic48', BasicBlock(48, 48), [formula_input('g5.basic48', (2, 48, 16, 16), -1.0, 1.0)])
+    ds = nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256, momentum=0.1))
+    run('bottle64', Bottleneck(64, 64, 1, ds), [formula_input('g5.bottle64', (2, 64, 16, 16), -1.0, 1.0)])
+    ds24 = nn.Sequential(nn.Conv2d(256 * 24, 128 * 24, 1, 2, bias=False, groups=24), nn.BatchNorm2d(128 * 24, momentum=0.1))
+    run('basic_g24', BasicBlock(256, 128, 2, ds24, groups=24), [formula_input('g5.basic_g24', (2, 256 * 24, 4, 4), -1.0, 1.0)])
+    hrm = HighResolutionModule(2, BasicBlock, [4, 4], [48, 96], [48, 96], 'SUM', True)
+    run('hrm2', hrm, [formula_input('g5.hrm2a', (2, 48, 16, 16), -1.0, 1.0), formula_input('g5.hrm2b', (2, 96, 8, 8), -1.0, 1.0)])
+    for (ci, co, k, st, pd, gr, hw) in [(48, 96, 3, 2, 1, 1, 16), (384, 48, 1, 1, 0, 1, 4), (3, 64, 3, 2, 1, 1, 32), (64, 64, 7, 2, 3, 1, 16)]:
+        run('conv_%d_%d_k%d_s%d' % (ci, co, k, st), nn.Conv2d(ci, co, k, st, pd, groups=gr, bias=False), [formula_input('g5.conv%d%d%d' % (ci, co, k), (2, ci, hw, hw), -1.0, 1.0)])
+    # keep the fixture small: arrays beyond 16k elements are stored as a strided sample of the flattened tensor
+    # (key suffix __s<stride>; the test takes the same sample)
+    small = {}
+    for k, v in out.items():
+        v = v.detach()
+        if v.numel() > 16384:
+            stride = (v.numel() + 8191) // 8192
+            small['%s__s%d' % (k, stride)] = v.flatten()[::stride].clone()
+        else:
+            small[k] = v
+    save('g5_layers', **small)
+
+
+ALL = {'g1': g1_geometry, 'g2': g2_iuvmap, 'g3': g3_graph, 'g4': g4_gcn, 'g5': g5_layers}
 
 # ----------------------------------------------------------------------------------------------
 # network-level fixtures (parameters = formula_params, so only inputs/outputs are stored)
