@@ -62,6 +62,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--dtype', choices=('bf16', 'fp32'), default='bf16',
+                    help='fp32: BASELINE config C4\'s arithmetic on the verification kernels (csrc/conv_f32.hip, eager launches; a correctness configuration, not a performance one)')
     ap.add_argument('--force-ddp', action='store_true', help='diagnostic: run the N > 1 code path (GradReducer + eager Adam) on a 1-rank group')
     return ap.parse_args()
 
@@ -149,6 +151,39 @@ def geometry_rooflines(tr, B, size, dev):
             mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 
+def fp32_line(args, tr, batch, world, rank, dev):
+    """BASELINE config C4 (full train step in fp32): the same model and step on the fp32 verification kernels."""
+    from danet_densepose2smpl_amd import conv
+    with conv.precision('fp32'):
+        for _ in range(min(args.warmup, 1)):
+            tr.train_step(batch)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.time()
+        steps = min(args.steps, 3)
+        for _ in range(steps):
+            _, losses = tr.train_step(batch)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        B = args.batch
+        print(json.dumps({'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(world * B * steps / elapsed, 3),
+                          'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': min(args.warmup, 1),
+                          'ms_per_step': round(elapsed / steps * 1e3, 1), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'f32', 'data': 'synthetic', 'exec': 'eager',
+                          'config': {'workload': 'BASELINE config C4 arithmetic: the full DaNet train step in fp32 on the verification kernels '
+                                                 '(direct fp32 convolutions, fp32 tensor-op glue) -- a correctness configuration, not tuned',
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world},
+                          'finite_losses': bool(all(torch.isfinite(v).all() for v in losses.values())), 'roofline': None}), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -178,6 +213,11 @@ def main():
     B = args.batch
     tr = Trainer(default_options(B), device=dev, distributed=world > 1 or args.force_ddp)
     batch = synthetic_in_dict(tr.model, B, dev, seed=1234 + rank)
+    if args.dtype == 'fp32':
+        fp32_line(args, tr, batch, world, rank, dev)
+        if world > 1 or args.force_ddp:
+            dist.destroy_process_group()
+        return
 
     def sync():
         torch.cuda.synchronize(dev)
