@@ -39,7 +39,7 @@ _SIGNATURES = {
     'danet_conv_forward_multi_ok': (c_i, [c_f, c_i]),
     'danet_conv_forward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_conv_forward_kernel': (c_i, [c_i] * 15),
-    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6),
+    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 7),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
     'danet_conv_wgrad_multi_ws_floats': (c_sz, [c_f, c_i]),
@@ -102,7 +102,7 @@ class BnBwdJob(ctypes.Structure):
 
 class ConvJob(ctypes.Structure):
     """One problem of danet_conv_forward_multi (include/danet_hip.h)."""
-    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'wp', 'y', 'bn_sums', 'bn_x', 'bn_y', 'bn_saved', 'bn_red')] + \
+    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'wp', 'y', 'bn_sums', 'bn_x', 'bn_y', 'bn_saved', 'bn_red', 'addend')] + \
                [(k, c_i) for k in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'R', 'S', 'stride', 'pad', 'dil', 'groups', 'transposed')]
 
 

@@ -299,7 +299,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32,
-                  bn_sums=None, bn_bwd=None):
+                  bn_sums=None, bn_bwd=None, addend=None):
     """bn_bwd = (bn_x, bn_y or None, saved, red): data-gradient launches also reduce the BatchNorm-backward
     sums of the BN that produced the conv's input (see include/danet_hip.h)."""
     L = _lib.lib()
@@ -317,7 +317,7 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
                                None if bn_bwd is None else ptr(bn_bwd[0].permute(0, 2, 3, 1)),
                                None if bn_bwd is None or bn_bwd[1] is None else ptr(bn_bwd[1].permute(0, 2, 3, 1)),
                                None if bn_bwd is None else ptr(bn_bwd[2]), None if bn_bwd is None else ptr(bn_bwd[3]),
-                               stream()), 'danet_conv_forward')
+                               None if addend is None else ptr(addend.permute(0, 2, 3, 1)), stream()), 'danet_conv_forward')
     if tok is not None:
         PROFILER.end(tok)
     if TRACE is not None:
@@ -325,9 +325,20 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     return y
 
 
+class ResLink(object):
+    """Carries the residual branch's gradient of a block (`out += residual`, res_module.py:39-56) from the closing
+    BatchNorm's backward to the data gradient of the block's first convolution, whose epilogue adds it -- instead of
+    autograd summing the two gradients of the block input in a pass of its own.  One per block and forward pass."""
+    __slots__ = ('dres', 'armed')
+
+    def __init__(self):
+        self.dres = None
+        self.armed = False        # set by the convolution that will consume dres in its backward (otherwise the BatchNorm keeps autograd's path)
+
+
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None, bn_ctx=None):
+    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None, bn_ctx=None, link=None):
         x = nhwc_bf16(x)
         B, Cin, H, W = x.shape
         Cout, Cin_g, R, S = weight.shape
@@ -340,6 +351,9 @@ class Conv2dFunction(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
         ctx.bn_ctx = bn_ctx
+        ctx.link = link
+        if link is not None and ctx.needs_input_grad[0]:
+            link.armed = True
         return y
 
     @staticmethod
@@ -370,13 +384,20 @@ class Conv2dFunction(torch.autograd.Function):
                     if red is None:
                         red = torch.zeros(n, dtype=torch.float32, device=x.device)
                     bn_bwd = (bn_x, bn_y, saved, red)
+            addend = None
+            if ctx.link is not None and ctx.link.dres is not None:
+                addend, ctx.link.dres = ctx.link.dres, None
+            fused_add = addend is not None and addend.shape == x.shape and \
+                L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 2
             gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
-                               None, bn_bwd)
+                               None, bn_bwd, addend if fused_add else None)
+            if addend is not None and not fused_add:
+                gx = gx + addend
             if bn_bwd is not None:
                 gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32)      # fp32 accumulation without a converted copy of gy
-        return gx, gw, gb, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches
@@ -506,7 +527,7 @@ def _pad_channels_nhwc(x, mult=8):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False, want_stats=False,
-           keep_group_padding=False):
+           keep_group_padding=False, link=None):
     """Convolution on the MFMA kernels.  Channel counts that are not a multiple of 8 (3-channel image,
     21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
     forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
@@ -546,16 +567,17 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     # the BatchNorm that produced x (if any) leaves its tensors on x: the data gradient then also reduces that
     # BatchNorm's backward sums (saves one pass over dy, x, y per BatchNorm with a single consumer)
     bn_ctx = getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and torch.is_grad_enabled()) else None
-    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums, bn_ctx)
+    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums, bn_ctx, link)
     if sums is not None:
         y._bn_sums = sums              # picked up by the BatchNorm2d that consumes y (nn.BatchNorm2d.forward)
     return y
 
 
-def _conv_job(job, x, wp, y, dims, transposed, bn_sums=None, bn_bwd=None):
+def _conv_job(job, x, wp, y, dims, transposed, bn_sums=None, bn_bwd=None, addend=None):
     (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims
     job.x, job.wp, job.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     job.bn_sums = None if bn_sums is None else bn_sums.data_ptr()
+    job.addend = None if addend is None else addend.data_ptr()
     if bn_bwd is None:
         job.bn_x = job.bn_y = job.bn_saved = job.bn_red = None
     else:
@@ -574,7 +596,7 @@ class MultiConvFunction(torch.autograd.Function):
     def forward(ctx, static, *tensors):
         import ctypes
         L = _lib.lib()
-        n, cfgs, want_stats, bn_ctxs = static
+        n, cfgs, want_stats, bn_ctxs, links = static
         xs = [nhwc_bf16(t) for t in tensors[:n]]
         ws = tensors[n:2 * n]
         jobs = (_lib.ConvJob * n)()
@@ -606,7 +628,11 @@ class MultiConvFunction(torch.autograd.Function):
             for y, d in zip(ys, dims_l):
                 TRACE.append(('conv', (d[0], d[1], d[2], d[3], d[6], d[7], d[9]), y.float().abs().mean()))
         ctx.save_for_backward(*xs, *ws)
-        ctx.cfg = (n, dims_l, bn_ctxs)
+        ctx.cfg = (n, dims_l, bn_ctxs, links)
+        if links is not None:
+            for i, lk in enumerate(links):
+                if lk is not None and ctx.needs_input_grad[1 + i]:
+                    lk.armed = True
         for y, sums in zip(ys, sums_l):
             if sums is not None:
                 y._bn_sums = sums
@@ -616,7 +642,7 @@ class MultiConvFunction(torch.autograd.Function):
     def backward(ctx, *gys):
         import ctypes
         L = _lib.lib()
-        n, dims_l, bn_ctxs = ctx.cfg
+        n, dims_l, bn_ctxs, links = ctx.cfg
         sv = ctx.saved_tensors
         xs, ws = sv[:n], sv[n:2 * n]
         gys = [nhwc_bf16(g) for g in gys]
@@ -630,7 +656,7 @@ class MultiConvFunction(torch.autograd.Function):
         need = [i for i in range(n) if ctx.needs_input_grad[1 + i]]
         if need:
             jobs = (_lib.ConvJob * len(need))()
-            keep, reds = [], []
+            keep, reds, adds = [], [], []
             for k, i in enumerate(need):
                 (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
                 wp1 = pack_weight(ws[i], groups, 1)
@@ -643,8 +669,14 @@ class MultiConvFunction(torch.autograd.Function):
                     if red is None:
                         red = torch.zeros(nfl, dtype=torch.float32, device=gx.device)
                     bn_bwd = (bn_x, xs[i] if bn_relu else None, saved, red)
+                addend = None
+                if links is not None and links[i] is not None and links[i].dres is not None:
+                    addend, links[i].dres = links[i].dres, None
+                    if addend.shape != xs[i].shape:
+                        raise RuntimeError('residual gradient shape %s != %s' % (tuple(addend.shape), tuple(xs[i].shape)))
+                adds.append(addend)
                 # data gradient = the transposed gather: roles of (H, W, Cin) and (OH, OW, Cout) swap
-                _conv_job(jobs[k], gys[i], wp1, gx, (B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups), True, None, bn_bwd)
+                _conv_job(jobs[k], gys[i], wp1, gx, (B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups), True, None, bn_bwd, addend)
                 gxs[i] = gx
                 reds.append(None if bn_bwd is None else bn_bwd[3])
                 keep.append(wp1)
@@ -664,6 +696,8 @@ class MultiConvFunction(torch.autograd.Function):
                 for k, i in enumerate(need):
                     (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
                     gxs[i] = _conv_fwd_raw(gys[i], keep[k], None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
+                    if adds[k] is not None:
+                        gxs[i] = gxs[i] + adds[k]
             if TRACE is not None:
                 for i in need:
                     d = dims_l[i]
@@ -671,7 +705,7 @@ class MultiConvFunction(torch.autograd.Function):
         return (None, *gxs, *gws)
 
 
-def multi_conv(convs, xs):
+def multi_conv(convs, xs, links=None):
     """[conv(x) for conv, x in zip(convs, xs)] for up to 4 bias-free Conv2d modules in one launch per pass; falls back
     to the per-module path when the set does not qualify (channel padding, bias, mixed tile counts, fp32 outputs)."""
     import ctypes
@@ -692,11 +726,11 @@ def multi_conv(convs, xs):
                 (B, H, W, Cin, conv_out_size(H, R, st, pd, dl), conv_out_size(W, S, st, pd, dl), Cout, R, S, st, pd, dl, c.groups, 0)
         ok = ok and bool(L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), n))
     if not ok:
-        return [c(x) for c, x in zip(convs, xs)]
+        return [c(x, link=None if links is None else links[i]) for i, (c, x) in enumerate(zip(convs, xs))]
     grad = torch.is_grad_enabled()
     cfgs = [(c.stride[0], c.padding[0], c.dilation[0], c.groups) for c in convs]
     bn_ctxs = [getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and grad) else None for x in xs]
-    static = (n, cfgs, all(c.training for c in convs), bn_ctxs)
+    static = (n, cfgs, all(c.training for c in convs), bn_ctxs, links)
     return list(MultiConvFunction.apply(static, *xs, *[c.weight for c in convs]))
 
 
@@ -708,10 +742,10 @@ class Conv2d(nn.Conv2d):
         assert self.padding_mode == 'zeros'
         self.out_fp32 = out_fp32
 
-    def forward(self, x):
+    def forward(self, x, link=None):
         s, p, d = self.stride, self.padding, self.dilation
         if s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
             raise ValueError('danet Conv2d supports square stride/padding/dilation only')
         # in training the epilogue also accumulates the BatchNorm statistics of the output (consumed by the
         # following BatchNorm2d; ignored otherwise)
-        return conv2d(x, self.weight, self.bias, s[0], p[0], d[0], self.groups, self.out_fp32, want_stats=self.training)
+        return conv2d(x, self.weight, self.bias, s[0], p[0], d[0], self.groups, self.out_fp32, want_stats=self.training, link=link)

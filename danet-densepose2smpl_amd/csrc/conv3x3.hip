@@ -41,6 +41,7 @@ constexpr int C3_MAXP = 4;
 struct C3Prob {
     const bf16_t* x; const bf16_t* w; void* y; const float* bias; float* stats;
     const bf16_t* bn_x; const bf16_t* bn_y; const float* bn_saved; float* bn_red;
+    const bf16_t* addend;     // optional bf16 tensor shaped like y, added before the output is rounded (residual-branch gradient)
     int B, H, W, Cin, Cout, Cout_pad;
     int flip, relu, out_fp32;
     int TH, NI, Wp, S, Sp, tiles_h, npt, nnb, nks, nc16;
@@ -52,7 +53,7 @@ struct C3Prob {
     int* dbg;                 // optional [blocks][8] phase timestamps of each workgroup's last tile (tools/c3_bench.py)
 };
 
-struct C3Launch { C3Prob p[C3_MAXP]; int n; int total; };
+struct C3Launch { C3Prob p[C3_MAXP]; int n; int total; int stagger; };
 
 __device__ inline unsigned udiv24(unsigned n, unsigned d, float rcp) {      // n < 2^24
     unsigned q = (unsigned)((float)n * rcp);
@@ -396,6 +397,12 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
                         const int mt = qq * MO + m;
                         const int off = (cok && outoff[mt] != OOB) ? outoff[mt] : OOB;
                         f32x4 v = acc[mt][nt] + bv;
+                        if (p.addend) {
+                            const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.addend), 0, p.y_bytes, 0x00020000);
+                            const i32x2 aq = __builtin_amdgcn_raw_buffer_load_b64(ar, off, so, 0);
+                            v[0] += __uint_as_float((unsigned)aq.x << 16); v[1] += __uint_as_float((unsigned)aq.x & 0xffff0000u);
+                            v[2] += __uint_as_float((unsigned)aq.y << 16); v[3] += __uint_as_float((unsigned)aq.y & 0xffff0000u);
+                        }
                         if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         if (p.out_fp32) {
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, off, so, 0);
@@ -458,6 +465,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(C3Launch L)
     // one tile list over all problems, workgroup b takes tiles b, b + grid, ...: measured faster than giving every
     // problem its own range of workgroups (44 vs 51 us for the four HRNet branches at B = 32)
     const int bid = blockIdx.x, nblk = gridDim.x;
+    // the second workgroup of every CU (ids >= 256) starts late by about half a tile period: from then on one workgroup of a
+    // CU computes while the other loads / stores, instead of both being in the same phase all the time
+    if (bid >= 256) for (int i = 0; i < L.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     // ... and every workgroup visits the problems in its own rotation (the two workgroups of a CU, ids 256 apart, are one
     // problem apart): 45.5 -> 44.3 us
     const int rot = (bid + bid / 256) % L.n;
@@ -479,6 +489,7 @@ template <int MT, int NT, int KW>
 __global__ __launch_bounds__(256, 2) void conv3x3_one_kernel(C3Launch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
+    if (blockIdx.x >= 256) for (int i = 0; i < L.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     c3_body<MT, NT, KW>(L.p[0], blockIdx.x, gridDim.x, c3_smem);
 }
 
@@ -504,6 +515,7 @@ int g_c3_blocks = getenv("DANET_C3_BLOCKS") ? atoi(getenv("DANET_C3_BLOCKS")) : 
 int g_c3_want = getenv("DANET_C3_WANT") ? atoi(getenv("DANET_C3_WANT")) : 0;     // tiles per problem the planner aims for (0: 512 / problems)
 Forced forced_cfg() { return g_force; }
 int* g_dbg = nullptr;
+int g_c3_stagger = getenv("DANET_C3_STAGGER") ? atoi(getenv("DANET_C3_STAGGER")) : 0;   // x 8128 cycles
 
 constexpr int LDS_TWO = 81920;        // two workgroups per CU
 constexpr int LDS_ONE = 160 * 1024;
@@ -618,6 +630,7 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
         C3Prob& q = L.p[i];
         q.x = p.x; q.w = p.w; q.y = p.y; q.bias = p.bias; q.stats = p.stats;
         q.bn_x = p.bn_x; q.bn_y = p.bn_y; q.bn_saved = p.bn_saved; q.bn_red = p.bn_red;
+        q.addend = p.addend;
         q.B = p.B; q.H = p.OH; q.W = p.OW; q.Cin = p.Cin; q.Cout = p.Cout; q.Cout_pad = p.Cout_pad;
         q.flip = p.transposed; q.relu = p.relu; q.out_fp32 = p.out_fp32;
         q.x_bytes = (int)p.x_bytes; q.y_bytes = (int)p.y_bytes;
@@ -629,6 +642,7 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
         if (lds > lds_max) lds_max = lds;
     }
     L.total = tile0;
+    L.stagger = g_c3_stagger;
     if (n > 1) for (int i = 0; i < n; ++i) if (!multi_has(L.p[i].cfg)) return -1;
     if (dry) {
         if (n == 1) { const int c = L.p[0].cfg, mt = c / 100, nt = (c / 10) % 10, kw = c % 10; return ((mt == 4 && nt >= 1 && nt <= 4) || (mt == 8 && nt == 3)) && (kw == 1 || kw == 2 || kw == 4) ? 0 : -1; }

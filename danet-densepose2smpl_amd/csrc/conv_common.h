@@ -33,6 +33,7 @@ struct ConvP {
     // sum(dy' * xhat) with dy' = dy * (bn_y > 0) under ReLU, xhat = (bn_x - mean) * invstd, bn_saved = [mean[Cout] | invstd[Cout]]
     const bf16_t* bn_x; const bf16_t* bn_y; const float* bn_saved; float* bn_red;
     long x_bytes, y_bytes;   // extents of the gathered / written tensors (buffer resources of conv_fast.hip)
+    const bf16_t* addend;    // optional (LDS-tile 3x3 kernel only): bf16 tensor shaped like y, added before rounding
 };
 
 // conv_fast.hip: the lean kernel for the common cases (conv_igemm.hip keeps the general one)

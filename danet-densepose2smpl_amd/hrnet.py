@@ -14,7 +14,7 @@ from .config import cfg
 from .nn import sum_relu, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
-from .conv import multi_conv
+from .conv import multi_conv, ResLink
 
 blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
 
@@ -98,10 +98,12 @@ class HighResolutionModule(nn.Module):
         xs = list(x[:self.num_branches])
         for k in range(len(self.branches[0])):
             blocks = [br[k] for br in self.branches]
-            h = multi_conv([b.conv1 for b in blocks], xs) if LOCKSTEP_CONVS else [b.conv1(v) for b, v in zip(blocks, xs)]
+            # identity shortcuts: their gradients ride on ResLinks into conv1's data-gradient epilogue (resnet.BasicBlock)
+            links = [ResLink() if (v.requires_grad and torch.is_grad_enabled()) else None for v in xs]
+            h = multi_conv([b.conv1 for b in blocks], xs, links) if LOCKSTEP_CONVS else [b.conv1(v, link=lk) for b, v, lk in zip(blocks, xs, links)]
             h = multi_batch_norm([b.bn1 for b in blocks], h, None, relu=True)
             h = multi_conv([b.conv2 for b in blocks], h) if LOCKSTEP_CONVS else [b.conv2(v) for b, v in zip(blocks, h)]
-            xs = multi_batch_norm([b.bn2 for b in blocks], h, xs, relu=True)
+            xs = multi_batch_norm([b.bn2 for b in blocks], h, xs, relu=True, links=links)
         return xs
 
     def _branches_on_streams(self, x):

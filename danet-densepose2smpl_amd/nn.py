@@ -16,7 +16,7 @@ class BatchNormActFunction(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ res]) on NHWC bf16; training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, fused_sums=None):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, fused_sums=None, link=None):
         L = _lib.lib()
         x = nhwc_bf16(x)
         B, C, H, W = x.shape
@@ -45,6 +45,7 @@ class BatchNormActFunction(torch.autograd.Function):
             ctx.save_for_backward(x, y if relu else None, g, saved)
             ctx.relu = relu
             ctx.has_res = res is not None
+            ctx.link = link
             ctx.has_affine = gamma is not None
         ctx.training = training
         from . import conv as _c
@@ -85,7 +86,10 @@ class BatchNormActFunction(torch.autograd.Function):
             _c.TRACE.append(('bn_bwd' + ('+red' if red_zero == 2 else ''), tuple(x.shape), dx.float().abs().mean()))
         # unbind gives two independent-looking tensors that AccumulateGrad can keep without a clone
         dbeta, dgamma = (dparam[0], dparam[1]) if ctx.has_affine else (None, None)
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        link = getattr(ctx, 'link', None)
+        if link is not None and link.armed and dres is not None:
+            link.dres, dres = dres, None          # the block's first convolution adds it in its data-gradient epilogue (conv.ResLink)
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -103,7 +107,7 @@ class BatchNorm2d(nn.BatchNorm2d):
             else:
                 BatchNorm2d._ran.append(self.num_batches_tracked)
 
-    def forward(self, x, res=None, relu=False):
+    def forward(self, x, res=None, relu=False, link=None):
         training = self.training or not self.track_running_stats
         if training:
             self._count()
@@ -119,7 +123,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         return BatchNormActFunction.apply(x, res, self.weight, self.bias,
                                           self.running_mean if self.track_running_stats else None,
                                           self.running_var if self.track_running_stats else None,
-                                          training, momentum, self.eps, relu, fused)
+                                          training, momentum, self.eps, relu, fused, link if training else None)
 
 
 class MultiBatchNormFunction(torch.autograd.Function):
@@ -130,7 +134,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, static, *tensors):
         L = _lib.lib()
-        n, relu, momentum, eps, rms, rvs, fused = static
+        n, relu, momentum, eps, rms, rvs, fused, links = static
         xs = [nhwc_bf16(t) for t in tensors[:n]]
         ress = [None if t is None else nhwc_bf16(t) for t in tensors[n:2 * n]]
         gammas = [t.detach().float().contiguous() for t in tensors[2 * n:3 * n]]
@@ -160,7 +164,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
             saveds.append(saved)
         check(L.danet_bn_forward_multi(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
         ctx.save_for_backward(*xs, *ys, *gammas, *saveds)
-        ctx.cfg = (n, relu, [r is not None for r in ress])
+        ctx.cfg = (n, relu, [r is not None for r in ress], links)
         for y, x, saved in zip(ys, xs, saveds):
             y._bn_ctx = (x, bool(relu), saved)
         return tuple(ys)
@@ -168,7 +172,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gys):
         L = _lib.lib()
-        n, relu, has_res = ctx.cfg
+        n, relu, has_res, links = ctx.cfg
         sv = ctx.saved_tensors
         xs, ys, gammas, saveds = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
         jobs = (_lib.BnBwdJob * n)()
@@ -195,27 +199,32 @@ class MultiBatchNormFunction(torch.autograd.Function):
             dress.append(dres)
             dparams.append(dparam)
         check(L.danet_bn_backward_multi(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
+        if links is not None:
+            for i, lk in enumerate(links):
+                if lk is not None and lk.armed and dress[i] is not None:
+                    lk.dres, dress[i] = dress[i], None      # added by the block's first convolution's data gradient (conv.ResLink)
         return (None, *dxs, *dress, *[d[1] for d in dparams], *[d[0] for d in dparams])
 
 
-def multi_batch_norm(bns, xs, ress=None, relu=False):
+def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     """[bn(x, res, relu) for bn, x, res in ...] for up to 4 training-mode BatchNorm2d modules in one launch per pass;
     falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
     n = len(bns)
     ress = list(ress) if ress is not None else [None] * n
     ok = _conv.PRECISION != 'fp32' and 1 <= n <= 4 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
+    lks = list(links) if links is not None else [None] * n
     if not ok:
-        return [b(x, r, relu) for b, x, r in zip(bns, xs, ress)]
+        return [b(x, r, relu, link=lk) for b, x, r, lk in zip(bns, xs, ress, lks)]
     mom = {0.1 if b.momentum is None else b.momentum for b in bns}
     eps = {b.eps for b in bns}
     if len(mom) != 1 or len(eps) != 1:
-        return [b(x, r, relu) for b, x, r in zip(bns, xs, ress)]
+        return [b(x, r, relu, link=lk) for b, x, r, lk in zip(bns, xs, ress, lks)]
     for b in bns:
         b._count()
     rms = [b.running_mean if b.track_running_stats else None for b in bns]
     rvs = [b.running_var if b.track_running_stats else None for b in bns]
     fused = [getattr(x, '_bn_sums', None) for x in xs]
-    static = (n, bool(relu), mom.pop(), eps.pop(), rms, rvs, fused)
+    static = (n, bool(relu), mom.pop(), eps.pop(), rms, rvs, fused, links)
     return list(MultiBatchNormFunction.apply(static, *xs, *ress, *[b.weight for b in bns], *[b.bias for b in bns]))
 
 

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from .config import cfg
 from .nn import Conv2d, BatchNorm2d, relu as relu_op
+from .conv import ResLink
 from .deconv import ConvTranspose2d
 
 BN_MOMENTUM = 0.1
@@ -48,8 +49,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), res=residual, relu=True)
+        # identity shortcut: its gradient rides on a ResLink into conv1's data-gradient epilogue (no separate add pass)
+        link = ResLink() if (self.downsample is None and x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else None
+        out = self.bn1(self.conv1(x, link=link), relu=True)
+        return self.bn2(self.conv2(out), res=residual, relu=True, link=link)
 
 
 class Bottleneck(nn.Module):

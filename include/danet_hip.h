@@ -170,6 +170,9 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      LDS-tile kernel (csrc/conv3x3.hip: halo tile staged once in LDS, taps = LDS address offsets, K-split across
  *      the waves of a workgroup for small-M layers); danet_conv_forward / danet_conv_forward_multi pick it by
  *      themselves, danet_conv_forward_kernel reports it (last digit 2).
+ *      addend (optional, LDS-tile 3x3 kernel with bf16 output only): a bf16 tensor shaped like y that is added before the
+ *      result is rounded -- a data-gradient launch thereby accumulates the residual branch's gradient (the `out += residual`
+ *      of res_module.py:39-56 in backward) instead of leaving the sum to a separate pass.
  *  danet_conv_forward       y = conv(x, wp) (+bias[Cout])(ReLU); y is bf16 or fp32 NHWC.
  *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
@@ -200,7 +203,7 @@ long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long sta
                               int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
 int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream);
 /* Up to 4 independent convolutions (forward or data gradient) in one launch -- HRNet branches in lockstep.
- * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red;
+ * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red; const void* addend;
  *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; }  (no bias / ReLU / fp32 output);
  * all problems must run on the fast kernel with the same danet_conv_nt(Cout/groups): query danet_conv_forward_multi_ok. */
 /* fp32 verification convolution (csrc/conv_f32.hip; BASELINE config C4's arithmetic type, slow by design): NHWC fp32
@@ -225,7 +228,7 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
                        int relu, int out_fp32, float* bn_sums,
-                       const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, void* stream);
+                       const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, const void* addend, void* stream);
 /* 3x3 / stride 1 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);

@@ -82,11 +82,25 @@ def _build(tag):
 TAGS = ['basic48', 'bottle64', 'basic_g24', 'hrm2', 'conv_48_96_k3_s2', 'conv_384_48_k1_s1', 'conv_3_64_k3_s2', 'conv_64_64_k7_s2']
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16-gather'])
 @pytest.mark.parametrize('tag', TAGS)
 def test_block_vs_reference_module_golden(tag, mode):
-    from danet_densepose2smpl_amd import conv
+    """'bf16-gather': the 3x3 layers pinned to the gather kernel (conv_fast.hip) -- also the path on which the residual
+    gradient (conv.ResLink) is added by a tensor op instead of the LDS-tile kernel's epilogue."""
+    from danet_densepose2smpl_amd import conv, _lib
     _cfg()
+    if mode == 'bf16-gather':
+        prev = _lib.lib().danet_conv3x3_set(0, -1, -1, 0, -1)
+        try:
+            _run_block_case(tag, 'bf16')
+        finally:
+            _lib.lib().danet_conv3x3_set(prev, -1, -1, 0, -1)
+    else:
+        _run_block_case(tag, mode)
+
+
+def _run_block_case(tag, mode):
+    from danet_densepose2smpl_amd import conv
     g = golden('g5_layers')
     mod, inputs = _build(tag)
     formula_params(mod)
