@@ -47,6 +47,39 @@ def normalize_digraph(A, AD_mode=True):
     return A * d[None, :] if AD_mode else d[:, None] * A
 
 
+class GraphConvFunction(torch.autograd.Function):
+    """y = (adj @ x) @ W (+ bias) for x [B,N,C], adj [N,N] (GCN.py:29-41).  The forward products are what autograd would
+    run; the backward is written out because autograd's weight and adjacency gradients are single GEMMs with a tiny
+    output and a long reduction (e.g. [256, B*24] x [B*24, 256], [24, B*C] x [B*C, 24]) that the BLAS library runs on ONE
+    workgroup (50-180 us each at B = 32): here the reduction is split over the batch (bmm) and summed."""
+
+    @staticmethod
+    def forward(ctx, x, adj, weight, bias):
+        ax = torch.matmul(adj, x)
+        y = torch.matmul(ax, weight)
+        if bias is not None:
+            y = y + bias
+        ctx.save_for_backward(x, adj, weight, ax)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, adj, weight, ax = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = dadj = dw = db = None
+        dax = torch.matmul(gy, weight.t())                                   # [B,N,C]
+        if ctx.needs_input_grad[2]:
+            dw = torch.bmm(ax.transpose(1, 2), gy).sum(0)                    # split-K over the batch
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = gy.sum(dim=(0, 1))
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(adj.t(), dax)
+        if ctx.needs_input_grad[1]:
+            dadj = torch.bmm(dax, x.transpose(1, 2)).sum(0)
+        return dx, dadj, dw, db
+
+
 class GraphConv(nn.Module):
     def __init__(self, input_dim, output_dim, bias=True):
         super().__init__()
@@ -54,6 +87,8 @@ class GraphConv(nn.Module):
         self.bias = nn.Parameter(torch.empty(output_dim)) if bias else None
 
     def forward(self, x, adj):
+        if x.dim() == 3 and adj.dim() == 2:
+            return GraphConvFunction.apply(x, adj, self.weight, self.bias)
         y = torch.matmul(torch.matmul(adj, x), self.weight)
         return y if self.bias is None else y + self.bias
 
