@@ -67,6 +67,10 @@ _SIGNATURES = {
     'danet_iuv_global_backward': (c_i, [c_f] * 4 + [c_i, c_i] + [c_f] * 6 + [c_i] * 4 + [c_f] * 5),
     'danet_softargmax_forward': (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),
     'danet_softargmax_backward': (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f, c_f]),
+    'danet_smpl_loss_param_bytes': (c_sz, []),
+    'danet_smpl_loss_grad_bytes': (c_sz, []),
+    'danet_smpl_loss_forward': (c_i, [c_f] * 5),
+    'danet_smpl_loss_backward': (c_i, [c_f] * 5),
     'danet_adam_chunk_bytes': (c_sz, []),
     'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),

@@ -30,6 +30,7 @@ UNITS = {
     'conv_f32.hip': ['-ffp-contract=off'],
     'part_ops.hip': [],
     'iuv_ops.hip': [],
+    'loss_ops.hip': [],
     'adam.hip': [],
     'norm_act.hip': [],
     'stn.hip': [],

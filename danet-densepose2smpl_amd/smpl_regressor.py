@@ -44,6 +44,9 @@ def _pool_conv1x1_grouped(cin, cout, groups):
     return seq
 
 
+FUSED_SMPL_LOSSES = True    # SMPL-side losses through csrc/loss_ops.hip (False: the tensor-op formulation below)
+
+
 def _masked_mean(per_sample_sum, mask, per_sample_count):
     """sum_b m_b * s_b / (sum_b m_b * count)  (0 when no sample is selected)."""
     m = mask.to(torch.float32)
@@ -115,11 +118,40 @@ class SMPL_Regressor(nn.Module):
             rd['losses']['Rs_orth'] = orth * D.ORTHOGONAL_WEIGHTS
             rd['metrics']['orth'] = rd['losses']['Rs_orth'].detach()
 
+        gt_rotmat = target[:, 13:].reshape(B, 24, 3, 3)
+        pred_camera, pred_betas = para[:, :3], para[:, 3:13]
+        pred_rotmat = para[:, 13:].reshape(B, 24, 3, 3)
+        fused = FUSED_SMPL_LOSSES and para.is_cuda and len(out['joint_rotation']) <= 2 and \
+            len(out.get('joint_position', ())) <= 2 and D.JOINT_POSITION_WEIGHTS > 0
+        if fused:
+            # every loss below in one op (csrc/loss_ops.hip): two launches forward, one backward
+            from . import loss_ops
+            with torch.no_grad():
+                gt_pts = self.smpl(betas=target[:, 3:13].contiguous(), body_pose=gt_rotmat[:, 1:].contiguous(),
+                                   global_orient=gt_rotmat[:, :1].contiguous(), pose2rot=False).smpl_joints
+            pred = self.smpl(betas=pred_betas, body_pose=pred_rotmat[:, 1:], global_orient=pred_rotmat[:, :1], pose2rot=False)
+            pred_vertices, pred_joints = pred.vertices, pred.joints
+            w = {'SMPL_POSE': D.SMPL_POSE_WEIGHTS, 'JOINT_POSITION': D.JOINT_POSITION_WEIGHTS, 'PROJ_KPS': D.PROJ_KPS_WEIGHTS,
+                 'KPS3D': D.KPS3D_WEIGHTS, 'SMPL_BETAS': D.SMPL_BETAS_WEIGHTS, 'VERTS': D.VERTS_WEIGHTS}
+            rd['losses'].update(loss_ops.smpl_losses(
+                para, out['joint_rotation'], out.get('joint_position', []), pred_joints, pred_vertices, target, gt_pts, target_vertices,
+                target_kps, target_kps3d, has_smpl, has_kp3d, self.focal_length, D.INIMG_SIZE,
+                self.options.openpose_train_weight, self.options.gt_train_weight, w))
+            with torch.no_grad():
+                pred_cam_t = torch.stack([pred_camera[:, 1], pred_camera[:, 2],
+                                          2 * self.focal_length / (D.INIMG_SIZE * pred_camera[:, 0] + 1e-9)], dim=-1)
+            rd['prediction']['vertices'] = pred_vertices
+            rd['prediction']['cam_t'] = pred_cam_t
+            for key in ('losses', 'metrics'):
+                for k, v in rd[key].items():
+                    if v.dim() == 0:
+                        rd[key][k] = v.unsqueeze(0)
+            return rd
+
         for i, rot in enumerate(out['joint_rotation']):                                 # smpl_regressor.py:147-155
             s = ((rot - target[:, 13:]) ** 2).sum(dim=1)
             rd['losses']['joint_rotation%d' % i] = _masked_mean(s, has_smpl, 216) * D.SMPL_POSE_WEIGHTS
 
-        gt_rotmat = target[:, 13:].reshape(B, 24, 3, 3)
         if 'joint_position' in out and D.JOINT_POSITION_WEIGHTS > 0:                    # :157-166
             with torch.no_grad():
                 gt_pts = self.smpl(betas=target[:, 3:13].contiguous(), body_pose=gt_rotmat[:, 1:].contiguous(),
@@ -127,8 +159,6 @@ class SMPL_Regressor(nn.Module):
             for i, pos in enumerate(out['joint_position']):
                 rd['losses']['joint_position%d' % i] = self.l1_losses(pos, gt_pts, has_smpl) * D.JOINT_POSITION_WEIGHTS
 
-        pred_camera, pred_betas = para[:, :3], para[:, 3:13]
-        pred_rotmat = para[:, 13:].reshape(B, 24, 3, 3)
         pred = self.smpl(betas=pred_betas, body_pose=pred_rotmat[:, 1:], global_orient=pred_rotmat[:, :1], pose2rot=False)
         pred_vertices, pred_joints = pred.vertices, pred.joints
         # weak perspective (s,tx,ty) -> translation (:182-193)

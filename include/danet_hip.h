@@ -129,6 +129,21 @@ int danet_softargmax_backward(const float* hm, int ld, int B, int J, int H, int 
                               const float* gout, float* dhm, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * SMPL-side losses of the regressor (csrc/loss_ops.hip; models/danet/smpl_regressor.py:141-218,233-298): joint_rotation{0,1},
+ * joint_position{0,1}, keypoints_2d (weak-perspective camera -> translation -> pin-hole projection), keypoints_3d (pelvis-
+ * centred), smpl_pose, smpl_betas, smpl_verts, cam -- masked means over the rows selected by has_smpl / has_kp3d, times
+ * the yaml weights.  `params` / `grads` are HOST structs of device pointers and scalars:
+ *   params { const float* para, *target [B,229]; const float* jrot[2] [B,216]; const float* jpos[2] [B,72]; const float* gt_pts [B,72];
+ *            const float* joints [B,49,3], *verts, *tverts [B,V,3] (verts NULL when its weight is 0); const float* kps2d [B,49,3],
+ *            *kps3d [B,24,4], *has_smpl, *has_kp3d [B]; int B, V; float focal, img, op_w, gt_w; float w[10], cnt[10]; }
+ *   grads  { float* dpara; float* djrot[2]; float* djpos[2]; float* djoints; float* dverts; }   (shapes of the inputs; NULL = skip)
+ * forward: ps [B,10] scratch, out [10] losses, norm [10] (feeds the backward); backward: gout [10]. */
+size_t danet_smpl_loss_param_bytes(void);
+size_t danet_smpl_loss_grad_bytes(void);
+int danet_smpl_loss_forward(const void* params, float* ps, float* out, float* norm, void* stream);
+int danet_smpl_loss_backward(const void* params, const float* gout, const float* norm, const void* grads, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimizer (replaces torch.optim.Adam at /root/reference/train/trainer.py:42-44): one launch over a device table of
  * <= 32768-element chunks { float* p; const float* g (NULL = skip); int64 off (into m, v); int32 n; int32 pad }.
  * lr and step (1-based count, float) are read from device memory; p, g, m+off, v+off 16-byte aligned.  grad_scale

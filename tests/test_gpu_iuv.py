@@ -140,3 +140,70 @@ def test_softargmax_vs_reference_golden_and_autograd():
     (rb * gout).sum().backward()
     assert (ra - rb).abs().max().item() <= 1e-4
     assert (a.grad - b.grad).abs().max().item() <= 1e-5 * a.grad.abs().max().item() + 1e-8
+
+
+def test_fused_smpl_losses_vs_reference_golden_and_tensor_ops():
+    """csrc/loss_ops.hip: (a) the reference's own loss values (g10: smpl_losses, keypoint_loss, keypoint_3d_loss, shape_loss,
+    l1_losses of smpl_regressor.py:233-298) for the golden inputs; (b) forward AND gradients of all ten terms against the
+    tensor-op formulation of smpl_regressor.SMPL_Regressor on random inputs with partially selected rows."""
+    from danet_densepose2smpl_amd import loss_ops
+    from danet_densepose2smpl_amd.smpl_regressor import SMPL_Regressor as R, _masked_mean
+    from danet_densepose2smpl_amd.geometry import perspective_projection
+    _cfg()
+    gen = torch.Generator().manual_seed(11)
+    B, V = 6, 50
+    rnd = lambda *s: torch.randn(*s, generator=gen).cuda()
+    para = torch.cat([torch.rand(B, 1, generator=gen).cuda() * 0.5 + 0.6, rnd(B, 2) * 0.1, rnd(B, 10), rnd(B, 216) * 0.5], 1)
+    target = torch.cat([rnd(B, 3), rnd(B, 10), rnd(B, 216) * 0.5], 1)
+    jr0, jp0, jp1, gt_pts = rnd(B, 216) * 0.5, rnd(B, 24, 3), rnd(B, 24, 3), rnd(B, 24, 3)
+    joints, verts, tverts = rnd(B, 49, 3) * 0.3, rnd(B, V, 3), rnd(B, V, 3)
+    kps2d = torch.cat([rnd(B, 49, 2) * 0.5, torch.rand(B, 49, 1, generator=gen).cuda()], 2)
+    kps3d = torch.cat([rnd(B, 24, 3) * 0.3, torch.rand(B, 24, 1, generator=gen).cuda()], 2)
+    has_smpl = torch.tensor([1., 0., 1., 1., 0., 1.]).cuda()
+    has_kp3d = torch.tensor([0., 1., 1., 0., 1., 1.]).cuda()
+    W = {'SMPL_POSE': 60., 'JOINT_POSITION': 1., 'PROJ_KPS': 300., 'KPS3D': 300., 'SMPL_BETAS': 0.06, 'VERTS': 0.7}
+    f, S, opw, gtw = 5000., 224., 0.25, 1.0
+
+    def ref(para, jr0, jp0, jp1, joints, verts):
+        cam, betas, rot = para[:, :3], para[:, 3:13], para[:, 13:].reshape(B, 24, 3, 3)
+        gt_rot = target[:, 13:].reshape(B, 24, 3, 3)
+        out = {}
+        out['joint_rotation0'] = _masked_mean(((jr0 - target[:, 13:]) ** 2).sum(1), has_smpl, 216) * W['SMPL_POSE']
+        out['joint_position0'] = R.l1_losses(jp0, gt_pts, has_smpl) * W['JOINT_POSITION']
+        out['joint_position1'] = R.l1_losses(jp1, gt_pts, has_smpl) * W['JOINT_POSITION']
+        cam_t = torch.stack([cam[:, 1], cam[:, 2], 2 * f / (S * cam[:, 0] + 1e-9)], -1)
+        kp = perspective_projection(joints, None, cam_t, f, torch.zeros(B, 2, device='cuda')) / (S / 2.)
+        lp, lb = R.smpl_losses(rot, betas, gt_rot, target[:, 3:13], has_smpl)
+        out['keypoints_2d'] = R.keypoint_loss(kp, kps2d, opw, gtw) * W['PROJ_KPS']
+        out['keypoints_3d'] = R.keypoint_3d_loss(joints, kps3d, has_kp3d) * W['KPS3D']
+        out['smpl_pose'], out['smpl_betas'] = lp * W['SMPL_POSE'], lb * W['SMPL_BETAS']
+        out['smpl_verts'] = R.shape_loss(verts, tverts, has_smpl) * W['VERTS']
+        out['cam'] = (torch.exp(-cam[:, 0] * 10) ** 2).mean()
+        return out
+    leaves_r = [t.clone().requires_grad_(True) for t in (para, jr0, jp0, jp1, joints, verts)]
+    leaves_m = [t.clone().requires_grad_(True) for t in (para, jr0, jp0, jp1, joints, verts)]
+    r = ref(*leaves_r)
+    m = loss_ops.smpl_losses(leaves_m[0], [leaves_m[1]], [leaves_m[2], leaves_m[3]], leaves_m[4], leaves_m[5], target, gt_pts, tverts,
+                             kps2d, kps3d, has_smpl, has_kp3d, f, S, opw, gtw, W)
+    assert set(m) == set(r)
+    coef = {k: 0.3 + 0.1 * i for i, k in enumerate(sorted(r))}
+    sum(r[k] * coef[k] for k in r).backward()
+    sum(m[k] * coef[k] for k in m).backward()
+    for k in r:
+        assert abs(float(m[k]) - float(r[k])) <= 2e-5 * abs(float(r[k])) + 1e-7, (k, float(m[k]), float(r[k]))
+    for a, b_, name in zip(leaves_m, leaves_r, 'para jrot0 jpos0 jpos1 joints verts'.split()):
+        assert (a.grad - b_.grad).abs().max().item() <= 2e-5 * b_.grad.abs().max().item() + 1e-7, name
+
+    # the reference's own values for its golden inputs (rows selected by has_smpl / has_kp3d)
+    g = golden('g10_losses')
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    Bg = 6
+    para_g = torch.cat([torch.ones(Bg, 3).cuda(), t('pb'), t('pred_rot').reshape(Bg, 216)], 1)
+    target_g = torch.cat([torch.zeros(Bg, 3).cuda(), t('gb'), t('gt_rot')], 1)
+    z = torch.zeros
+    out = loss_ops.smpl_losses(para_g, [para_g[:, 13:]], [t('a'), t('a')], t('pj'), t('pv'), target_g, t('b'), t('gv'),
+                               torch.zeros(Bg, 49, 3).cuda(), t('g3'), t('has_smpl').float(), t('has_kp3d').float(), f, S, 0.25, 1.0,
+                               {'SMPL_POSE': 1., 'JOINT_POSITION': 1., 'PROJ_KPS': 1., 'KPS3D': 1., 'SMPL_BETAS': 1., 'VERTS': 1.})
+    for k, gk in (('smpl_pose', 'loss_pose'), ('joint_rotation0', 'loss_pose'), ('smpl_betas', 'loss_betas'), ('keypoints_3d', 'loss_kp3d'),
+                  ('smpl_verts', 'loss_verts'), ('joint_position0', 'loss_l1')):
+        np.testing.assert_allclose(float(out[k]), float(g[gk]), rtol=1e-5, err_msg=k)
