@@ -63,13 +63,15 @@ class SmplLossFunction(torch.autograd.Function):
         check(L.danet_smpl_loss_forward(ctypes.addressof(p), ps.data_ptr(), out.data_ptr(), norm.data_ptr(), stream()), 'danet_smpl_loss_forward')
         ctx.p, ctx.keep, ctx.norm = p, ts, norm
         ctx.shapes = [None if t is None else t.shape for t in (para, jrot0, jrot1, jpos0, jpos1, joints, verts)]
-        return out
+        return tuple(out[i] for i in range(NT))          # ten 0-dim views: no select / select-backward launches downstream
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, *gouts):
         L = _lib.lib()
         ts, p = ctx.keep, ctx.p
-        dev = gout.device
+        dev = ctx.norm.device
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        gout = torch.stack([zero if g is None else g.to(torch.float32).reshape(()) for g in gouts])
         mk = lambda t: None if t is None else torch.empty_like(t)      # noqa: E731
         dpara, djr0, djr1, djp0, djp1, djo = mk(ts['para']), mk(ts['jrot0']), mk(ts['jrot1']), mk(ts['jpos0']), mk(ts['jpos1']), mk(ts['joints'])
         dve = mk(ts['verts'])
@@ -101,4 +103,4 @@ def smpl_losses(para, joint_rotation, joint_position, joints, verts, target, gt_
     out = SmplLossFunction.apply(para, jr[0], jr[1], jp[0], jp[1], joints, verts if weights['VERTS'] != 0 else None, const)
     present = {'joint_rotation0': jr[0] is not None, 'joint_rotation1': jr[1] is not None, 'joint_position0': jp[0] is not None,
                'joint_position1': jp[1] is not None}
-    return {k: out[i] for i, k in enumerate(KEYS) if present.get(k, True)}
+    return {k: out[i] for i, k in enumerate(KEYS) if present.get(k, True)}       # (out: tuple of ten 0-dim tensors)

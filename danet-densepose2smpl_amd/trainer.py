@@ -200,7 +200,8 @@ class Trainer(object):
             BatchNorm2d.count_batches = True
         bump_batch_counters(self.model)
         losses = out['losses']
-        loss_total = torch.stack([v.sum() for v in losses.values()]).sum()
+        # (every loss is a 1-element tensor, models/danet/danet.py:359-364: views + one cat + one sum)
+        loss_total = torch.cat([v.reshape(-1) for v in losses.values()]).sum()
         self.optimizer.zero_grad(set_to_none=True)
         _conv.GRAD_STORE = st
         _conv.DEFER_WGRAD = DEFER_WGRAD
