@@ -60,6 +60,13 @@ FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '1')))   # dgr
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 TRACE = None           # debugging: a list that receives (tag, shape, mean |value|) for every conv / BN launch (tools/debug_flaky.py)
+
+# How often each attribute-carried fusion was taken / missed since the last FUSION.clear().  The fusions ride on
+# tensor attributes (_bn_sums, _bn_ctx, _bn_red) and ResLink objects, which vanish silently if a view or copy gets
+# in between; Trainer.capture() snapshots these counts for the captured step (trainer.fusion_counts) and
+# tests/test_gpu_models.py asserts them, so a refactor that breaks a fusion fails a test instead of losing time.
+import collections as _collections
+FUSION = _collections.Counter()
 PROFILER = None        # set by bench.py: object with begin(key, flops) -> token / end(token)
 
 
@@ -391,8 +398,10 @@ class Conv2dFunction(torch.autograd.Function):
                 L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 2
             gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
                                None, bn_bwd, addend if fused_add else None)
-            if addend is not None and not fused_add:
-                gx = gx + addend
+            if addend is not None:
+                FUSION['residual_grad_fused' if fused_add else 'residual_grad_added'] += 1
+                if not fused_add:
+                    gx = gx + addend
             if bn_bwd is not None:
                 gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
@@ -692,11 +701,14 @@ class MultiConvFunction(torch.autograd.Function):
                 for k, i in enumerate(need):
                     if reds[k] is not None:
                         gxs[i]._bn_red = reds[k]
+                    if adds[k] is not None:
+                        FUSION['residual_grad_fused'] += 1
             else:                                   # e.g. tile counts differ between the problems: per-layer launches
                 for k, i in enumerate(need):
                     (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
                     gxs[i] = _conv_fwd_raw(gys[i], keep[k], None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
                     if adds[k] is not None:
+                        FUSION['residual_grad_added'] += 1
                         gxs[i] = gxs[i] + adds[k]
             if TRACE is not None:
                 for i in need:

@@ -48,9 +48,8 @@ class BatchNormActFunction(torch.autograd.Function):
             ctx.link = link
             ctx.has_affine = gamma is not None
         ctx.training = training
-        from . import conv as _c
-        if _c.TRACE is not None:
-            _c.TRACE.append(('bn', tuple(x.shape), y.float().abs().mean()))
+        if _conv.TRACE is not None:
+            _conv.TRACE.append(('bn', tuple(x.shape), y.float().abs().mean()))
         if training:
             y._bn_ctx = (x, bool(relu), saved)     # lets a consumer conv fuse this BN's backward reduction (no reference to y: no cycle)
         return y
@@ -68,6 +67,7 @@ class BatchNormActFunction(torch.autograd.Function):
         dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
         dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
         red = getattr(gy_in, '_bn_red', None)        # reduced by the consumer conv's data-gradient epilogue (conv.py)
+        _conv.FUSION['bn_bwd_reduce_fused' if red is not None else 'bn_bwd_reduce_own'] += 1
         if red is not None:
             red_zero = 2
         else:
@@ -81,9 +81,8 @@ class BatchNormActFunction(torch.autograd.Function):
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
                                   None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero), stream()),
               'danet_bn_backward')
-        from . import conv as _c
-        if _c.TRACE is not None:
-            _c.TRACE.append(('bn_bwd' + ('+red' if red_zero == 2 else ''), tuple(x.shape), dx.float().abs().mean()))
+        if _conv.TRACE is not None:
+            _conv.TRACE.append(('bn_bwd' + ('+red' if red_zero == 2 else ''), tuple(x.shape), dx.float().abs().mean()))
         # unbind gives two independent-looking tensors that AccumulateGrad can keep without a clone
         dbeta, dgamma = (dparam[0], dparam[1]) if ctx.has_affine else (None, None)
         link = getattr(ctx, 'link', None)
@@ -120,6 +119,8 @@ class BatchNorm2d(nn.BatchNorm2d):
             return F.relu(y) if relu else y
         momentum = 0.1 if self.momentum is None else self.momentum
         fused = getattr(x, '_bn_sums', None) if training else None
+        if training:
+            _conv.FUSION['bn_stats_fused' if fused is not None else 'bn_stats_own'] += 1
         return BatchNormActFunction.apply(x, res, self.weight, self.bias,
                                           self.running_mean if self.track_running_stats else None,
                                           self.running_var if self.track_running_stats else None,
@@ -180,6 +181,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
         for i in range(n):
             B, C, H, W = xs[i].shape
             red = getattr(gys[i], '_bn_red', None)
+            _conv.FUSION['bn_bwd_reduce_fused' if red is not None else 'bn_bwd_reduce_own'] += 1
             state = 2
             if red is None:
                 red, state = ARENA.alloc(L.danet_bn_ws_floats(C)), 1
@@ -224,6 +226,8 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     rms = [b.running_mean if b.track_running_stats else None for b in bns]
     rvs = [b.running_var if b.track_running_stats else None for b in bns]
     fused = [getattr(x, '_bn_sums', None) for x in xs]
+    for f in fused:
+        _conv.FUSION['bn_stats_fused' if f is not None else 'bn_stats_own'] += 1
     static = (n, bool(relu), mom.pop(), eps.pop(), rms, rvs, fused, links)
     return list(MultiBatchNormFunction.apply(static, *xs, *ress, *[b.weight for b in bns], *[b.bias for b in bns]))
 

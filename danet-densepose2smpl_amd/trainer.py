@@ -268,12 +268,14 @@ class Trainer(object):
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
+            conv.FUSION.clear()
             try:
                 # thread_local: the communication library's watchdog thread may poll events of earlier collectives while
                 # this thread captures (the default, global mode turns that into a capture error)
                 with torch.cuda.graph(graph, stream=self.stream, capture_error_mode='thread_local' if self.distributed else 'global'):
                     self._static_out = self._core(self._static, reduce=in_graph, with_optimizer=in_graph)
                 self._reduce_in_graph = in_graph
+                self.fusion_counts = dict(conv.FUSION)      # which attribute-carried fusions the captured step contains
                 break
             except RuntimeError:
                 if not in_graph:

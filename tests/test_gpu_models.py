@@ -265,6 +265,12 @@ def test_danet_resnet50_inference_config2(B):
     assert (part == iuv[:, 0] * 24).all() and part.min() >= 0 and part.max() <= 24        # integer-valued part-index plane
 
 
+# measured on the bench configuration (round 2); the bounds leave a little room for deliberate changes
+# (measured: bn_stats 337 fused / 6 own, bn_bwd_reduce 235 fused / 108 own, residual_grad 110 fused / 4 added)
+FUSION_MIN = {'bn_stats_fused': 330, 'bn_bwd_reduce_fused': 225, 'residual_grad_fused': 105}
+FUSION_MAX = {'residual_grad_added': 8, 'bn_stats_own': 12}
+
+
 def test_full_size_graphed_step_properties():
     """The bench configuration itself (B = 32, 256x256, hipGraph replay): the losses of a replay are finite and equal to
     the eager step's on the same batch and weights (learning rate ~0) within the bf16 noise of the atomics' summation
@@ -296,6 +302,15 @@ def test_full_size_graphed_step_properties():
             assert p.grad.data_ptr() == tr.store.grad_ptr(p), n
     uv = tr.model.iuv_renderer.verts2uvimg(batch['target_verts'], batch['target_cam'])
     assert uv.shape == (32, 3, 64, 64) and (torch.round(uv[:, 0] * 24) == uv[:, 0] * 24).all()
+    # the attribute-carried fusions really are in the captured graph (conv.FUSION; they vanish silently if a view or
+    # a copy gets between producer and consumer)
+    fc = tr.fusion_counts
+    print('fusion counts of the captured step:', fc)
+    assert fc.get('bn_stats_fused', 0) >= FUSION_MIN['bn_stats_fused'], fc
+    assert fc.get('bn_bwd_reduce_fused', 0) >= FUSION_MIN['bn_bwd_reduce_fused'], fc
+    assert fc.get('residual_grad_fused', 0) >= FUSION_MIN['residual_grad_fused'], fc
+    assert fc.get('residual_grad_added', 0) <= FUSION_MAX['residual_grad_added'], fc
+    assert fc.get('bn_stats_own', 0) <= FUSION_MAX['bn_stats_own'], fc
 
 
 def test_graphed_step_matches_eager_step():
