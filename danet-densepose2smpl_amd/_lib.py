@@ -50,11 +50,11 @@ _SIGNATURES = {
     'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 6 + [c_fl, c_i, c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
-    'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f]),
+    'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
-    'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f]),
+    'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f]),
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
@@ -94,14 +94,14 @@ class WgJob(ctypes.Structure):
 
 class BnFwdJob(ctypes.Structure):
     """One tensor of danet_bn_forward_multi (csrc/norm_act.hip)."""
-    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'res', 'y', 'gamma', 'beta', 'running_mean', 'running_var', 'saved', 'sums')] + \
+    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'res', 'y', 'gamma', 'beta', 'running_mean', 'running_var', 'saved', 'sums', 'mask')] + \
                [('M', ctypes.c_int64), ('C', c_i), ('sums_state', c_i), ('relu', c_i)]
 
 
 class BnBwdJob(ctypes.Structure):
     """One tensor of danet_bn_backward_multi."""
-    _fields_ = [(k, ctypes.c_void_p) for k in ('dy', 'x', 'y', 'gamma', 'saved', 'dx', 'dres', 'dparam', 'red')] + \
-               [('M', ctypes.c_int64), ('C', c_i), ('red_state', c_i), ('relu', c_i)]
+    _fields_ = [(k, ctypes.c_void_p) for k in ('dy', 'x', 'y', 'gamma', 'saved', 'dx', 'dres', 'dparam', 'red', 'beta', 'mask')] + \
+               [('M', ctypes.c_int64), ('C', c_i), ('red_state', c_i), ('relu', c_i), ('mask_mode', c_i)]
 
 
 class ConvJob(ctypes.Structure):

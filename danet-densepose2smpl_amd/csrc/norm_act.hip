@@ -65,6 +65,13 @@ __device__ inline void stv(__amdgpu_buffer_rsrc_t r, int off, const Vec& a) {
     __builtin_amdgcn_raw_buffer_store_b64(q, r, off, 0, 0);
 }
 
+// ReLU gate of the backward passes (mask_mode): 0 = from the saved output (y > 0); 1 = from the byte mask the forward
+// wrote (one byte per lane-run of VW channels, bit j = y_j > 0: the residual case, where y cannot be recomputed
+// without reading the residual); 2 = recomputed from x with the forward's own expression fmaf(x, sc, sh) (no
+// residual).  Modes 1 and 2 save the read of y: 1/5 .. 1/4 of the backward traffic.
+__device__ inline int ldmask(__amdgpu_buffer_rsrc_t r, int off) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off >> 3, 0, 0); }
+__device__ inline void stmask(__amdgpu_buffer_rsrc_t r, int off, int m) { __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, r, off >> 3, 0, 0); }
+
 struct RowIter {
     int row, off, rstep, ostride, M;
     __device__ inline void init(const FlatMap& fm, int bid, int t, int& cv) {
@@ -146,12 +153,13 @@ __device__ __forceinline__ void bn_apply_body(
     const int bid, const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved /* [2][Cst] mean, invstd */,
-    int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu)
+    int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu, unsigned char* __restrict__ mask)
 {
     const int t = threadIdx.x;
     const int C = Cst;
     __shared__ float sStat[2][SLAB];
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes), rr = make_rsrc(res ? res : x, fm.bytes), yr = make_rsrc(y, fm.bytes);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask ? (const void*)mask : (const void*)x, mask ? fm.bytes >> 3 : 0);
     int cv = 0; RowIter it; it.init(fm, bid, t < fm.span ? t : 0, cv);
     Vec a[UNR], r[UNR];
     int o[UNR];
@@ -181,7 +189,7 @@ __device__ __forceinline__ void bn_apply_body(
         const float invstd = rsqrtf(var + eps);
         const float g = gamma ? gamma[c0 + j] : 1.f, b = beta ? beta[c0 + j] : 0.f;
         sc[j] = invstd * g;
-        sh[j] = b - mean * sc[j];
+        sh[j] = fmaf(-mean, sc[j], b);
         if (mode == 0 && bid == 0 && t < fm.CV) {
             if (saved) { saved[c0 + j] = mean; saved[C + c0 + j] = invstd; }
             if (running_mean) {
@@ -192,27 +200,33 @@ __device__ __forceinline__ void bn_apply_body(
     }
     while (it.more()) {
         Vec outv[UNR];
-        int oo[UNR];
+        int oo[UNR], mb[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             oo[u] = o[u];
+            mb[u] = 0;
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
-                float v = a[u].v[j] * sc[j] + sh[j];
+                float v = fmaf(a[u].v[j], sc[j], sh[j]);           // (the backward's mask_mode 2 repeats exactly this)
                 if (res) v += r[u].v[j];
+                mb[u] |= (v > 0.f ? 1 : 0) << j;
                 outv[u].v[j] = relu ? fmaxf(v, 0.f) : v;
             }
         }
         it.next();
         if (it.more()) fetch();
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) stv(yr, oo[u], outv[u]);
+        for (int u = 0; u < UNR; ++u) {
+            stv(yr, oo[u], outv[u]);
+            if (mask) stmask(mr, oo[u], mb[u]);
+        }
     }
 }
 
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const int bid, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */)
+    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */,
+    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
 {
     __shared__ float sm[256][VW];
     const int t = threadIdx.x;
@@ -221,26 +235,36 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
 #pragma unroll
     for (int j = 0; j < VW; ++j) { s1.v[j] = 0.f; s2.v[j] = 0.f; }
     if (t < fm.span) {
-        const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(relu ? y : x, fm.bytes);
+        const bool from_y = relu && mask_mode == 0;
+        const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(from_y ? y : x, fm.bytes);
+        const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> 3 : 0);
         int cv; RowIter it; it.init(fm, bid, t, cv);
         const int c0 = cv * VW;
-        float mean[VW], invstd[VW];
+        float mean[VW], invstd[VW], sc[VW], sh[VW];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) { mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j]; }
+        for (int j = 0; j < VW; ++j) {
+            mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j];
+            sc[j] = invstd[j] * (gamma ? gamma[c0 + j] : 1.f);
+            sh[j] = fmaf(-mean[j], sc[j], beta ? beta[c0 + j] : 0.f);
+        }
         for (; it.more(); it.next()) {
             Vec g[UNR], a[UNR], o[UNR];
+            int mb[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int off = it.offset(u);
                 g[u] = ldv(gr, off);
                 a[u] = ldv(xr, off);
-                if (relu) o[u] = ldv(yr, off);
+                if (from_y) o[u] = ldv(yr, off);
+                if (relu && mask_mode == 1) mb[u] = ldmask(mr, off);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
 #pragma unroll
                 for (int j = 0; j < VW; ++j) {
-                    const float gv = (!relu || o[u].v[j] > 0.f) ? g[u].v[j] : 0.f;        // rows past the end load dy = 0
+                    const bool on = !relu || (mask_mode == 0 ? o[u].v[j] > 0.f : mask_mode == 1 ? ((mb[u] >> j) & 1) != 0
+                                                                                                 : fmaf(a[u].v[j], sc[j], sh[j]) > 0.f);
+                    const float gv = on ? g[u].v[j] : 0.f;        // rows past the end load dy = 0
                     s1.v[j] += gv; s2.v[j] += gv * (a[u].v[j] - mean[j]) * invstd[j];
                 }
         }
@@ -253,34 +277,40 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
 __device__ __forceinline__ void bn_bwd_apply_body(
     const int bid, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
-    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam)
+    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam,
+    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
 {
     const int t = threadIdx.x;
     const int C = Cst;
     __shared__ float sStat[2][SLAB];
-    const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(relu ? y : x, fm.bytes);
+    const bool from_y = relu && mask_mode == 0;
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(from_y ? y : x, fm.bytes);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> 3 : 0);
     const __amdgpu_buffer_rsrc_t dxr = make_rsrc(dx, fm.bytes), drr = make_rsrc(dres ? dres : dx, fm.bytes);
     int cv = 0; RowIter it; it.init(fm, bid, t < fm.span ? t : 0, cv);
     Vec g[UNR], a[UNR], o[UNR];
-    int of[UNR];
+    int of[UNR], mb[UNR];
     auto fetch = [&]() {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             of[u] = it.offset(u);
             g[u] = ldv(gr, of[u]);
             a[u] = ldv(xr, of[u]);
-            if (relu) o[u] = ldv(yr, of[u]);
+            if (from_y) o[u] = ldv(yr, of[u]);
+            if (relu && mask_mode == 1) mb[u] = ldmask(mr, of[u]);
         }
     };
     if (t < fm.span) fetch();
     reduce_replicas(red, C, fm.CV * VW, t, sStat);
     if (t >= fm.span) return;
     const int c0 = cv * VW;
-    float mean[VW], invstd[VW], k0[VW], m1[VW], m2[VW];
+    float mean[VW], invstd[VW], k0[VW], m1[VW], m2[VW], sc[VW], sh[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
         mean[j] = saved[c0 + j]; invstd[j] = saved[C + c0 + j];
         k0[j] = (gamma ? gamma[c0 + j] : 1.f) * invstd[j];
+        sc[j] = invstd[j] * (gamma ? gamma[c0 + j] : 1.f);
+        sh[j] = fmaf(-mean[j], sc[j], beta ? beta[c0 + j] : 0.f);
         const float s0 = sStat[0][c0 + j], s1 = sStat[1][c0 + j];
         m1[j] = s0 * inv_count; m2[j] = s1 * inv_count;
         if (bid == 0 && t < fm.CV && dparam) { dparam[c0 + j] = s0; dparam[C + c0 + j] = s1; }
@@ -293,7 +323,9 @@ __device__ __forceinline__ void bn_bwd_apply_body(
             oo[u] = of[u];
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
-                const float gv = (!relu || o[u].v[j] > 0.f) ? g[u].v[j] : 0.f;
+                const bool on = !relu || (mask_mode == 0 ? o[u].v[j] > 0.f : mask_mode == 1 ? ((mb[u] >> j) & 1) != 0
+                                                                                             : fmaf(a[u].v[j], sc[j], sh[j]) > 0.f);
+                const float gv = on ? g[u].v[j] : 0.f;
                 gm[u].v[j] = gv;
                 d[u].v[j] = k0[j] * (gv - m1[j] - (a[u].v[j] - mean[j]) * invstd[j] * m2[j]);
             }
@@ -312,22 +344,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, FlatMap fm,
     const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved,
-    int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu)
+    int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu, unsigned char* __restrict__ mask)
 {
-    bn_apply_body(blockIdx.x, x, res, y, fm, sums, gamma, beta, running_mean, running_var, saved, Cst, inv_count, unbias, momentum, eps, mode, relu);
+    bn_apply_body(blockIdx.x, x, res, y, fm, sums, gamma, beta, running_mean, running_var, saved, Cst, inv_count, unbias, momentum, eps, mode, relu, mask);
 }
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
-    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red)
+    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red,
+    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
 {
-    bn_bwd_reduce_body(blockIdx.x, dy, x, y, fm, saved, Cst, relu, red);
+    bn_bwd_reduce_body(blockIdx.x, dy, x, y, fm, saved, Cst, relu, red, mask_mode, mask, gamma, beta);
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
-    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam)
+    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam,
+    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
 {
-    bn_bwd_apply_body(blockIdx.x, dy, x, y, fm, saved, gamma, red, Cst, inv_count, relu, dx, dres, dparam);
+    bn_bwd_apply_body(blockIdx.x, dy, x, y, fm, saved, gamma, red, Cst, inv_count, relu, dx, dres, dparam, mask_mode, mask, beta);
 }
 
 // Up to 4 independent BatchNorms in one launch (the HRNet branches advance in lockstep: nn.multi_batch_norm): the
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 constexpr int NBM = 4;
 struct BnFwdOne {
     const bf16_t* x; const bf16_t* res; bf16_t* y; const float* sums; const float* gamma; const float* beta;
-    float* running_mean; float* running_var; float* saved; FlatMap fm; int C; float inv_count, unbias; int relu;
+    float* running_mean; float* running_var; float* saved; unsigned char* mask; FlatMap fm; int C; float inv_count, unbias; int relu;
 };
 struct BnFwdMulti { BnFwdOne a[NBM]; int start[NBM + 1]; int n; float momentum, eps; int mode; };
 __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdMulti m)
@@ -344,11 +378,12 @@ __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdMulti m)
     while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
     const BnFwdOne& a = m.a[i];
     bn_apply_body(blockIdx.x - m.start[i], a.x, a.res, a.y, a.fm, a.sums, a.gamma, a.beta, a.running_mean, a.running_var, a.saved,
-                  a.C, a.inv_count, a.unbias, m.momentum, m.eps, m.mode, a.relu);
+                  a.C, a.inv_count, a.unbias, m.momentum, m.eps, m.mode, a.relu, a.mask);
 }
 struct BnBwdOne {
     const bf16_t* dy; const bf16_t* x; const bf16_t* y; const float* saved; const float* gamma; float* red;
-    bf16_t* dx; bf16_t* dres; float* dparam; FlatMap fm; int C; float inv_count; int relu; int have_red;
+    bf16_t* dx; bf16_t* dres; float* dparam; const float* beta; const unsigned char* mask;
+    FlatMap fm; int C; float inv_count; int relu; int have_red; int mask_mode;
 };
 struct BnBwdMulti { BnBwdOne a[NBM]; int start[NBM + 1]; int n; };
 __global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnBwdMulti m)
@@ -357,14 +392,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnBwdMulti m)
     while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
     const BnBwdOne& a = m.a[i];
     if (a.have_red) return;                              // already reduced by the consumer conv's data-gradient epilogue
-    bn_bwd_reduce_body(blockIdx.x - m.start[i], a.dy, a.x, a.y, a.fm, a.saved, a.C, a.relu, a.red);
+    bn_bwd_reduce_body(blockIdx.x - m.start[i], a.dy, a.x, a.y, a.fm, a.saved, a.C, a.relu, a.red, a.mask_mode, a.mask, a.gamma, a.beta);
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
 {
     int i = 0;
     while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
     const BnBwdOne& a = m.a[i];
-    bn_bwd_apply_body(blockIdx.x - m.start[i], a.dy, a.x, a.y, a.fm, a.saved, a.gamma, a.red, a.C, a.inv_count, a.relu, a.dx, a.dres, a.dparam);
+    bn_bwd_apply_body(blockIdx.x - m.start[i], a.dy, a.x, a.y, a.fm, a.saved, a.gamma, a.red, a.C, a.inv_count, a.relu, a.dx, a.dres, a.dparam,
+                      a.mask_mode, a.mask, a.beta);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -457,7 +493,8 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
 
 extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu, void* stream)
+                                float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu,
+                                void* relu_mask, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && y && M > 0 && C > 0, "bn_forward: bad arguments");
@@ -481,7 +518,7 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
         hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, fm,
                            sums_ws ? sums_ws + c0 : nullptr, gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr,
                            running_mean ? running_mean + c0 : nullptr, running_var ? running_var + c0 : nullptr,
-                           saved ? saved + c0 : nullptr, C, inv, unbias, momentum, eps, training ? 0 : 1, relu);
+                           saved ? saved + c0 : nullptr, C, inv, unbias, momentum, eps, training ? 0 : 1, relu, (unsigned char*)relu_mask);
         DANET_CHECK_LAUNCH("bn_apply_kernel");
     }
     return DANET_OK;
@@ -492,10 +529,13 @@ extern "C" size_t danet_bn_ws_floats(int C) { return (size_t)NCOPY * 2 * C; }
 
 extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                                  const float* gamma, const float* saved, int relu,
-                                 void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero, void* stream)
+                                 void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero,
+                                 int mask_mode, const void* relu_mask, const float* beta, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(dy && x && dx && saved && red_ws && M > 0 && C > 0 && (!relu || y), "bn_backward: bad arguments");
+    DANET_CHECK_ARG(dy && x && dx && saved && red_ws && M > 0 && C > 0, "bn_backward: bad arguments");
+    DANET_CHECK_ARG(!relu || (mask_mode == 0 && y) || (mask_mode == 1 && relu_mask) || (mask_mode == 2 && !dres),
+                    "bn_backward: ReLU gate: mask_mode 0 needs y, 1 the forward's byte mask, 2 (recompute from x) no residual");
     DANET_CHECK_ARG(C % VW == 0, "bn_backward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
     if (!ws_is_zero) {
@@ -508,12 +548,13 @@ extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, i
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         if (ws_is_zero != 2) {                     // ws_is_zero == 2: the sums were accumulated by the consumer conv's dgrad epilogue
             hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
-                               fm, saved + c0, C, relu, red_ws + c0);
+                               fm, saved + c0, C, relu, red_ws + c0, mask_mode, (const unsigned char*)relu_mask,
+                               gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr);
             DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
         }
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
                            fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (bf16_t*)dx, (bf16_t*)dres,
-                           dparam ? dparam + c0 : nullptr);
+                           dparam ? dparam + c0 : nullptr, mask_mode, (const unsigned char*)relu_mask, beta ? beta + c0 : nullptr);
         DANET_CHECK_LAUNCH("bn_bwd_apply_kernel");
     }
     return DANET_OK;
@@ -554,11 +595,13 @@ extern "C" int danet_sum_relu_backward(const void* gy, const void* y, int B, int
 // Multi-tensor BatchNorm (training mode): jobs on the host, up to 4 per call, C <= 1024 each.
 //  forward job:  { x, res, y, gamma, beta, running_mean, running_var, saved, sums; int64 M; int C, sums_state, relu }
 //      sums_state: 1 = sums is zeroed scratch (statistics pass needed), 2 = statistics already accumulated by the conv epilogue
-//  backward job: { dy, x, y, gamma, saved, dx, dres, dparam, red; int64 M; int C, red_state, relu }   (red_state as above)
+//      mask: NULL or M*C/4 bytes that receive the ReLU gate of y (bit j of byte i = channel 4i+j positive)
+//  backward job: { dy, x, y, gamma, saved, dx, dres, dparam, red, beta, mask; int64 M; int C, red_state, relu, mask_mode }
+//      (red_state as above; mask_mode: see ldmask above)
 struct BnFwdJob { const void* x; const void* res; void* y; const float* gamma; const float* beta; float* running_mean; float* running_var;
-                  float* saved; float* sums; int64_t M; int C, sums_state, relu; };
+                  float* saved; float* sums; void* mask; int64_t M; int C, sums_state, relu; };
 struct BnBwdJob { const void* dy; const void* x; const void* y; const float* gamma; const float* saved; void* dx; void* dres; float* dparam;
-                  float* red; int64_t M; int C, red_state, relu; };
+                  float* red; const float* beta; const void* mask; int64_t M; int C, red_state, relu, mask_mode; };
 
 extern "C" int danet_bn_forward_multi(const void* jobs_, int n, float momentum, float eps, void* stream)
 {
@@ -579,7 +622,7 @@ extern "C" int danet_bn_forward_multi(const void* jobs_, int n, float momentum, 
             DANET_CHECK_LAUNCH("bn_stats_kernel");
         }
         a.x = (const bf16_t*)j.x; a.res = (const bf16_t*)j.res; a.y = (bf16_t*)j.y; a.sums = j.sums; a.gamma = j.gamma; a.beta = j.beta;
-        a.running_mean = j.running_mean; a.running_var = j.running_var; a.saved = j.saved; a.C = j.C;
+        a.running_mean = j.running_mean; a.running_var = j.running_var; a.saved = j.saved; a.C = j.C; a.mask = (unsigned char*)j.mask;
         a.inv_count = 1.0f / (float)j.M; a.unbias = j.M > 1 ? (float)j.M / (float)(j.M - 1) : 1.f; a.relu = j.relu;
         m.start[i + 1] = m.start[i] + grid;
     }
@@ -598,14 +641,16 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
     bool need_reduce = false;
     for (int i = 0; i < n; ++i) {
         const BnBwdJob& j = jobs[i];
-        DANET_CHECK_ARG(j.dy && j.x && j.dx && j.saved && j.red && j.M > 0 && j.C > 0 && j.C <= SLAB && (!j.relu || j.y) &&
+        DANET_CHECK_ARG(j.dy && j.x && j.dx && j.saved && j.red && j.M > 0 && j.C > 0 && j.C <= SLAB &&
                         (j.red_state == 1 || j.red_state == 2), "bn_backward_multi: job %d: bad arguments", i);
+        DANET_CHECK_ARG(!j.relu || (j.mask_mode == 0 && j.y) || (j.mask_mode == 1 && j.mask) || (j.mask_mode == 2 && !j.dres),
+                        "bn_backward_multi: job %d: ReLU gate (mask_mode %d) lacks its input", i, j.mask_mode);
         BnBwdOne& a = m.a[i];
         int grid;
         DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_backward_multi: job %d: C=%d unsupported", i, j.C);
         a.dy = (const bf16_t*)j.dy; a.x = (const bf16_t*)j.x; a.y = (const bf16_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
         a.dx = (bf16_t*)j.dx; a.dres = (bf16_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
-        a.have_red = j.red_state == 2;
+        a.have_red = j.red_state == 2; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
         need_reduce = need_reduce || !a.have_red;
         m.start[i + 1] = m.start[i] + grid;
     }

@@ -2,6 +2,7 @@
 reference's torch modules (state-dict compatible)."""
 import ctypes
 
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -10,6 +11,9 @@ from . import _lib
 from . import conv as _conv
 from ._lib import ptr, check, stream
 from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc, ARENA  # noqa: F401
+
+
+RELU_MASK = bool(int(os.environ.get('DANET_BN_RELU_MASK', '1')))     # A/B knob: 0 = the backward gates on the saved output y
 
 
 class BatchNormActFunction(torch.autograd.Function):
@@ -37,12 +41,17 @@ class BatchNormActFunction(torch.autograd.Function):
                 sums = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         g = None if gamma is None else gamma.detach().float().contiguous()
         b = None if beta is None else beta.detach().float().contiguous()
+        # ReLU gate for the backward without re-reading y (csrc/norm_act.hip ldmask): a byte mask with a residual,
+        # recomputed from x without one
+        mask = torch.empty(M * C // 4, dtype=torch.uint8, device=x.device) if (training and relu and res is not None and RELU_MASK) else None
         check(L.danet_bn_forward(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
                                  ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(b), ptr(running_mean), ptr(running_var),
-                                 ptr(saved), ptr(sums), int(sums_zero), float(momentum), float(eps), int(training), int(relu), stream()),
+                                 ptr(saved), ptr(sums), int(sums_zero), float(momentum), float(eps), int(training), int(relu),
+                                 ptr(mask), stream()),
               'danet_bn_forward')
         if training:
-            ctx.save_for_backward(x, y if relu else None, g, saved)
+            ctx.mask_mode = 1 if mask is not None else (2 if (relu and res is None and RELU_MASK) else 0)
+            ctx.save_for_backward(x, y if (relu and ctx.mask_mode == 0) else None, g, saved, b, mask)
             ctx.relu = relu
             ctx.has_res = res is not None
             ctx.link = link
@@ -59,7 +68,7 @@ class BatchNormActFunction(torch.autograd.Function):
         if not ctx.training:
             raise RuntimeError('BatchNorm backward in eval mode is not on the hot path')
         L = _lib.lib()
-        x, y, g, saved = ctx.saved_tensors
+        x, y, g, saved, b, mask = ctx.saved_tensors
         gy_in = gy
         gy = nhwc_bf16(gy)
         B, C, H, W = x.shape
@@ -79,7 +88,8 @@ class BatchNormActFunction(torch.autograd.Function):
         check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
-                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero), stream()),
+                                  None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero),
+                                  int(ctx.mask_mode), ptr(mask), ptr(b), stream()),
               'danet_bn_backward')
         if _conv.TRACE is not None:
             _conv.TRACE.append(('bn_bwd' + ('+red' if red_zero == 2 else ''), tuple(x.shape), dx.float().abs().mean()))
@@ -141,7 +151,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
         gammas = [t.detach().float().contiguous() for t in tensors[2 * n:3 * n]]
         betas = [t.detach().float().contiguous() for t in tensors[3 * n:4 * n]]
         jobs = (_lib.BnFwdJob * n)()
-        ys, saveds, keep = [], [], []
+        ys, saveds, keep, masks = [], [], [], []
         for i in range(n):
             B, C, H, W = xs[i].shape
             if ress[i] is not None and ress[i].shape != xs[i].shape:
@@ -154,7 +164,10 @@ class MultiBatchNormFunction(torch.autograd.Function):
                 if sums is None:
                     sums = torch.zeros(L.danet_bn_ws_floats(C), dtype=torch.float32, device=xs[i].device)
             keep.append(sums)
+            mask = torch.empty(B * H * W * C // 4, dtype=torch.uint8, device=xs[i].device) if (relu and ress[i] is not None and RELU_MASK) else None
+            masks.append(mask)
             j = jobs[i]
+            j.mask = None if mask is None else mask.data_ptr()
             j.x, j.res, j.y = xs[i].data_ptr(), None if ress[i] is None else ress[i].data_ptr(), y.data_ptr()
             j.gamma, j.beta = gammas[i].data_ptr(), betas[i].data_ptr()
             j.running_mean = None if rms[i] is None else rms[i].data_ptr()
@@ -164,8 +177,9 @@ class MultiBatchNormFunction(torch.autograd.Function):
             ys.append(y)
             saveds.append(saved)
         check(L.danet_bn_forward_multi(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
-        ctx.save_for_backward(*xs, *ys, *gammas, *saveds)
-        ctx.cfg = (n, relu, [r is not None for r in ress], links)
+        modes = [1 if m is not None else (2 if (relu and r is None and RELU_MASK) else 0) for m, r in zip(masks, ress)]
+        ctx.save_for_backward(*xs, *[y if (relu and md == 0) else None for y, md in zip(ys, modes)], *gammas, *saveds, *betas, *masks)
+        ctx.cfg = (n, relu, [r is not None for r in ress], links, modes)
         for y, x, saved in zip(ys, xs, saveds):
             y._bn_ctx = (x, bool(relu), saved)
         return tuple(ys)
@@ -173,9 +187,9 @@ class MultiBatchNormFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gys):
         L = _lib.lib()
-        n, relu, has_res, links = ctx.cfg
+        n, relu, has_res, links, modes = ctx.cfg
         sv = ctx.saved_tensors
-        xs, ys, gammas, saveds = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
+        xs, ys, gammas, saveds, betas, masks = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n], sv[4 * n:5 * n], sv[5 * n:6 * n]
         jobs = (_lib.BnBwdJob * n)()
         dxs, dress, dparams, keep = [], [], [], []
         for i in range(n):
@@ -193,7 +207,8 @@ class MultiBatchNormFunction(torch.autograd.Function):
             dparam = torch.empty(2, C, dtype=torch.float32, device=xs[i].device)
             keep += [red, gy]
             j = jobs[i]
-            j.dy, j.x, j.y = gy.data_ptr(), xs[i].data_ptr(), ys[i].data_ptr()
+            j.dy, j.x, j.y = gy.data_ptr(), xs[i].data_ptr(), None if ys[i] is None else ys[i].data_ptr()
+            j.beta, j.mask, j.mask_mode = betas[i].data_ptr(), None if masks[i] is None else masks[i].data_ptr(), modes[i]
             j.gamma, j.saved = gammas[i].data_ptr(), saveds[i].data_ptr()
             j.dx, j.dres, j.dparam, j.red = dx.data_ptr(), None if dres is None else dres.data_ptr(), dparam.data_ptr(), red.data_ptr()
             j.M, j.C, j.red_state, j.relu = B * H * W, C, state, int(relu)

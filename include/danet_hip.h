@@ -274,24 +274,31 @@ int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
  *                     the running estimate, torch semantics); y = [relu](bn(x) [+ res]);
  *                     saved [2][C] (mean, invstd) is an fp32 output, sums_ws is scratch of
  *                     danet_bn_ws_floats(C) floats.  eval: running statistics.  gamma/beta may be NULL.
+ *                     relu_mask (optional, M*C/4 bytes): receives the ReLU gate of y, bit j of byte i = channel
+ *                     4i+j positive, so that the backward need not read y again.
  *  danet_bn_backward  dx, optional dres (= masked dy), dparam [2][C] <- (d beta, d gamma);
- *                     red_ws: danet_bn_ws_floats(C) floats of scratch.
+ *                     red_ws: danet_bn_ws_floats(C) floats of scratch.  The ReLU gate comes from
+ *                     mask_mode 0: the saved output y;  1: relu_mask written by the forward;  2: recomputed from x,
+ *                     gamma, beta and saved (only without a residual; y and relu_mask may then be NULL).
  *  danet_sum_relu_*   y = [relu](sum_t nearest_upsample_{2^shift_t}(term_t)), up to 4 terms; `terms`
  *                     and `shifts` are HOST arrays of nterms entries.  The backward of one term is
  *                     the window sum of gy * (y > 0).
  */
 int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
-                     float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu, void* stream);
+                     float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu,
+                     void* relu_mask, void* stream);
 size_t danet_bn_ws_floats(int C);
 int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                       const float* gamma, const float* saved, int relu,
-                      void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero, void* stream);
+                      void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero,
+                      int mask_mode, const void* relu_mask, const float* beta, void* stream);
 /* Up to 4 independent training-mode BatchNorms per launch (HRNet branches in lockstep); C <= 1024 each.
  *  forward job  { const void* x, *res; void* y; const float* gamma, *beta; float* running_mean, *running_var, *saved, *sums;
- *                 int64_t M; int C, sums_state, relu; }   sums_state 1: zeroed scratch, 2: accumulated by the conv epilogue
- *  backward job { const void* dy, *x, *y; const float* gamma, *saved; void* dx, *dres; float* dparam, *red;
- *                 int64_t M; int C, red_state, relu; }    red_state 1: zeroed scratch, 2: accumulated by the dgrad epilogue */
+ *                 void* mask; int64_t M; int C, sums_state, relu; }   sums_state 1: zeroed scratch, 2: accumulated by the conv epilogue
+ *  backward job { const void* dy, *x, *y; const float* gamma, *saved; void* dx, *dres; float* dparam, *red; const float* beta;
+ *                 const void* mask; int64_t M; int C, red_state, relu, mask_mode; }
+ *                 red_state 1: zeroed scratch, 2: accumulated by the dgrad epilogue; mask / mask_mode as above */
 int danet_bn_forward_multi(const void* jobs, int n, float momentum, float eps, void* stream);
 int danet_bn_backward_multi(const void* jobs, int n, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,

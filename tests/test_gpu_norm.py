@@ -114,7 +114,9 @@ def test_stn_gather_vs_torch_grid_sample(align):
                                                           (384, 384, 8, 2, 3, 1, 1), (40, 24, 17, 3, 3, 1, 1), (64, 64, 16, 2, 3, 1, 4)])
 def test_conv_epilogue_bn_statistics(Cin, Cout, H, B, k, stride, groups):
     """BatchNorm statistics accumulated by the conv epilogue == the separate statistics pass on the
-    same bf16 conv output (fp32 sums, atomics: order differs, so 1e-4 relative)."""
+    same bf16 conv output.  The LDS-tile 3x3 kernel sums its fp32 accumulators, the separate pass the rounded bf16
+    values: the means differ by the mean of the rounding errors (~2^-9 |y| / sqrt(count)), so the bound on the
+    running mean is relative to the size of the activations, not to the (near zero) mean itself."""
     from danet_densepose2smpl_amd import conv as dconv, nn as dnn
     torch.manual_seed(0)
     dev = 'cuda'
@@ -132,8 +134,9 @@ def test_conv_epilogue_bn_statistics(Cin, Cout, H, B, k, stride, groups):
     assert getattr(y_u, '_bn_sums', None) is None
     assert torch.equal(y_f, y_u)
     out_u = bn(y_u, relu=True).float()
-    _close(rm_f, bn.running_mean, 1e-4, 'running_mean')
-    _close(rv_f, bn.running_var, 1e-4, 'running_var')
+    err = (rm_f - bn.running_mean).abs().max().item()
+    assert err <= 2e-5 * y_u.float().abs().max().item(), ('running_mean', err)
+    _close(rv_f, bn.running_var, 2e-3, 'running_var')
     _close(out_f, out_u, 1e-2, 'bn output')          # bf16 outputs: one ulp where the mean differs in the last fp32 bits
 
 
@@ -206,3 +209,44 @@ def test_multi_batch_norm_matches_per_module():
             if use_res:
                 _close(ra[i].grad, rb[i].grad, 1e-2, 'dres %d' % i)
             assert int(bns_a[i].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('C,H,B,use_res', [(48, 64, 4, False), (96, 32, 4, True), (12, 16, 2, True), (2052, 2, 4, False), (2052, 2, 4, True)])
+def test_relu_gate_modes_agree(C, H, B, use_res):
+    """The backward's ReLU gate from the forward's byte mask (residual) or recomputed from x (no residual) equals the
+    gate read from the saved output y (csrc/norm_act.hip ldmask), for the single and the multi launch."""
+    from danet_densepose2smpl_amd import nn as dnn
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3).cuda()
+    res = torch.randn(B, C, H, H, generator=g).cuda() if use_res else None
+    gy = torch.randn(B, C, H, H, generator=g).bfloat16().cuda()
+    wgt, bia = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    out = {}
+    for mode in (True, False):
+        dnn.RELU_MASK = mode
+        try:
+            for multi in (False, True):
+                if multi and C > 1024:
+                    continue
+                bn = dnn.BatchNorm2d(C).cuda().train()
+                with torch.no_grad():
+                    bn.weight.copy_(wgt); bn.bias.copy_(bia)
+                xt = x.clone().requires_grad_(True)
+                rt = None if res is None else res.clone().requires_grad_(True)
+                y = dnn.multi_batch_norm([bn], [xt], [rt], relu=True)[0] if multi else bn(xt, res=rt, relu=True)
+                y.backward(gy)
+                out[(mode, multi)] = (y.detach(), xt.grad, None if rt is None else rt.grad, bn.weight.grad.clone(), bn.bias.grad.clone())
+        finally:
+            dnn.RELU_MASK = True
+    for multi in (False, True):
+        if (True, multi) not in out:
+            continue
+        a, b = out[(True, multi)], out[(False, multi)]
+        if use_res:                      # the gate itself, exactly: d_res = gy where this run's own y is positive
+            assert torch.equal(a[2], (gy.float() * (a[0] > 0).float()).to(a[2].dtype))
+        if use_res and torch.equal(a[0], b[0]):
+            assert torch.equal(a[2], b[2])
+        # dx: the per-channel sums are float atomics (order differs from run to run: last-bit differences), while one
+        # wrong gate bit is an error of a whole gradient value
+        _close(a[1], b[1], 4e-3 if torch.equal(a[0], b[0]) else 2e-2, 'dx')
+        _close(a[3], b[3], 1e-5, 'dgamma'); _close(a[4], b[4], 1e-5, 'dbeta')      # (float atomics)
