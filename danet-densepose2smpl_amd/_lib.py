@@ -40,6 +40,9 @@ _SIGNATURES = {
     'danet_conv_forward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_conv_forward_kernel': (c_i, [c_i] * 15),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 7),
+    'danet_conv_wgrad_rows_ok': (c_i, [c_i] * 13),
+    'danet_conv_wgrad_rows_ws_floats': (c_sz, [c_i] * 8),
+    'danet_conv_wgrad_rows': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 12 + [c_fl, c_f]),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
     'danet_conv_wgrad_multi_ws_floats': (c_sz, [c_f, c_i]),

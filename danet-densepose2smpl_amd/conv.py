@@ -483,6 +483,17 @@ def flush_wgrads(bucket=None):
 
 def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight=None):
     L = _lib.lib()
+    if L.danet_conv_wgrad_rows_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
+        # the regressor ResNets' 7x7 stride-2 stems over the 768 part crops: a chip-filling launch of its own, never queued
+        nws = L.danet_conv_wgrad_rows_ws_floats(B, OH, OW, Cin, Cout, R, S, groups)
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        tok = PROFILER.begin('conv_wgrad_rows_kernel', 2.0 * B * OH * OW * Cout * Cin_g * R * S,
+                             ('wgrad', B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
+        check(L.danet_conv_wgrad_rows(ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws,
+                                      B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, groups, 0.0, stream()), 'danet_conv_wgrad_rows')
+        if tok is not None:
+            PROFILER.end(tok)
+        return
     if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None and USE_WGRAD3X3 and \
             L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         # only the ADDRESS of gw is kept: holding the tensor would make autograd clone it instead of adopting it as .grad

@@ -25,6 +25,7 @@ UNITS = {
     'conv_igemm.hip': MFMA_VGPR,
     'conv_wgrad.hip': MFMA_VGPR,
     'conv_wgrad3x3.hip': MFMA_VGPR,
+    'conv_wgrad_rows.hip': MFMA_VGPR,
     'conv3x3.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
     'conv_f32.hip': ['-ffp-contract=off'],

@@ -260,6 +260,13 @@ int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, size_t ws_floa
 int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups);   /* CT*10 + NI */
 int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                         int B, int H, int W, int Cin, int Cout, int groups, float beta, int phase /* 0 both kernels, 1 MFMA kernel only, 2 reduction only */, void* stream);
+/* 7x7 / stride 2 / pad 3 weight gradient of large batches (the regressor ResNets' stems, res_module.py:407), one
+ * filter row per workgroup through the LDS transpose read (conv_wgrad_rows.hip); use when danet_conv_wgrad_rows_ok != 0. */
+int danet_conv_wgrad_rows_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+size_t danet_conv_wgrad_rows_ws_floats(int B, int OH, int OW, int Cin, int Cout, int R, int S, int groups);
+int danet_conv_wgrad_rows(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
+                          int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                          int R, int S, int stride, int pad, int groups, float beta, void* stream);
 size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
 int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,

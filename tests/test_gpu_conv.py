@@ -264,3 +264,35 @@ def test_lds_tile_3x3_bias_fp32_relu_and_lockstep_launch():
         yr.backward(gyi.float())
         assert (yi.float() - yr).abs().max().item() <= 1e-2 * yr.abs().max().item()
         assert (xi.grad.float() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout', [(64, 64, 64, 64), (160, 64, 64, 64), (36, 96, 64, 128)])
+def test_filter_row_wgrad_7x7_stride2(B, H, Cin, Cout):
+    """conv_wgrad_rows.hip (7x7 stride-2 stems of the regressor ResNets at part-crop batch sizes) == the generic weight
+    gradient kernel (same bf16 operands, fp32 accumulation; only the summation order differs) and == torch fp32."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    from danet_densepose2smpl_amd._lib import ptr, stream, check
+    L = _lib.lib()
+    torch.manual_seed(B)
+    OH = H // 2
+    assert L.danet_conv_wgrad_rows_ok(B, H, H, Cin, OH, OH, Cout, 7, 7, 2, 3, 1, 1)
+    x = dconv.nhwc_bf16(torch.randn(B, Cin, H, H, device='cuda'))
+    gy = dconv.nhwc_bf16(torch.randn(B, Cout, OH, OH, device='cuda'))
+    xp, gyp = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
+    gw = torch.full((Cout, Cin, 7, 7), float('nan'), device='cuda')
+    nws = L.danet_conv_wgrad_rows_ws_floats(B, OH, OH, Cin, Cout, 7, 7, 1)
+    ws = torch.full((nws,), float('nan'), device='cuda')
+    check(L.danet_conv_wgrad_rows(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, H, Cin, OH, OH, Cout, 7, 7, 2, 3, 1, 0.0, stream()), 'rows')
+    ref = torch.empty_like(gw)
+    n2 = L.danet_conv_wgrad_ws_floats(Cout, Cin, 7, 7)
+    ws2 = torch.empty(n2, device='cuda')
+    check(L.danet_conv_wgrad(ptr(xp), ptr(gyp), ptr(ref), ptr(ws2), n2, B, H, H, Cin, OH, OH, Cout, 7, 7, 2, 3, 1, 1, 0.0, 0, stream()), 'generic')
+    scale = ref.abs().max().item()
+    assert torch.isfinite(gw).all()
+    assert (gw - ref).abs().max().item() <= 2e-4 * scale
+    if B <= 64:
+        t = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin, 7, 7), gy.float(), stride=2, padding=3)
+        assert (gw - t).abs().max().item() <= 2e-4 * scale
+    # accumulate form
+    check(L.danet_conv_wgrad_rows(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, H, Cin, OH, OH, Cout, 7, 7, 2, 3, 1, 1.0, stream()), 'rows')
+    assert (gw - 2 * ref).abs().max().item() <= 4e-4 * scale

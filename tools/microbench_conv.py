@@ -38,6 +38,8 @@ def main():
     only = sys.argv[2] if len(sys.argv) > 2 else ''
     sel = os.environ.get('DANET_MB_SHAPES')
     shapes = SHAPES if not sel else [SHAPES[int(i)] for i in sel.split(',')]
+    if os.environ.get('DANET_MB_SHAPE'):               # "Cin,Cout,k,stride,pad,groups,H,W"
+        shapes = [tuple(int(v) for v in os.environ['DANET_MB_SHAPE'].split(','))]
     for (Cin, Cout, k, s, p, g, H, W) in shapes:
         OH, OW = conv.conv_out_size(H, k, s, p, 1), conv.conv_out_size(W, k, s, p, 1)
         flops = 2.0 * B * OH * OW * Cout * (Cin // g) * k * k
@@ -56,6 +58,13 @@ def main():
         xp, gyp = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
         t = timeit(lambda: L.danet_conv_wgrad(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g, 0.0, 0, stream()))
         res['wgrad_us'] = t * 1e6; res['wgrad_TF'] = flops / t / 1e12
+        if L.danet_conv_wgrad_rows_ok(B, H, W, Cin, OH, OW, Cout, k, k, s, p, 1, g):
+            nr = L.danet_conv_wgrad_rows_ws_floats(B, OH, OW, Cin, Cout, k, k, g)
+            wsr = torch.empty(nr, device='cuda')
+            gwr = torch.empty_like(w.data)
+            t = timeit(lambda: L.danet_conv_wgrad_rows(ptr(xp), ptr(gyp), ptr(gwr), ptr(wsr), nr, B, H, W, Cin, OH, OW, Cout, k, k, s, p, g, 0.0, stream()))
+            res['wgrad_rows_us'] = t * 1e6; res['wgrad_rows_TF'] = flops / t / 1e12
+            res['wgrad_rows_vs_old_maxrel'] = float((gwr - gw).abs().max() / (gw.abs().max() + 1e-9))
         if L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
             n3 = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, g)
             ws3 = torch.empty(n3, device='cuda')
