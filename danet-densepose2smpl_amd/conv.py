@@ -224,30 +224,34 @@ class WeightBank(object):
         for (wid, mode, groups, chunk), w in reqs.items():
             Cout, Cin_g, R, S = w.shape
             sizes.append((int(L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode, chunk)) + 63) // 64 * 64)
-        self.flat = torch.empty(sum(sizes), dtype=torch.bfloat16, device=dev)
+        self.flat = torch.zeros(sum(sizes), dtype=torch.bfloat16, device=dev)      # zeroed once: the brick launch never writes padding
         jb = int(L.danet_conv_pack_job_bytes())
         import ctypes
         host = (ctypes.c_uint8 * (jb * len(reqs)))()
-        off, start = 0, 0
+        off, start, bstart = 0, 0, 0
         self.entries = []
         for ((wid, mode, groups, chunk), w), n in zip(reqs.items(), sizes):
             assert w.dtype == torch.float32 and w.is_contiguous()
             view = self.flat[off:off + n]
             Cout, Cin_g, R, S = w.shape
-            tot = L.danet_conv_pack_job_fill(ctypes.addressof(host) + jb * len(self.entries), w.data_ptr(), view.data_ptr(), start,
+            tot = L.danet_conv_pack_job_fill(ctypes.addressof(host) + jb * len(self.entries), w.data_ptr(), view.data_ptr(), start, bstart,
                                              Cout, Cin_g, R, S, groups, mode, chunk)
             assert 0 < tot <= n
             self.entries.append(((wid, mode, groups, chunk), weakref.ref(w), view, w.data_ptr()))
             off += n
-            start += tot
-        self.total = start
+            bricks = L.danet_conv_pack_job_bricks(Cout, Cin_g, R, S, groups, mode, chunk)
+            if bricks > 0:                 # brick launch (csrc/conv_igemm.hip pack_weights_brick_kernel)
+                bstart += bricks
+            else:                          # per-element launch
+                start += tot
+        self.total, self.total_bricks = start, bstart
         self.jobs = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
         return self
 
     def refresh(self):
         if self.jobs is None:
             return
-        check(_lib.lib().danet_conv_pack_weights_batched(ptr(self.jobs), len(self.entries), self.total, stream()),
+        check(_lib.lib().danet_conv_pack_weights_batched(ptr(self.jobs), len(self.entries), self.total, self.total_bricks, stream()),
               'danet_conv_pack_weights_batched')
         for key, wref, view, dptr in self.entries:
             w = wref()

@@ -317,9 +317,99 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
 // One launch that (re)packs a whole table of weights: element i of the concatenated index space belongs to
 // the job whose [start, start + total) range holds it (binary search over the table).
 struct PackJob {
-    const float* w; bf16_t* wp; long start;
-    int Cout_g, Cin_g, R, S, G, rows_pad, Kp, mode, chunk;
+    const float* w; bf16_t* wp; long start; long bstart;
+    int Cout_g, Cin_g, R, S, G, rows_pad, Kp, mode, chunk, brick_ch;
 };
+
+// Brick path of the batched packing (jobs with brick_ch > 0: unchunked K order, channel counts that are multiples of
+// 8).  A workgroup owns one brick = 16 packed rows x CH folded channels x all R*S taps of one group: it loads the
+// brick's fp32 source with coalesced reads (mode 0: 16 runs of CH*RS consecutive floats, one per output channel; mode 1:
+// CH runs of 16*RS floats, one per output channel), parks it in LDS and writes the bf16 fragments as 16-byte vectors
+// in destination order (16 rows x 16 bytes = 256 contiguous bytes per (tap, 8-channel group)).  Every source element is
+// read from memory once; the per-element gather of the kernel below reads 4-byte elements 36 (3x3) .. 2304 bytes apart.
+// Padding (rows beyond the last real row tile, the K tail) is never written: the destination is zeroed once at build time.
+__global__ __launch_bounds__(256) void pack_weights_brick_kernel(const PackJob* __restrict__ jobs, int njobs)
+{
+    extern __shared__ float sBrick[];
+    __shared__ int sJob;
+    const long b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].bstart <= b) lo = mid; else hi = mid - 1;
+        }
+        sJob = lo;
+    }
+    __syncthreads();
+    const PackJob j = jobs[sJob];
+    const int t = threadIdx.x;
+    const int CH = j.brick_ch, RS = j.R * j.S;
+    const int inner = j.mode == 0 ? j.Cin_g : j.Cout_g, rows = j.mode == 0 ? j.Cout_g : j.Cin_g;
+    const int nch = inner / CH, ntile = (rows + 15) / 16;
+    const int bl = (int)(b - j.bstart);
+    const int cidx = bl % nch, rt = (bl / nch) % ntile, g = bl / (nch * ntile);
+    const int r0 = rt * 16, c0 = cidx * CH;
+    const int nrow = min(16, rows - r0);
+    // source runs: mode 0: run = packed row (cout), L = CH*RS;  mode 1: run = folded channel (cout), L = nrow*RS
+    const int nrun = j.mode == 0 ? nrow : CH;
+    const int L = j.mode == 0 ? CH * RS : nrow * RS;
+    const int Lp = (j.mode == 0 ? CH * RS : 16 * RS) | 1;
+    const float* src = j.mode == 0 ? j.w + ((size_t)(g * j.Cout_g + r0) * j.Cin_g + c0) * RS
+                                   : j.w + ((size_t)(g * j.Cout_g + c0) * j.Cin_g + r0) * RS;
+    const size_t run_stride = (size_t)j.Cin_g * RS;          // one output channel further
+    // flat index over (run, position): consecutive lanes read consecutive addresses; four (vector) or eight (scalar)
+    // loads are in flight per lane before the first LDS store -- one load per round trip made the launch latency-bound
+    if (L % 4 == 0 && run_stride % 4 == 0 && ((src - j.w) & 3) == 0) {
+        const int L4 = L / 4, tot4 = nrun * L4;
+        for (int base = 0; base < tot4; base += 256 * 4) {
+            float4 v[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + t;
+                const int run = idx / L4, i4 = idx - run * L4;
+                at[u] = idx < tot4 ? run * Lp + 4 * i4 : -1;
+                v[u] = idx < tot4 ? *reinterpret_cast<const float4*>(src + run * run_stride + 4 * i4) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) { sBrick[at[u]] = v[u].x; sBrick[at[u] + 1] = v[u].y; sBrick[at[u] + 2] = v[u].z; sBrick[at[u] + 3] = v[u].w; }
+        }
+    } else {
+        const int tot = nrun * L;
+        for (int base = 0; base < tot; base += 256 * 8) {
+            float v[8];
+            int at[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + t;
+                const int run = idx / L, i = idx - run * L;
+                at[u] = idx < tot ? run * Lp + i : -1;
+                v[u] = idx < tot ? src[run * run_stride + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (at[u] >= 0) sBrick[at[u]] = v[u];
+        }
+    }
+    __syncthreads();
+    const int nq = CH / 8, nvec = 16 * nq * RS;
+    for (int o = t; o < nvec; o += 256) {
+        const int row = o & 15, q = (o >> 4) % nq, tap = (o >> 4) / nq;
+        union { bf16_t h[8]; int4 v; } out;
+        if (row < nrow) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                out.h[e] = f2bf(j.mode == 0 ? sBrick[row * Lp + (8 * q + e) * RS + tap] : sBrick[(8 * q + e) * Lp + row * RS + tap]);
+        } else {
+            out.v = int4{0, 0, 0, 0};
+        }
+        const int k0 = tap * inner + c0 + 8 * q;
+        const size_t dst = (((((size_t)g * (j.rows_pad / 16) + rt) * (j.Kp / 32) + k0 / 32) * 4 + (k0 % 32) / 8) * 16 + row) * 8;
+        *reinterpret_cast<int4*>(j.wp + dst) = out.v;
+    }
+}
 
 __global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs, long total_all)
 {
@@ -436,12 +526,34 @@ extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int C
     return DANET_OK;
 }
 
-// Batched packing: the caller fills a host table of jobs with danet_conv_pack_job_fill (entry i at
-// byte offset i * danet_conv_pack_job_bytes(); `start` = running sum of the returned element counts),
-// copies it to the device and (re)packs every weight with one launch.
+// Batched packing: the caller fills a host table of jobs with danet_conv_pack_job_fill (entry i at byte offset
+// i * danet_conv_pack_job_bytes()), copies it to the device and (re)packs every weight with two launches.  A job
+// with danet_conv_pack_job_bricks(...) > 0 belongs to the brick launch: `bstart` = running sum of the brick counts of
+// the jobs before it, and it does NOT advance `start`; the others belong to the per-element launch: `start` =
+// running sum of the element counts danet_conv_pack_job_fill returned for the per-element jobs before it.  The
+// destination must be zeroed once (the brick launch does not write padding).
 extern "C" size_t danet_conv_pack_job_bytes(void) { return sizeof(PackJob); }
 
-extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
+// Channels per brick of the brick path (0: the job takes the per-element path): unchunked K order, folded channel
+// count a multiple of 8; the largest of 256..8 that divides it and keeps the brick (16 x CH x R*S floats) under 36 KB.
+static int pack_brick_ch(int inner, int RS, int chunk) {
+    if (chunk != 0 || inner % 8 != 0 || getenv("DANET_NO_PACK_BRICKS")) return 0;
+    for (int ch = 256; ch >= 8; ch >>= 1)
+        if (inner % ch == 0 && ch * RS <= 576) return ch;
+    return 0;
+}
+
+// Workgroups (bricks) the job needs in the brick launch; 0 = per-element path.
+extern "C" long danet_conv_pack_job_bricks(int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk)
+{
+    if (groups <= 0 || Cout % groups != 0) return 0;
+    const int Cout_g = Cout / groups;
+    const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
+    const int ch = pack_brick_ch(inner, R * S, chunk);
+    return ch ? (long)groups * ((rows + 15) / 16) * (inner / ch) : 0;
+}
+
+extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start, long bstart,
                                          int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk)
 {
     if (!job_host || groups <= 0 || Cout % groups != 0 || chunk < 0) return -1;
@@ -449,7 +561,8 @@ extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* w
     const int Cout_g = Cout / groups;
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
     const int nt = danet_conv_nt(rows);
-    j->w = w; j->wp = (bf16_t*)wp; j->start = start;
+    j->w = w; j->wp = (bf16_t*)wp; j->start = start; j->bstart = bstart;
+    j->brick_ch = pack_brick_ch(inner, R * S, chunk);
     j->Cout_g = Cout_g; j->Cin_g = Cin_g; j->R = R; j->S = S; j->G = groups; j->mode = mode;
     j->rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
     if (chunk > 0 && inner % chunk != 0) return -1;
@@ -458,13 +571,21 @@ extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* w
     return (long)groups * j->rows_pad * j->Kp;
 }
 
-extern "C" int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream)
+extern "C" int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, long total_bricks, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(jobs_dev && njobs > 0 && total_elems > 0, "pack_weights_batched: empty job table");
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(danet::cdiv(total_elems, 2048)), dim3(256), 0, (hipStream_t)stream,
-                       (const PackJob*)jobs_dev, njobs, total_elems);
-    DANET_CHECK_LAUNCH("pack_weights_batched_kernel");
+    DANET_CHECK_ARG(jobs_dev && njobs > 0 && total_elems >= 0 && total_bricks >= 0 && total_elems + total_bricks > 0 &&
+                    total_bricks < (1L << 31), "pack_weights_batched: empty job table");
+    if (total_bricks > 0) {
+        hipLaunchKernelGGL(pack_weights_brick_kernel, dim3((unsigned)total_bricks), dim3(256), (16 * 576 + 256) * sizeof(float),
+                           (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
+        DANET_CHECK_LAUNCH("pack_weights_brick_kernel");
+    }
+    if (total_elems > 0) {
+        hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(danet::cdiv(total_elems, 2048)), dim3(256), 0, (hipStream_t)stream,
+                           (const PackJob*)jobs_dev, njobs, total_elems);
+        DANET_CHECK_LAUNCH("pack_weights_batched_kernel");
+    }
     return DANET_OK;
 }
 

@@ -192,10 +192,15 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      transposed = 1 gathers x at (o + pad - r*dil)/stride when divisible: with mode-1 weights
  *      this is the data gradient (x := dY, (H,W) := dY size, Cin := Cout of the layer, (OH,OW),
  *      Cout := size / channels of dX) and also ConvTranspose2d.
- *  danet_conv_pack_job_* / danet_conv_pack_weights_batched   one launch that repacks a table of weights
+ *  danet_conv_pack_job_* / danet_conv_pack_weights_batched   two launches that repack a table of weights
  *      (a training step repacks ~600 of them after every optimizer step): fill a host table with
- *      danet_conv_pack_job_fill (entry i at byte i*danet_conv_pack_job_bytes(), start = running sum of
- *      the returned element counts), copy it to the device, launch.
+ *      danet_conv_pack_job_fill (entry i at byte i*danet_conv_pack_job_bytes()), copy it to the device, launch.
+ *      A job with danet_conv_pack_job_bricks(...) > 0 belongs to the brick launch (coalesced reads through LDS):
+ *      bstart = running sum of the brick counts of the jobs before it, and it does not advance `start`; the
+ *      others (chunked K order, channel counts that are not multiples of 8) belong to the per-element launch:
+ *      start = running sum of the element counts danet_conv_pack_job_fill returned for the per-element jobs
+ *      before it.  total_elems / total_bricks are the two final sums.  The destination buffers must be zeroed
+ *      once (the brick launch does not write padding).
  *      bn_sums (optional, [32][2][Cout] fp32, zeroed by the caller): per-channel sum and sum of squares of the
  *      bf16 output, accumulated by the epilogue; pass it to danet_bn_forward with ws_is_zero = 2 to skip
  *      the separate statistics pass.
@@ -214,9 +219,10 @@ size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, 
 int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
                             int mode, int chunk, void* stream);
 size_t danet_conv_pack_job_bytes(void);
-long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start,
+long danet_conv_pack_job_bricks(int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
+long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start, long bstart,
                               int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
-int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, void* stream);
+int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, long total_bricks, void* stream);
 /* Up to 4 independent convolutions (forward or data gradient) in one launch -- HRNet branches in lockstep.
  * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red; const void* addend;
  *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; }  (no bias / ReLU / fp32 output);
