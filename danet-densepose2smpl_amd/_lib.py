@@ -45,13 +45,13 @@ _SIGNATURES = {
     'danet_conv_wgrad_rows_ws_floats': (c_sz, [c_i] * 8),
     'danet_conv_wgrad_rows': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 12 + [c_fl, c_f]),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
-    'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 6),
+    'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 7),
     'danet_conv_wgrad_multi_ws_floats': (c_sz, [c_f, c_i]),
     'danet_conv_wgrad_multi': (c_i, [c_f, c_i, c_f, c_sz, c_fl, c_f]),
     'danet_conv_wgrad3x3_multi_ws_floats': (c_sz, [c_f, c_i]),
     'danet_conv_wgrad3x3_multi': (c_i, [c_f, c_i, c_f, c_sz, c_fl, c_f]),
-    'danet_conv_wgrad3x3_kernel_id': (c_i, [c_i] * 6),
-    'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 6 + [c_fl, c_i, c_f]),
+    'danet_conv_wgrad3x3_kernel_id': (c_i, [c_i] * 7),
+    'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 7 + [c_fl, c_i, c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
@@ -87,7 +87,7 @@ _SIGNATURES = {
 class Wg3Job(ctypes.Structure):
     """One problem of danet_conv_wgrad3x3_multi (include/danet_hip.h)."""
     _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p),
-                ('B', c_i), ('H', c_i), ('W', c_i), ('Cin', c_i), ('Cout', c_i), ('groups', c_i)]
+                ('B', c_i), ('H', c_i), ('W', c_i), ('Cin', c_i), ('Cout', c_i), ('groups', c_i), ('stride', c_i)]
 
 
 class WgJob(ctypes.Structure):

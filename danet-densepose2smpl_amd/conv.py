@@ -414,7 +414,7 @@ class Conv2dFunction(torch.autograd.Function):
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches
-_WQ = []                  # 3x3 / stride-1 problems (conv_wgrad3x3.hip)
+_WQ = []                  # 3x3 / stride 1 or 2 problems (conv_wgrad3x3.hip)
 _WQG = []                 # everything else (conv_wgrad.hip)
 GRAD_STORE = None         # distributed.GradStore of the running trainer: weight gradients are written into its views
 
@@ -453,13 +453,13 @@ def flush_wgrads(bucket=None):
     if wq:
         _check_adopted(wq)
         jobs = (_lib.Wg3Job * len(wq))()
-        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups) in zip(jobs, wq):
+        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups, stride) in zip(jobs, wq):
             j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
-            j.B, j.H, j.W, j.Cin, j.Cout, j.groups = B, H, W, Cin, Cout, groups
+            j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = B, H, W, Cin, Cout, groups, stride
         n = len(wq)
         need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), n)
         ws = torch.empty(need, dtype=torch.float32, device=wq[0][2].device)
-        tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * q[5] * q[6] * q[8] * (q[7] // q[9]) * 9 for q in wq),
+        tok = PROFILER.begin('conv_wgrad3x3_multi', sum(2.0 * q[4] * (q[5] // q[10]) * (q[6] // q[10]) * q[8] * (q[7] // q[9]) * 9 for q in wq),
                              ('wgrad-multi', n)) if PROFILER is not None else None
         check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
         if tok is not None:
@@ -501,19 +501,19 @@ def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad,
     if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None and USE_WGRAD3X3 and \
             L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         # only the ADDRESS of gw is kept: holding the tensor would make autograd clone it instead of adopting it as .grad
-        _WQ.append((gw.data_ptr(), weight, x, gy, B, H, W, Cin, Cout, groups))      # x, gy stay alive until the flush
+        _WQ.append((gw.data_ptr(), weight, x, gy, B, H, W, Cin, Cout, groups, stride))      # x, gy stay alive until the flush
         return
     if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None:
         _WQG.append((gw.data_ptr(), weight, x, gy, (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)))
         return
     if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
-        nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups)
+        nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups, stride)
         ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-        args = (ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws, B, H, W, Cin, Cout, groups, 0.0)
+        args = (ptr(x.permute(0, 2, 3, 1)), ptr(gy.permute(0, 2, 3, 1)), ptr(gw), ptr(ws), nws, B, H, W, Cin, Cout, groups, stride, 0.0)
         if PROFILER is None:
             check(L.danet_conv_wgrad3x3(*args, 0, stream()), 'danet_conv_wgrad3x3')
         else:                                          # the MFMA kernel and the reduction bracketed separately
-            kid = L.danet_conv_wgrad3x3_kernel_id(B, H, W, Cin, Cout, groups)
+            kid = L.danet_conv_wgrad3x3_kernel_id(B, H, W, Cin, Cout, groups, stride)
             tok = PROFILER.begin('conv_wgrad3x3_kernel<%d, %d>' % (kid // 10, kid % 10), 2.0 * B * OH * OW * Cout * Cin_g * 9,
                                  ('wgrad', B, H, W, Cin, Cout, R, stride, groups))
             check(L.danet_conv_wgrad3x3(*args, 1, stream()), 'danet_conv_wgrad3x3')

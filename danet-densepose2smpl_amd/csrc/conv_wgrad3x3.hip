@@ -25,11 +25,14 @@ namespace {
 using namespace danet_conv;
 
 constexpr int TH = 4, TW = 8;                 // output pixels per chunk (= one MFMA k-step of 32)
-constexpr int HH = TH + 2, HW = TW + 2;       // halo tile
+// halo tile of a chunk at stride ST (1 or 2): input rows ST*oy - 1 .. ST*(oy + TH - 1) + 1
+constexpr int halo_h(int st) { return st * (TH - 1) + 3; }
+constexpr int halo_w(int st) { return st * (TW - 1) + 3; }
 
 struct Wg3P {
     const bf16_t* x; const bf16_t* dy; float* part;
-    int B, H, W, Cin, Cout, groups, Cin_g, Cout_g;
+    int B, H, W, Cin, Cout, groups, Cin_g, Cout_g;      // H, W: OUTPUT size (= input size / stride)
+    int IH, IW;                                         // input size
     int tiles_h, tiles_w, msplit;
     long nchunks;                              // B * tiles_h * tiles_w
     long x_bytes, dy_bytes;                    // extents from the group / channel-block offset on (buffer resources)
@@ -44,9 +47,10 @@ __device__ inline v2u tr_read(unsigned lds_byte_addr) {
 }
 
 // One workgroup's share of one problem: (bx of msplit pixel ranges, by = cout-block x cin-block, bz = group).
-template <int CT, int NI>
+template <int CT, int NI, int ST>
 __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const int by, const int bz)
 {
+    constexpr int HH = halo_h(ST), HW = halo_w(ST);
     constexpr int BCO = CT * 16, BCI = NI * 16;
     constexpr int PXY = BCO * 2, PXX = BCI * 2;                  // bytes per staged pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -74,8 +78,9 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
         const int pair = min(wave + 4 * pi, NPAIR - 1);
         const int tap = pair / NI, ni = pair - tap * NI;
         const int r = tap / 3, s = tap - r * 3;
-        // lane i of 16-lane group lg supplies pixel (ty = lg, tx = 4h + (i>>2)), channels ni*16 + 4(i&3)
-        boff[pi] = (unsigned)(((lg + r) * HW + (li >> 2) + s) * PXX + (ni * 16 + 4 * (li & 3)) * 2);
+        // lane i of 16-lane group lg supplies output pixel (ty = lg, tx = 4h + (i>>2)) = halo pixel (ST*ty + r, ST*tx + s),
+        // channels ni*16 + 4(i&3)
+        boff[pi] = (unsigned)(((ST * lg + r) * HW + ST * (li >> 2) + s) * PXX + (ni * 16 + 4 * (li & 3)) * 2);
     }
     const unsigned aoff = (unsigned)((lg * TW + (li >> 2)) * PXY + (4 * (li & 3)) * 2);   // dY fragment, h = 0, ct = 0
 
@@ -103,7 +108,7 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
     for (int u = 0; u < NRX; ++u) {
         const int pc = t + u * 256;
         const int c8 = pc % (BCI / 8), q = pc / (BCI / 8);
-        xrel[u] = (((q / HW - 1) * p.W + q % HW - 1) * p.Cin + c8 * 8) * 2;
+        xrel[u] = (((q / HW - 1) * p.IW + q % HW - 1) * p.Cin + c8 * 8) * 2;
         const bool live = pc < NPX && ci0 + c8 * 8 < p.Cin_g;
         xhy[u] = live ? q / HW : -100000;                                 // (-100000: never inside the image)
         xhx[u] = q % HW;
@@ -115,13 +120,13 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
     auto fetch = [&]() {
         const int oh0 = f_th * TH, ow0 = f_tw * TW;
         const int pix0 = (f_b * p.H + oh0) * p.W + ow0;
-        const int by = pix0 * p.Cout * 2, bx = pix0 * p.Cin * 2;
+        const int by = pix0 * p.Cout * 2, bx = ((f_b * p.IH + ST * oh0) * p.IW + ST * ow0) * p.Cin * 2;
 #pragma unroll
         for (int u = 0; u < NRY; ++u)
             ystage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yr, yrel[u] != OOB ? by + yrel[u] : OOB, 0, 0));
 #pragma unroll
         for (int u = 0; u < NRX; ++u) {
-            const bool ok = (unsigned)(oh0 - 1 + xhy[u]) < (unsigned)p.H && (unsigned)(ow0 - 1 + xhx[u]) < (unsigned)p.W;
+            const bool ok = (unsigned)(ST * oh0 - 1 + xhy[u]) < (unsigned)p.IH && (unsigned)(ST * ow0 - 1 + xhx[u]) < (unsigned)p.IW;
             xstage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? bx + xrel[u] : OOB, 0, 0));
         }
         if (++f_tw == p.tiles_w) { f_tw = 0; if (++f_th == p.tiles_h) { f_th = 0; ++f_b; } }
@@ -155,7 +160,7 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
 #pragma unroll
         for (int pi = 0; pi < MAXP; ++pi) {
             blo[pi] = tr_read(xbase + boff[pi]);
-            bhi[pi] = tr_read(xbase + boff[pi] + 4 * PXX);
+            bhi[pi] = tr_read(xbase + boff[pi] + ST * 4 * PXX);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -193,10 +198,10 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
     }
 }
 
-template <int CT, int NI>
+template <int CT, int NI, int ST>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
 {
-    wgrad3x3_body<CT, NI>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    wgrad3x3_body<CT, NI, ST>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several independent problems in one launch (weight gradients are only needed by the optimizer, so a trainer
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
 constexpr int NPM = 20;
 struct Wg3Multi { Wg3P p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; };
 
-template <int CT, int NI>
+template <int CT, int NI, int ST>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
 {
     int i = 0;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
     const int l = blockIdx.x - mp.start[i];
     const Wg3P& p = mp.p[i];
     const int bx = l % p.msplit, rest = l / p.msplit;
-    wgrad3x3_body<CT, NI>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
+    wgrad3x3_body<CT, NI, ST>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
 }
 
 struct Red3Multi { const float* part[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], msplit[NPM]; long start[NPM + 1]; int n; float beta; };
@@ -268,11 +273,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float* __res
     dw[o] = beta != 0.f ? dw[o] * beta + s : s;
 }
 
-template <int CT, int NI>
+template <int CT, int NI, int ST>
 int launch3(const Wg3P& p, hipStream_t st) {
     const int nco = (p.Cout_g + CT * 16 - 1) / (CT * 16), nci = (p.Cin_g + NI * 16 - 1) / (NI * 16);
-    const size_t lds = 2 * (size_t)(TH * TW * CT * 32 + HH * HW * NI * 32);
-    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CT, NI>), dim3(p.msplit, nco * nci, p.groups), dim3(256), lds, st, p);
+    const size_t lds = 2 * (size_t)(TH * TW * CT * 32 + halo_h(ST) * halo_w(ST) * NI * 32);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CT, NI, ST>), dim3(p.msplit, nco * nci, p.groups), dim3(256), lds, st, p);
     return 0;
 }
 
@@ -280,12 +285,16 @@ inline int tiles3(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : ((c % 48 == 0 || 
 
 }  // namespace
 
-// Applicability: 3x3, stride 1, pad 1, dilation 1, OW % 8 == 0, OH % 4 == 0, channels per group % 8 == 0.
+// Applicability ((H, W) = INPUT size): 3x3, stride 1 or 2, pad 1, dilation 1, OW % 8 == 0, OH % 4 == 0, channels per
+// group % 8 == 0.
 extern "C" int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups) {
-    return R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && H % TH == 0 && W % TW == 0 &&
-           (Cin / groups) % 8 == 0 && (Cout / groups) % 8 == 0;
+    static const bool no_s2 = getenv("DANET_NO_WGRAD3_S2") != nullptr;         // A/B knob
+    if (!(R == 3 && S == 3 && (stride == 1 || (stride == 2 && !no_s2)) && pad == 1 && dil == 1)) return 0;
+    if (H % stride != 0 || W % stride != 0) return 0;
+    return (H / stride) % TH == 0 && (W / stride) % TW == 0 && (Cin / groups) % 8 == 0 && (Cout / groups) % 8 == 0;
 }
 
+// (H, W): OUTPUT size
 static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, int* ni, int* msplit) {
     const int Cout_g = Cout / groups, Cin_g = Cin / groups;
     *ct = tiles3(Cout_g); *ni = tiles3(Cin_g);
@@ -302,40 +311,43 @@ static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, i
 }
 
 // CT*10 + NI of the conv_wgrad3x3_kernel<CT, NI> instance that runs (profiling attribution).
-extern "C" int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups) {
+extern "C" int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups, int stride) {
     int ct, ni, ms;
-    plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &ms);
+    plan3(B, H / stride, W / stride, Cin, Cout, groups, &ct, &ni, &ms);
     return ct * 10 + ni;
 }
 
-extern "C" size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups) {
+extern "C" size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups, int stride) {
     int ct, ni, ms;
-    plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &ms);
+    if (stride < 1) return 0;
+    plan3(B, H / stride, W / stride, Cin, Cout, groups, &ct, &ni, &ms);
     return (size_t)ms * Cout * (Cin / groups) * 9;
 }
 
+// x [B,H,W,Cin], dy [B,H/stride,W/stride,Cout]
 extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
-                                   int B, int H, int W, int Cin, int Cout, int groups, float beta, int phase, void* stream)
+                                   int B, int H, int W, int Cin, int Cout, int groups, int stride, float beta, int phase, void* stream)
 {
     // phase: 0 = both kernels; 1 = the MFMA kernel only (partials into ws); 2 = the reduction only (profiling brackets)
     DANET_ENTER();
     DANET_CHECK_ARG(x && dy && dw && ws && B > 0 && phase >= 0 && phase <= 2, "conv_wgrad3x3: bad arguments");
-    DANET_CHECK_ARG(danet_conv_wgrad3x3_ok(H, W, Cin, Cout, 3, 3, 1, 1, 1, groups), "conv_wgrad3x3: unsupported shape");
+    DANET_CHECK_ARG(danet_conv_wgrad3x3_ok(H, W, Cin, Cout, 3, 3, stride, 1, 1, groups), "conv_wgrad3x3: unsupported shape");
     Wg3P p;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.part = ws;
+    p.IH = H; p.IW = W; H /= stride; W /= stride;                      // from here on (H, W) = output size
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.groups = groups;
     p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
     p.tiles_h = H / TH; p.tiles_w = W / TW;
     p.nchunks = (long)B * p.tiles_h * p.tiles_w;
-    p.x_bytes = (long)B * H * W * Cin * 2; p.dy_bytes = (long)B * H * W * Cout * 2;
+    p.x_bytes = (long)B * p.IH * p.IW * Cin * 2; p.dy_bytes = (long)B * H * W * Cout * 2;
     DANET_CHECK_ARG(p.x_bytes < (1L << 31) && p.dy_bytes < (1L << 31), "conv_wgrad3x3: tensors of 2 GB or more are not supported");
     int ct, ni;
     plan3(B, H, W, Cin, Cout, groups, &ct, &ni, &p.msplit);
-    if (ws_floats < danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups))
+    if (ws_floats < (size_t)p.msplit * Cout * p.Cin_g * 9)
         return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (phase != 2) {
-#define W3(a, b) if (ct == a && ni == b) launch3<a, b>(p, st); else
+#define W3(a, b) if (ct == a && ni == b) { if (stride == 1) launch3<a, b, 1>(p, st); else launch3<a, b, 2>(p, st); } else
         W3(1, 1) W3(1, 2) W3(1, 3) W3(2, 1) W3(2, 2) W3(2, 3) W3(3, 1) W3(3, 2) W3(3, 3)
         return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3: no kernel for tiles %dx%d", ct, ni);
 #undef W3
@@ -351,10 +363,10 @@ extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, flo
 
 
 // ---------------------------------------------------------------------------------------------
-// Batched form: n independent 3x3 weight-gradient problems (jobs[i] = {x, dy, dw, B, H, W, Cin, Cout, groups}),
-// grouped internally by kernel instance and launched NPM at a time.  ws must hold
+// Batched form: n independent 3x3 weight-gradient problems (jobs[i] = {x, dy, dw, B, H, W, Cin, Cout, groups, stride};
+// (H, W) = input size), grouped internally by kernel instance and launched NPM at a time.  ws must hold
 // danet_conv_wgrad3x3_multi_ws_floats(jobs, n) floats.
-struct Wg3Job { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups; };
+struct Wg3Job { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups, stride; };
 
 static long multi_target_blocks() {
     if (const char* e = getenv("DANET_WGRAD3_MULTI_BLOCKS")) return atol(e);
@@ -366,14 +378,14 @@ static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int 
     double tot = 0;
     for (int k = 0; k < cnt; ++k) {
         const Wg3Job& j = jobs[idx[k]];
-        tot += (double)j.B * (j.H / TH) * (j.W / TW) * j.Cout * (j.Cin / j.groups);
+        tot += (double)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW) * j.Cout * (j.Cin / j.groups);
     }
     const long target = multi_target_blocks();
     for (int k = 0; k < cnt; ++k) {
         const Wg3Job& j = jobs[idx[k]];
         const int Cout_g = j.Cout / j.groups, Cin_g = j.Cin / j.groups;
         const long other = (long)((Cout_g + ct * 16 - 1) / (ct * 16)) * ((Cin_g + ni * 16 - 1) / (ni * 16)) * j.groups;
-        const long nchunks = (long)j.B * (j.H / TH) * (j.W / TW);
+        const long nchunks = (long)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW);
         const double w = (double)nchunks * j.Cout * Cin_g;
         long ms = (long)(target * (w / tot) / other + 0.5);
         if (ms > nchunks / 4) ms = nchunks / 4;
@@ -391,12 +403,13 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
         int ct, ni, dummy;
-        plan3(jobs[i].B, jobs[i].H, jobs[i].W, jobs[i].Cin, jobs[i].Cout, jobs[i].groups, &ct, &ni, &dummy);
+        const int stride = jobs[i].stride;
+        plan3(jobs[i].B, jobs[i].H / stride, jobs[i].W / stride, jobs[i].Cin, jobs[i].Cout, jobs[i].groups, &ct, &ni, &dummy);
         int idx[NPM], cnt = 0;
         for (int k = i; k < n && cnt < NPM; ++k) {
-            if (done[k]) continue;
+            if (done[k] || jobs[k].stride != stride) continue;
             int c2, n2;
-            plan3(jobs[k].B, jobs[k].H, jobs[k].W, jobs[k].Cin, jobs[k].Cout, jobs[k].groups, &c2, &n2, &dummy);
+            plan3(jobs[k].B, jobs[k].H / stride, jobs[k].W / stride, jobs[k].Cin, jobs[k].Cout, jobs[k].groups, &c2, &n2, &dummy);
             if (c2 == ct && n2 == ni) { idx[cnt++] = k; done[k] = true; }
         }
         int msplit[NPM];
@@ -408,11 +421,12 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
             const Wg3Job& j = jobs[idx[k]];
             Wg3P& p = mp.p[k];
             p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.part = ws ? ws + used : nullptr;
-            p.B = j.B; p.H = j.H; p.W = j.W; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
+            p.IH = j.H; p.IW = j.W;
+            p.B = j.B; p.H = j.H / stride; p.W = j.W / stride; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
             p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
-            p.tiles_h = j.H / TH; p.tiles_w = j.W / TW;
+            p.tiles_h = p.H / TH; p.tiles_w = p.W / TW;
             p.nchunks = (long)j.B * p.tiles_h * p.tiles_w;
-            p.x_bytes = (long)j.B * j.H * j.W * j.Cin * 2; p.dy_bytes = (long)j.B * j.H * j.W * j.Cout * 2;
+            p.x_bytes = (long)j.B * j.H * j.W * j.Cin * 2; p.dy_bytes = (long)j.B * p.H * p.W * j.Cout * 2;
             p.msplit = msplit[k];
             const int nyb = ((p.Cout_g + ct * 16 - 1) / (ct * 16)) * ((p.Cin_g + ni * 16 - 1) / (ni * 16));
             mp.nyb[k] = nyb;
@@ -426,9 +440,11 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         }
         if (!ws) continue;                                   // sizing pass
         if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3_multi: workspace too small");
-        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + HH * HW * ni * 32);
+        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + halo_h(stride) * halo_w(stride) * ni * 32);
         const dim3 grid((unsigned)mp.start[cnt]);
-#define W3M(a, b) if (ct == a && ni == b) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b>), grid, dim3(256), lds, st, mp); else
+#define W3M(a, b) if (ct == a && ni == b) { \
+            if (stride == 1) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1>), grid, dim3(256), lds, st, mp); \
+            else hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 2>), grid, dim3(256), lds, st, mp); } else
         W3M(1, 1) W3M(1, 2) W3M(1, 3) W3M(2, 1) W3M(2, 2) W3M(2, 3) W3M(3, 1) W3M(3, 2) W3M(3, 3)
         return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: no kernel for tiles %dx%d", ct, ni);
 #undef W3M
@@ -455,7 +471,7 @@ extern "C" int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, siz
     const Wg3Job* jb = (const Wg3Job*)jobs;
     for (int i = 0; i < n; ++i)
         DANET_CHECK_ARG(jb[i].x && jb[i].dy && jb[i].dw && jb[i].B > 0 &&
-                        danet_conv_wgrad3x3_ok(jb[i].H, jb[i].W, jb[i].Cin, jb[i].Cout, 3, 3, 1, 1, 1, jb[i].groups),
+                        danet_conv_wgrad3x3_ok(jb[i].H, jb[i].W, jb[i].Cin, jb[i].Cout, 3, 3, jb[i].stride, 1, 1, jb[i].groups),
                         "conv_wgrad3x3_multi: job %d is not a supported 3x3 problem", i);
     return multi_foreach_launch(jb, n, ws, ws_floats, beta, (hipStream_t)stream, nullptr);
 }

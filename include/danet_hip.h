@@ -250,22 +250,23 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
                        int relu, int out_fp32, float* bn_sums,
                        const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, const void* addend, void* stream);
-/* 3x3 / stride 1 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
- * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch. */
+/* 3x3 / stride 1 or 2 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
+ * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch.  (H, W) is the INPUT
+ * size; dy is [B, H/stride, W/stride, Cout]. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
-size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups);
+size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups, int stride);
 /* Batched 3x3 weight gradients: weight gradients are only needed by the optimizer, so a trainer may queue them during the
  * backward pass and compute them with a few multi-problem launches (up to 20 problems per launch, grouped by kernel instance).
- * jobs: array of n { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups; } (host memory). */
+ * jobs: array of n { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups, stride; } (host memory). */
 size_t danet_conv_wgrad3x3_multi_ws_floats(const void* jobs, int n);
 /* the same for the general weight-gradient kernel; jobs: { const void* x; const void* dy; float* dw;
  * int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; }; ws must be ZEROED by the caller. */
 size_t danet_conv_wgrad_multi_ws_floats(const void* jobs, int n);
 int danet_conv_wgrad_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
 int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
-int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups);   /* CT*10 + NI */
+int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups, int stride);   /* CT*10 + NI */
 int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
-                        int B, int H, int W, int Cin, int Cout, int groups, float beta, int phase /* 0 both kernels, 1 MFMA kernel only, 2 reduction only */, void* stream);
+                        int B, int H, int W, int Cin, int Cout, int groups, int stride, float beta, int phase /* 0 both kernels, 1 MFMA kernel only, 2 reduction only */, void* stream);
 /* 7x7 / stride 2 / pad 3 weight gradient of large batches (the regressor ResNets' stems, res_module.py:407), one
  * filter row per workgroup through the LDS transpose read (conv_wgrad_rows.hip); use when danet_conv_wgrad_rows_ok != 0. */
 int danet_conv_wgrad_rows_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);

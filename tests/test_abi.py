@@ -87,6 +87,6 @@ def test_new_ops_refuse_cpu_tensors_and_host_queries_work():
     jobs = (_lib.Wg3Job * 2)()
     for j, c in zip(jobs, (48, 96)):
         j.x = j.dy = j.dw = 16
-        j.B, j.H, j.W, j.Cin, j.Cout, j.groups = 4, 32, 32, c, c, 1
+        j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = 4, 32, 32, c, c, 1, 1
     assert lib.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), 2) >= 9 * (48 * 48 + 96 * 96)
     assert lib.danet_adam_chunk_bytes() == 32 and lib.danet_conv_pack_job_bytes() >= 56

@@ -304,3 +304,42 @@ def test_filter_row_wgrad_7x7_stride2(B, H, Cin, Cout):
     # accumulate form
     check(L.danet_conv_wgrad_rows(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, H, Cin, OH, OH, Cout, 7, 7, 2, 3, 1, 1.0, stream()), 'rows')
     assert (gw - 2 * ref).abs().max().item() <= 4e-4 * scale
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,groups', [(4, 64, 64, 48, 96, 1), (3, 32, 32, 96, 192, 1), (2, 16, 16, 192, 384, 1),
+                                                   (5, 64, 64, 48, 48, 1), (2, 128, 128, 64, 64, 1), (6, 16, 16, 64, 128, 1),
+                                                   (2, 32, 48, 80, 48, 2), (2, 64, 64, 256, 96, 1)])
+def test_transpose_read_wgrad_3x3_stride2(B, H, W, Cin, Cout, groups):
+    """conv_wgrad3x3.hip at stride 2 (HRNet transitions / fuse downsamples, ResNet stage entries) == the generic weight
+    gradient kernel == torch fp32."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    from danet_densepose2smpl_amd._lib import ptr, stream, check
+    L = _lib.lib()
+    torch.manual_seed(B + Cin)
+    OH, OW = H // 2, W // 2
+    assert L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, 3, 3, 2, 1, 1, groups)
+    x = dconv.nhwc_bf16(torch.randn(B, Cin, H, W, device='cuda'))
+    gy = dconv.nhwc_bf16(torch.randn(B, Cout, OH, OW, device='cuda'))
+    xp, gyp = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
+    gw = torch.full((Cout, Cin // groups, 3, 3), float('nan'), device='cuda')
+    nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups, 2)
+    ws = torch.full((nws,), float('nan'), device='cuda')
+    check(L.danet_conv_wgrad3x3(ptr(xp), ptr(gyp), ptr(gw), ptr(ws), nws, B, H, W, Cin, Cout, groups, 2, 0.0, 0, stream()), 'wgrad3x3 s2')
+    t = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin // groups, 3, 3), gy.float(), stride=2, padding=1, groups=groups)
+    scale = t.abs().max().item()
+    assert torch.isfinite(gw).all()
+    assert (gw - t).abs().max().item() <= 2e-4 * scale
+    # multi-problem form, mixed with a stride-1 problem of the same tile shape
+    x1 = dconv.nhwc_bf16(torch.randn(B, Cin, OH, OW, device='cuda'))
+    gw_m, gw_1 = torch.empty_like(gw), torch.empty_like(gw)
+    jobs = (_lib.Wg3Job * 2)()
+    for j, (xx, hh, ww, st, out) in zip(jobs, ((x, H, W, 2, gw_m), (x1, OH, OW, 1, gw_1))):
+        j.x, j.dy, j.dw = xx.data_ptr(), gy.data_ptr(), out.data_ptr()
+        j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = B, hh, ww, Cin, Cout, groups, st
+    import ctypes
+    need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), 2)
+    wsm = torch.empty(need, device='cuda')
+    check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), 2, ptr(wsm), need, 0.0, stream()), 'multi')
+    assert (gw_m - t).abs().max().item() <= 2e-4 * scale
+    t1 = torch.nn.grad.conv2d_weight(x1.float(), (Cout, Cin // groups, 3, 3), gy.float(), stride=1, padding=1, groups=groups)
+    assert (gw_1 - t1).abs().max().item() <= 2e-4 * t1.abs().max().item()

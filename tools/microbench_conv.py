@@ -66,10 +66,10 @@ def main():
             res['wgrad_rows_us'] = t * 1e6; res['wgrad_rows_TF'] = flops / t / 1e12
             res['wgrad_rows_vs_old_maxrel'] = float((gwr - gw).abs().max() / (gw.abs().max() + 1e-9))
         if L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, k, k, s, p, 1, g):
-            n3 = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, g)
+            n3 = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, g, s)
             ws3 = torch.empty(n3, device='cuda')
             gw3 = torch.empty_like(w.data)
-            t = timeit(lambda: L.danet_conv_wgrad3x3(ptr(xp), ptr(gyp), ptr(gw3), ptr(ws3), n3, B, H, W, Cin, Cout, g, 0.0, 0, stream()))
+            t = timeit(lambda: L.danet_conv_wgrad3x3(ptr(xp), ptr(gyp), ptr(gw3), ptr(ws3), n3, B, H, W, Cin, Cout, g, s, 0.0, 0, stream()))
             res['wgrad3_us'] = t * 1e6; res['wgrad3_TF'] = flops / t / 1e12
             res['wgrad3_vs_old_maxrel'] = float((gw3 - gw).abs().max() / (gw.abs().max() + 1e-9))
         if only != 'nomiopen':

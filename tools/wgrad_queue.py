@@ -24,7 +24,7 @@ orig = conv.flush_wgrads
 
 def spy(bucket=None):
     for q in conv._WQ:
-        (gptr, weight, x, gy, B_, H, W, Cin, Cout, groups) = q
+        (gptr, weight, x, gy, B_, H, W, Cin, Cout, groups, stride_) = q
         k = ('w3x3', B_, H, W, Cin, Cout, groups)
         if (id(weight), bucket) not in spy.done:
             seen[k] += 1; flops[k] += 2.0 * B_ * H * W * Cout * (Cin // groups) * 9
