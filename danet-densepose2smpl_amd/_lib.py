@@ -40,7 +40,7 @@ _SIGNATURES = {
     'danet_conv_forward_multi_ok': (c_i, [c_f, c_i]),
     'danet_conv_forward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_conv_forward_kernel': (c_i, [c_i] * 15),
-    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 7),
+    'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6 + [c_i, c_f]),
     'danet_conv_wgrad_rows_ok': (c_i, [c_i] * 13),
     'danet_conv_wgrad_rows_ws_floats': (c_sz, [c_i] * 8),
     'danet_conv_wgrad_rows': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 12 + [c_fl, c_f]),
@@ -111,7 +111,7 @@ class BnBwdJob(ctypes.Structure):
 class ConvJob(ctypes.Structure):
     """One problem of danet_conv_forward_multi (include/danet_hip.h)."""
     _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'wp', 'y', 'bn_sums', 'bn_x', 'bn_y', 'bn_saved', 'bn_red', 'addend')] + \
-               [(k, c_i) for k in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'R', 'S', 'stride', 'pad', 'dil', 'groups', 'transposed')]
+               [(k, c_i) for k in ('B', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'R', 'S', 'stride', 'pad', 'dil', 'groups', 'transposed', 'bn_gate')]
 
 
 def exported_symbols():

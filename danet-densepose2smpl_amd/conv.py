@@ -311,8 +311,8 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32,
                   bn_sums=None, bn_bwd=None, addend=None):
-    """bn_bwd = (bn_x, bn_y or None, saved, red): data-gradient launches also reduce the BatchNorm-backward
-    sums of the BN that produced the conv's input (see include/danet_hip.h)."""
+    """bn_bwd = (bn_x, gate tensor or None, saved, red, bn_gate) (see _bn_gate): data-gradient launches also reduce the
+    BatchNorm-backward sums of the BN that produced the conv's input (see include/danet_hip.h)."""
     L = _lib.lib()
     y = _empty_nhwc(B, Cout, OH, OW, torch.float32 if out_fp32 else torch.bfloat16, x.device)
     tok = None
@@ -326,9 +326,10 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
                                B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed),
                                int(relu), int(out_fp32), ptr(bn_sums),
                                None if bn_bwd is None else ptr(bn_bwd[0].permute(0, 2, 3, 1)),
-                               None if bn_bwd is None or bn_bwd[1] is None else ptr(bn_bwd[1].permute(0, 2, 3, 1)),
+                               None if bn_bwd is None or bn_bwd[1] is None else (ptr(bn_bwd[1]) if bn_bwd[1].dim() == 1 else ptr(bn_bwd[1].permute(0, 2, 3, 1))),
                                None if bn_bwd is None else ptr(bn_bwd[2]), None if bn_bwd is None else ptr(bn_bwd[3]),
-                               None if addend is None else ptr(addend.permute(0, 2, 3, 1)), stream()), 'danet_conv_forward')
+                               None if addend is None else ptr(addend.permute(0, 2, 3, 1)),
+                               0 if bn_bwd is None else bn_bwd[4], stream()), 'danet_conv_forward')
     if tok is not None:
         PROFILER.end(tok)
     if TRACE is not None:
@@ -387,14 +388,15 @@ class Conv2dFunction(torch.autograd.Function):
             bn_bwd = None
             if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
                     L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2):
-                bn_x, bn_relu, saved = ctx.bn_ctx
-                bn_y = x if bn_relu else None            # the conv's input IS that BatchNorm's output
+                bn_x, saved = ctx.bn_ctx[0], ctx.bn_ctx[2]
+                c3 = L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 2
+                gate_t, gate = _bn_gate(ctx.bn_ctx, x, c3)
                 if bn_x.shape == x.shape:
                     n = L.danet_bn_ws_floats(Cin)
                     red = ARENA.alloc(n)
                     if red is None:
                         red = torch.zeros(n, dtype=torch.float32, device=x.device)
-                    bn_bwd = (bn_x, bn_y, saved, red)
+                    bn_bwd = (bn_x, gate_t, saved, red, gate)
             addend = None
             if ctx.link is not None and ctx.link.dres is not None:
                 addend, ctx.link.dres = ctx.link.dres, None
@@ -597,6 +599,23 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     return y
 
 
+BN_GATE_MODES = bool(int(os.environ.get('DANET_BN_GATE_MODES', '1')))    # A/B knob: 0 = the fused reduction always gates on the BN output
+
+
+def _bn_gate(bn_ctx, x, c3):
+    """Where a fused BatchNorm-backward reduction takes that BatchNorm's ReLU gate from: (tensor or None, bn_gate).
+    bn_ctx = (bn_x, relu, saved, mask, mask_mode) as left on the BatchNorm's output by nn.BatchNorm2d; x is that
+    output (the conv's input).  The LDS-tile 3x3 kernel reads the byte mask (1 byte instead of 8 per lane); the gather
+    kernel reads the output."""
+    relu = bn_ctx[1]
+    mask, mode = (bn_ctx[3], bn_ctx[4]) if len(bn_ctx) > 3 else (None, 0)
+    if not relu:
+        return None, 0
+    if c3 and BN_GATE_MODES and mask is not None:
+        return mask, 2
+    return x, 0
+
+
 def _conv_job(job, x, wp, y, dims, transposed, bn_sums=None, bn_bwd=None, addend=None):
     (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims
     job.x, job.wp, job.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
@@ -604,7 +623,9 @@ def _conv_job(job, x, wp, y, dims, transposed, bn_sums=None, bn_bwd=None, addend
     job.addend = None if addend is None else addend.data_ptr()
     if bn_bwd is None:
         job.bn_x = job.bn_y = job.bn_saved = job.bn_red = None
+        job.bn_gate = 0
     else:
+        job.bn_gate = bn_bwd[4]
         job.bn_x, job.bn_y = bn_bwd[0].data_ptr(), None if bn_bwd[1] is None else bn_bwd[1].data_ptr()
         job.bn_saved, job.bn_red = bn_bwd[2].data_ptr(), bn_bwd[3].data_ptr()
     (job.B, job.H, job.W, job.Cin, job.OH, job.OW, job.Cout, job.R, job.S, job.stride, job.pad, job.dil, job.groups) = dims
@@ -687,12 +708,13 @@ class MultiConvFunction(torch.autograd.Function):
                 gx = _empty_nhwc(B, Cin, H, W, torch.bfloat16, xs[i].device)
                 bn_bwd = None
                 if FUSE_BN_BWD_REDUCE and bn_ctxs[i] is not None and bn_ctxs[i][0].shape == xs[i].shape:
-                    bn_x, bn_relu, saved = bn_ctxs[i]
+                    bn_x, saved = bn_ctxs[i][0], bn_ctxs[i][2]
                     nfl = L.danet_bn_ws_floats(Cin)
                     red = ARENA.alloc(nfl)
                     if red is None:
                         red = torch.zeros(nfl, dtype=torch.float32, device=gx.device)
-                    bn_bwd = (bn_x, xs[i] if bn_relu else None, saved, red)
+                    gate_t, gate = _bn_gate(bn_ctxs[i], xs[i], True)       # as for the LDS-tile 3x3 kernel; revised below if not
+                    bn_bwd = (bn_x, gate_t, saved, red, gate)
                 addend = None
                 if links is not None and links[i] is not None and links[i].dres is not None:
                     addend, links[i].dres = links[i].dres, None
@@ -704,7 +726,13 @@ class MultiConvFunction(torch.autograd.Function):
                 gxs[i] = gx
                 reds.append(None if bn_bwd is None else bn_bwd[3])
                 keep.append(wp1)
-            if L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), len(need)):
+            ok = L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), len(need))
+            if ok != 2 and any(j.bn_gate for j in jobs):      # not the LDS-tile 3x3 kernel: its gate modes do not apply
+                for k, i in enumerate(need):
+                    if jobs[k].bn_gate:
+                        jobs[k].bn_y, jobs[k].bn_gate = xs[i].data_ptr(), 0
+                ok = L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), len(need))
+            if ok:
                 tok = None
                 if PROFILER is not None:
                     dd = [dims_l[i] for i in need]

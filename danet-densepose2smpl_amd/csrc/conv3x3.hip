@@ -40,7 +40,7 @@ constexpr int C3_MAXP = 4;
 
 struct C3Prob {
     const bf16_t* x; const bf16_t* w; void* y; const float* bias; float* stats;
-    const bf16_t* bn_x; const bf16_t* bn_y; const float* bn_saved; float* bn_red;
+    const bf16_t* bn_x; const bf16_t* bn_y; const float* bn_saved; float* bn_red; int bn_gate;
     const bf16_t* addend;     // optional bf16 tensor shaped like y, added before the output is rounded (residual-branch gradient)
     int B, H, W, Cin, Cout, Cout_pad;
     int flip, relu, out_fp32;
@@ -426,17 +426,24 @@ __device__ __forceinline__ void c3_body(const C3Prob& p, const int bid, const in
                                 const __amdgpu_buffer_rsrc_t bxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bn_x), 0, p.y_bytes, 0x00020000);
                                 const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bn_y ? p.bn_y : p.bn_x), 0, p.y_bytes, 0x00020000);
                                 const i32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(bxr, off, so, 0);
-                                i32x2 yq = {0x3f803f80, 0x3f803f80};
-                                if (p.bn_y) yq = __builtin_amdgcn_raw_buffer_load_b64(byr, off, so, 0);
                                 const float xv[4] = {__uint_as_float((unsigned)xq.x << 16), __uint_as_float((unsigned)xq.x & 0xffff0000u),
                                                      __uint_as_float((unsigned)xq.y << 16), __uint_as_float((unsigned)xq.y & 0xffff0000u)};
-                                const float yv[4] = {__uint_as_float((unsigned)yq.x << 16), __uint_as_float((unsigned)yq.x & 0xffff0000u),
-                                                     __uint_as_float((unsigned)yq.y << 16), __uint_as_float((unsigned)yq.y & 0xffff0000u)};
+                                // the ReLU gate as 4 bits: from the BatchNorm's output (8 bytes per lane) or its byte mask (1 byte)
+                                int gm = 15;
+                                if (p.bn_gate == 2) {
+                                    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bn_y), 0, p.y_bytes >> 3, 0x00020000);
+                                    gm = (int)__builtin_amdgcn_raw_buffer_load_b8(mr, off != OOB ? off >> 3 : OOB, so >> 3, 0);
+                                } else if (p.bn_y) {
+                                    const i32x2 yq = __builtin_amdgcn_raw_buffer_load_b64(byr, off, so, 0);
+                                    gm = ((yq.x << 16) > 0 ? 1 : 0) | ((int)((unsigned)yq.x & 0xffff0000u) > 0 ? 2 : 0) |
+                                         ((yq.y << 16) > 0 ? 4 : 0) | ((int)((unsigned)yq.y & 0xffff0000u) > 0 ? 8 : 0);
+                                }
+                                if (off == OOB) gm = 0;
                                 const float gq[4] = {__uint_as_float((unsigned)pk.x << 16), __uint_as_float((unsigned)pk.x & 0xffff0000u),
                                                      __uint_as_float((unsigned)pk.y << 16), __uint_as_float((unsigned)pk.y & 0xffff0000u)};
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const float gv = (off != OOB && yv[r] > 0.f) ? gq[r] : 0.f;
+                                    const float gv = (gm >> r) & 1 ? gq[r] : 0.f;
                                     s1[nt][r] += gv; s2[nt][r] += gv * (xv[r] - mean[r]) * invs[r];
                                 }
                             }
@@ -629,7 +636,7 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
         const ConvP& p = ps[i];
         C3Prob& q = L.p[i];
         q.x = p.x; q.w = p.w; q.y = p.y; q.bias = p.bias; q.stats = p.stats;
-        q.bn_x = p.bn_x; q.bn_y = p.bn_y; q.bn_saved = p.bn_saved; q.bn_red = p.bn_red;
+        q.bn_x = p.bn_x; q.bn_y = p.bn_y; q.bn_saved = p.bn_saved; q.bn_red = p.bn_red; q.bn_gate = p.bn_gate;
         q.addend = p.addend;
         q.B = p.B; q.H = p.OH; q.W = p.OW; q.Cin = p.Cin; q.Cout = p.Cout; q.Cout_pad = p.Cout_pad;
         q.flip = p.transposed; q.relu = p.relu; q.out_fp32 = p.out_fp32;

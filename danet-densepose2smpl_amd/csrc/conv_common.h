@@ -32,6 +32,9 @@ struct ConvP {
     // input into bn_red [BN_NCOPY][2][Cout] while the gradient tile is still in registers: sum(dy') and
     // sum(dy' * xhat) with dy' = dy * (bn_y > 0) under ReLU, xhat = (bn_x - mean) * invstd, bn_saved = [mean[Cout] | invstd[Cout]]
     const bf16_t* bn_x; const bf16_t* bn_y; const float* bn_saved; float* bn_red;
+    // ReLU gate of that reduction: 0 = from bn_y (NULL: no ReLU); 2 = bn_y is the byte mask the BatchNorm forward wrote
+    // (norm_act.hip; LDS-tile 3x3 kernel only: one byte per lane instead of eight).
+    int bn_gate;
     long x_bytes, y_bytes;   // extents of the gathered / written tensors (buffer resources of conv_fast.hip)
     const bf16_t* addend;    // optional (LDS-tile 3x3 kernel only): bf16 tensor shaped like y, added before rounding
 };

@@ -633,7 +633,8 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
                                   int B, int H, int W, int Cin, int OH, int OW, int Cout,
                                   int R, int S, int stride, int pad, int dil, int groups, int transposed,
                                   int relu, int out_fp32, float* bn_sums,
-                                  const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, const void* addend, void* stream)
+                                  const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, const void* addend,
+                                  int bn_gate, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && wp && y, "conv_forward: null pointer");
@@ -643,10 +644,12 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
                     "conv_forward: bad sizes B=%d H=%d W=%d Cin=%d OH=%d OW=%d Cout=%d R=%d S=%d stride=%d (power of two) pad=%d groups=%d",
                     B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, groups);
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.bias = bias; p.y = y; p.stats = bn_sums;
-    p.bn_x = (const bf16_t*)bn_x; p.bn_y = (const bf16_t*)bn_y; p.bn_saved = bn_saved; p.bn_red = bn_red;
+    p.bn_x = (const bf16_t*)bn_x; p.bn_y = (const bf16_t*)bn_y; p.bn_saved = bn_saved; p.bn_red = bn_red; p.bn_gate = bn_gate;
     p.addend = (const bf16_t*)addend;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
     const bool c3 = conv3x3_ok(p, vec8);
+    DANET_CHECK_ARG(bn_gate == 0 || (bn_red && c3 && bn_gate == 2 && bn_y),
+                    "conv_forward: bn_gate %d: only 2 (byte mask in bn_y, LDS-tile 3x3 kernel) is defined", bn_gate);
     DANET_CHECK_ARG(!addend || (c3 && !out_fp32), "conv_forward: the fused addend needs the LDS-tile 3x3 kernel and a bf16 output (check danet_conv_forward_kernel)");
     DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && (c3 || conv_fast_ok(p, vec8, mt))),
                     "conv_forward: the fused BatchNorm-backward reduction needs the fast kernel and a plain bf16 output (check danet_conv_forward_kernel)");
@@ -676,10 +679,10 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
 
 // ---------------------------------------------------------------------------------------------
 // Up to 4 independent convolutions in one launch (all on the fast kernel, same danet_conv_nt of their Cout_g).
-// job = { x, wp, y, bn_sums, bn_x, bn_y, bn_saved, bn_red, addend; int B,H,W,Cin,OH,OW,Cout,R,S,stride,pad,dil,groups,transposed }
+// job = { x, wp, y, bn_sums, bn_x, bn_y, bn_saved, bn_red, addend; int B,H,W,Cin,OH,OW,Cout,R,S,stride,pad,dil,groups,transposed,bn_gate }
 // danet_conv_forward_multi_ok says whether a set qualifies (then the call cannot fail for shape reasons).
 struct ConvJob { const void* x; const void* wp; void* y; float* bn_sums; const void* bn_x; const void* bn_y; const float* bn_saved; float* bn_red; const void* addend;
-                 int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; };
+                 int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, bn_gate; };
 
 // *all3 = every problem runs on the LDS-tile 3x3 kernel (then nt / mts are not needed)
 static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, int* nt_out, bool* all3) {
@@ -694,11 +697,11 @@ static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, i
         if (!conv3x3_ok(ps[i], vec8)) { *all3 = false; break; }
         ps[i].x = (const bf16_t*)j.x; ps[i].w = (const bf16_t*)j.wp; ps[i].bias = nullptr; ps[i].y = j.y; ps[i].stats = j.bn_sums;
         ps[i].bn_x = (const bf16_t*)j.bn_x; ps[i].bn_y = (const bf16_t*)j.bn_y; ps[i].bn_saved = j.bn_saved; ps[i].bn_red = j.bn_red;
-        ps[i].addend = (const bf16_t*)j.addend;
+        ps[i].addend = (const bf16_t*)j.addend; ps[i].bn_gate = j.bn_gate;
     }
     if (*all3 && conv3x3_launch(ps, n, nullptr, true) != 0) *all3 = false;      // e.g. a tiling the multi-problem kernel lacks
     if (*all3) { *nt_out = 0; return 0; }
-    for (int i = 0; i < n; ++i) if (jobs[i].addend) return -1;      // the gather kernel has no fused addend
+    for (int i = 0; i < n; ++i) if (jobs[i].addend || jobs[i].bn_gate) return -1;      // the gather kernel has no fused addend / mask gate
     for (int i = 0; i < n; ++i) {
         const ConvJob& j = jobs[i];
         bool vec8;

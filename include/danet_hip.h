@@ -208,6 +208,8 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      BatchNorm that produced this conv's input -- its input bn_x, its output bn_y (NULL = no ReLU), its
  *      saved [mean | invstd] -- for which the epilogue accumulates sum(dy') and sum(dy'*xhat) into bn_red
  *      ([32][2][C], zeroed); danet_bn_backward with ws_is_zero = 2 then skips its reduction pass.
+ *      bn_gate (LDS-tile 3x3 kernel only; 0 elsewhere) says where that reduction takes the ReLU gate from: 0 = bn_y
+ *      as above, 2 = bn_y points at the byte mask danet_bn_forward wrote (relu_mask): one byte per lane instead of eight.
  *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
  *  Scratch buffers that must start zeroed (BN sums, wgrad accumulator) are cleared by the call unless
  *  ws_is_zero != 0 (the host then zeroes one arena per step instead of ~800 small memsets).
@@ -225,7 +227,7 @@ long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long sta
 int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, long total_bricks, void* stream);
 /* Up to 4 independent convolutions (forward or data gradient) in one launch -- HRNet branches in lockstep.
  * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red; const void* addend;
- *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed; }  (no bias / ReLU / fp32 output);
+ *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, bn_gate; }  (no bias / ReLU / fp32 output);
  * all problems must run on the fast kernel with the same danet_conv_nt(Cout/groups): query danet_conv_forward_multi_ok. */
 /* fp32 verification convolution (csrc/conv_f32.hip; BASELINE config C4's arithmetic type, slow by design): NHWC fp32
  * tensors, weights in torch's [Cout][Cin/groups][R][S] layout.  mode 0: out = conv(a = x, b = w) + bias; mode 1: out = dX
@@ -249,7 +251,8 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
                        int B, int H, int W, int Cin, int OH, int OW, int Cout,
                        int R, int S, int stride, int pad, int dil, int groups, int transposed,
                        int relu, int out_fp32, float* bn_sums,
-                       const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, const void* addend, void* stream);
+                       const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, const void* addend,
+                       int bn_gate, void* stream);
 /* 3x3 / stride 1 or 2 / pad 1 weight gradient through the LDS transpose read (conv_wgrad3x3.hip); use when
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch.  (H, W) is the INPUT
  * size; dy is [B, H/stride, W/stride, Cout]. */
