@@ -56,7 +56,10 @@ class ZeroArena(object):
 
 
 ARENA = ZeroArena()
-FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '1')))   # dgrad epilogue reduces the producing BN's backward sums
+# dgrad epilogue reduces the producing BN's backward sums.  Off by default since the one-pass BatchNorm backward (nn.ONEPASS:
+# dy and x read once, sums and apply in one launch) -- measured 34.7 vs 35.1 ms/step with both, 35.4 with the fused
+# reduction alone (the reduction costs the 3x3 data gradients +18 us per launch, as much as it saves elsewhere)
+FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '0')))
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 TRACE = None           # debugging: a list that receives (tag, shape, mean |value|) for every conv / BN launch (tools/debug_flaky.py)

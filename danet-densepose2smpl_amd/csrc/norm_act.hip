@@ -404,6 +404,154 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
 }
 
 // ------------------------------------------------------------------------------------------
+// One-pass BatchNorm backward: the two-kernel form reads dy and x twice (once for the per-channel sums, once to apply
+// them).  Here every lane keeps its share of dy / x (and the gate) in registers across a grid-wide barrier: phase 1
+// accumulates sum(dy') and sum(dy' * xhat) (block reduction, one atomic per channel and block), all workgroups meet at
+// the barrier, phase 2 applies the sums to the registers and stores dx (and d_res).  Traffic drops from 5..6 to 3..4
+// tensor passes.  Conditions (host): at most OP_NV rows per lane with a grid of at most OP_MAX_BLOCKS workgroups -- which
+// all fit on the chip at once (2 workgroups per CU), so the barrier cannot wait for a workgroup that has
+// not started -- and launches of this kernel never overlap each other (the caller issues them on ONE stream).  The spin
+// is bounded: if the barrier is not met in time the launch sets an error flag instead of hanging (results are then
+// garbage; bar[2] reports it).
+constexpr int OP_NV = 16;             // rows (8-byte channel vectors) per lane held in registers
+constexpr int OP_MAX_BLOCKS = 512;    // 2 workgroups per CU (<= 256 VGPRs each)
+
+__device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
+    // bar[0]: arrivals of the current generation, bar[1]: generation, bar[2]: error flag.
+    // No agent-scope fences: on this chip they write back / invalidate the XCD's whole L2 (78 us per barrier, measured).
+    // What crosses the barrier are device-scope float atomics (performed at the memory side, coherent across the XCDs'
+    // L2s) that every wave has waited for (workgroup-scope release = s_waitcnt) before its workgroup arrives; after the
+    // barrier they are read with plain loads of lines no cache can hold yet (nothing read them earlier in the kernel).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the reset is performed before the release
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) { __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct BnOnePass { BnBwdOne a[NBM]; int start[NBM + 1]; int n; unsigned* bar; int dbg; };
+
+__global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
+{
+    int ji = 0;
+    while (ji + 1 < m.n && (int)blockIdx.x >= m.start[ji + 1]) ++ji;
+    const BnBwdOne& a = m.a[ji];
+    const int bid = blockIdx.x - m.start[ji];
+    const FlatMap& fm = a.fm;
+    const int t = threadIdx.x, C = a.C;
+    __shared__ float sm[256][VW];
+    __shared__ float sStat[2][SLAB];
+    const bool live = t < fm.span;
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(a.dy, fm.bytes), xr = make_rsrc(a.x, fm.bytes);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_mode == 1 ? (const void*)a.mask : (const void*)a.x, a.mask_mode == 1 ? fm.bytes >> 3 : 0);
+    const __amdgpu_buffer_rsrc_t dxr = make_rsrc(a.dx, fm.bytes), drr = make_rsrc(a.dres ? a.dres : a.dx, fm.bytes);
+    int cv = 0; RowIter it; it.init(fm, bid, live ? t : 0, cv);
+    const int c0 = cv * VW;
+    // ---- phase 0: everything this lane owns goes into registers (independent loads, all in flight)
+    // (no branches inside the unrolled loops: wave-uniform options become selects / out-of-range offsets, otherwise
+    // the loops split into ~100 basic blocks and the register allocator spills)
+    i32x2 gq[OP_NV], xq[OP_NV];
+    unsigned gate[OP_NV / 8];                      // 4 gate bits per row, 8 rows per register
+#pragma unroll
+    for (int w = 0; w < OP_NV / 8; ++w) gate[w] = 0u;
+    const bool use_mask = a.relu && a.mask_mode == 1, recompute = a.relu && a.mask_mode == 2;
+#pragma unroll
+    for (int k = 0; k < OP_NV; ++k) {
+        const int off = live ? it.offset(k) : OOB;
+        gq[k] = __builtin_amdgcn_raw_buffer_load_b64(gr, off, 0, 0);
+        xq[k] = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
+        gate[k / 8] |= ((unsigned)ldmask(mr, use_mask ? off : OOB) & 15u) << (4 * (k % 8));      // (zero-sized resource otherwise: 0)
+    }
+    float mean[VW], invstd[VW], sc[VW], sh[VW], gam[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+        mean[j] = a.saved[c0 + j]; invstd[j] = a.saved[C + c0 + j];
+        gam[j] = a.gamma ? a.gamma[c0 + j] : 1.f;
+        sc[j] = invstd[j] * gam[j];
+        sh[j] = fmaf(-mean[j], sc[j], a.beta ? a.beta[c0 + j] : 0.f);
+    }
+    auto unpack = [](const i32x2 q, float* v) {
+        v[0] = __uint_as_float((unsigned)q.x << 16); v[1] = __uint_as_float((unsigned)q.x & 0xffff0000u);
+        v[2] = __uint_as_float((unsigned)q.y << 16); v[3] = __uint_as_float((unsigned)q.y & 0xffff0000u);
+    };
+    // ---- phase 1: per-channel sums of the masked gradient (rows past the end loaded zeros)
+    Vec s1, s2;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { s1.v[j] = 0.f; s2.v[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < OP_NV; ++k) {
+        float g[VW], x[VW];
+        unpack(gq[k], g); unpack(xq[k], x);
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) bits |= (fmaf(x[j], sc[j], sh[j]) > 0.f ? 1u : 0u) << j;
+        gate[k / 8] |= (!a.relu ? 15u : (recompute ? bits : 0u)) << (4 * (k % 8));
+        const unsigned mbk = gate[k / 8] >> (4 * (k % 8));
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const float gv = (mbk >> j) & 1 ? g[j] : 0.f;
+            s1.v[j] += gv; s2.v[j] = fmaf(gv * (x[j] - mean[j]), invstd[j], s2.v[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // one row's temporaries at a time (else the scheduler unpacks all rows up front)
+    }
+    // the packed registers cross the barrier as they are: without this the compiler keeps the UNPACKED floats of phase 1
+    // alive for phase 2 (14 instead of 4 registers per row)
+#pragma unroll
+    for (int k = 0; k < OP_NV; ++k) {
+        int q0 = gq[k].x, q1 = gq[k].y, q2 = xq[k].x, q3 = xq[k].y;
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+        gq[k].x = q0; gq[k].y = q1; xq[k].x = q2; xq[k].y = q3;
+    }
+    float* dst = a.red + (size_t)(bid % NCOPY) * 2 * C;
+    block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
+    block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
+    if (!(m.dbg & 1)) grid_barrier(m.bar, gridDim.x);
+    if (m.dbg & 2) return;
+    // ---- phase 2: the complete sums, then dx / d_res from the registers
+    // (plain loads: this CU's L1 cannot hold these lines from before the barrier -- nothing read them -- and the atomics
+    // completed in L2; agent-scope atomic loads here were serialised one round trip each, 30 us per launch)
+    reduce_replicas(a.red, C, fm.CV * VW, t, sStat);
+    if (!live) return;
+    float k0[VW], m1[VW], m2[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+        const float q0 = sStat[0][c0 + j], q1 = sStat[1][c0 + j];
+        k0[j] = gam[j] * invstd[j];
+        m1[j] = q0 * a.inv_count; m2[j] = q1 * a.inv_count;
+        if (bid == 0 && t < fm.CV && a.dparam) { a.dparam[c0 + j] = q0; a.dparam[C + c0 + j] = q1; }
+    }
+#pragma unroll
+    for (int k = 0; k < OP_NV; ++k) {
+        const int off = it.offset(k);
+        float g[VW], x[VW];
+        unpack(gq[k], g); unpack(xq[k], x);
+        Vec d, gm;
+        const unsigned mbk = gate[k / 8] >> (4 * (k % 8));
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const float gv = (mbk >> j) & 1 ? g[j] : 0.f;
+            gm.v[j] = gv;
+            d.v[j] = k0[j] * (gv - m1[j] - (x[j] - mean[j]) * invstd[j] * m2[j]);
+        }
+        stv(drr, a.dres ? off : OOB, gm);
+        stv(dxr, off, d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 struct SumP {
     const bf16_t* in[4]; int shift[4]; int nterms;
     int B, H, W, C;
@@ -660,5 +808,64 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
     }
     hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(m.start[n]), dim3(256), 0, st, m);
     DANET_CHECK_LAUNCH("bn_bwd_apply_multi_kernel");
+    return DANET_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// One-pass form of danet_bn_backward_multi (bn_bwd_onepass_kernel).  `bar`: 4 uints of device memory, zeroed ONCE by
+// the caller and then owned by these launches (barrier state + error flag), shared by all launches -- which must not
+// overlap (one stream).  danet_bn_backward_onepass_ok says whether a job set qualifies: every job needs its own reduction
+// (red_state 1: zeroed scratch), a ReLU gate that does not need y (mask_mode 1 or 2, or no ReLU), C <= 1024, and the
+// every job must fit the register budget (rows per lane <= 16 with <= 512 workgroups); jobs are packed into as few
+// launches as that allows.
+// Packs the jobs, in order, into launches of at most OP_MAX_BLOCKS workgroups; returns the number of launches (0: the
+// set does not qualify).
+static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) {
+    if (!jobs || n < 1 || n > NBM || getenv("DANET_NO_BN_ONEPASS")) return 0;
+    int nl = 0;
+    BnOnePass* m = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const BnBwdJob& j = jobs[i];
+        if (!(j.dy && j.x && j.dx && j.saved && j.red && j.M > 0 && j.C > 0 && j.C <= SLAB && j.red_state == 1)) return 0;
+        if (j.relu && !((j.mask_mode == 1 && j.mask) || (j.mask_mode == 2 && !j.dres))) return 0;
+        BnBwdOne a;
+        int grid;
+        if (make_map(j.M, j.C, 0, j.C, &a.fm, &grid) != 0) return 0;
+        // rows per lane <= OP_NV: blocks >= rows / (rows per block step * OP_NV)
+        const long rows_per_block = a.fm.span / a.fm.CV;
+        long blocks = (j.M + rows_per_block * OP_NV - 1) / (rows_per_block * OP_NV);
+        if (blocks < 1) blocks = 1;
+        if (blocks > OP_MAX_BLOCKS) return 0;
+        a.fm.rstep = (int)(rows_per_block * blocks);
+        a.dy = (const bf16_t*)j.dy; a.x = (const bf16_t*)j.x; a.y = (const bf16_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
+        a.dx = (bf16_t*)j.dx; a.dres = (bf16_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
+        a.have_red = 0; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
+        if (!m || m->start[m->n] + blocks > OP_MAX_BLOCKS) { m = &ms[nl++]; m->n = 0; m->start[0] = 0; }
+        m->a[m->n] = a;
+        m->start[m->n + 1] = m->start[m->n] + (int)blocks;
+        ++m->n;
+    }
+    return nl;
+}
+
+extern "C" int danet_bn_backward_onepass_ok(const void* jobs, int n)
+{
+    BnOnePass ms[NBM];
+    return onepass_plan((const BnBwdJob*)jobs, n, ms) > 0 ? 1 : 0;
+}
+
+extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, void* stream)
+{
+    DANET_ENTER();
+    BnOnePass ms[NBM];
+    const int nl = onepass_plan((const BnBwdJob*)jobs, n, ms);
+    DANET_CHECK_ARG(bar && nl > 0, "bn_backward_onepass: the job set does not qualify (see danet_bn_backward_onepass_ok)");
+    for (int l = 0; l < nl; ++l) {
+        ms[l].bar = (unsigned*)bar;
+        ms[l].dbg = getenv("DANET_BN_ONEPASS_DBG") ? atoi(getenv("DANET_BN_ONEPASS_DBG")) : 0;
+        hipLaunchKernelGGL(bn_bwd_onepass_kernel, dim3(ms[l].start[ms[l].n]), dim3(256), 0, (hipStream_t)stream, ms[l]);
+        DANET_CHECK_LAUNCH("bn_bwd_onepass_kernel");
+    }
     return DANET_OK;
 }

@@ -16,6 +16,33 @@ from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc, ARENA  # noqa: F401
 RELU_MASK = bool(int(os.environ.get('DANET_BN_RELU_MASK', '1')))     # A/B knob: 0 = the backward gates on the saved output y
 
 
+# One-pass BatchNorm backward (csrc/norm_act.hip bn_bwd_onepass_kernel: dy and x stay in registers across a grid-wide
+# barrier).  Its launches must not overlap each other, so it is only used on ONE stream: the default stream, or the one a
+# trainer names in ONEPASS_STREAM (its capture stream); BatchNorms running on other (side) streams take the two-kernel path.
+ONEPASS = bool(int(os.environ.get('DANET_BN_ONEPASS', '1')))
+ONEPASS_STREAM = None
+_ONEPASS_BAR = {}
+
+
+def _onepass_bar(device):
+    """The barrier state of the one-pass launches on `device` (4 uints, zeroed once), or None when the current stream is
+    not the one these launches are confined to."""
+    if not ONEPASS:
+        return None
+    cur = torch.cuda.current_stream(device)
+    if cur != (ONEPASS_STREAM if ONEPASS_STREAM is not None else torch.cuda.default_stream(device)):
+        return None
+    bar = _ONEPASS_BAR.get(device)
+    if bar is None:
+        bar = _ONEPASS_BAR[device] = torch.zeros(4, dtype=torch.int32, device=device)
+    return bar
+
+
+def onepass_error(device=None):
+    """True if a one-pass launch gave up waiting at its barrier (its results are garbage)."""
+    return any(int(b[2]) != 0 for d, b in _ONEPASS_BAR.items() if device is None or d == device)
+
+
 class BatchNormActFunction(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ res]) on NHWC bf16; training or eval statistics."""
 
@@ -88,7 +115,24 @@ class BatchNormActFunction(torch.autograd.Function):
             if red is None:
                 red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)      # rows: d beta, d gamma
-        check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
+        bar = _onepass_bar(x.device) if (red_zero != 2 and C <= 1024) else None
+        done = False
+        if bar is not None:
+            if red_zero is False:
+                red.zero_()
+            job = (_lib.BnBwdJob * 1)()
+            j = job[0]
+            j.dy, j.x, j.y = gy.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr()
+            j.gamma, j.saved = None if g is None else g.data_ptr(), saved.data_ptr()
+            j.dx, j.dres, j.dparam, j.red = dx.data_ptr(), None if dres is None else dres.data_ptr(), dparam.data_ptr(), red.data_ptr()
+            j.beta, j.mask, j.mask_mode = None if b is None else b.data_ptr(), None if mask is None else mask.data_ptr(), int(ctx.mask_mode)
+            j.M, j.C, j.red_state, j.relu = M, C, 1, int(ctx.relu)
+            if L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1):
+                check(L.danet_bn_backward_onepass(ctypes.addressof(job), 1, ptr(bar), stream()), 'danet_bn_backward_onepass')
+                _conv.FUSION['bn_bwd_onepass'] += 1
+                done = True
+        if not done:
+            check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
                                   None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero),
@@ -218,7 +262,12 @@ class MultiBatchNormFunction(torch.autograd.Function):
             dxs.append(dx)
             dress.append(dres)
             dparams.append(dparam)
-        check(L.danet_bn_backward_multi(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
+        bar = _onepass_bar(xs[0].device) if all(jobs[i].red_state == 1 for i in range(n)) else None
+        if bar is not None and L.danet_bn_backward_onepass_ok(ctypes.addressof(jobs), n):
+            check(L.danet_bn_backward_onepass(ctypes.addressof(jobs), n, ptr(bar), stream()), 'danet_bn_backward_onepass')
+            _conv.FUSION['bn_bwd_onepass'] += n
+        else:
+            check(L.danet_bn_backward_multi(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
         if links is not None:
             for i, lk in enumerate(links):
                 if lk is not None and lk.armed and dress[i] is not None:

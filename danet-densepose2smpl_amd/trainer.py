@@ -104,6 +104,8 @@ class Trainer(object):
         self.stream = torch.cuda.Stream(device=self.device) if on_gpu else None
         if on_gpu:
             _conv.ARENA.enable(self.device)
+            from . import nn as _nn
+            _nn.ONEPASS_STREAM = self.stream        # the one-pass BatchNorm backward is confined to the step's own stream
         self._graph = None
         self._static = None
         self._reduce_in_graph = True

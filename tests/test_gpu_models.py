@@ -266,8 +266,8 @@ def test_danet_resnet50_inference_config2(B):
 
 
 # measured on the bench configuration (round 2); the bounds leave a little room for deliberate changes
-# (measured: bn_stats 337 fused / 6 own, bn_bwd_reduce 235 fused / 108 own, residual_grad 110 fused / 4 added)
-FUSION_MIN = {'bn_stats_fused': 330, 'bn_bwd_reduce_fused': 225, 'residual_grad_fused': 105}
+# (measured: bn_stats 337 fused / 6 own, one-pass BatchNorm backward 3xx of 343, residual_grad 110 fused / 4 added)
+FUSION_MIN = {'bn_stats_fused': 330, 'bn_bwd_onepass': 250, 'residual_grad_fused': 105}
 FUSION_MAX = {'residual_grad_added': 8, 'bn_stats_own': 12}
 
 
@@ -307,7 +307,9 @@ def test_full_size_graphed_step_properties():
     fc = tr.fusion_counts
     print('fusion counts of the captured step:', fc)
     assert fc.get('bn_stats_fused', 0) >= FUSION_MIN['bn_stats_fused'], fc
-    assert fc.get('bn_bwd_reduce_fused', 0) >= FUSION_MIN['bn_bwd_reduce_fused'], fc
+    assert fc.get('bn_bwd_onepass', 0) >= FUSION_MIN['bn_bwd_onepass'], fc
+    from danet_densepose2smpl_amd import nn as dnn
+    assert not dnn.onepass_error()
     assert fc.get('residual_grad_fused', 0) >= FUSION_MIN['residual_grad_fused'], fc
     assert fc.get('residual_grad_added', 0) <= FUSION_MAX['residual_grad_added'], fc
     assert fc.get('bn_stats_own', 0) <= FUSION_MAX['bn_stats_own'], fc

@@ -168,7 +168,7 @@ def test_dgrad_epilogue_bn_backward_reduction(C, Cout, H, B, relu, use_res):
             y.backward(gy)
             outs.append((x.grad.float(), None if r is None else r.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone()))
         finally:
-            dconv.FUSE_BN_BWD_REDUCE = True
+            dconv.FUSE_BN_BWD_REDUCE = False
     (xf, rf, gwf, gbf), (xu, ru, gwu, gbu) = outs
     _close(gwf, gwu, 1e-4, 'd gamma')
     _close(gbf, gbu, 1e-4, 'd beta')
@@ -250,3 +250,41 @@ def test_relu_gate_modes_agree(C, H, B, use_res):
         # wrong gate bit is an error of a whole gradient value
         _close(a[1], b[1], 4e-3 if torch.equal(a[0], b[0]) else 2e-2, 'dx')
         _close(a[3], b[3], 1e-5, 'dgamma'); _close(a[4], b[4], 1e-5, 'dbeta')      # (float atomics)
+
+
+@pytest.mark.parametrize('C,H,B,use_res', [(48, 64, 8, False), (96, 32, 8, True), (192, 16, 4, True), (64, 16, 96, False), (12, 16, 2, True)])
+def test_onepass_backward_matches_two_kernel_backward(C, H, B, use_res):
+    """bn_bwd_onepass_kernel (registers across a grid barrier) == reduce + apply kernels: same gate bits, same sums up to
+    the atomics' order; the barrier never times out."""
+    from danet_densepose2smpl_amd import nn as dnn, conv as dconv
+    g = torch.Generator().manual_seed(C + B)
+    x = (torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3).cuda()
+    res = torch.randn(B, C, H, H, generator=g).cuda() if use_res else None
+    gy = torch.randn(B, C, H, H, generator=g).bfloat16().cuda()
+    wgt, bia = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    out = {}
+    dnn.ONEPASS_STREAM = None          # (a Trainer of an earlier test confines the one-pass launches to its own stream)
+    for one in (True, False):
+        dnn.ONEPASS = one
+        try:
+            for multi in (False, True):
+                bn = dnn.BatchNorm2d(C).cuda().train()
+                with torch.no_grad():
+                    bn.weight.copy_(wgt); bn.bias.copy_(bia)
+                xt = x.clone().requires_grad_(True)
+                rt = None if res is None else res.clone().requires_grad_(True)
+                dconv.FUSION.clear()
+                y = dnn.multi_batch_norm([bn], [xt], [rt], relu=True)[0] if multi else bn(xt, res=rt, relu=True)
+                y.backward(gy)
+                assert (dconv.FUSION.get('bn_bwd_onepass', 0) > 0) == one
+                out[(one, multi)] = (xt.grad, None if rt is None else rt.grad, bn.weight.grad.clone(), bn.bias.grad.clone())
+        finally:
+            dnn.ONEPASS = True
+    torch.cuda.synchronize()
+    assert not dnn.onepass_error()
+    for multi in (False, True):
+        a, b = out[(True, multi)], out[(False, multi)]
+        _close(a[0], b[0], 4e-3, 'dx')
+        if use_res:
+            assert torch.equal(a[1], b[1])
+        _close(a[2], b[2], 1e-5, 'dgamma'); _close(a[3], b[3], 1e-5, 'dbeta')
