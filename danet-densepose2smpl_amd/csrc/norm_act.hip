@@ -413,7 +413,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
 // not started -- and launches of this kernel never overlap each other (the caller issues them on ONE stream).  The spin
 // is bounded: if the barrier is not met in time the launch sets an error flag instead of hanging (results are then
 // garbage; bar[2] reports it).
-constexpr int OP_NV = 16;             // rows (8-byte channel vectors) per lane held in registers
+constexpr int OP_NV = 10;             // rows (8-byte channel vectors of dy and x) per lane held in registers ...
+constexpr int OP_NL = 15;             // ... and in the lane's private LDS slots (17 bytes per row: 64 KB per workgroup; with the 12 KB of
+                                      // reduction scratch two workgroups fit a CU's 160 KB)
+constexpr int OP_CH = 5;              // LDS rows loaded per batch
+static_assert(OP_NL % OP_CH == 0, "OP_NL");
+constexpr int OP_ROWS = OP_NV + OP_NL;
 constexpr int OP_MAX_BLOCKS = 512;    // 2 workgroups per CU (<= 256 VGPRs each)
 
 __device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
@@ -453,6 +458,9 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     const int t = threadIdx.x, C = a.C;
     __shared__ float sm[256][VW];
     __shared__ float sStat[2][SLAB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char op_smem[];
+    uint4 (*sRow)[256] = reinterpret_cast<uint4 (*)[256]>(op_smem);                              // [OP_NL][256] {dy, x} rows
+    unsigned char (*sGate)[256] = reinterpret_cast<unsigned char (*)[256]>(op_smem + OP_NL * 256 * 16);   // [OP_NL][256] gate bits
     const bool live = t < fm.span;
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(a.dy, fm.bytes), xr = make_rsrc(a.x, fm.bytes);
     const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_mode == 1 ? (const void*)a.mask : (const void*)a.x, a.mask_mode == 1 ? fm.bytes >> 3 : 0);
@@ -463,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     // (no branches inside the unrolled loops: wave-uniform options become selects / out-of-range offsets, otherwise
     // the loops split into ~100 basic blocks and the register allocator spills)
     i32x2 gq[OP_NV], xq[OP_NV];
-    unsigned gate[OP_NV / 8];                      // 4 gate bits per row, 8 rows per register
+    unsigned gate[(OP_NV + 7) / 8];                // 4 gate bits per row, 8 rows per register
 #pragma unroll
-    for (int w = 0; w < OP_NV / 8; ++w) gate[w] = 0u;
+    for (int w = 0; w < (OP_NV + 7) / 8; ++w) gate[w] = 0u;
     const bool use_mask = a.relu && a.mask_mode == 1, recompute = a.relu && a.mask_mode == 2;
 #pragma unroll
     for (int k = 0; k < OP_NV; ++k) {
@@ -473,6 +481,23 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
         gq[k] = __builtin_amdgcn_raw_buffer_load_b64(gr, off, 0, 0);
         xq[k] = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
         gate[k / 8] |= ((unsigned)ldmask(mr, use_mask ? off : OOB) & 15u) << (4 * (k % 8));      // (zero-sized resource otherwise: 0)
+    }
+    // the rows beyond the register budget go to this lane's own LDS slots, OP_CH at a time (2 * OP_CH more loads in flight)
+    for (int l0 = 0; l0 < OP_NL; l0 += OP_CH) {
+        i32x2 tg[OP_CH], tx[OP_CH];
+        int tm[OP_CH];
+#pragma unroll
+        for (int u = 0; u < OP_CH; ++u) {
+            const int off = live ? it.offset(OP_NV + l0 + u) : OOB;
+            tg[u] = __builtin_amdgcn_raw_buffer_load_b64(gr, off, 0, 0);
+            tx[u] = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
+            tm[u] = ldmask(mr, use_mask ? off : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < OP_CH; ++u) {
+            sRow[l0 + u][t] = uint4{(unsigned)tg[u].x, (unsigned)tg[u].y, (unsigned)tx[u].x, (unsigned)tx[u].y};
+            sGate[l0 + u][t] = (unsigned char)(tm[u] & 15);
+        }
     }
     float mean[VW], invstd[VW], sc[VW], sh[VW], gam[VW];
 #pragma unroll
@@ -505,6 +530,22 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
             s1.v[j] += gv; s2.v[j] = fmaf(gv * (x[j] - mean[j]), invstd[j], s2.v[j]);
         }
         __builtin_amdgcn_sched_barrier(0);        // one row's temporaries at a time (else the scheduler unpacks all rows up front)
+    }
+#pragma unroll 2
+    for (int l = 0; l < OP_NL; ++l) {
+        const uint4 rw = sRow[l][t];
+        float g[VW], x[VW];
+        unpack(i32x2{(int)rw.x, (int)rw.y}, g); unpack(i32x2{(int)rw.z, (int)rw.w}, x);
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) bits |= (fmaf(x[j], sc[j], sh[j]) > 0.f ? 1u : 0u) << j;
+        const unsigned mbk = !a.relu ? 15u : (recompute ? bits : (unsigned)sGate[l][t]);
+        sGate[l][t] = (unsigned char)mbk;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const float gv = (mbk >> j) & 1 ? g[j] : 0.f;
+            s1.v[j] += gv; s2.v[j] = fmaf(gv * (x[j] - mean[j]), invstd[j], s2.v[j]);
+        }
     }
     // the packed registers cross the barrier as they are: without this the compiler keeps the UNPACKED floats of phase 1
     // alive for phase 2 (14 instead of 4 registers per row)
@@ -548,6 +589,23 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
         stv(drr, a.dres ? off : OOB, gm);
         stv(dxr, off, d);
         __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 2
+    for (int l = 0; l < OP_NL; ++l) {
+        const int off = it.offset(OP_NV + l);
+        const uint4 rw = sRow[l][t];
+        float g[VW], x[VW];
+        unpack(i32x2{(int)rw.x, (int)rw.y}, g); unpack(i32x2{(int)rw.z, (int)rw.w}, x);
+        const unsigned mbk = sGate[l][t];
+        Vec d, gm;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const float gv = (mbk >> j) & 1 ? g[j] : 0.f;
+            gm.v[j] = gv;
+            d.v[j] = k0[j] * (gv - m1[j] - (x[j] - mean[j]) * invstd[j] * m2[j]);
+        }
+        stv(drr, a.dres ? off : OOB, gm);
+        stv(dxr, off, d);
     }
 }
 
@@ -817,8 +875,8 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
 // the caller and then owned by these launches (barrier state + error flag), shared by all launches -- which must not
 // overlap (one stream).  danet_bn_backward_onepass_ok says whether a job set qualifies: every job needs its own reduction
 // (red_state 1: zeroed scratch), a ReLU gate that does not need y (mask_mode 1 or 2, or no ReLU), C <= 1024, and the
-// every job must fit the register budget (rows per lane <= 16 with <= 512 workgroups); jobs are packed into as few
-// launches as that allows.
+// every job must fit the register + LDS budget (rows per lane <= 26 with <= 512 workgroups); jobs are packed into as
+// few launches as that allows.
 // Packs the jobs, in order, into launches of at most OP_MAX_BLOCKS workgroups; returns the number of launches (0: the
 // set does not qualify).
 static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) {
@@ -832,9 +890,9 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) 
         BnBwdOne a;
         int grid;
         if (make_map(j.M, j.C, 0, j.C, &a.fm, &grid) != 0) return 0;
-        // rows per lane <= OP_NV: blocks >= rows / (rows per block step * OP_NV)
+        // rows per lane <= OP_ROWS: blocks >= rows / (rows per block step * OP_ROWS)
         const long rows_per_block = a.fm.span / a.fm.CV;
-        long blocks = (j.M + rows_per_block * OP_NV - 1) / (rows_per_block * OP_NV);
+        long blocks = (j.M + rows_per_block * OP_ROWS - 1) / (rows_per_block * OP_ROWS);
         if (blocks < 1) blocks = 1;
         if (blocks > OP_MAX_BLOCKS) return 0;
         a.fm.rstep = (int)(rows_per_block * blocks);
@@ -859,12 +917,17 @@ extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, voi
 {
     DANET_ENTER();
     BnOnePass ms[NBM];
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OP_NL * 256 * 17);
+        attr_set = true;
+    }
     const int nl = onepass_plan((const BnBwdJob*)jobs, n, ms);
     DANET_CHECK_ARG(bar && nl > 0, "bn_backward_onepass: the job set does not qualify (see danet_bn_backward_onepass_ok)");
     for (int l = 0; l < nl; ++l) {
         ms[l].bar = (unsigned*)bar;
         ms[l].dbg = getenv("DANET_BN_ONEPASS_DBG") ? atoi(getenv("DANET_BN_ONEPASS_DBG")) : 0;
-        hipLaunchKernelGGL(bn_bwd_onepass_kernel, dim3(ms[l].start[ms[l].n]), dim3(256), 0, (hipStream_t)stream, ms[l]);
+        hipLaunchKernelGGL(bn_bwd_onepass_kernel, dim3(ms[l].start[ms[l].n]), dim3(256), OP_NL * 256 * 17, (hipStream_t)stream, ms[l]);
         DANET_CHECK_LAUNCH("bn_bwd_onepass_kernel");
     }
     return DANET_OK;
