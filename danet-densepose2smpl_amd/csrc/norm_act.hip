@@ -882,6 +882,7 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
 static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) {
     if (!jobs || n < 1 || n > NBM || getenv("DANET_NO_BN_ONEPASS")) return 0;
     int nl = 0;
+    long total = 0;
     BnOnePass* m = nullptr;
     for (int i = 0; i < n; ++i) {
         const BnBwdJob& j = jobs[i];
@@ -903,8 +904,13 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) 
         m->a[m->n] = a;
         m->start[m->n + 1] = m->start[m->n] + (int)blocks;
         ++m->n;
+        total += blocks;
     }
-    return nl;
+    // small sets are launch-bound either way: in isolation the barrier (~9 us; 17 + 0.055 us per workgroup in all) costs
+    // more than a second ~6 us launch, but inside the captured step a threshold did not pay (33.38 / 33.39 / 33.52 / 33.70
+    // ms per step for 0 / 100 / 200 / 300 workgroups), so every qualifying set takes the one-pass kernel
+    static const long min_blocks = getenv("DANET_BN_ONEPASS_MIN") ? atol(getenv("DANET_BN_ONEPASS_MIN")) : 0;
+    return total >= min_blocks ? nl : 0;
 }
 
 extern "C" int danet_bn_backward_onepass_ok(const void* jobs, int n)

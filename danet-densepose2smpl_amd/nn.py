@@ -70,7 +70,9 @@ class BatchNormActFunction(torch.autograd.Function):
         b = None if beta is None else beta.detach().float().contiguous()
         # ReLU gate for the backward without re-reading y (csrc/norm_act.hip ldmask): a byte mask with a residual,
         # recomputed from x without one
-        mask = torch.empty(M * C // 4, dtype=torch.uint8, device=x.device) if (training and relu and RELU_MASK) else None
+        # (without a residual the BatchNorm's own backward recomputes the gate; the mask then only serves conv._bn_gate)
+        mask = torch.empty(M * C // 4, dtype=torch.uint8, device=x.device) \
+            if (training and relu and RELU_MASK and (res is not None or _conv.FUSE_BN_BWD_REDUCE)) else None
         check(L.danet_bn_forward(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
                                  ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(b), ptr(running_mean), ptr(running_var),
                                  ptr(saved), ptr(sums), int(sums_zero), float(momentum), float(eps), int(training), int(relu),
@@ -79,7 +81,7 @@ class BatchNormActFunction(torch.autograd.Function):
         if training:
             # the BatchNorm's own backward recomputes the gate from x when it can (no residual: no mask read); the mask then
             # only serves the consumer conv's fused reduction (conv._bn_gate)
-            ctx.mask_mode = (2 if res is None else 1) if mask is not None else 0
+            ctx.mask_mode = (2 if res is None else (1 if mask is not None else 0)) if RELU_MASK else 0
             ctx.save_for_backward(x, y if (relu and ctx.mask_mode == 0) else None, g, saved, b, mask)
             ctx.relu = relu
             ctx.has_res = res is not None
@@ -211,7 +213,8 @@ class MultiBatchNormFunction(torch.autograd.Function):
                 if sums is None:
                     sums = torch.zeros(L.danet_bn_ws_floats(C), dtype=torch.float32, device=xs[i].device)
             keep.append(sums)
-            mask = torch.empty(B * H * W * C // 4, dtype=torch.uint8, device=xs[i].device) if (relu and RELU_MASK) else None
+            mask = torch.empty(B * H * W * C // 4, dtype=torch.uint8, device=xs[i].device) \
+                if (relu and RELU_MASK and (ress[i] is not None or _conv.FUSE_BN_BWD_REDUCE)) else None
             masks.append(mask)
             j = jobs[i]
             j.mask = None if mask is None else mask.data_ptr()
@@ -224,7 +227,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
             ys.append(y)
             saveds.append(saved)
         check(L.danet_bn_forward_multi(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
-        modes = [(2 if r is None else 1) if m is not None else 0 for m, r in zip(masks, ress)]
+        modes = [((2 if r is None else (1 if m is not None else 0)) if RELU_MASK else 0) if relu else 0 for m, r in zip(masks, ress)]
         ctx.save_for_backward(*xs, *[y if (relu and md == 0) else None for y, md in zip(ys, modes)], *gammas, *saveds, *betas, *masks)
         ctx.cfg = (n, relu, [r is not None for r in ress], links, modes)
         for y, x, saved, mask, md in zip(ys, xs, saveds, masks, modes):
