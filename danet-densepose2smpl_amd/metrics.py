@@ -32,3 +32,26 @@ def reconstruction_error(pred, gt, reduction=None):
     """Procrustes-aligned MPJPE (pose_utils.py:67-75): per sample, or its 'mean' / 'sum'."""
     re = torch.sqrt(((similarity_transform(pred, gt) - gt) ** 2).sum(dim=-1)).mean(dim=-1)
     return re.mean() if reduction == 'mean' else (re.sum() if reduction == 'sum' else re)
+
+
+def regress_joints(vertices, J_regressor):
+    """H36M joints from mesh vertices (eval.py:186,203): [B,V,3] x [17,V] -> [B,17,3]."""
+    return torch.matmul(J_regressor.to(vertices.dtype).to(vertices.device)[None], vertices)
+
+
+def pose_errors(pred_vertices, J_regressor, joint_mapper, gt_keypoints_3d=None, gt_vertices=None):
+    """The 3D pose evaluation block of eval.py:183-216 on the device: the 14 common joints regressed from the predicted
+    mesh and centred on its pelvis (regressed joint 0), against either given ground-truth joints (H36M / MPI-INF:
+    `gt_keypoints_3d` [B,14,3], already mapped and pelvis-centred by the dataset) or joints regressed the same way
+    from `gt_vertices` (3DPW).  Returns (mpjpe [B], reconstruction_error [B], pred_joints17 [B,17,3])."""
+    if (gt_keypoints_3d is None) == (gt_vertices is None):
+        raise ValueError('pose_errors: give exactly one of gt_keypoints_3d / gt_vertices')
+    mapper = torch.as_tensor(joint_mapper, dtype=torch.long, device=pred_vertices.device)
+    j17 = regress_joints(pred_vertices, J_regressor)
+    pred = j17[:, mapper, :] - j17[:, [0], :]
+    if gt_vertices is not None:
+        g17 = regress_joints(gt_vertices, J_regressor)
+        gt = g17[:, mapper, :] - g17[:, [0], :]
+    else:
+        gt = gt_keypoints_3d.to(pred.dtype)
+    return mpjpe(pred, gt), reconstruction_error(pred, gt, reduction=None), j17

@@ -70,3 +70,30 @@ def test_raster_degenerate_inputs(smpl_model, dp_tables):
     np.testing.assert_array_equal(fidx.cpu().numpy(), ref_f)
     np.testing.assert_array_equal(img.cpu().numpy(), ref_img)
     assert (ref_f[0] < 0).all() and (ref_f[2] < 0).all()
+
+
+def test_part_renderer_mask_and_parts(smpl_model):
+    """PartRenderer (part_utils.py:8-53) on the HIP rasteriser.  Both windings of the SMPL faces are drawn
+    (fill_back), so every pixel the oracle covers with either winding is covered; the part index of a pixel is the
+    cube_parts entry of its face's colour, and the mask is 1 exactly on covered pixels."""
+    from danet_densepose2smpl_amd.renderer import PartRenderer
+    rng = np.random.default_rng(3)
+    faces = np.asarray(smpl_model['faces']).astype(np.int32)
+    F = faces.shape[0]
+    tex = (rng.integers(0, 100, (F, 3)).astype(np.float32) + 0.5) / 100.0          # colours in the middle of a cube cell
+    cube = rng.integers(0, 7, (100, 100, 100)).astype(np.float32)
+    rend = PartRenderer(faces, tex[None, :, None, None, None, :].repeat(2, 2).repeat(2, 3).repeat(2, 4), cube, render_res=224)
+    B = 6
+    verts, cam = _scene(smpl_model, B, 77, 224.0, 224)
+    mask, parts = rend(torch.from_numpy(verts).cuda(), torch.from_numpy(cam).cuda())
+    assert mask.shape == (B, 224, 224) and parts.shape == (B, 224, 224) and parts.dtype == torch.long
+    f2 = np.concatenate([faces, faces[:, ::-1]], 0).astype(np.int32)
+    t2 = np.concatenate([tex, tex], 0)
+    vm = np.arange(verts.shape[1], dtype=np.int32)
+    ref_img, ref_f, _ = oracle.raster_forward(verts, cam, vm, f2, t2, 5000.0, 224.0, 224)
+    np.testing.assert_array_equal(mask.cpu().numpy() > 0, ref_f >= 0)
+    idx = np.floor(100 * np.transpose(ref_img, (0, 2, 3, 1))).astype(np.int64)
+    want = cube[idx[..., 0], idx[..., 1], idx[..., 2]] * (ref_f >= 0)
+    np.testing.assert_array_equal(parts.cpu().numpy(), want.astype(np.int64))
+    front, _, _ = [a for a in oracle.raster_forward(verts, cam, vm, faces, tex, 5000.0, 224.0, 224)]
+    assert ((ref_f >= 0).sum() >= (np.abs(front).sum(1) > 0).sum()) and (ref_f >= 0).mean() > 0.03

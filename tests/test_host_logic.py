@@ -186,6 +186,27 @@ def test_eval_metrics_vs_reference():
     assert abs(float(metrics.reconstruction_error(pred, gt, 'mean')) - float(g['recon'].mean())) < 1e-6
 
 
+def test_pose_evaluation_block():
+    """eval.py:183-216 as one call -- joints regressed from the mesh, pelvis-centred, mapped to the 14 common
+    joints, MPJPE + Procrustes error -- against the same steps written out with the pinned primitives."""
+    from danet_densepose2smpl_amd import metrics
+    rng = np.random.default_rng(5)
+    B, V = 5, 300
+    Jr = rng.random((17, V)).astype(np.float32); Jr /= Jr.sum(1, keepdims=True)
+    mapper = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10]              # constants.H36M_TO_J14 of the reference
+    pv, gv = rng.normal(size=(B, V, 3)).astype(np.float32), rng.normal(size=(B, V, 3)).astype(np.float32)
+    j = np.einsum('jv,bvk->bjk', Jr, pv); pj = j[:, mapper] - j[:, [0]]
+    g = np.einsum('jv,bvk->bjk', Jr, gv); gj = g[:, mapper] - g[:, [0]]
+    e, r, j17 = metrics.pose_errors(torch.from_numpy(pv), torch.from_numpy(Jr), mapper, gt_vertices=torch.from_numpy(gv))
+    np.testing.assert_allclose(j17.numpy(), j, atol=1e-5)
+    np.testing.assert_allclose(e.numpy(), np.sqrt(((pj - gj) ** 2).sum(-1)).mean(-1), rtol=1e-5)
+    np.testing.assert_allclose(r.numpy(), metrics.reconstruction_error(torch.from_numpy(pj), torch.from_numpy(gj)).numpy(), rtol=1e-5)
+    e2, r2, _ = metrics.pose_errors(torch.from_numpy(pv), torch.from_numpy(Jr), mapper, gt_keypoints_3d=torch.from_numpy(gj))
+    np.testing.assert_allclose(e2.numpy(), e.numpy(), rtol=1e-6)
+    with pytest.raises(ValueError):
+        metrics.pose_errors(torch.from_numpy(pv), torch.from_numpy(Jr), mapper)
+
+
 def test_bench_cpu_baseline_leg_runs_on_host_cores():
     """bench.py's `cpu_baseline` (the oracle timed on the host; the only place outside tests / smoke that may use it)
     produces the fields the bench line carries."""
