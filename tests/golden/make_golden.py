@@ -481,7 +481,64 @@ def g13_eval_metrics():
          recon=reconstruction_error(pred, gt, reduction=None).astype(np.float32))
 
 
-ALL.update({'g13': g13_eval_metrics, 'g12': g12_label_prologue, 'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
+def g14_augment():
+    """Label-side augmentation arithmetic (utils/imutils.py:11-153, datasets/base_dataset.py:158-187): the crop transform
+    with its truncation to integers, keypoint / pose flips, 2D / 3D keypoint processing, Gaussian heat-map targets."""
+    ref_env()
+    import utils.imutils as im
+    rng = np.random.default_rng(14)
+    B = 12
+    center = rng.uniform(80, 400, (B, 2))
+    scale = rng.uniform(0.6, 2.5, B)
+    rot = rng.uniform(-60, 60, B)
+    rot[::3] = 0
+    flip = (rng.uniform(size=B) < 0.5).astype(np.int64)
+    T = np.stack([im.get_transform(center[b], scale[b], [224, 224], rot=rot[b]) for b in range(B)])
+    pts = rng.uniform(1, 500, (B, 9, 2))
+    fwd = np.stack([np.stack([im.transform(pts[b, n], center[b], scale[b], [224, 224], rot=rot[b]) for n in range(9)]) for b in range(B)])
+    opts = rng.uniform(1, 224, (B, 9, 2))
+    inv = np.stack([np.stack([im.transform(opts[b, n], center[b], scale[b], [224, 224], invert=1, rot=rot[b]) for n in range(9)]) for b in range(B)])
+    out = dict(center=center, scale=scale, rot=rot, flip=flip, T=T, pts=pts, fwd=fwd.astype(np.float64), opts=opts, inv=inv.astype(np.float64))
+    for N in (24, 49):
+        kp = np.concatenate([rng.uniform(0, 500, (B, N, 2)), rng.uniform(0, 1, (B, N, 1))], -1)
+        res = []
+        for b in range(B):                               # base_dataset.py:158-171 with the reference's transform / flip_kp
+            k = kp[b].copy()
+            for i in range(N):
+                k[i, 0:2] = im.transform(k[i, 0:2] + 1, center[b], scale[b], [224, 224], rot=rot[b])
+            k[:, :-1] = 2. * k[:, :-1] / 224 - 1.
+            if flip[b]:
+                k = im.flip_kp(k)
+            res.append(k.astype('float32'))
+        out['kp%d' % N], out['j2d%d' % N] = kp, np.stack(res)
+    S = np.concatenate([rng.normal(0, 0.5, (B, 24, 3)), rng.uniform(0, 1, (B, 24, 1))], -1)
+    res = []
+    for b in range(B):                                   # base_dataset.py:173-187
+        s_ = S[b].copy()
+        rm = np.eye(3)
+        if not rot[b] == 0:
+            rr = -rot[b] * np.pi / 180
+            sn, cs = np.sin(rr), np.cos(rr)
+            rm[0, :2] = [cs, -sn]
+            rm[1, :2] = [sn, cs]
+        s_[:, :-1] = np.einsum('ij,kj->ki', rm, s_[:, :-1])
+        if flip[b]:
+            s_ = im.flip_kp(s_)
+        res.append(s_.astype('float32'))
+    out['S'], out['j3d'] = S, np.stack(res)
+    pose = rng.normal(0, 0.4, (B, 72))
+    out['pose'], out['pose_flipped'] = pose, np.stack([im.flip_pose(pose[b].copy()) for b in range(B)])
+    joints = np.concatenate([rng.uniform(-0.15, 1.15, (B, 17, 2)), np.ones((B, 17, 1))], -1).astype(np.float32)
+    vis = (rng.uniform(size=(B, 17, 1)) < 0.8).astype(np.float32)
+    hm, hw = [], []
+    for b in range(B):
+        t_, w_ = im.generate_heatmap(torch.from_numpy(joints[b]), 56, sigma=1 + b % 2, joints_vis=np.repeat(vis[b], 3, 1))
+        hm.append(t_.numpy()); hw.append(np.asarray(w_))
+    out['hm_joints'], out['hm_vis'], out['hm'], out['hm_w'] = joints, vis, np.stack(hm).astype(np.float16), np.stack(hw).astype(np.float32)
+    save('g14_augment', **out)
+
+
+ALL.update({'g14': g14_augment, 'g13': g13_eval_metrics, 'g12': g12_label_prologue, 'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
 
 
 def _main():

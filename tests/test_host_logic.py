@@ -207,6 +207,86 @@ def test_pose_evaluation_block():
         metrics.pose_errors(torch.from_numpy(pv), torch.from_numpy(Jr), mapper)
 
 
+def test_augmentation_arithmetic_vs_reference():
+    """SURVEY 8 row f4 (input pipeline): the batched crop transform (with the reference's truncation to integers),
+    keypoint / pose flips, 2D / 3D keypoint processing and Gaussian heat-map targets == the reference's per-sample numpy
+    code (golden g14); rot_aa against scipy's rotation algebra (cv2.Rodrigues is not available here)."""
+    from danet_densepose2smpl_amd import augment
+    from scipy.spatial.transform import Rotation
+    g = golden('g14_augment')
+    c, sc, rot, flip = (torch.from_numpy(g[k]) for k in ('center', 'scale', 'rot', 'flip'))
+    np.testing.assert_allclose(augment.get_transform(c, sc, [224, 224], rot).numpy(), g['T'], rtol=1e-12, atol=1e-10)
+    np.testing.assert_array_equal(augment.transform(torch.from_numpy(g['pts']), c, sc, [224, 224], rot=rot).numpy(), g['fwd'])
+    np.testing.assert_array_equal(augment.transform(torch.from_numpy(g['opts']), c, sc, [224, 224], invert=1, rot=rot).numpy(), g['inv'])
+    for N in (24, 49):
+        got = augment.j2d_processing(torch.from_numpy(g['kp%d' % N]), c, sc, rot, flip)
+        np.testing.assert_allclose(got.numpy(), g['j2d%d' % N], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(augment.j3d_processing(torch.from_numpy(g['S']), rot, flip).numpy(), g['j3d'], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(augment.flip_pose(torch.from_numpy(g['pose'])).numpy(), g['pose_flipped'])
+    B = g['hm_joints'].shape[0]
+    for sigma in (1, 2):
+        sel = [b for b in range(B) if 1 + b % 2 == sigma]
+        hm, w = augment.generate_heatmap(torch.from_numpy(g['hm_joints'][sel]), 56, sigma=sigma, joints_vis=torch.from_numpy(g['hm_vis'][sel]))
+        np.testing.assert_array_equal(w.numpy(), g['hm_w'][sel])
+        np.testing.assert_allclose(hm.numpy(), g['hm'][sel].astype(np.float32), atol=1e-3)
+        assert ((hm.numpy() > 0) == (g['hm'][sel] > 0)).mean() > 0.9999            # same support (fp16 storage flushes the far tail)
+    # rot_aa / pose_processing: R_z(-rot) composed with the global orientation
+    rng = np.random.default_rng(0)
+    aa = rng.normal(0, 1.2, (64, 3)); aa[0] = [0, 0, 0]; aa[1] = [np.pi - 1e-6, 0, 0]
+    rots = rng.uniform(-60, 60, 64); rots[::4] = 0
+    want = (Rotation.from_euler('z', -rots, degrees=True) * Rotation.from_rotvec(aa)).as_matrix()
+    got = Rotation.from_rotvec(augment.rot_aa(torch.from_numpy(aa), torch.from_numpy(rots)).numpy()).as_matrix()
+    np.testing.assert_allclose(got, want, atol=1e-6)
+    pose = torch.from_numpy(rng.normal(0, 0.4, (8, 72)))
+    out = augment.pose_processing(pose, torch.zeros(8), torch.tensor([0, 1] * 4))
+    np.testing.assert_allclose(out[0].numpy(), pose[0].numpy(), atol=1e-6)
+    np.testing.assert_allclose(out[1].numpy(), augment.flip_pose(pose[1:2])[0].numpy(), atol=1e-6)
+    # the image crop uses the same matrix: a bright source pixel lands where transform() says
+    img = torch.zeros(1, 3, 300, 400); img[0, :, 150, 210] = 255.
+    cc, ss, rr = torch.tensor([[200., 160.]]), torch.tensor([1.1]), torch.tensor([25.])
+    out = augment.crop_images(img, cc, ss, rr, 224)
+    v, u = np.unravel_index(int(out[0, 0].argmax()), (224, 224))
+    p = (augment.get_transform(cc, ss, [224, 224], rr)[0] @ torch.tensor([210., 150., 1.], dtype=torch.float64)).numpy()
+    assert abs(u - p[0]) <= 1.0 and abs(v - p[1]) <= 1.0
+    full = augment.rgb_processing(img, cc, ss, rr, torch.tensor([1]), torch.ones(1, 3))
+    assert full.shape == (1, 3, 224, 224) and abs(int(full[0, 0].argmax()) % 224 - (223 - u)) <= 1
+
+
+def test_dp_dict_producer_construction():
+    """dp_utils.dp_annot_process (parity unpinned: the reference needs cv2 / pycocotools).  Analytic case: the
+    crop window equals the annotated box, so the label image is sampled on its own 256-grid and points keep their
+    relative position; points outside the crop are dropped; the per-part weight blocks select the points of each part."""
+    from danet_densepose2smpl_amd import dp_utils, augment
+    M, res = 56, 224
+    center, scale = [150., 130.], 1.0                      # crop window = 200-pixel square around the centre
+    ul = augment.transform(torch.tensor([[[1., 1.]]]), torch.tensor([center]), torch.tensor([scale]), [res, res], invert=1)[0, 0].numpy() - 1
+    br = augment.transform(torch.tensor([[[res + 1., res + 1.]]]), torch.tensor([center]), torch.tensor([scale]), [res, res], invert=1)[0, 0].numpy() - 1
+    bbox = [ul[0], ul[1], br[0] - ul[0], br[1] - ul[1]]
+    lab = (np.arange(256)[:, None] // 19 + 1) * np.ones((1, 256), np.int64)        # horizontal bands 1..14
+    lab = lab.astype(np.uint8)
+    ann = {'bbox': bbox, 'dp_Ilabel': lab, 'dp_I': [1, 5, 24, 7, 3], 'dp_U': [.1, .2, .3, .4, .5], 'dp_V': [.9, .8, .7, .6, .5],
+           'dp_x': [0., 127.5, 250., 300., 64.], 'dp_y': [0., 127.5, 200., 10., -20.]}
+    d = dp_utils.dp_annot_process(ann, M, res, center, scale, 0)
+    ref = dp_utils.empty_dp_dict(M)
+    assert set(d) == set(ref) and all(d[k].shape == ref[k].shape and d[k].dtype == ref[k].dtype for k in ref)
+    L = d['body_uv_ann_labels'].reshape(M, M)
+    ys = np.rint(np.arange(M) * 255. / M).astype(int)
+    np.testing.assert_array_equal(L, lab[ys][:, np.rint(np.arange(M) * 255. / M).astype(int)])
+    assert (d['body_uv_ann_weights'] == 1).all()
+    n = 3                                                  # points 4 (x beyond the box) and 5 (y above it) are dropped (as is x = 255: > M - 1)
+    np.testing.assert_allclose(d['body_uv_X_points'][:n], np.array([0., 127.5, 250.]) / 255. * M, atol=1e-4)
+    np.testing.assert_allclose(d['body_uv_Y_points'][:n], np.array([0., 127.5, 200.]) / 255. * M, atol=1e-4)
+    np.testing.assert_array_equal(d['body_uv_I_points'][:n + 2], [1, 5, 24, 0, 0])
+    assert d['body_uv_U_points'].shape == (196 * 25,) and np.allclose(d['body_uv_U_points'][196:199], [.1, .2, .3])
+    w = d['body_uv_point_weights'].reshape(25, 196)
+    assert w[0].sum() == 0 and w[1, 0] == 1 and w[5, 1] == 1 and w[24, 2] == 1 and w.sum() == 3
+    with pytest.raises(ValueError):
+        dp_utils.dp_annot_process(ann, M, res, center, scale, 1)
+    sym = lambda I, U, V, x, y, Il: (I, U, V, 255. - x, y, Il[:, ::-1])      # a stand-in for the licensed symmetry tables
+    df = dp_utils.dp_annot_process(ann, M, res, center, scale, 1, symmetric=sym)
+    assert df['body_uv_I_points'][:3].tolist() != [] and df['body_uv_ann_labels'].shape == (M * M,)
+
+
 def test_bench_cpu_baseline_leg_runs_on_host_cores():
     """bench.py's `cpu_baseline` (the oracle timed on the host; the only place outside tests / smoke that may use it)
     produces the fields the bench line carries."""
