@@ -153,6 +153,25 @@ class Trainer(object):
             out['dp_dict'].setdefault('dp_active', bool((has_dp > 0).any()))        # (one host read per batch, outside the step)
         return out
 
+    def save(self, path, epoch=0, batch_idx=0, batch_size=0, dataset_perm=None):
+        """A training checkpoint in the reference's format (utils/saver.py:24-50): model, optimizer, bookkeeping with
+        `total_step_count` = this trainer's step count."""
+        from . import checkpoint
+        return checkpoint.save_checkpoint(path, {'model': self.model}, {'optimizer': self.optimizer}, epoch=epoch, batch_idx=batch_idx,
+                                          batch_size=batch_size, dataset_perm=dataset_perm, total_step_count=self.step_count)
+
+    def resume(self, path, trusted=False):
+        """Continue from a checkpoint (base_trainer.py:37-51): parameters, BatchNorm buffers, Adam moments and learning rate
+        come from the file, and `step_count` -- which drives the step-LR decay -- from its `total_step_count`.  Works
+        with a captured graph too: the tensors are updated in place and the weight repack is part of the graph.
+        Returns the bookkeeping values (epoch, batch_idx, ...)."""
+        from . import checkpoint
+        book = checkpoint.load_checkpoint(path, {'model': self.model}, {'optimizer': self.optimizer},
+                                          map_location=self.device, trusted=trusted)
+        self.step_count = int(book.get('total_step_count') or 0)
+        _conv._PACK_CACHE.clear()
+        return book
+
     def _decay_lr(self):
         """manual step-LR decay (trainer.py:120-128)"""
         for i, s in enumerate(cfg.SOLVER.STEPS):

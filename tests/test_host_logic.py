@@ -287,6 +287,30 @@ def test_dp_dict_producer_construction():
     assert df['body_uv_I_points'][:3].tolist() != [] and df['body_uv_ann_labels'].shape == (M * M,)
 
 
+def test_trainer_save_and_resume(tmp_path):
+    """Trainer.save / Trainer.resume: parameters, optimizer state and the step count that drives the LR decay survive a
+    round trip through a reference-format checkpoint (utils/saver.py, base_trainer.py:37-51)."""
+    from danet_densepose2smpl_amd.config import reset_cfg, cfg_from_dict
+    from danet_densepose2smpl_amd.trainer import Trainer, default_options
+    reset_cfg()
+    cfg_from_dict({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16})
+    torch.manual_seed(1)
+    a = Trainer(default_options(2), device=torch.device('cpu'), distributed=False, lr=3e-4)
+    a.step_count = 1234
+    for g in a.optimizer.param_groups:
+        g['lr'] = 1.5e-4 if not torch.is_tensor(g['lr']) else g['lr'].fill_(1.5e-4)
+    path = a.save(str(tmp_path / 'ck' / '00001234.pt'), epoch=2, batch_idx=17)
+    torch.manual_seed(2)
+    b = Trainer(default_options(2), device=torch.device('cpu'), distributed=False, lr=3e-4)
+    pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
+    k0 = next(k for k in pa if pa[k].dim() == 4)
+    assert not torch.equal(pa[k0], pb[k0])
+    book = b.resume(path)
+    assert b.step_count == 1234 and book['epoch'] == 2 and book['batch_idx'] == 17
+    assert all(torch.equal(pa[k], pb[k]) for k in pa)
+    assert abs(float(b.optimizer.param_groups[0]['lr']) - 1.5e-4) < 1e-12
+
+
 def test_bench_cpu_baseline_leg_runs_on_host_cores():
     """bench.py's `cpu_baseline` (the oracle timed on the host; the only place outside tests / smoke that may use it)
     produces the fields the bench line carries."""
