@@ -168,6 +168,10 @@ def fp32_line(args, tr, batch, world, rank, dev):
         if world > 1:
             dist.barrier()
         elapsed = time.time() - t0
+    from danet_densepose2smpl_amd import nn as _dnn
+    if _dnn.onepass_error(dev):                      # a grid barrier of the one-pass BatchNorm backward timed out: results are garbage
+        raise RuntimeError('bench: a one-pass BatchNorm launch gave up at its grid barrier (nn.onepass_error); '
+                           'run with DANET_BN_ONEPASS=0')
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -71,7 +71,7 @@ class Trainer(object):
     """Single-process-per-GPU trainer.  Gradients live in one flat store (distributed.GradStore); with world_size > 1
     its buckets are all-reduced (RCCL) while the remaining weight gradients of the step are still being computed."""
 
-    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None, bucket_mb=32.0):
+    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None, bucket_mb=None):
         self.options = options or default_options()
         self.device = device or torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.model = (model or DaNet(self.options, None, pretrained=False, smpl_model=smpl_model)).to(self.device)
@@ -88,6 +88,8 @@ class Trainer(object):
         self.store = None
         if on_gpu and USE_FUSED_ADAM:
             from .optim import FusedAdam
+            if bucket_mb is None:
+                bucket_mb = float(os.environ.get('DANET_BUCKET_MB', '32'))
             self.store = GradStore(params, bucket_mb=bucket_mb, device=self.device,
                                    world=torch.distributed.get_world_size() if self.distributed else 1)
             self.optimizer = FusedAdam(params, lr=lr0, grad_store=self.store)      # one HIP launch per step (csrc/adam.hip)
