@@ -18,6 +18,7 @@ c_fl = ctypes.c_float
 _SIGNATURES = {
     'danet_version': (c_i, []),
     'danet_last_error': (ctypes.c_char_p, []),
+    'danet_smpl_lbs_debug': (c_i, [c_f]),
     'danet_smpl_lbs_ctx_floats': (c_sz, [c_i]),
     'danet_smpl_lbs_fwd_ws_floats': (c_sz, [c_i, c_i, c_i]),
     'danet_smpl_lbs_bwd_ws_floats': (c_sz, [c_i, c_i, c_i]),

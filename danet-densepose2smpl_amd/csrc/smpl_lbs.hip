@@ -27,8 +27,6 @@ constexpr int TV = 64;             // vertices per tile
 constexpr int TC = TV * 3;         // coordinates per tile
 constexpr int NBG = 8;             // batch items per block
 constexpr int WPAD = 25;           // padded row of the staged skin weights (bank spread)
-constexpr int KC = 52;             // posedirs rows per LDS chunk in the backward (4 chunks cover 208)
-constexpr int PPAD = TC + 1;
 constexpr int NB_MAX = 16;
 constexpr int NE_MAX = 28;
 constexpr int NL_MAX = 32;
@@ -281,6 +279,9 @@ __global__ __launch_bounds__(256) void smpl_finalize_kernel(
 //   gPf  [ntiles][Bpad][208]   d/d pose feature
 //   gBt  [ntiles][Bpad][NBmax] d/d beta through v_shaped
 
+__device__ long long g_lbs_dbg[16];     // phase time stamps of workgroup (0, 0) (tools: danet_smpl_lbs_debug)
+#define LBS_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lbs_dbg[i] = clock64(); } while (0)
+
 __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
     const float* __restrict__ lbs_weights, const float* __restrict__ Jx,
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     const float* __restrict__ v_posed, const float* __restrict__ g_verts,
     const float* __restrict__ g_j54,
     int B, int Bpad, int V, int NB, int NL, int NE,
-    float* __restrict__ gA_part, float* __restrict__ gPf_part, float* __restrict__ gBt_part)
+    float* __restrict__ gA_part, float* __restrict__ gvpT /* [C][Bpad] d v_posed */, float* __restrict__ gBt_part)
 {
     const int tile = blockIdx.x, b0 = blockIdx.y * NBG, t = threadIdx.x;
     const int v0 = tile * TV;
@@ -299,11 +300,11 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     __shared__ float sG[NBG][TC];            // seed gradient per vertex coordinate
     __shared__ float sVp[NBG][TC];           // saved v_posed
     __shared__ __attribute__((aligned(16))) float sGvpT[TC][NBG];   // d v_posed, transposed
-    __shared__ float sP[KC][PPAD];
-    __shared__ float sRed[4][KC][NBG];
+    __shared__ float sGj[NBG][(NJ + NL_MAX + NE_MAX) * 3];      // d joints54 of the 8 items (was re-read from global per coordinate)
     __shared__ float sJx[NE_MAX][TV];
     __shared__ int sLm[NL_MAX];
 
+    LBS_STAMP(0);
     for (int i = t; i < NBG * 288; i += 256) {
         const int bb = i / 288, e = i % 288;
         sA[bb][e] = ctx[(size_t)(b0 + bb) * CTX_STRIDE + CTX_A + e];
@@ -317,7 +318,13 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
         sJx[e][vv] = (g_j54 && e < NE && v < V) ? Jx[(size_t)e * V + v] : 0.f;
     }
     if (t < NL_MAX) sLm[t] = (g_j54 && t < NL) ? landmark_verts[t] - v0 : -1;
+    if (g_j54)
+        for (int i = t; i < NBG * NJ54 * 3; i += 256) {
+            const int bb = i / (NJ54 * 3), e = i - bb * (NJ54 * 3);
+            sGj[bb][e] = b0 + bb < B ? g_j54[(size_t)(b0 + bb) * NJ54 * 3 + e] : 0.f;
+        }
     __syncthreads();
+    LBS_STAMP(1);
     // seeds + saved v_posed
 #pragma unroll
     for (int it_ = 0; it_ < (NBG * TC + 255) / 256; ++it_) {
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
             if (g_verts) g = g_verts[(size_t)b * C + v * 3 + k];
             vp = v_posed[(size_t)b * C + v * 3 + k];
             if (g_j54) {
-                const float* gj = g_j54 + (size_t)b * NJ54 * 3;
+                const float* gj = sGj[bb];
                 for (int l = 0; l < NL; ++l)
                     if (sLm[l] == vv) g += gj[(NJ + l) * 3 + k];
                 for (int e = 0; e < NE; ++e) g += sJx[e][vv] * gj[(NJ + NL + e) * 3 + k];
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
         sVp[bb][cc] = vp;
     }
     __syncthreads();
+    LBS_STAMP(2);
     // d v_posed = (sum_j w_vj Rg_j)^T g
     for (int pair = t; pair < TV * NBG; pair += 256) {
         const int vv = pair & (TV - 1), bb = pair / TV;
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
         for (int cc = 0; cc < 3; ++cc) sGvpT[vv * 3 + cc][bb] = T[0 * 3 + cc] * g0 + T[1 * 3 + cc] * g1 + T[2 * 3 + cc] * g2;
     }
     __syncthreads();
+    LBS_STAMP(3);
     // gA partial: thread <-> (bb, j)
     if (t < NBG * NJ) {
         const int bb = t / NJ, j = t % NJ;
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 12; ++e) dst[e] = acc[e];
     }
+    LBS_STAMP(4);
     // d beta partial through v_shaped (= d v_posed): thread <-> (bb, l)
     if (t < NBG * NB) {
         const int bb = t / NB, l = t % NB;
@@ -390,38 +400,66 @@ __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
         }
         gBt_part[((size_t)tile * Bpad + b0 + bb) * NB_MAX + l] = s;
     }
-    // d pose-feature partial: posedirs tile staged through LDS in 4 chunks of 52 rows
-    for (int chunk = 0; chunk < NPB_PAD / KC; ++chunk) {
-        const int k0 = chunk * KC;
+    LBS_STAMP(5);
+    // d v_posed of the tile leaves as [coordinate][batch] for the pose-feature contraction (smpl_pf_bwd_kernel): the former
+    // in-kernel version staged posedirs in 8 chunks with three barriers each and was 59 % of this kernel (phase stamps)
+    for (int i = t; i < TC * NBG; i += 256) {
+        const int cc = i / NBG, bb = i - cc * NBG, c = v0 * 3 + cc;
+        if (c < C) gvpT[(size_t)c * Bpad + b0 + bb] = sGvpT[cc][bb];
+    }
+    LBS_STAMP(6);
+}
+
+// Backward, pose-feature contraction: gPf[b][k] = sum_c posedirs[k][c] * d v_posed[b][c].  One workgroup per HALF vertex tile
+// (96 coordinates) and 16 batch items at a time: lane k streams its own posedirs row segment (384 contiguous bytes, 8-byte
+// loads) against the [96][16] gradient tile in LDS (broadcast float4 reads, 16 accumulators per lane) -- posedirs leaves HBM
+// once per call.  Partials per half tile, reduced in fixed order by smpl_finalize_bwd_kernel.
+constexpr int PF_C = 96;            // coordinates per workgroup
+constexpr int PF_B = 16;            // batch items per workgroup (grid.y walks the batch: two workgroups share a posedirs segment through L2)
+
+__global__ __launch_bounds__(256) void smpl_pf_bwd_kernel(const float* __restrict__ posedirs, const float* __restrict__ gvpT,
+                                                          int Bpad, int C, float* __restrict__ gPf_part /* [2*ntiles][Bpad][NPB_PAD] */)
+{
+    const int part = blockIdx.x, t = threadIdx.x;
+    const int c0 = part * PF_C;
+    __shared__ __attribute__((aligned(16))) float sG[PF_C][PF_B];
+    const int nc = min(PF_C, C - c0);
+    for (int bb0 = blockIdx.y * PF_B; bb0 < Bpad; bb0 += gridDim.y * PF_B) {
+        const int nb = min(PF_B, Bpad - bb0);
         __syncthreads();
-#pragma unroll
-        for (int it_ = 0; it_ < (KC * TC + 255) / 256; ++it_) {           // 39 independent loads per lane
-            const int i = t + it_ * 256;
-            if (i >= KC * TC) break;
-            const int kk = i / TC, cc = i % TC, k = k0 + kk, c = v0 * 3 + cc;
-            sP[kk][cc] = (k < NPB && c < C) ? posedirs[(size_t)k * C + c] : 0.f;
+        for (int i = t; i < PF_C * PF_B; i += 256) {
+            const int cc = i / PF_B, b = i - cc * PF_B;
+            sG[cc][b] = (cc < nc && b < nb) ? gvpT[(size_t)(c0 + cc) * Bpad + bb0 + b] : 0.f;
         }
         __syncthreads();
-        if (t < 4 * KC) {
-            const int kk = t % KC, q = t / KC;
-            float acc[NBG];
+        if (t < NPB_PAD) {
+            const int k = t < NPB ? t : NPB - 1;
+            float acc[PF_B];
 #pragma unroll
-            for (int bb = 0; bb < NBG; ++bb) acc[bb] = 0.f;
-            for (int cc = q * (TC / 4); cc < (q + 1) * (TC / 4); ++cc) {
-                const float p = sP[kk][cc];
-                const float4 ga = *reinterpret_cast<const float4*>(&sGvpT[cc][0]);
-                const float4 gb = *reinterpret_cast<const float4*>(&sGvpT[cc][4]);
-                acc[0] += p * ga.x; acc[1] += p * ga.y; acc[2] += p * ga.z; acc[3] += p * ga.w;
-                acc[4] += p * gb.x; acc[5] += p * gb.y; acc[6] += p * gb.z; acc[7] += p * gb.w;
+            for (int b = 0; b < PF_B; ++b) acc[b] = 0.f;
+            const float* row = posedirs + (size_t)k * C + c0;            // 8-byte aligned: C is even, c0 a multiple of 96
+#pragma unroll 4           // (8: 256 VGPRs, 44 us; all 48 loads up front: scratch, 420 us; 4: 27 us)
+            for (int cc = 0; cc < PF_C; cc += 2) {
+                float2 p = {0.f, 0.f};
+                if (cc + 1 < nc) p = *reinterpret_cast<const float2*>(row + cc);
+                else if (cc < nc) p.x = row[cc];
+#pragma unroll
+                for (int q = 0; q < PF_B / 4; ++q) {
+                    const float4 g0 = *reinterpret_cast<const float4*>(&sG[cc][4 * q]);
+                    const float4 g1 = *reinterpret_cast<const float4*>(&sG[cc + 1][4 * q]);
+                    acc[4 * q + 0] += p.x * g0.x + p.y * g1.x; acc[4 * q + 1] += p.x * g0.y + p.y * g1.y;
+                    acc[4 * q + 2] += p.x * g0.z + p.y * g1.z; acc[4 * q + 3] += p.x * g0.w + p.y * g1.w;
+                }
             }
+            if (t < NPB) {
 #pragma unroll
-            for (int bb = 0; bb < NBG; ++bb) sRed[q][kk][bb] = acc[bb];
-        }
-        __syncthreads();
-        for (int i = t; i < KC * NBG; i += 256) {
-            const int kk = i / NBG, bb = i % NBG;
-            const float s = sRed[0][kk][bb] + sRed[1][kk][bb] + sRed[2][kk][bb] + sRed[3][kk][bb];
-            gPf_part[((size_t)tile * Bpad + b0 + bb) * NPB_PAD + k0 + kk] = s;
+                for (int b = 0; b < PF_B; ++b)
+                    if (b < nb) gPf_part[((size_t)part * Bpad + bb0 + b) * NPB_PAD + t] = acc[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < PF_B; ++b)
+                    if (b < nb) gPf_part[((size_t)part * Bpad + bb0 + b) * NPB_PAD + t] = 0.f;
+            }
         }
     }
 }
@@ -431,7 +469,7 @@ __global__ __launch_bounds__(256) void smpl_finalize_bwd_kernel(
     const float* __restrict__ rot, const float* __restrict__ J_dirs, const int* __restrict__ parents,
     const float* __restrict__ ctx, const float* __restrict__ g_j54,
     const float* __restrict__ gA_part, const float* __restrict__ gPf_part, const float* __restrict__ gBt_part,
-    int Bpad, int NB, int NL, int NE, int ntiles,
+    int Bpad, int NB, int NL, int NE, int ntiles, int ntiles_pf,
     float* __restrict__ g_betas, float* __restrict__ g_rot)
 {
     const int b = blockIdx.x, t = threadIdx.x;
@@ -445,24 +483,26 @@ __global__ __launch_bounds__(256) void smpl_finalize_bwd_kernel(
         gJp[i] = g_j54 ? g_j54[(size_t)b * NJ54 * 3 + i] : 0.f;
     }
     {
-        const int o = t >> 3, sub = t & 7;            // 32 outputs per pass, 8 lanes each
-        for (int e0 = 0; e0 < 288; e0 += 32) {
-            const int e = e0 + o;
-            const float s = tile_sum8(gA_part + (size_t)b * 288 + e, (size_t)Bpad * 288, ntiles, sub);
+        // fixed-order sums over the tiles, ONE lane per output (consecutive lanes read consecutive addresses), 12 loads in
+        // flight per lane: 512 outputs in two passes.  (8 lanes per output and 32 outputs per pass was 16 passes of
+        // dependent load batches: 43 us.)
+        auto tsum = [&](const float* part, size_t tile_stride, int n) {
+            float s = 0.f;
+            for (int t0 = 0; t0 < n; t0 += 12) {
+                float v[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) v[u] = t0 + u < n ? part[(size_t)(t0 + u) * tile_stride] : 0.f;
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + ((v[8] + v[9]) + (v[10] + v[11]));
+            }
+            return s;
+        };
+        for (int e = t; e < 288; e += 256) {
+            const float s = tsum(gA_part + (size_t)b * 288 + e, (size_t)Bpad * 288, ntiles);
             const int j = e / 12, r = (e % 12) / 4, cc = e % 4;
-            if (sub == 0) { if (cc < 3) gRg[j * 9 + r * 3 + cc] = s; else gtt[j * 3 + r] = s; }
+            if (cc < 3) gRg[j * 9 + r * 3 + cc] = s; else gtt[j * 3 + r] = s;
         }
-        for (int k0 = 0; k0 < NPB_PAD; k0 += 32) {
-            const int k = k0 + o;
-            const int kl = k < NPB_PAD ? k : NPB_PAD - 1;
-            const float s = tile_sum8(gPf_part + (size_t)b * NPB_PAD + kl, (size_t)Bpad * NPB_PAD, ntiles, sub);
-            if (sub == 0 && k < NPB_PAD) gPf[k] = s;
-        }
-        {
-            const int l = o < NB_MAX ? o : NB_MAX - 1;
-            const float s = tile_sum8(gBt_part + (size_t)b * NB_MAX + l, (size_t)Bpad * NB_MAX, ntiles, sub);
-            if (sub == 0 && o < NB) gBt[o] = s;
-        }
+        if (t < NPB_PAD) gPf[t] = tsum(gPf_part + (size_t)b * NPB_PAD + t, (size_t)Bpad * NPB_PAD, ntiles_pf);
+        if (t >= 224 && t - 224 < NB) gBt[t - 224] = tsum(gBt_part + (size_t)b * NB_MAX + (t - 224), (size_t)Bpad * NB_MAX, ntiles);
     }
     __syncthreads();
     // tt_j = Jp_j - Rg_j J_j
@@ -524,7 +564,8 @@ extern "C" size_t danet_smpl_lbs_fwd_ws_floats(int B, int V, int NE) {
 extern "C" size_t danet_smpl_lbs_bwd_ws_floats(int B, int V, int NB) {
     (void)NB;
     const size_t Bp = bpad_of(B);
-    return (size_t)ntiles_of(V) * Bp * (288 + NPB_PAD + NB_MAX);
+    const size_t npf = ((size_t)V * 3 + 95) / 96;              // half-tile partials of the pose-feature kernel (PF_C = 96)
+    return (size_t)ntiles_of(V) * Bp * (288 + NB_MAX) + npf * Bp * NPB_PAD + (size_t)V * 3 * Bp;     // + d v_posed [C][Bpad]
 }
 
 extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, int B,
@@ -591,15 +632,30 @@ extern "C" int danet_smpl_lbs_backward(const float* betas, const float* rotmats,
                            danet_smpl_lbs_bwd_ws_floats(B, V, NB));
     hipStream_t s = (hipStream_t)stream;
     const int Bp = bpad_of(B), nt = ntiles_of(V);
+    const int npf = (V * 3 + PF_C - 1) / PF_C;
     float* gA = ws;
     float* gPf = gA + (size_t)nt * Bp * 288;
-    float* gBt = gPf + (size_t)nt * Bp * NPB_PAD;
+    float* gBt = gPf + (size_t)npf * Bp * NPB_PAD;
+    float* gvpT = gBt + (size_t)nt * Bp * NB_MAX;
     hipLaunchKernelGGL(smpl_lbs_bwd_kernel, dim3(nt, Bp / NBG), dim3(256), 0, s, shapedirs, posedirs, lbs_weights,
                        J_regressor_extra, landmark_verts, ctx, v_posed, g_verts, g_joints54, B, Bp, V, NB, NL, NE,
-                       gA, gPf, gBt);
+                       gA, gvpT, gBt);
     DANET_CHECK_LAUNCH("smpl_lbs_bwd_kernel");
+    hipLaunchKernelGGL(smpl_pf_bwd_kernel, dim3(npf, Bp >= 32 ? 2 : 1), dim3(256), 0, s, posedirs, gvpT, Bp, V * 3, gPf);
+    DANET_CHECK_LAUNCH("smpl_pf_bwd_kernel");
     hipLaunchKernelGGL(smpl_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rotmats, J_shapedirs, parents, ctx,
-                       g_joints54, gA, gPf, gBt, Bp, NB, NL, NE, nt, g_betas, g_rotmats);
+                       g_joints54, gA, gPf, gBt, Bp, NB, NL, NE, nt, npf, g_betas, g_rotmats);
     DANET_CHECK_LAUNCH("smpl_finalize_bwd_kernel");
+    return DANET_OK;
+}
+
+
+// Profiling aid: the phase time stamps (clock64) workgroup (0, 0) of the last smpl_lbs_bwd_kernel launch wrote.
+extern "C" int danet_smpl_lbs_debug(long long* out16)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(out16, "smpl_lbs_debug: null pointer");
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lbs_dbg), sizeof(long long) * 16, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "smpl_lbs_debug: %s", hipGetErrorString(e));
     return DANET_OK;
 }

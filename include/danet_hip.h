@@ -73,6 +73,8 @@ int danet_smpl_lbs_backward(const float* betas, const float* rotmats, int B,
                             const float* g_verts, const float* g_joints54,
                             float* g_betas, float* g_rotmats,
                             float* ws, size_t ws_floats, void* stream);
+/* profiling aid: clock64 phase stamps of workgroup (0,0) of the last backward launch (16 values) */
+int danet_smpl_lbs_debug(long long* out16);
 
 /* ---------------------------------------------------------------------------------------
  * IUV renderer.  Replaces IUV_Renderer.verts2uvimg

@@ -1,0 +1,26 @@
+"""Phase stamps of smpl_lbs_bwd_kernel (workgroup (0,0)): python tools/lbs_phases.py [B]"""
+import ctypes
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from danet_densepose2smpl_amd import assets, _lib                  # noqa: E402
+from danet_densepose2smpl_amd.smpl import SMPL                     # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device('cuda')
+smpl = SMPL(model=assets.make_synthetic_smpl(0)).to(dev)
+betas = torch.randn(B, 10, device=dev, requires_grad=True)
+rot = torch.eye(3, device=dev).repeat(B, 24, 1, 1).requires_grad_(True)
+for it in range(3):
+    out = smpl(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+    (out.vertices.sum() + out.joints.sum()).backward()
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 16)()
+_lib.check(_lib.lib().danet_smpl_lbs_debug(ctypes.addressof(buf)), 'dbg')
+st = list(buf)[:7]
+names = ['load A/W/Jx', 'seeds', 'd v_posed', 'gA', 'd beta', 'pose-feature chunks']
+for i, n in enumerate(names):
+    print('%-22s %8d cycles' % (n, st[i + 1] - st[i]))
+print('total %d cycles (100 MHz clock64 ticks? see ratio below)' % (st[6] - st[0]))
