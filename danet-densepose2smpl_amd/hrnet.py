@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .config import cfg
-from .nn import sum_relu, multi_batch_norm
+from .nn import fan_out, sum_relu, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
 from .conv import multi_conv, ResLink
@@ -132,14 +132,24 @@ class HighResolutionModule(nn.Module):
             x = self._branches_on_streams(x)
         else:
             x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        # branch j feeds the exchange path to every other output and its own fuse sum: its gradient is the sum of that many
+        # contributions -- one kernel (nn.fan_out) instead of autograd's pairwise adds
+        nout = len(self.fuse_layers)
+        fan = [fan_out(x[j], nout) for j in range(self.num_branches)]       # (nout - 1 paths + own sum, or nout paths)
+        take = [0] * self.num_branches
+
+        def use(j):
+            take[j] += 1
+            return fan[j][take[j] - 1]
+        xin = {(i, j): use(j) for i in range(nout) for j in range(self.num_branches) if j != i}
         if LOCKSTEP_BRANCHES and x[0].is_cuda and self.training:
-            fused = self._fuse_paths_in_lockstep(x)
+            fused = self._fuse_paths_in_lockstep(xin)
         else:
-            fused = {(i, j): self.fuse_layers[i][j](x[j]) for i in range(len(self.fuse_layers))
+            fused = {(i, j): self.fuse_layers[i][j](xin[(i, j)]) for i in range(nout)
                      for j in range(self.num_branches) if j != i}
         out = []
         for i in range(len(self.fuse_layers)):
-            terms = [x[j] if j == i else fused[(i, j)] for j in range(self.num_branches)]
+            terms = [use(j) if j == i else fused[(i, j)] for j in range(self.num_branches)]
             shifts = [j - i if j > i else 0 for j in range(self.num_branches)]
             out.append(sum_relu(terms, shifts, relu=True))
         return out
@@ -154,7 +164,7 @@ class HighResolutionModule(nn.Module):
                 if j != i:
                     m = self.fuse_layers[i][j]
                     paths[(i, j)] = [m] if isinstance(m, ConvBN) else list(m._modules.values())
-        cur = {key: x[key[1]] for key in paths}
+        cur = {key: x[key] for key in paths}              # x: {(output i, input j): branch j's output for that path}
         depth = max(len(st) for st in paths.values())
         for k in range(depth):
             for relu in (False, True):

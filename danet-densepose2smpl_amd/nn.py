@@ -347,6 +347,55 @@ class SumReluFunction(torch.autograd.Function):
         return (None, None) + tuple(outs)
 
 
+class FanOutFunction(torch.autograd.Function):
+    """n aliases of x for n consumers; the backward sums the n incoming gradients in ONE launch (the fuse-layer sum
+    kernel without ReLU or shifts) instead of autograd's n - 1 pairwise adds: (n + 1) instead of 3 (n - 1) tensor passes.
+    Used where an HRNet branch output feeds the exchange convolutions of all other branches plus its own fuse sum."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        total = None
+        while gs:                                   # groups of four (the kernel's limit); a running total rides along
+            grp, gs = gs[:4 if total is None else 3], gs[4 if total is None else 3:]
+            if total is not None:
+                grp = [total] + grp
+            if len(grp) == 1:
+                total = grp[0]
+                continue
+            L = _lib.lib()
+            terms = [nhwc_bf16(t) for t in grp]
+            B, C, H, W = terms[0].shape
+            y = _empty_nhwc(B, C, H, W, torch.bfloat16, terms[0].device)
+            ptrs = (ctypes.c_void_p * len(terms))(*[ptr(t.permute(0, 2, 3, 1)) for t in terms])
+            sh = (ctypes.c_int * len(terms))(*([0] * len(terms)))
+            check(L.danet_sum_relu_forward(ptrs, sh, len(terms), B, H, W, C, 0, ptr(y.permute(0, 2, 3, 1)), stream()),
+                  'danet_sum_relu_forward')
+            total = y
+        return total, None
+
+
+FAN_OUT = bool(int(os.environ.get('DANET_FAN_OUT', '1')))
+
+
+def fan_out(x, n):
+    """n views of x whose gradients are summed by one kernel (CUDA bf16 NHWC tensors with channels % 4 == 0; plain
+    aliases otherwise)."""
+    if not (FAN_OUT and n > 2 and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and _conv.PRECISION != 'fp32'
+            and x.dim() == 4 and x.shape[1] % 4 == 0):
+        return [x] * n
+    return list(FanOutFunction.apply(x, n))
+
+
 def sum_relu(terms, shifts=None, relu=True):
     shifts = [0] * len(terms) if shifts is None else list(shifts)
     if _conv.PRECISION == 'fp32':                           # verification mode: fp32 tensor ops
