@@ -34,7 +34,8 @@ def test_workspace_queries_are_host_side():
     assert lib.danet_smpl_lbs_ctx_floats(32) == 32 * 648
     assert lib.danet_smpl_lbs_ctx_floats(4) == 8 * 648          # padded to batch groups of 8
     assert lib.danet_smpl_lbs_fwd_ws_floats(32, 6890, 9) == 208 * 32 + 108 * 32 * 27
-    assert lib.danet_smpl_lbs_bwd_ws_floats(32, 6890, 10) == 108 * 32 * (288 + 208 + 16)
+    # per-tile partials of dA and d beta, half-tile partials of d pose-feature (216 of 96 coordinates), d v_posed [C][Bpad]
+    assert lib.danet_smpl_lbs_bwd_ws_floats(32, 6890, 10) == 108 * 32 * (288 + 16) + 216 * 32 * 208 + 20670 * 32
 
 
 def test_no_cpu_fallback():
