@@ -349,8 +349,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
 
 // Up to 4 independent convolutions with the same NT in one launch (HRNet branches in lockstep): workgroup id ->
 // problem through the prefix table, then the problem's own (MT, grid).
-constexpr int NCM = 4;
+constexpr int NCM = 8;      // problems per multi launch (kernel arguments: 8 x ~300 B)
 struct ConvMulti { ConvP p[NCM]; int start[NCM + 1]; int gx[NCM], gy[NCM], mt[NCM]; int n; };
+static_assert(sizeof(ConvMulti) <= 4096, "kernel arguments");
 
 template <int NT>
 __global__ __launch_bounds__(256) void conv_fast_multi_kernel(ConvMulti m)

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 // Up to 4 independent BatchNorms in one launch (the HRNet branches advance in lockstep: nn.multi_batch_norm): the
 // small branches' launches are dominated by the per-launch floor, one launch over all of them is not.
-constexpr int NBM = 4;
+constexpr int NBM = 8;
 struct BnFwdOne {
     const bf16_t* x; const bf16_t* res; bf16_t* y; const float* sums; const float* gamma; const float* beta;
     float* running_mean; float* running_var; float* saved; unsigned char* mask; FlatMap fm; int C; float inv_count, unbias; int relu;

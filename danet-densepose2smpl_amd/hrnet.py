@@ -35,6 +35,7 @@ class _Chain(nn.Module):
 
 LOCKSTEP_BRANCHES = bool(int(os.environ.get('DANET_LOCKSTEP', '1')))    # one multi-tensor BatchNorm launch per block level
 LOCKSTEP_CONVS = bool(int(os.environ.get('DANET_LOCKSTEP_CONVS', '1')))     # ... and one multi-problem conv launch
+FUSE_GROUP = int(os.environ.get('DANET_FUSE_GROUP', '8'))     # exchange paths per multi-problem launch (the kernels take up to 8)
 BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)
 _SIDE = {}
 
@@ -171,8 +172,8 @@ class HighResolutionModule(nn.Module):
                 keys = [key for key, st in paths.items() if len(st) > k and bool(st[k].relu) == relu]
                 # same output-tile count first, so that a group of four qualifies for the multi-problem conv launch
                 keys.sort(key=lambda key: (paths[key][k]._modules['0'].out_channels % 48 == 0, paths[key][k]._modules['0'].out_channels))
-                for g0 in range(0, len(keys), 4):
-                    grp = keys[g0:g0 + 4]
+                for g0 in range(0, len(keys), FUSE_GROUP):
+                    grp = keys[g0:g0 + FUSE_GROUP]
                     convs = [paths[key][k]._modules['0'] for key in grp]
                     bns = [paths[key][k]._modules['1'] for key in grp]
                     h = multi_conv(convs, [cur[key] for key in grp]) if LOCKSTEP_CONVS else [c(cur[key]) for c, key in zip(convs, grp)]

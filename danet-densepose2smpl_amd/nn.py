@@ -283,7 +283,7 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
     n = len(bns)
     ress = list(ress) if ress is not None else [None] * n
-    ok = _conv.PRECISION != 'fp32' and 1 <= n <= 4 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
+    ok = _conv.PRECISION != 'fp32' and 1 <= n <= 8 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
     lks = list(links) if links is not None else [None] * n
     if not ok:
         return [b(x, r, relu, link=lk) for b, x, r, lk in zip(bns, xs, ress, lks)]
