@@ -676,6 +676,58 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const bf16_t* __restr
     }
 }
 
+// All shifts of one fuse output at once: d_s[b, h >> s, w >> s, c] = window sums of gy * (y > 0) for every requested s <= smax.
+// A lane owns one coarsest window (2^smax squared pixels) of one channel vector and walks it in Morton order, so every 2x2,
+// 4x4, 8x8 group completes consecutively: gy and y are read ONCE (the per-shift kernel read them once per shift: 4 launches
+// and 8 tensor passes for the highest-resolution output of a 4-branch module).
+struct SumBwdAll { bf16_t* d[4]; };
+__global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                               int B, int H, int W, int C, int smax, int relu, SumBwdAll out)
+{
+    const int CV = C / VW;
+    const int F = 1 << smax, Hc = H >> smax, Wc = W >> smax;
+    const long nvec = (long)B * Hc * Wc * CV;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const int cv = (int)(v % CV);
+        long pix = v / CV;
+        const int wc = (int)(pix % Wc); pix /= Wc;
+        const int hc = (int)(pix % Hc);
+        const int b = (int)(pix / Hc);
+        Vec a1, a2, a3;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) { a1.v[j] = 0.f; a2.v[j] = 0.f; a3.v[j] = 0.f; }
+        for (int m = 0; m < F * F; ++m) {
+            const int dw = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4), dh = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
+            const int h = hc * F + dh, w = wc * F + dw;
+            const size_t off = ((((size_t)b * H + h) * W + w) * CV + cv) * VW;
+            Vec g = load_bf(gy + off);
+            if (relu) {
+                const Vec o = load_bf(y + off);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) g.v[j] = o.v[j] > 0.f ? g.v[j] : 0.f;
+            }
+            if (out.d[0]) store_bf(out.d[0] + off, g);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) a1.v[j] += g.v[j];
+            if ((m & 3) == 3) {
+                if (out.d[1]) store_bf(out.d[1] + ((((size_t)b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * CV + cv) * VW, a1);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) { a2.v[j] += a1.v[j]; a1.v[j] = 0.f; }
+                if ((m & 15) == 15) {
+                    if (out.d[2]) store_bf(out.d[2] + ((((size_t)b * (H >> 2) + (h >> 2)) * (W >> 2) + (w >> 2)) * CV + cv) * VW, a2);
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) { a3.v[j] += a2.v[j]; a2.v[j] = 0.f; }
+                    if ((m & 63) == 63) {
+                        if (out.d[3]) store_bf(out.d[3] + ((((size_t)b * (H >> 3) + (h >> 3)) * (W >> 3) + (w >> 3)) * CV + cv) * VW, a3);
+#pragma unroll
+                        for (int j = 0; j < VW; ++j) a3.v[j] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // slab [c_begin, c_begin + Cs) of a [M, C] tensor; Cs <= 1024
 inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* grid) {
     if (C % VW != 0 || Cs % VW != 0 || c_begin % VW != 0 || Cs / VW > 256) return -1;
@@ -780,6 +832,27 @@ extern "C" int danet_sum_relu_forward(const void* const* terms /* host array */,
     long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sum_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)y, relu);
     DANET_CHECK_LAUNCH("sum_relu_kernel");
+    return DANET_OK;
+}
+
+// All requested shifts in one launch: d[s] (s = 0..3, NULL = not needed) receives the [B, H >> s, W >> s, C] gradient of the
+// terms that entered the sum up-sampled by 2^s.
+extern "C" int danet_sum_relu_backward_all(const void* gy, const void* y, int B, int H, int W, int C, int relu,
+                                           void* d0, void* d1, void* d2, void* d3, void* stream)
+{
+    DANET_ENTER();
+    void* d[4] = {d0, d1, d2, d3};
+    int smax = -1;
+    for (int s_ = 0; s_ < 4; ++s_) if (d[s_]) smax = s_;
+    DANET_CHECK_ARG(gy && (!relu || y) && C % VW == 0 && smax >= 0 && H % (1 << smax) == 0 && W % (1 << smax) == 0,
+                    "sum_relu_backward_all: bad arguments");
+    SumBwdAll out;
+    for (int s_ = 0; s_ < 4; ++s_) out.d[s_] = (bf16_t*)d[s_];
+    const long nvec = (long)B * (H >> smax) * (W >> smax) * (C / VW);
+    long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_relu_bwd_all_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gy,
+                       (const bf16_t*)y, B, H, W, C, smax, relu, out);
+    DANET_CHECK_LAUNCH("sum_relu_bwd_all_kernel");
     return DANET_OK;
 }
 

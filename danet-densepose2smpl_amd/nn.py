@@ -302,6 +302,9 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     return list(MultiBatchNormFunction.apply(static, *xs, *ress, *[b.weight for b in bns], *[b.bias for b in bns]))
 
 
+SUM_BWD_ALL = bool(int(os.environ.get('DANET_SUM_BWD_ALL', '1')))
+
+
 class SumReluFunction(torch.autograd.Function):
     """y = [relu](sum_t nearest_upsample_{2^shift_t}(term_t)) -- HRNet fuse layer (hr_module.py:166-177)."""
 
@@ -333,6 +336,15 @@ class SumReluFunction(torch.autograd.Function):
         gy = nhwc_bf16(gy)
         outs = []
         cache = {}
+        need = sorted({s for i, s in enumerate(shifts) if ctx.needs_input_grad[2 + i]})
+        if SUM_BWD_ALL and len(need) > 1 and need[-1] <= 3:
+            # every shift in one launch: gy and y are read once (csrc/norm_act.hip sum_relu_bwd_all_kernel)
+            for s in need:
+                cache[s] = _empty_nhwc(B, C, H >> s, W >> s, torch.bfloat16, gy.device)
+            dp = [None if s not in cache else ptr(cache[s].permute(0, 2, 3, 1)) for s in range(4)]
+            check(L.danet_sum_relu_backward_all(ptr(gy.permute(0, 2, 3, 1)), None if y is None else ptr(y.permute(0, 2, 3, 1)),
+                                                B, H, W, C, int(relu), dp[0], dp[1], dp[2], dp[3], stream()),
+                  'danet_sum_relu_backward_all')
         for i, s in enumerate(shifts):
             if not ctx.needs_input_grad[2 + i]:
                 outs.append(None)

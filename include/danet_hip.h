@@ -332,6 +332,9 @@ int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nter
                            int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
                             void* d_term, void* stream);
+/* every requested shift in one launch: d0..d3 (NULL = not needed) <- [B, H >> s, W >> s, C]; gy and y are read once */
+int danet_sum_relu_backward_all(const void* gy, const void* y, int B, int H, int W, int C, int relu,
+                                void* d0, void* d1, void* d2, void* d3, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Joint-centric part decomposition (STN).  Replaces the 24 x (F.affine_grid + F.grid_sample) +

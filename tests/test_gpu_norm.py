@@ -74,6 +74,24 @@ def test_sum_relu_fuse():
     _close(at.grad, ar.grad, 1e-2, 'da')
     _close(bt.grad, br.grad, 1e-2, 'db')
     _close(ct.grad, cr.grad, 1e-2, 'dc')
+    # four terms (shifts 0..3, as for the highest-resolution output of a 4-branch module): the one-launch backward equals
+    # the per-shift launches bit for bit (same fp32 window sums, rounded once)
+    d = torch.randn(B, C, 4, 4, generator=g).bfloat16().float().cuda()
+    res = {}
+    for mode in (True, False):
+        dnn.SUM_BWD_ALL = mode
+        ts = [t.clone().requires_grad_(True) for t in (a, b, c, d)]
+        y4 = dnn.sum_relu(ts, [0, 1, 2, 3], relu=True)
+        y4.backward(gy.bfloat16())
+        res[mode] = [t.grad.clone() for t in ts]
+    dnn.SUM_BWD_ALL = True
+    for u, v in zip(res[True], res[False]):
+        assert torch.equal(u, v)
+    ar4 = [t.clone().requires_grad_(True) for t in (a, b, c, d)]
+    yr4 = F.relu(ar4[0] + sum(F.interpolate(t, scale_factor=2 ** k, mode='nearest') for k, t in enumerate(ar4[1:], 1)))
+    yr4.backward(gy)
+    for u, v in zip(res[True], ar4):
+        _close(u, v.grad, 1e-2, 'd term')
     # plain relu
     xt = a.clone().requires_grad_(True)
     r = dnn.relu(xt)
