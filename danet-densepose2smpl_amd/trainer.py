@@ -238,11 +238,16 @@ class Trainer(object):
         else:
             _conv.GRAD_STORE = st
             try:
-                for bi in range(len(st.buckets)):
-                    _conv.flush_wgrads(bucket=bi)
-                    st.collect(bi)
-                    if self.distributed and reduce:
+                if self.distributed and reduce:
+                    for bi in range(len(st.buckets)):
+                        _conv.flush_wgrads(bucket=bi)
+                        st.collect(bi)
                         st.reduce_bucket(bi)
+                else:
+                    # one process: no all-reduce to overlap with, so all queued weight gradients go out in the fewest, largest
+                    # multi-problem launches (-0.15 ms against 13 bucket-sized flushes)
+                    _conv.flush_wgrads()
+                    st.collect()
                 _conv.flush_wgrads()                     # (nothing left: every parameter belongs to a bucket)
             finally:
                 _conv.GRAD_STORE = None
