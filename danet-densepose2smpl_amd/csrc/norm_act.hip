@@ -952,8 +952,22 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
 // few launches as that allows.
 // Packs the jobs, in order, into launches of at most OP_MAX_BLOCKS workgroups; returns the number of launches (0: the
 // set does not qualify).
+// Workgroups that are certainly resident together: two per CU of the current device (256 CUs on an MI355X in SPX mode; a
+// partitioned device exposes fewer, and a barrier over more workgroups than fit would only end by its spin bound).
+static int onepass_max_blocks() {
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 1;
+        cached = 2 * cus < OP_MAX_BLOCKS ? 2 * cus : OP_MAX_BLOCKS;
+    }
+    return cached;
+}
+
 static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) {
     if (!jobs || n < 1 || n > NBM || getenv("DANET_NO_BN_ONEPASS")) return 0;
+    const int max_blocks = onepass_max_blocks();
     int nl = 0;
     long total = 0;
     BnOnePass* m = nullptr;
@@ -968,12 +982,12 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) 
         const long rows_per_block = a.fm.span / a.fm.CV;
         long blocks = (j.M + rows_per_block * OP_ROWS - 1) / (rows_per_block * OP_ROWS);
         if (blocks < 1) blocks = 1;
-        if (blocks > OP_MAX_BLOCKS) return 0;
+        if (blocks > max_blocks) return 0;
         a.fm.rstep = (int)(rows_per_block * blocks);
         a.dy = (const bf16_t*)j.dy; a.x = (const bf16_t*)j.x; a.y = (const bf16_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
         a.dx = (bf16_t*)j.dx; a.dres = (bf16_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
         a.have_red = 0; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
-        if (!m || m->start[m->n] + blocks > OP_MAX_BLOCKS) { m = &ms[nl++]; m->n = 0; m->start[0] = 0; }
+        if (!m || m->start[m->n] + blocks > max_blocks) { m = &ms[nl++]; m->n = 0; m->start[0] = 0; }
         m->a[m->n] = a;
         m->start[m->n + 1] = m->start[m->n] + (int)blocks;
         ++m->n;
