@@ -380,7 +380,8 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
     bool done[4096];
     for (int i = 0; i < n; ++i) done[i] = false;
     size_t used = 0;
-    long target = 1536;     // swept on MI355X: the one large 7x7 problem of a launch needs many workgroups to balance
+    long target = 1024;     // swept on MI355X (512 / 768 / 1024 / 1536 / 2048: 33.04 / 32.82 / 32.67 / 32.81 / 32.89 ms per step once
+                            // the 7x7 stem has its own kernel and one process flushes all problems at once)
     if (const char* e = getenv("DANET_WGRAD_MULTI_BLOCKS")) target = atol(e);
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
