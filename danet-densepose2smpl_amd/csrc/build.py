@@ -27,6 +27,7 @@ UNITS = {
     'conv_wgrad3x3.hip': MFMA_VGPR,
     'conv_wgrad_rows.hip': MFMA_VGPR,
     'conv3x3.hip': MFMA_VGPR,
+    'conv3x3s.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
     'conv_f32.hip': ['-ffp-contract=off'],
     'part_ops.hip': [],

@@ -612,6 +612,8 @@ int plan(const ConvP& p, C3Prob& q, int nprob) {
 
 namespace danet_conv {
 
+int* conv3x3_debug_buffer() { return g_dbg; }
+
 bool conv3x3_ok(const ConvP& p, bool vec8) {
     if (!shape_ok(p, vec8)) return false;
     C3Prob q{};
@@ -629,6 +631,7 @@ int conv3x3_config(const ConvP& p, bool vec8, int nprob) {
 // launched then); dry = true only answers that question.
 int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
     if (n < 1 || n > C3_MAXP) return -1;
+    if (g_c3_on && g_force.mt == 0 && conv3x3s_launch(ps, n, stream, dry) == 0) return 0;      // the streamed kernel takes what it can (no forced tiling)
     C3Launch L{};
     L.n = n;
     int lds_max = 0, tile0 = 0;
