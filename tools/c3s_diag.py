@@ -49,8 +49,7 @@ def main():
             def ph(a, b):
                 return int(((d[:, b] - d[:, a]) & 0xffffffff).mean())
             rec['wgs'] = int(d.shape[0])
-            rec['mfma'] = {'prologue': ph(0, 1), 'ringfill': ph(1, 2), 'kloop': ph(2, 3), 'ksplit': ph(3, 4), 'epilogue': ph(4, 5), 'flush+bar': ph(5, 6), 'total': ph(0, 7)}
-            rec['loader'] = {'start_vs_mfma': ph(0, 8), 'setup': ph(8, 13), 'rows': ph(13, 9), 'wait': ph(9, 10), 'stage0_done': ph(10, 11), 'total': ph(8, 12)}
+            rec['phases'] = {'issue0': ph(0, 9), 'wait0': ph(9, 10), 'desc': ph(10, 8), 'lanebase': ph(8, 11), 'fill': ph(11, 12), 'issue1': ph(12, 2), 'kloop': ph(2, 3), 'ksplit': ph(3, 4), 'epilogue': ph(4, 5), 'flush+bar': ph(5, 6), 'total': ph(0, 7)}
             # workgroups resident together on a CU: overlapping [start, end) intervals of the MFMA role per CU id
             res = []
             for cu in np.unique(d[:, 15]):
@@ -65,5 +64,43 @@ def main():
         L.danet_conv3x3_stream_set(1, 512, 0)
 
 
+def multi_subsets():
+    """Per-problem error of multi-problem launches over subsets of the four HRNet branches (isolates hand-over bugs between problems)."""
+    import ctypes
+    import itertools
+    L = _lib.lib()
+    chans, sizes = (48, 96, 192, 384), (64, 32, 16, 8)
+    B = 32
+    xs = [conv.nhwc_bf16(torch.randn(B, c, s, s, device='cuda')) for c, s in zip(chans, sizes)]
+    ws = [torch.nn.Parameter(torch.randn(c, c, 3, 3, device='cuda') * 0.05) for c in chans]
+    wps = [conv.pack_weight(w, 1, 0) for w in ws]
+    ys = [torch.empty_like(x) for x in xs]
+    refs = []
+    L.danet_conv3x3_set(0, 0, 0, 512, 0)
+    for x, wp, c, s in zip(xs, wps, chans, sizes):
+        refs.append(conv._conv_fwd_raw(x, wp, None, B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1, False, False, False, None).float())
+    L.danet_conv3x3_set(1, 0, 0, 512, 0)
+    L.danet_conv3x3_stream_set(1, 512, 0)
+    for n in (1, 2, 3, 4):
+        for sub in itertools.combinations(range(4), n):
+            jobs = (_lib.ConvJob * n)()
+            for j, i in zip(jobs, sub):
+                c, s = chans[i], sizes[i]
+                conv._conv_job(j, xs[i], wps[i], ys[i], (B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1), False, None)
+            errs = []
+            for rep in range(2):
+                for i in sub:
+                    ys[i].zero_()
+                conv.check(L.danet_conv_forward_multi(ctypes.addressof(jobs), n, _lib.stream()), 'multi')
+                torch.cuda.synchronize()
+                errs.append([round(float((ys[i].float() - refs[i]).abs().max() / refs[i].abs().max()), 4) for i in sub])
+            plans = [L.danet_conv3x3_stream_plan(B, sizes[i], sizes[i], chans[i], chans[i], n) for i in sub]
+            print(json.dumps({'multi_subset': [chans[i] for i in sub], 'plans': plans, 'err': errs}), flush=True)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'multi':
+        multi_subsets()
+    else:
+        main()
+        multi_subsets()
