@@ -36,7 +36,7 @@ _SIGNATURES = {
     'danet_conv_f32': (c_i, [c_i, c_f, c_f, c_f, c_f] + [c_i] * 13 + [c_f]),
     'danet_conv3x3_set': (c_i, [c_i] * 5),
     'danet_conv3x3_debug': (None, [c_f]),
-    'danet_conv3x3_stream_set': (c_i, [c_i, c_i, c_i]),
+    'danet_conv3x3_stream_set': (c_i, [c_i, c_i, c_i, c_i]),
     'danet_conv3x3_stream_plan': (c_i, [c_i] * 6),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, ctypes.c_long, c_f]),
     'danet_conv_pack_job_bricks': (ctypes.c_long, [c_i] * 7),

@@ -404,7 +404,8 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                 for (int m = 0; m < MO; ++m) {
                     const int mt = qq * MO + m;
                     const int off = (cok && outoff[mt] != OOB) ? outoff[mt] : OOB;
-                    f32x4 v = acc[mt][nt] + bv;
+                    f32x4 v = acc[mt][nt];
+                    if (p.bias) v += bv;
                     if (p.addend) {
                         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.addend), 0, p.y_bytes, 0x00020000);
                         const i32x2 aq = __builtin_amdgcn_raw_buffer_load_b64(ar, off, so, 0);
@@ -417,15 +418,13 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                     } else {
                         const i32x2 pk = {(int)f2bf_pk(v[0], v[1]), (int)f2bf_pk(v[2], v[3])};
                         __builtin_amdgcn_raw_buffer_store_b64(pk, yr, off, so, 0);
-                        if (p.stats) {           // BatchNorm statistics from the fp32 accumulators (see conv3x3.hip)
-                            if (p.has_idle) {
-                                const float msk = off != OOB ? 1.f : 0.f;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { const float q = v[r] * msk; s1[nt][r] += q; s2[nt][r] = fmaf(q, q, s2[nt][r]); }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { s1[nt][r] += v[r]; s2[nt][r] = fmaf(v[r], v[r], s2[nt][r]); }
-                            }
+                        if (p.stats) {           // BatchNorm statistics from the fp32 accumulators (see conv3x3.hip), two values per instruction
+                            if (p.has_idle) { const float msk = off != OOB ? 1.f : 0.f; v *= msk; }
+                            f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                            f32x2_& a0 = *reinterpret_cast<f32x2_*>(&s1[nt][0]); f32x2_& a1 = *reinterpret_cast<f32x2_*>(&s1[nt][2]);
+                            f32x2_& q0 = *reinterpret_cast<f32x2_*>(&s2[nt][0]); f32x2_& q1 = *reinterpret_cast<f32x2_*>(&s2[nt][2]);
+                            a0 += lo; a1 += hi;
+                            q0 = __builtin_elementwise_fma(lo, lo, q0); q1 = __builtin_elementwise_fma(hi, hi, q1);
                         }
                     }
                 }
@@ -679,6 +678,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch 
 bool g_s3_on = getenv("DANET_NO_C3_STREAM") == nullptr;
 int g_s3_blocks = getenv("DANET_C3S_BLOCKS") ? atoi(getenv("DANET_C3S_BLOCKS")) : 512;
 int g_s3_kw = getenv("DANET_C3S_KW") ? atoi(getenv("DANET_C3S_KW")) : 0;          // forced K split (tests, A-B timing); 0: the planner's choice
+int g_s3_want = getenv("DANET_C3S_WANT") ? atoi(getenv("DANET_C3S_WANT")) : 0;     // tiles per problem the planner aims for (0: 512 / problems of the launch)
 
 int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
@@ -746,10 +746,13 @@ bool s3_shape_ok(const ConvP& p) {
     return danet_conv_nt(p.Cout) <= 3;
 }
 
+// The first K split that gives a launch of nprob problems enough tiles, else the one with the most tiles: fewer, larger tiles
+// with less K splitting win as long as every workgroup gets work (measured on the four HRNet branches, tools/c3s_bench.py:
+// 39.2 us with 512 + 3 x 256 tiles, 42.6 us with the per-workgroup load balanced through smaller tiles, 43.1 us with 512 each).
 bool s3_plan(const ConvP& p, S3Prob& q, int nprob) {
     const int NT = danet_conv_nt(p.Cout);
     static const int cand[3] = {1, 2, 4};
-    const int want = (2 * 256 + nprob - 1) / nprob;
+    const int want = g_s3_want > 0 ? g_s3_want : (2 * 256 + nprob - 1) / nprob;
     int best = -1;
     S3Prob tmp = q;
     for (int c = 0; c < 3; ++c) {
@@ -794,7 +797,10 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
         q.B = p.B; q.H = p.OH; q.W = p.OW; q.Cin = p.Cin; q.Cout = p.Cout;
         q.flip = p.transposed ? 1 : 0; q.relu = p.relu ? 1 : 0; q.out_fp32 = p.out_fp32 ? 1 : 0;
         q.x_bytes = (int)p.x_bytes; q.y_bytes = (int)p.y_bytes;
-        if (!s3_plan(p, q, n)) return -1;
+    }
+    for (int i = 0; i < n; ++i) {
+        S3Prob& q = L.p[i];
+        if (!s3_plan(ps[i], q, n)) return -1;
         if (NT == 0) NT = q.nt; else if (NT != q.nt) return -1;
         q.tile0 = tile0;
         tile0 += q.ntiles;
@@ -806,6 +812,12 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
     L.total = tile0;
     L.dbg = conv3x3_debug_buffer();
     if (dry) return 0;
+    static const bool verbose = getenv("DANET_C3S_VERBOSE") != nullptr;
+    if (verbose) {
+        fprintf(stderr, "[c3s] %d problems:", n);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " C%d@%dx%d kw%d st%d tiles%d", L.p[i].Cin, L.p[i].H, L.p[i].W, L.p[i].kw, L.p[i].nst, L.p[i].ntiles);
+        fprintf(stderr, "\n");
+    }
     const int grid = L.total < g_s3_blocks ? L.total : g_s3_blocks;
     for (int i = 0; i < n; ++i) L.p[i].tile0m = L.p[i].tile0 % grid;
     switch (NT) {
@@ -819,12 +831,14 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
 }  // namespace danet_conv
 
 // enable: 0 / 1 (-1 keeps); blocks: workgroup cap of a launch (<= 0 keeps); kw: forced K split 1 / 2 / 4 (0: the planner's
-// choice, < 0 keeps).  Returns the previous `enable`.
-extern "C" int danet_conv3x3_stream_set(int enable, int blocks, int kw) {
+// choice, < 0 keeps); want_tiles: tiles per problem the planner aims for (0: 512 / problems of the launch, < 0 keeps).
+// Returns the previous `enable`.
+extern "C" int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want_tiles) {
     const int prev = g_s3_on ? 1 : 0;
     if (enable >= 0) g_s3_on = enable != 0;
     if (blocks > 0) g_s3_blocks = blocks;
     if (kw >= 0) g_s3_kw = kw;
+    if (want_tiles >= 0) g_s3_want = want_tiles;
     return prev;
 }
 // What the streamed kernel would do with a problem: KW * 100 + stages * 10 + NT (0: not taken).

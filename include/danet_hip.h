@@ -246,10 +246,11 @@ int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks, int wa
 /* The streamed 3x3 kernel (csrc/conv3x3s.hip: a loader wave copies the next stage's halo tile into a two-deep LDS ring with
  * LDS-DMA while four waves run the MFMA loop on the current one) takes the 3x3 / stride-1 problems with at most 48 output
  * channels per block ahead of conv3x3_tile_kernel.  enable 0/1 (-1 keeps), blocks = workgroup cap (<= 0 keeps), kw = forced K
- * split over the four MFMA waves 1/2/4 (0 = planner's choice, < 0 keeps); returns the previous enable.  A forced register tiling
- * (danet_conv3x3_set) keeps a problem on conv3x3.hip.  danet_conv3x3_stream_plan: KW*100 + stages*10 + NT the kernel would use
- * for a problem in a launch of nprob problems (0: not taken). */
-int danet_conv3x3_stream_set(int enable, int blocks, int kw);
+ * split over the four waves 1/2/4 (0 = planner's choice, < 0 keeps), want_tiles = tiles per problem the planner aims for (0 = 512 /
+ * problems of the launch, < 0 keeps); returns the previous enable.  A forced register tiling (danet_conv3x3_set) keeps a problem on
+ * conv3x3.hip.  danet_conv3x3_stream_plan: KW*100 + stages*10 + NT the kernel would use for a problem in a launch of nprob
+ * problems (0: not taken). */
+int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want_tiles);
 int danet_conv3x3_stream_plan(int B, int H, int W, int Cin, int Cout, int nprob);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);

@@ -63,7 +63,7 @@ def main():
         base = {'shape': [Cin, Cout, H, W, B], 'GFLOP': round(flops / 1e9, 2)}
         for stream_on in (0, 1):
             L.danet_conv3x3_set(1, 0, 0, 512, -1)
-            L.danet_conv3x3_stream_set(stream_on, 512, -1)
+            L.danet_conv3x3_stream_set(stream_on, 512, -1, -1)
             sums = torch.zeros(nws, device='cuda')
             y = fwd(sums).float()
             torch.cuda.synchronize()
@@ -72,14 +72,14 @@ def main():
             s = sums.view(-1, 2, Cout).sum(0)
             err_s = float(((s - s_ref).abs().max(dim=1)[0] / s_ref.abs().max(dim=1)[0]).max())
             for bl in blocks:
-                L.danet_conv3x3_stream_set(stream_on, bl, -1)
+                L.danet_conv3x3_stream_set(stream_on, bl, -1, -1)
                 tf, tg = timeit(fwd), timeit(dgrad)
                 sums.zero_()
                 ts = timeit(lambda: fwd(sums))
                 print(json.dumps(dict(base, kernel='stream' if stream_on else 'tile', blocks=bl, fwd_us=round(tf * 1e6, 2), fwd_stats_us=round(ts * 1e6, 2),
                                       dgrad_us=round(tg * 1e6, 2), frac=round(flops / tf / PEAK, 4), err_fwd=round(err_f, 5), err_dgrad=round(err_g, 5),
                                       err_stats=round(err_s, 5))), flush=True)
-        L.danet_conv3x3_stream_set(1, 512, 0)
+        L.danet_conv3x3_stream_set(1, 512, 0, -1)
 
     # the four HRNet branches in one launch
     chans, sizes = (48, 96, 192, 384), (64, 32, 16, 8)
@@ -102,19 +102,21 @@ def main():
         refs = [y.float().clone() for y in ys]
         for name, c3, st in (('conv_fast', 0, 0), ('tile', 1, 0), ('stream', 1, 1)):
             L.danet_conv3x3_set(c3, 0, 0, 512, 0)
-            L.danet_conv3x3_stream_set(st, 512, -1)
+            L.danet_conv3x3_stream_set(st, 512, -1, -1)
             for y in ys:
                 y.zero_()
             multi()
             torch.cuda.synchronize()
             err = max(float((y.float() - r).abs().max() / r.abs().max()) for y, r in zip(ys, refs))
-            for bl in (blocks if st else (512,)):
-                L.danet_conv3x3_stream_set(st, bl, -1)
+            for want in ((0, 256, 512) if st else (0,)):
+                L.danet_conv3x3_stream_set(st, 512, -1, want)
                 t = timeit(multi)
-                print(json.dumps({'multi4': name, 'stats': with_stats, 'blocks': bl, 'us': round(t * 1e6, 2), 'GFLOP': round(flops / 1e9, 2),
+                plans = [L.danet_conv3x3_stream_plan(B, s, s, c, c, 4) for c, s in zip(chans, sizes)] if st else None
+                print(json.dumps({'multi4': name, 'stats': with_stats, 'want': want, 'plans': plans, 'us': round(t * 1e6, 2), 'GFLOP': round(flops / 1e9, 2),
                                   'frac': round(flops / t / PEAK, 4), 'err': round(err, 5)}), flush=True)
+            L.danet_conv3x3_stream_set(st, 512, -1, 0)
     L.danet_conv3x3_set(1, 0, 0, 512, 0)
-    L.danet_conv3x3_stream_set(1, 512, 0)
+    L.danet_conv3x3_stream_set(1, 512, 0, -1)
 
 
 if __name__ == '__main__':

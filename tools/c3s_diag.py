@@ -27,7 +27,7 @@ def main():
         y_ref = fwd().float()
         L.danet_conv3x3_set(1, 0, 0, 512, -1)
         for kw in (1, 2, 4):
-            L.danet_conv3x3_stream_set(1, 512, kw)
+            L.danet_conv3x3_stream_set(1, 512, kw, -1)
             plan = L.danet_conv3x3_stream_plan(B, H, W, Cin, Cout, 1)
             if plan == 0:
                 continue
@@ -58,10 +58,10 @@ def main():
             rec['cus'] = len(res)
             rec['resident_per_cu'] = [min(res), round(float(np.mean(res)), 2), max(res)]
             for bl in (256, 512):
-                L.danet_conv3x3_stream_set(1, bl, kw)
+                L.danet_conv3x3_stream_set(1, bl, kw, -1)
                 rec['us_%d' % bl] = round(timeit(fwd) * 1e6, 2)
             print(json.dumps(rec), flush=True)
-        L.danet_conv3x3_stream_set(1, 512, 0)
+        L.danet_conv3x3_stream_set(1, 512, 0, -1)
 
 
 def multi_subsets():
@@ -80,7 +80,7 @@ def multi_subsets():
     for x, wp, c, s in zip(xs, wps, chans, sizes):
         refs.append(conv._conv_fwd_raw(x, wp, None, B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1, False, False, False, None).float())
     L.danet_conv3x3_set(1, 0, 0, 512, 0)
-    L.danet_conv3x3_stream_set(1, 512, 0)
+    L.danet_conv3x3_stream_set(1, 512, 0, -1)
     for n in (1, 2, 3, 4):
         for sub in itertools.combinations(range(4), n):
             jobs = (_lib.ConvJob * n)()
