@@ -447,7 +447,7 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
             const int which = t / (NT * 16), c = t - which * (NT * 16);
             const float v = (sScr[(0 * 2 + which) * (NT * 16) + c] + sScr[(1 * 2 + which) * (NT * 16) + c]) +
                             (sScr[(2 * 2 + which) * (NT * 16) + c] + sScr[(3 * 2 + which) * (NT * 16) + c]);
-            if (n0 + c < p.Cout) atomicAdd(p.stats + ((size_t)(bid % BN_NCOPY) * 2 + which) * p.Cout + n0 + c, v);
+            if (n0 + c < p.Cout) atomicAdd(p.stats + ((size_t)(bid % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + n0 + c, v);
         }
     }
 }

@@ -17,8 +17,12 @@ __device__ inline unsigned f2bf_pk(float lo, float hi) {
 __device__ inline bf16_t f2bf(float f) { return (bf16_t)(f2bf_pk(f, 0.f) & 0xffffu); }
 __device__ inline float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 
-// replicas of per-channel BatchNorm accumulators: block b adds into replica b % BN_NCOPY
-constexpr int BN_NCOPY = 32;
+// Replicas of per-channel BatchNorm accumulators ([BN_NCOPY][2][C] workspaces): block b adds into replica b % bn_ncopy(C)
+// (same-address atomic contention was 52 % of the step with one copy).  Every consumer block sums the replicas again,
+// so a wide layer keeps fewer of them: the product replicas x channels -- what a consumer block reads before it can
+// start -- stays ~2 K values (with 32 copies a block of the 384-channel BatchNorm read 98 KB to normalise 1.5 KB).
+constexpr int BN_NCOPY = 32;                        // copies a workspace has room for
+__host__ __device__ inline int bn_ncopy(int C) { return C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); }
 
 struct ConvP {
     const bf16_t* x; const bf16_t* w; const float* bias; void* y;

@@ -110,14 +110,17 @@ constexpr int SLAB = 1024;   // channels per launch (wider tensors are processed
 // Sum the NCOPY replicas of a [2][Cst] accumulator for the Cs channels of this slab into LDS: the
 // 2*Cs sums are spread over the block's lanes, each issuing NCOPY independent loads (fixed order).
 __device__ inline void reduce_replicas(const float* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
+    const int ncopy = danet_conv::bn_ncopy(Cst);             // 4 .. 32 (a multiple of 4): the replicas this width uses
     for (int i = t; i < 2 * Cs; i += 256) {
         const int which = i >= Cs ? 1 : 0, c = i - which * Cs;
-        float v[NCOPY];
-#pragma unroll
-        for (int r = 0; r < NCOPY; ++r) v[r] = rep[(size_t)r * 2 * Cst + (size_t)which * Cst + c];
         float s = 0.f;
+        for (int r0 = 0; r0 < ncopy; r0 += 4) {
+            float v[4];
 #pragma unroll
-        for (int r = 0; r < NCOPY; ++r) s += v[r];
+            for (int r = 0; r < 4; ++r) v[r] = rep[(size_t)(r0 + r) * 2 * Cst + (size_t)which * Cst + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += v[r];
+        }
         sStat[which][c] = s;
     }
     __syncthreads();
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
                 for (int j = 0; j < VW; ++j) { s.v[j] += a[u].v[j]; q.v[j] += a[u].v[j] * a[u].v[j]; }
         }
     }
-    float* dst = sums + (size_t)(blockIdx.x % NCOPY) * 2 * Cst;
+    float* dst = sums + (size_t)(blockIdx.x % danet_conv::bn_ncopy(Cst)) * 2 * Cst;
     block_channel_reduce(sm, s, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, q, t, fm.CV, fm.span, dst + Cst);
 }
@@ -269,7 +272,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
                 }
         }
     }
-    float* dst = red + (size_t)(bid % NCOPY) * 2 * C;
+    float* dst = red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
 }
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
         gq[k].x = q0; gq[k].y = q1; xq[k].x = q2; xq[k].y = q3;
     }
-    float* dst = a.red + (size_t)(bid % NCOPY) * 2 * C;
+    float* dst = a.red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
     if (!(m.dbg & 1)) grid_barrier(m.bar, gridDim.x);
@@ -740,6 +743,12 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
     fm->span = (256 / fm->CV) * fm->CV;
     const long nvec = M * fm->CV;
     long blocks = (nvec + fm->span - 1) / fm->span;
+    // a block reads the replicas of its slab's statistics before it can start (~8 KB): at least ~24 KB of the tensor each
+    // (tools/experiments/bn_micro.cpp: the four-branch forward 24.7 -> 12.9 us, the two-kernel backward 81 -> 40 us together
+    // with bn_ncopy; eight rows per trip instead of four measured slower: 14.8 / 62 us)
+    static const long per_block = getenv("DANET_BN_BLOCK_BYTES") ? atol(getenv("DANET_BN_BLOCK_BYTES")) : 24576;
+    const long by_bytes = (M * Cs * 2 + per_block - 1) / per_block;
+    if (blocks > by_bytes) blocks = by_bytes;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     *grid = (int)blocks;
