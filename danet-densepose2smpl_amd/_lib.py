@@ -62,6 +62,7 @@ _SIGNATURES = {
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_bn_backward_onepass_ok': (c_i, [c_f, c_i]),
+    'danet_bn_backward_onepass_bar_words': (c_i, []),
     'danet_bn_backward_onepass': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f]),
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -38,7 +38,7 @@ UNITS = {
     'stn.hip': [],
 }
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + os.path.join(ROOT, 'include'), '-I' + HERE,
-          '-Wall', '-Wno-unused-function']
+          '-Wall', '-Wno-unused-function'] + os.environ.get('DANET_EXTRA_CFLAGS', '').split()
 
 
 def _hipcc():

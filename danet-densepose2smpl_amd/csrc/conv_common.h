@@ -22,7 +22,7 @@ __device__ inline float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 1
 // so a wide layer keeps fewer of them: the product replicas x channels -- what a consumer block reads before it can
 // start -- stays ~2 K values (with 32 copies a block of the 384-channel BatchNorm read 98 KB to normalise 1.5 KB).
 constexpr int BN_NCOPY = 32;                        // copies a workspace has room for
-__host__ __device__ inline int bn_ncopy(int C) { return C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); }
+__host__ __device__ inline int bn_ncopy(int C) { return C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); }   // (8/4 and 16/8/4 measured the same step time)
 
 struct ConvP {
     const bf16_t* x; const bf16_t* w; const float* bias; void* y;

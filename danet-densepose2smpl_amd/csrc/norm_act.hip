@@ -419,32 +419,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
 constexpr int OP_NV = 10;             // rows (8-byte channel vectors of dy and x) per lane held in registers ...
 constexpr int OP_NL = 15;             // ... and in the lane's private LDS slots (17 bytes per row: 64 KB per workgroup; with the 12 KB of
                                       // reduction scratch two workgroups fit a CU's 160 KB)
-constexpr int OP_CH = 5;              // LDS rows loaded per batch
+#ifndef DANET_OP_CH
+#define DANET_OP_CH 5
+#endif
+constexpr int OP_CH = DANET_OP_CH;              // LDS rows loaded per batch
 static_assert(OP_NL % OP_CH == 0, "OP_NL");
 constexpr int OP_ROWS = OP_NV + OP_NL;
 constexpr int OP_MAX_BLOCKS = 512;    // 2 workgroups per CU (<= 256 VGPRs each)
 
+// State (OP_BAR_WORDS uints, zeroed once by the caller): word 2 = error flag; group g (workgroups with id % 8 == g:
+// observed to share an XCD, which only matters for speed) owns the 64-byte lines at 16 * (1 + g) (arrivals) and
+// 16 * (9 + g) (generation); the line at 16 * 17 counts the groups that are complete.
+constexpr int OP_BAR_WORDS = 16 * 18;
 __device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
-    // bar[0]: arrivals of the current generation, bar[1]: generation, bar[2]: error flag.
+    // Two levels: a workgroup arrives at its group's counter; the last one of a group arrives at the top counter; the last
+    // group bumps every group's generation word, on which that group's workgroups spin.  512 arrivals on one word and 512
+    // pollers of one word cost 17 us per barrier (measured with the phase knob of tools/experiments/bn_micro.cpp); spread
+    // over 8 + 1 words the hand-off is a few us.
     // No agent-scope fences: on this chip they write back / invalidate the XCD's whole L2 (78 us per barrier, measured).
     // What crosses the barrier are device-scope float atomics (performed at the memory side, coherent across the XCDs'
     // L2s) that every wave has waited for (workgroup-scope release = s_waitcnt) before its workgroup arrives; after the
-    // barrier they are read with plain loads of lines no cache can hold yet (nothing read them earlier in the kernel).
+    // barrier they are read with agent-scope (sc1, L1-bypassing) loads: reduce_replicas_sc1.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
-            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the reset is performed before the release
-            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+        const unsigned g = blockIdx.x & 7u;
+        const unsigned gsize = (nblocks + 7u - g) >> 3;                          // ids congruent to g below nblocks
+        const unsigned ngroups = nblocks < 8u ? nblocks : 8u;
+        unsigned* const cnt = bar + 16 * (1 + g);
+        unsigned* const gen = bar + 16 * (9 + g);
+        unsigned* const top = bar + 16 * 17;
+        const unsigned my_gen = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool released = false;
+        if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the resets are performed before the release
+                for (unsigned h = 0; h < ngroups; ++h)
+                    __hip_atomic_fetch_add(bar + 16 * (9 + h), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                released = true;
+            }
+        }
+        if (!released) {
             unsigned spins = 0;
-            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1u << 22)) { __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
+    }
+    __syncthreads();
+}
+
+// reduce_replicas with agent-scope loads (sc1: served by L2, never by this CU's L1): the sums other workgroups added
+// before a grid barrier.  The loads of a lane are independent buffer loads (a loop of __hip_atomic_load was serialised
+// one round trip each: 30 us per launch).
+__device__ inline void reduce_replicas_sc1(const float* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
+    const int ncopy = danet_conv::bn_ncopy(Cst);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(rep, (int)((size_t)NCOPY * 2 * Cst * 4));
+    for (int i = t; i < 2 * Cs; i += 256) {
+        const int which = i >= Cs ? 1 : 0, c = i - which * Cs;
+        float s = 0.f;
+        for (int r0 = 0; r0 < ncopy; r0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (((r0 + r) * 2 + which) * Cst + c) * 4, 0, 16 /* sc1 */));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += v[r];
+        }
+        sStat[which][c] = s;
     }
     __syncthreads();
 }
@@ -563,10 +608,8 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
     if (!(m.dbg & 1)) grid_barrier(m.bar, gridDim.x);
     if (m.dbg & 2) return;
-    // ---- phase 2: the complete sums, then dx / d_res from the registers
-    // (plain loads: this CU's L1 cannot hold these lines from before the barrier -- nothing read them -- and the atomics
-    // completed in L2; agent-scope atomic loads here were serialised one round trip each, 30 us per launch)
-    reduce_replicas(a.red, C, fm.CV * VW, t, sStat);
+    // ---- phase 2: the complete sums (agent-scope loads), then dx / d_res from the registers
+    reduce_replicas_sc1(a.red, C, fm.CV * VW, t, sStat);
     if (!live) return;
     float k0[VW], m1[VW], m2[VW];
 #pragma unroll
@@ -953,7 +996,7 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
 
 
 // ---------------------------------------------------------------------------------------------
-// One-pass form of danet_bn_backward_multi (bn_bwd_onepass_kernel).  `bar`: 4 uints of device memory, zeroed ONCE by
+// One-pass form of danet_bn_backward_multi (bn_bwd_onepass_kernel).  `bar`: danet_bn_backward_onepass_bar_words() uints of device memory, zeroed ONCE by
 // the caller and then owned by these launches (barrier state + error flag), shared by all launches -- which must not
 // overlap (one stream).  danet_bn_backward_onepass_ok says whether a job set qualifies: every job needs its own reduction
 // (red_state 1: zeroed scratch), a ReLU gate that does not need y (mask_mode 1 or 2, or no ReLU), C <= 1024, and the
@@ -1008,6 +1051,8 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) 
     static const long min_blocks = getenv("DANET_BN_ONEPASS_MIN") ? atol(getenv("DANET_BN_ONEPASS_MIN")) : 0;
     return total >= min_blocks ? nl : 0;
 }
+
+extern "C" int danet_bn_backward_onepass_bar_words(void) { return OP_BAR_WORDS; }
 
 extern "C" int danet_bn_backward_onepass_ok(const void* jobs, int n)
 {

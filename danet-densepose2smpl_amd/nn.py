@@ -25,7 +25,7 @@ _ONEPASS_BAR = {}
 
 
 def _onepass_bar(device):
-    """The barrier state of the one-pass launches on `device` (4 uints, zeroed once), or None when the current stream is
+    """The barrier state of the one-pass launches on `device` (zeroed once), or None when the current stream is
     not the one these launches are confined to."""
     if not ONEPASS:
         return None
@@ -34,13 +34,29 @@ def _onepass_bar(device):
         return None
     bar = _ONEPASS_BAR.get(device)
     if bar is None:
-        bar = _ONEPASS_BAR[device] = torch.zeros(4, dtype=torch.int32, device=device)
+        bar = _ONEPASS_BAR[device] = torch.zeros(_lib.lib().danet_bn_backward_onepass_bar_words(), dtype=torch.int32, device=device)
     return bar
 
 
 def onepass_error(device=None):
     """True if a one-pass launch gave up waiting at its barrier (its results are garbage)."""
     return any(int(b[2]) != 0 for d, b in _ONEPASS_BAR.items() if device is None or d == device)
+
+
+def onepass_recover(device=None):
+    """After a barrier time-out (onepass_error): the arrival counts of the expired barrier are stale, so every later one-pass
+    launch would time out as well.  Zeroes the barrier state and switches the one-pass backward off (the two-kernel path
+    takes over); returns True when there was an error to recover from.  Steps computed since the time-out are garbage:
+    the caller decides what to redo (trainer.Trainer re-captures its graph and raises)."""
+    global ONEPASS
+    if not onepass_error(device):
+        return False
+    torch.cuda.synchronize()
+    for d, b in _ONEPASS_BAR.items():
+        if device is None or d == device:
+            b.zero_()
+    ONEPASS = False
+    return True
 
 
 class BatchNormActFunction(torch.autograd.Function):

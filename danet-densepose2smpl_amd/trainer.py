@@ -155,10 +155,26 @@ class Trainer(object):
             out['dp_dict'].setdefault('dp_active', bool((has_dp > 0).any()))        # (one host read per batch, outside the step)
         return out
 
+    ONEPASS_CHECK_EVERY = 64       # steps between looks at the one-pass BatchNorm's barrier error flag (one 4-byte read each)
+
+    def check_onepass(self):
+        """The one-pass BatchNorm backward (csrc/norm_act.hip) spins at a grid-wide barrier with a bound; a time-out -- a GPU
+        shared with another process, a partitioned device -- leaves garbage gradients and a stale barrier.  Called every
+        ONEPASS_CHECK_EVERY steps and before a checkpoint is written: on an error the barrier is reset, the one-pass path
+        switched off (two-kernel BatchNorm backward from here on), a captured graph dropped, and the caller told: the
+        parameters have been updated with garbage since the time-out, so training must resume from a checkpoint."""
+        from . import nn as dnn
+        if self.device.type == 'cuda' and dnn.onepass_recover(self.device):
+            self._graph = None
+            raise RuntimeError('a one-pass BatchNorm launch timed out at its grid barrier: gradients since then are invalid. '
+                               'The barrier was reset and the one-pass path switched off (nn.ONEPASS = False); resume from the '
+                               'last checkpoint (and capture() again if you replay a graph)')
+
     def save(self, path, epoch=0, batch_idx=0, batch_size=0, dataset_perm=None):
         """A training checkpoint in the reference's format (utils/saver.py:24-50): model, optimizer, bookkeeping with
         `total_step_count` = this trainer's step count."""
         from . import checkpoint
+        self.check_onepass()
         return checkpoint.save_checkpoint(path, {'model': self.model}, {'optimizer': self.optimizer}, epoch=epoch, batch_idx=batch_idx,
                                           batch_size=batch_size, dataset_perm=dataset_perm, total_step_count=self.step_count)
 
@@ -196,6 +212,16 @@ class Trainer(object):
             elif self.bank.requests is not None:
                 self.bank.build()
             self.bank.refresh()
+
+    def _abort_cleanup(self):
+        """Host-side state an aborted step (a failed graph capture) leaves behind: BatchNorm call counters of the modules
+        that ran, gradients that point into the aborted pool.  (The arena cursor and the weight bank are re-armed by the
+        next step's _begin_step; queued weight-gradient jobs are dropped by the caller.)"""
+        BatchNorm2d._ran = []
+        BatchNorm2d.count_batches = True
+        _conv.DEFER_WGRAD = False
+        _conv.GRAD_STORE = None
+        self.optimizer.zero_grad(set_to_none=True)
 
     @contextlib.contextmanager
     def _on_stream(self):
@@ -263,6 +289,8 @@ class Trainer(object):
         with self._on_stream():
             out, losses = self._core(in_dict)
         self.step_count += 1
+        if self.step_count % self.ONEPASS_CHECK_EVERY == 0:
+            self.check_onepass()
         return out, losses
 
     # ------------------------------------------------------------------------------------------
@@ -309,7 +337,12 @@ class Trainer(object):
                 if not in_graph:
                     raise
                 torch.cuda.synchronize(self.device)
+                # the aborted capture left host-side state behind: queued weight-gradient jobs that point at tensors of its
+                # pool, BatchNorm call counters, the arena cursor, pending collectives
                 self.store._works = []
+                conv._WQ.clear()
+                conv._WQG.clear()
+                self._abort_cleanup()
             finally:
                 hrnet.BRANCH_STREAMS = False
         self._graph = graph
@@ -339,4 +372,6 @@ class Trainer(object):
                 self.store.reduce_all()
                 self.optimizer.step()
         self.step_count += 1
+        if self.step_count % self.ONEPASS_CHECK_EVERY == 0:
+            self.check_onepass()
         return self._static_out

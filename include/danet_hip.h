@@ -332,9 +332,11 @@ int danet_bn_forward_multi(const void* jobs, int n, float momentum, float eps, v
 int danet_bn_backward_multi(const void* jobs, int n, void* stream);
 /* One-pass form of danet_bn_backward_multi: every lane keeps its share of dy / x in registers across a grid-wide barrier,
  * so dy and x are read once instead of twice.  Qualifying sets (danet_bn_backward_onepass_ok): every job with red_state 1,
- * a ReLU gate that does not need y (mask_mode 1 or 2), C <= 1024 and at most 512 x 256 x 16 channel vectors.  bar: 4 uints
- * of device memory, zeroed once, shared by all such launches, which must not overlap (issue them on one stream).  The
- * barrier spin is bounded: after a timeout bar[2] != 0 (and the results of that launch are garbage). */
+ * a ReLU gate that does not need y (mask_mode 1 or 2), C <= 1024 and at most 512 x 256 x 16 channel vectors.  bar:
+ * danet_bn_backward_onepass_bar_words() uints of device memory, zeroed once, shared by all such launches, which must not overlap
+ * (issue them on one stream).  The barrier (two levels: eight arrival groups, then one) spin is bounded: after a timeout
+ * bar[2] != 0, the results of that launch are garbage and the state must be zeroed again before another launch. */
+int danet_bn_backward_onepass_bar_words(void);
 int danet_bn_backward_onepass_ok(const void* jobs, int n);
 int danet_bn_backward_onepass(const void* jobs, int n, void* bar, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,

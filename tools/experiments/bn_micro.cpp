@@ -49,7 +49,7 @@ int main()
         CK(hipMalloc((void**)&sums[i], ws)); CK(hipMemset(sums[i], 0, ws));
         CK(hipMalloc((void**)&red[i], ws)); CK(hipMemset(red[i], 0, ws));
     }
-    unsigned* bar; CK(hipMalloc((void**)&bar, 64)); CK(hipMemset(bar, 0, 64));
+    unsigned* bar; CK(hipMalloc((void**)&bar, 4096)); CK(hipMemset(bar, 0, 4096));
     printf("four branches: %.1f MB per tensor set\n", bytes / 1e6);
     for (int n : {4, 1}) {
         for (int with_res : {0, 1}) {
