@@ -34,6 +34,12 @@ _SIGNATURES = {
     'danet_conv_pack_job_bytes': (c_sz, []),
     'danet_conv_pack_job_fill': (ctypes.c_long, [c_f, c_f, c_f, ctypes.c_long, ctypes.c_long] + [c_i] * 7),
     'danet_conv_f32': (c_i, [c_i, c_f, c_f, c_f, c_f] + [c_i] * 13 + [c_f]),
+    'danet_conv_f32m_packed_elems': (c_sz, [c_i] * 6),
+    'danet_conv_f32m_pack_weights': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f]),
+    'danet_conv_f32m_ok': (c_i, [c_i] * 14),
+    'danet_conv_f32m_forward': (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 15 + [c_f]),
+    'danet_conv_f32m_wgrad_ws_floats': (c_sz, [c_i] * 15),
+    'danet_conv_f32m_wgrad': (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 15 + [c_f]),
     'danet_conv3x3_set': (c_i, [c_i] * 5),
     'danet_conv3x3_debug': (None, [c_f]),
     'danet_conv3x3_stream_set': (c_i, [c_i, c_i, c_i, c_i]),
@@ -89,6 +95,11 @@ _SIGNATURES = {
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_backward': (c_i, [c_f, c_f, c_i, c_f, c_f]),
 }
+
+# fp32 instantiations (csrc/norm_act_f32.hip, stn.hip): same arguments, fp32 NHWC activations
+for _n in ('danet_bn_forward', 'danet_bn_backward', 'danet_bn_forward_multi', 'danet_bn_backward_multi', 'danet_sum_relu_forward',
+           'danet_sum_relu_backward', 'danet_sum_relu_backward_all', 'danet_stn_gather_forward', 'danet_stn_gather_backward'):
+    _SIGNATURES[_n + '_f32'] = _SIGNATURES[_n]
 
 
 class Wg3Job(ctypes.Structure):

@@ -110,8 +110,9 @@ class KernelProfiler(object):
 
 
 
-PRECISION = 'bf16'     # 'fp32': verification mode (BASELINE config C4's arithmetic): convolutions on the fp32 HIP kernels of
-                       # csrc/conv_f32.hip, normalisation / activation / resampling glue as fp32 tensor ops.  Slow; used by the parity tests.
+PRECISION = 'bf16'     # 'fp32': BASELINE config C4's arithmetic: fp32 NHWC activations, convolutions on the fp32 MFMA kernels of
+                       # csrc/conv_f32m.hip (the direct kernels of csrc/conv_f32.hip where those do not take a problem), normalisation /
+                       # activation / resampling on the fp32 instantiation of the same HIP kernels (csrc/norm_act_f32.hip, stn.hip).
 
 
 class precision(object):
@@ -137,8 +138,37 @@ def fp32_mode():
     return PRECISION == 'fp32'
 
 
+F32_MFMA = bool(int(os.environ.get('DANET_F32_MFMA', '1')))     # fp32 mode on the matrix cores (csrc/conv_f32m.hip); 0 = the direct verification kernels only
+
+
+def _pack_weight_f32(weight, w, groups, mode, Cout_gp, Cin_gp):
+    """fp32 fragment-major operand of csrc/conv_f32m.hip for the fp32 weight `w` (= weight.detach()); cached per Parameter
+    and version like pack_weight."""
+    key = (id(weight), 10 + mode, groups, Cout_gp * 65536 + Cin_gp)
+    cacheable = isinstance(weight, nn.Parameter)
+    if cacheable:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0] == weight._version and hit[2]() is weight:
+            return hit[1]
+    L = _lib.lib()
+    Cout, Cin_g, R, S = w.shape
+    wp = torch.empty(L.danet_conv_f32m_packed_elems(Cout_gp, Cin_gp, R, S, groups, mode), dtype=torch.float32, device=w.device)
+    check(L.danet_conv_f32m_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, Cout_gp, Cin_gp, stream()), 'danet_conv_f32m_pack_weights')
+    if cacheable:
+        _PACK_CACHE[key] = (weight._version, wp, weakref.ref(weight))
+    return wp
+
+
+def _pad_last(t, n):
+    """[..., C] -> [..., n] with zero channels appended (a copy; t itself when C == n)."""
+    return t if t.shape[-1] == n else F.pad(t, (0, n - t.shape[-1]))
+
+
 class Conv2dF32Function(torch.autograd.Function):
-    """fp32 convolution on the verification kernels (csrc/conv_f32.hip): forward, data and weight gradient."""
+    """fp32 convolution: forward, data and weight gradient on the fp32 MFMA kernels (csrc/conv_f32m.hip) -- channel counts
+    zero-padded to multiples of 4 for its 16-byte operand loads --, or on the direct verification kernels
+    (csrc/conv_f32.hip) where that kernel family does not take the problem (grouped convolutions with odd channel counts,
+    strided data gradients whose channel count is no multiple of 16) or F32_MFMA is off."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, groups):
@@ -151,41 +181,88 @@ class Conv2dF32Function(torch.autograd.Function):
         xh = x.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
         w = weight.detach().to(torch.float32).contiguous()
         b = None if bias is None else bias.detach().to(torch.float32).contiguous()
-        y = torch.empty(B, OH, OW, Cout, dtype=torch.float32, device=x.device)
-        check(L.danet_conv_f32(0, ptr(xh), ptr(w), ptr(b), ptr(y), B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, stream()), 'danet_conv_f32')
+        Cout_g = Cout // groups
+        Cin_gp, Cout_gp = (Cin_g + 3) // 4 * 4, (Cout_g + 3) // 4 * 4
+        Cin_p, Cout_p = Cin_gp * groups, Cout_gp * groups
+        mfma = F32_MFMA and (groups == 1 or (Cin_gp == Cin_g and Cout_gp == Cout_g)) and \
+            bool(L.danet_conv_f32m_ok(B, H, W, Cin_p, OH, OW, Cout_p, R, S, stride, pad, dil, groups, 0))
+        if mfma:
+            xh = _pad_last(xh, Cin_p)
+            wp = _pack_weight_f32(weight, w, groups, 0, Cout_gp, Cin_gp)
+            y = torch.empty(B, OH, OW, Cout_p, dtype=torch.float32, device=x.device)
+            tok = PROFILER.begin('conv_f32m_kernel', 2.0 * B * OH * OW * Cout * R * S * Cin_g, (B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
+            check(L.danet_conv_f32m_forward(ptr(xh), ptr(wp), ptr(None if b is None else _pad_last(b, Cout_p)), ptr(y), B, H, W, Cin_p, OH, OW, Cout_p,
+                                            R, S, stride, pad, dil, groups, 0, 0, stream()), 'danet_conv_f32m_forward')
+            if tok is not None:
+                PROFILER.end(tok)
+            y = y[..., :Cout]
+        else:
+            y = torch.empty(B, OH, OW, Cout, dtype=torch.float32, device=x.device)
+            check(L.danet_conv_f32(0, ptr(xh), ptr(w), ptr(b), ptr(y), B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, stream()), 'danet_conv_f32')
         ctx.save_for_backward(xh, w)
-        ctx.cfg = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, bias is not None)
+        ctx.weight = weight
+        ctx.cfg = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, bias is not None, mfma)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
         xh, w = ctx.saved_tensors
-        (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, has_bias) = ctx.cfg
+        (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, has_bias, mfma) = ctx.cfg
         g = gy.to(torch.float32).permute(0, 2, 3, 1).contiguous()
         gx = gw = gb = None
         dims = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)
+        Cin_g, Cout_g = Cin // groups, Cout // groups
+        Cin_gp, Cout_gp = (Cin_g + 3) // 4 * 4, (Cout_g + 3) // 4 * 4
+        Cin_p, Cout_p = Cin_gp * groups, Cout_gp * groups
+        gp = _pad_last(g, Cout_p) if mfma else g
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=g.device)
-            check(L.danet_conv_f32(1, ptr(g), ptr(w), None, ptr(gx), *dims, stream()), 'danet_conv_f32')
+            if mfma and L.danet_conv_f32m_ok(B, OH, OW, Cout_p, H, W, Cin_p, R, S, stride, pad, dil, groups, 1):
+                wp = _pack_weight_f32(ctx.weight, w, groups, 1, Cout_gp, Cin_gp)
+                gx = torch.empty(B, H, W, Cin_p, dtype=torch.float32, device=g.device)
+                check(L.danet_conv_f32m_forward(ptr(gp), ptr(wp), None, ptr(gx), B, OH, OW, Cout_p, H, W, Cin_p, R, S, stride, pad, dil, groups, 1, 0,
+                                                stream()), 'danet_conv_f32m_forward')
+                gx = gx[..., :Cin]
+            else:
+                gx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=g.device)
+                check(L.danet_conv_f32(1, ptr(g), ptr(w), None, ptr(gx), *dims, stream()), 'danet_conv_f32')
             gx = gx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            check(L.danet_conv_f32(2, ptr(xh), ptr(g), None, ptr(gw), *dims, stream()), 'danet_conv_f32')
+            if mfma:
+                wdims = (B, H, W, Cin_p, OH, OW, Cout_p, R, S, stride, pad, dil, groups, Cout, Cin_g)
+                ws = torch.empty(L.danet_conv_f32m_wgrad_ws_floats(*wdims), dtype=torch.float32, device=g.device)
+                check(L.danet_conv_f32m_wgrad(ptr(xh), ptr(gp), ptr(gw), ptr(ws), *wdims, stream()), 'danet_conv_f32m_wgrad')
+            else:
+                check(L.danet_conv_f32(2, ptr(xh), ptr(g), None, ptr(gw), *dims, stream()), 'danet_conv_f32')
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=(0, 1, 2))
         return gx, gw, gb, None, None, None, None
 
 
-def nhwc_bf16(x):
-    """bf16, channels_last-contiguous view/copy of a [B,C,H,W] tensor."""
-    if x.dtype != torch.bfloat16:
-        x = x.to(torch.bfloat16)
+def nhwc_as(x, dtype):
+    """`dtype`, channels_last-contiguous view/copy of a [B,C,H,W] tensor."""
+    if x.dtype != dtype:
+        x = x.to(dtype)
     if not x.permute(0, 2, 3, 1).is_contiguous():
         x = x.contiguous(memory_format=torch.channels_last)
         if not x.permute(0, 2, 3, 1).is_contiguous():       # degenerate strides (C == 1 or H*W == 1)
             x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     return x
+
+
+def nhwc_bf16(x):
+    """bf16, channels_last-contiguous view/copy of a [B,C,H,W] tensor."""
+    return nhwc_as(x, torch.bfloat16)
+
+
+def act_dtype():
+    """Element type of the activations between the kernels: bf16, or fp32 under `precision('fp32')`."""
+    return torch.float32 if PRECISION == 'fp32' else torch.bfloat16
+
+
+def nhwc_act(x):
+    return nhwc_as(x, act_dtype())
 
 
 def _empty_nhwc(B, C, H, W, dtype, device):

@@ -30,13 +30,16 @@ UNITS = {
     'conv3x3s.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
     'conv_f32.hip': ['-ffp-contract=off'],
+    'conv_f32m.hip': MFMA_VGPR,
     'part_ops.hip': [],
     'iuv_ops.hip': [],
     'loss_ops.hip': [],
     'adam.hip': [],
     'norm_act.hip': [],
+    'norm_act_f32.hip': [],
     'stn.hip': [],
 }
+INCLUDES = {'norm_act_f32.hip': ['norm_act.hip']}
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + os.path.join(ROOT, 'include'), '-I' + HERE,
           '-Wall', '-Wno-unused-function'] + os.environ.get('DANET_EXTRA_CFLAGS', '').split()
 
@@ -62,7 +65,8 @@ def build(force=False, verbose=False):
         s = os.path.join(HERE, src)
         o = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        incl = [os.path.join(HERE, i) for i in INCLUDES.get(src, [])]       # .hip files a unit #includes
+        if force or _stale(o, [s] + incl + headers):
             jobs.append([_hipcc()] + COMMON + extra + ['-c', s, '-o', o])
 
     def run(cmd):

@@ -21,23 +21,46 @@ namespace {
 using namespace danet_conv;
 
 constexpr int NCOPY = danet_conv::BN_NCOPY;   // replicas of the per-channel accumulators: block b adds into replica b % NCOPY (cuts same-address atomic contention)
-constexpr int VW = 4;     // channels per lane (8-byte runs; every BN width on the path is a multiple of 4)
+constexpr int VW = 4;     // channels per lane (8-byte runs in bf16, 16-byte runs in fp32; every BN width on the path is a multiple of 4)
+
+// This file is compiled twice: as it is for the bf16 production path, and through norm_act_f32.hip (NA_F32) for fp32 NHWC
+// tensors -- BASELINE config C4's arithmetic type, the same kernels with 4-byte elements, exported with an _f32 suffix.
+#ifdef NA_F32
+typedef float elem_t;
+constexpr int ES = 4;         // bytes per element
+constexpr int MSH = 4;        // byte offset -> ReLU-mask byte (one per lane-run of VW channels)
+#define NA_NAME(n) n##_f32
+#else
+typedef bf16_t elem_t;
+constexpr int ES = 2;
+constexpr int MSH = 3;
+#define NA_NAME(n) n
+#endif
 
 struct Vec { float v[VW]; };
 
-__device__ inline Vec load_bf(const bf16_t* p) {
+#ifdef NA_F32
+__device__ inline Vec load_bf(const elem_t* p) {
+    const float4 r = *reinterpret_cast<const float4*>(p);
+    Vec o; o.v[0] = r.x; o.v[1] = r.y; o.v[2] = r.z; o.v[3] = r.w;
+    return o;
+}
+__device__ inline void store_bf(elem_t* p, const Vec& a) { *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+#else
+__device__ inline Vec load_bf(const elem_t* p) {
     const uint2 r = *reinterpret_cast<const uint2*>(p);
     Vec o;
     o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
     o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
     return o;
 }
-__device__ inline void store_bf(bf16_t* p, const Vec& a) {
+__device__ inline void store_bf(elem_t* p, const Vec& a) {
     uint2 r;
     r.x = f2bf_pk(a.v[0], a.v[1]);
     r.y = f2bf_pk(a.v[2], a.v[3]);
     *reinterpret_cast<uint2*>(p) = r;
 }
+#endif
 
 // Flat mapping: vector id v = blockIdx.x*span + t + k*gridspan, span = RY*CV (CV = C/VW).
 // Requires t < span; then v % CV == t % CV for every k: a lane keeps its channel vector cv = t % CV and
@@ -53,6 +76,20 @@ constexpr int UNR = 4;       // rows per trip; the next trip's loads are issued 
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+#ifdef NA_F32
+typedef __attribute__((ext_vector_type(4))) int i32x4_;
+__device__ inline Vec ldv(__amdgpu_buffer_rsrc_t r, int off) {
+    const i32x4_ q = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    Vec o;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) o.v[j] = __int_as_float(q[j]);
+    return o;
+}
+__device__ inline void stv(__amdgpu_buffer_rsrc_t r, int off, const Vec& a) {
+    const i32x4_ q = {__float_as_int(a.v[0]), __float_as_int(a.v[1]), __float_as_int(a.v[2]), __float_as_int(a.v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, off, 0, 0);
+}
+#else
 __device__ inline Vec ldv(__amdgpu_buffer_rsrc_t r, int off) {
     const i32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
     Vec o;
@@ -64,21 +101,22 @@ __device__ inline void stv(__amdgpu_buffer_rsrc_t r, int off, const Vec& a) {
     const i32x2 q = {(int)f2bf_pk(a.v[0], a.v[1]), (int)f2bf_pk(a.v[2], a.v[3])};
     __builtin_amdgcn_raw_buffer_store_b64(q, r, off, 0, 0);
 }
+#endif
 
 // ReLU gate of the backward passes (mask_mode): 0 = from the saved output (y > 0); 1 = from the byte mask the forward
 // wrote (one byte per lane-run of VW channels, bit j = y_j > 0: the residual case, where y cannot be recomputed
 // without reading the residual); 2 = recomputed from x with the forward's own expression fmaf(x, sc, sh) (no
 // residual).  Modes 1 and 2 save the read of y: 1/5 .. 1/4 of the backward traffic.
-__device__ inline int ldmask(__amdgpu_buffer_rsrc_t r, int off) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off >> 3, 0, 0); }
-__device__ inline void stmask(__amdgpu_buffer_rsrc_t r, int off, int m) { __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, r, off >> 3, 0, 0); }
+__device__ inline int ldmask(__amdgpu_buffer_rsrc_t r, int off) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off >> MSH, 0, 0); }
+__device__ inline void stmask(__amdgpu_buffer_rsrc_t r, int off, int m) { __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, r, off >> MSH, 0, 0); }
 
 struct RowIter {
     int row, off, rstep, ostride, M;
     __device__ inline void init(const FlatMap& fm, int bid, int t, int& cv) {
         cv = t % fm.CV;
         row = (bid * fm.span + t) / fm.CV;
-        off = ((row * fm.ldv + fm.coff + cv) * VW) * 2;
-        rstep = fm.rstep; ostride = fm.rstep * fm.ldv * VW * 2; M = fm.M;
+        off = ((row * fm.ldv + fm.coff + cv) * VW) * ES;
+        rstep = fm.rstep; ostride = fm.rstep * fm.ldv * VW * ES; M = fm.M;
     }
     __device__ inline int offset(int u) const { return row + u * rstep < M ? off + u * ostride : OOB; }
     __device__ inline bool more() const { return row < M; }
@@ -126,7 +164,7 @@ __device__ inline void reduce_replicas(const float* __restrict__ rep, int Cst, i
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, FlatMap fm, float* __restrict__ sums /* [2][Cst] */, int Cst)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict__ x, FlatMap fm, float* __restrict__ sums /* [2][Cst] */, int Cst)
 {
     __shared__ float sm[256][VW];
     const int t = threadIdx.x;
@@ -153,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 
 // mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
 __device__ __forceinline__ void bn_apply_body(
-    const int bid, const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, const FlatMap& fm,
+    const int bid, const elem_t* __restrict__ x, const elem_t* __restrict__ res, elem_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved /* [2][Cst] mean, invstd */,
     int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu, unsigned char* __restrict__ mask)
@@ -162,7 +200,7 @@ __device__ __forceinline__ void bn_apply_body(
     const int C = Cst;
     __shared__ float sStat[2][SLAB];
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes), rr = make_rsrc(res ? res : x, fm.bytes), yr = make_rsrc(y, fm.bytes);
-    const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask ? (const void*)mask : (const void*)x, mask ? fm.bytes >> 3 : 0);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask ? (const void*)mask : (const void*)x, mask ? fm.bytes >> MSH : 0);
     int cv = 0; RowIter it; it.init(fm, bid, t < fm.span ? t : 0, cv);
     Vec a[UNR], r[UNR];
     int o[UNR];
@@ -227,7 +265,7 @@ __device__ __forceinline__ void bn_apply_body(
 }
 
 __device__ __forceinline__ void bn_bwd_reduce_body(
-    const int bid, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const FlatMap& fm,
+    const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
 {
@@ -240,7 +278,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
     if (t < fm.span) {
         const bool from_y = relu && mask_mode == 0;
         const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(from_y ? y : x, fm.bytes);
-        const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> 3 : 0);
+        const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> MSH : 0);
         int cv; RowIter it; it.init(fm, bid, t, cv);
         const int c0 = cv * VW;
         float mean[VW], invstd[VW], sc[VW], sh[VW];
@@ -278,9 +316,9 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
 }
 
 __device__ __forceinline__ void bn_bwd_apply_body(
-    const int bid, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const FlatMap& fm,
+    const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
-    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam,
+    int Cst, float inv_count, int relu, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
 {
     const int t = threadIdx.x;
@@ -288,7 +326,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     __shared__ float sStat[2][SLAB];
     const bool from_y = relu && mask_mode == 0;
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(from_y ? y : x, fm.bytes);
-    const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> 3 : 0);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> MSH : 0);
     const __amdgpu_buffer_rsrc_t dxr = make_rsrc(dx, fm.bytes), drr = make_rsrc(dres ? dres : dx, fm.bytes);
     int cv = 0; RowIter it; it.init(fm, bid, t < fm.span ? t : 0, cv);
     Vec g[UNR], a[UNR], o[UNR];
@@ -344,7 +382,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(
-    const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ y, FlatMap fm,
+    const elem_t* __restrict__ x, const elem_t* __restrict__ res, elem_t* __restrict__ y, FlatMap fm,
     const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved,
     int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu, unsigned char* __restrict__ mask)
@@ -352,16 +390,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     bn_apply_body(blockIdx.x, x, res, y, fm, sums, gamma, beta, running_mean, running_var, saved, Cst, inv_count, unbias, momentum, eps, mode, relu, mask);
 }
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+    const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, FlatMap fm,
     const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
 {
     bn_bwd_reduce_body(blockIdx.x, dy, x, y, fm, saved, Cst, relu, red, mask_mode, mask, gamma, beta);
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, FlatMap fm,
+    const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, FlatMap fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
-    int Cst, float inv_count, int relu, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ dparam,
+    int Cst, float inv_count, int relu, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
 {
     bn_bwd_apply_body(blockIdx.x, dy, x, y, fm, saved, gamma, red, Cst, inv_count, relu, dx, dres, dparam, mask_mode, mask, beta);
@@ -371,7 +409,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // small branches' launches are dominated by the per-launch floor, one launch over all of them is not.
 constexpr int NBM = 8;
 struct BnFwdOne {
-    const bf16_t* x; const bf16_t* res; bf16_t* y; const float* sums; const float* gamma; const float* beta;
+    const elem_t* x; const elem_t* res; elem_t* y; const float* sums; const float* gamma; const float* beta;
     float* running_mean; float* running_var; float* saved; unsigned char* mask; FlatMap fm; int C; float inv_count, unbias; int relu;
 };
 struct BnFwdMulti { BnFwdOne a[NBM]; int start[NBM + 1]; int n; float momentum, eps; int mode; };
@@ -384,8 +422,8 @@ __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdMulti m)
                   a.C, a.inv_count, a.unbias, m.momentum, m.eps, m.mode, a.relu, a.mask);
 }
 struct BnBwdOne {
-    const bf16_t* dy; const bf16_t* x; const bf16_t* y; const float* saved; const float* gamma; float* red;
-    bf16_t* dx; bf16_t* dres; float* dparam; const float* beta; const unsigned char* mask;
+    const elem_t* dy; const elem_t* x; const elem_t* y; const float* saved; const float* gamma; float* red;
+    elem_t* dx; elem_t* dres; float* dparam; const float* beta; const unsigned char* mask;
     FlatMap fm; int C; float inv_count; int relu; int have_red; int mask_mode;
 };
 struct BnBwdMulti { BnBwdOne a[NBM]; int start[NBM + 1]; int n; };
@@ -406,6 +444,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
                       a.mask_mode, a.mask, a.beta);
 }
 
+#ifndef NA_F32      // (bf16 only: the register / LDS budget of the one-pass form is sized for 2-byte elements)
 // ------------------------------------------------------------------------------------------
 // One-pass BatchNorm backward: the two-kernel form reads dy and x twice (once for the per-channel sums, once to apply
 // them).  Here every lane keeps its share of dy / x (and the gate) in registers across a grid-wide barrier: phase 1
@@ -511,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     unsigned char (*sGate)[256] = reinterpret_cast<unsigned char (*)[256]>(op_smem + OP_NL * 256 * 16);   // [OP_NL][256] gate bits
     const bool live = t < fm.span;
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(a.dy, fm.bytes), xr = make_rsrc(a.x, fm.bytes);
-    const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_mode == 1 ? (const void*)a.mask : (const void*)a.x, a.mask_mode == 1 ? fm.bytes >> 3 : 0);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_mode == 1 ? (const void*)a.mask : (const void*)a.x, a.mask_mode == 1 ? fm.bytes >> MSH : 0);
     const __amdgpu_buffer_rsrc_t dxr = make_rsrc(a.dx, fm.bytes), drr = make_rsrc(a.dres ? a.dres : a.dx, fm.bytes);
     int cv = 0; RowIter it; it.init(fm, bid, live ? t : 0, cv);
     const int c0 = cv * VW;
@@ -655,13 +694,15 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     }
 }
 
+#endif  // NA_F32
+
 // ------------------------------------------------------------------------------------------
 struct SumP {
-    const bf16_t* in[4]; int shift[4]; int nterms;
+    const elem_t* in[4]; int shift[4]; int nterms;
     int B, H, W, C;
 };
 
-__global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, bf16_t* __restrict__ y, int relu)
+__global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, elem_t* __restrict__ y, int relu)
 {
     const int CV = p.C / VW;
     const long nvec = (long)p.B * p.H * p.W * CV;
@@ -690,8 +731,8 @@ __global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, bf16_t* __restric
 }
 
 // d_term[b,h',w',c] = sum over the 2^sh x 2^sh window of gy * (y > 0)
-__global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
-                                                           int B, int H, int W, int C, int sh, int relu, bf16_t* __restrict__ d)
+__global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const elem_t* __restrict__ gy, const elem_t* __restrict__ y,
+                                                           int B, int H, int W, int C, int sh, int relu, elem_t* __restrict__ d)
 {
     const int CV = C / VW;
     const int Ht = H >> sh, Wt = W >> sh, f = 1 << sh;
@@ -726,8 +767,8 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const bf16_t* __restr
 // A lane owns one coarsest window (2^smax squared pixels) of one channel vector and walks it in Morton order, so every 2x2,
 // 4x4, 8x8 group completes consecutively: gy and y are read ONCE (the per-shift kernel read them once per shift: 4 launches
 // and 8 tensor passes for the highest-resolution output of a 4-branch module).
-struct SumBwdAll { bf16_t* d[4]; };
-__global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+struct SumBwdAll { elem_t* d[4]; };
+__global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const elem_t* __restrict__ gy, const elem_t* __restrict__ y,
                                                                int B, int H, int W, int C, int smax, int relu, SumBwdAll out)
 {
     const int CV = C / VW;
@@ -777,12 +818,12 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const bf16_t* __r
 // slab [c_begin, c_begin + Cs) of a [M, C] tensor; Cs <= 1024
 inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* grid) {
     if (C % VW != 0 || Cs % VW != 0 || c_begin % VW != 0 || Cs / VW > 256) return -1;
-    if (M * C * 2 >= (1LL << 31) - (64 << 20)) return -1;          // 32-bit byte offsets
+    if (M * C * ES >= (1LL << 31) - (64 << 20)) return -1;          // 32-bit byte offsets
     fm->CV = Cs / VW;
     fm->ldv = C / VW;
     fm->coff = c_begin / VW;
     fm->M = (int)M;
-    fm->bytes = (int)(M * C * 2);
+    fm->bytes = (int)(M * C * ES);
     fm->span = (256 / fm->CV) * fm->CV;
     const long nvec = M * fm->CV;
     long blocks = (nvec + fm->span - 1) / fm->span;
@@ -790,7 +831,7 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
     // (tools/experiments/bn_micro.cpp: the four-branch forward 24.7 -> 12.9 us, the two-kernel backward 81 -> 40 us together
     // with bn_ncopy; eight rows per trip instead of four measured slower: 14.8 / 62 us)
     static const long per_block = getenv("DANET_BN_BLOCK_BYTES") ? atol(getenv("DANET_BN_BLOCK_BYTES")) : 24576;
-    const long by_bytes = (M * Cs * 2 + per_block - 1) / per_block;
+    const long by_bytes = (M * Cs * ES + per_block - 1) / per_block;
     if (blocks > by_bytes) blocks = by_bytes;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
@@ -801,7 +842,7 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
 
 }  // namespace
 
-extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
+extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu,
                                 void* relu_mask, void* stream)
@@ -822,10 +863,10 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_forward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         // per-slab views of the per-channel buffers: [2][C] buffers are addressed as base+c0 with stride C
         if (training && ws_is_zero != 2) {          // ws_is_zero == 2: the statistics were accumulated by the conv epilogue
-            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, fm, sums_ws + c0, C);
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, sums_ws + c0, C);
             DANET_CHECK_LAUNCH("bn_stats_kernel");
         }
-        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, fm,
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, (const elem_t*)res, (elem_t*)y, fm,
                            sums_ws ? sums_ws + c0 : nullptr, gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr,
                            running_mean ? running_mean + c0 : nullptr, running_var ? running_var + c0 : nullptr,
                            saved ? saved + c0 : nullptr, C, inv, unbias, momentum, eps, training ? 0 : 1, relu, (unsigned char*)relu_mask);
@@ -835,9 +876,11 @@ extern "C" int danet_bn_forward(const void* x, const void* res, void* y, int64_t
 }
 
 // red_ws: danet_bn_ws_floats(C) floats of scratch; dparam [2][C] (may be NULL) receives (d beta, d gamma).
+#ifndef NA_F32
 extern "C" size_t danet_bn_ws_floats(int C) { return (size_t)NCOPY * 2 * C; }
+#endif
 
-extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
+extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const void* y, int64_t M, int C,
                                  const float* gamma, const float* saved, int relu,
                                  void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero,
                                  int mask_mode, const void* relu_mask, const float* beta, void* stream)
@@ -857,39 +900,39 @@ extern "C" int danet_bn_backward(const void* dy, const void* x, const void* y, i
         FlatMap fm; int grid;
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         if (ws_is_zero != 2) {                     // ws_is_zero == 2: the sums were accumulated by the consumer conv's dgrad epilogue
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)y,
                                fm, saved + c0, C, relu, red_ws + c0, mask_mode, (const unsigned char*)relu_mask,
                                gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr);
             DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
         }
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
-                           fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (bf16_t*)dx, (bf16_t*)dres,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)y,
+                           fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (elem_t*)dx, (elem_t*)dres,
                            dparam ? dparam + c0 : nullptr, mask_mode, (const unsigned char*)relu_mask, beta ? beta + c0 : nullptr);
         DANET_CHECK_LAUNCH("bn_bwd_apply_kernel");
     }
     return DANET_OK;
 }
 
-extern "C" int danet_sum_relu_forward(const void* const* terms /* host array */, const int* shifts /* host */, int nterms,
+extern "C" int NA_NAME(danet_sum_relu_forward)(const void* const* terms /* host array */, const int* shifts /* host */, int nterms,
                                       int B, int H, int W, int C, int relu, void* y, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(terms && shifts && y && nterms >= 1 && nterms <= 4 && C % VW == 0, "sum_relu_forward: bad arguments");
     SumP p;
     p.nterms = nterms; p.B = B; p.H = H; p.W = W; p.C = C;
-    for (int i = 0; i < 4; ++i) { p.in[i] = i < nterms ? (const bf16_t*)terms[i] : nullptr; p.shift[i] = i < nterms ? shifts[i] : 0; }
+    for (int i = 0; i < 4; ++i) { p.in[i] = i < nterms ? (const elem_t*)terms[i] : nullptr; p.shift[i] = i < nterms ? shifts[i] : 0; }
     for (int i = 0; i < nterms; ++i)
         DANET_CHECK_ARG(p.in[i] && p.shift[i] >= 0 && (H % (1 << p.shift[i])) == 0 && (W % (1 << p.shift[i])) == 0, "sum_relu_forward: term %d", i);
     const long nvec = (long)B * H * W * (C / VW);
     long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sum_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)y, relu);
+    hipLaunchKernelGGL(sum_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, (elem_t*)y, relu);
     DANET_CHECK_LAUNCH("sum_relu_kernel");
     return DANET_OK;
 }
 
 // All requested shifts in one launch: d[s] (s = 0..3, NULL = not needed) receives the [B, H >> s, W >> s, C] gradient of the
 // terms that entered the sum up-sampled by 2^s.
-extern "C" int danet_sum_relu_backward_all(const void* gy, const void* y, int B, int H, int W, int C, int relu,
+extern "C" int NA_NAME(danet_sum_relu_backward_all)(const void* gy, const void* y, int B, int H, int W, int C, int relu,
                                            void* d0, void* d1, void* d2, void* d3, void* stream)
 {
     DANET_ENTER();
@@ -899,24 +942,24 @@ extern "C" int danet_sum_relu_backward_all(const void* gy, const void* y, int B,
     DANET_CHECK_ARG(gy && (!relu || y) && C % VW == 0 && smax >= 0 && H % (1 << smax) == 0 && W % (1 << smax) == 0,
                     "sum_relu_backward_all: bad arguments");
     SumBwdAll out;
-    for (int s_ = 0; s_ < 4; ++s_) out.d[s_] = (bf16_t*)d[s_];
+    for (int s_ = 0; s_ < 4; ++s_) out.d[s_] = (elem_t*)d[s_];
     const long nvec = (long)B * (H >> smax) * (W >> smax) * (C / VW);
     long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sum_relu_bwd_all_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gy,
-                       (const bf16_t*)y, B, H, W, C, smax, relu, out);
+    hipLaunchKernelGGL(sum_relu_bwd_all_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gy,
+                       (const elem_t*)y, B, H, W, C, smax, relu, out);
     DANET_CHECK_LAUNCH("sum_relu_bwd_all_kernel");
     return DANET_OK;
 }
 
-extern "C" int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
+extern "C" int NA_NAME(danet_sum_relu_backward)(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
                                        void* d_term, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(gy && d_term && (!relu || y) && C % VW == 0 && shift >= 0, "sum_relu_backward: bad arguments");
     const long nvec = (long)B * (H >> shift) * (W >> shift) * (C / VW);
     long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sum_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gy,
-                       (const bf16_t*)y, B, H, W, C, shift, relu, (bf16_t*)d_term);
+    hipLaunchKernelGGL(sum_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gy,
+                       (const elem_t*)y, B, H, W, C, shift, relu, (elem_t*)d_term);
     DANET_CHECK_LAUNCH("sum_relu_bwd_kernel");
     return DANET_OK;
 }
@@ -934,7 +977,7 @@ struct BnFwdJob { const void* x; const void* res; void* y; const float* gamma; c
 struct BnBwdJob { const void* dy; const void* x; const void* y; const float* gamma; const float* saved; void* dx; void* dres; float* dparam;
                   float* red; const float* beta; const void* mask; int64_t M; int C, red_state, relu, mask_mode; };
 
-extern "C" int danet_bn_forward_multi(const void* jobs_, int n, float momentum, float eps, void* stream)
+extern "C" int NA_NAME(danet_bn_forward_multi)(const void* jobs_, int n, float momentum, float eps, void* stream)
 {
     DANET_ENTER();
     const BnFwdJob* jobs = (const BnFwdJob*)jobs_;
@@ -949,10 +992,10 @@ extern "C" int danet_bn_forward_multi(const void* jobs_, int n, float momentum, 
         int grid;
         DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_forward_multi: job %d: C=%d unsupported", i, j.C);
         if (j.sums_state == 1) {
-            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)j.x, a.fm, j.sums, j.C);
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)j.x, a.fm, j.sums, j.C);
             DANET_CHECK_LAUNCH("bn_stats_kernel");
         }
-        a.x = (const bf16_t*)j.x; a.res = (const bf16_t*)j.res; a.y = (bf16_t*)j.y; a.sums = j.sums; a.gamma = j.gamma; a.beta = j.beta;
+        a.x = (const elem_t*)j.x; a.res = (const elem_t*)j.res; a.y = (elem_t*)j.y; a.sums = j.sums; a.gamma = j.gamma; a.beta = j.beta;
         a.running_mean = j.running_mean; a.running_var = j.running_var; a.saved = j.saved; a.C = j.C; a.mask = (unsigned char*)j.mask;
         a.inv_count = 1.0f / (float)j.M; a.unbias = j.M > 1 ? (float)j.M / (float)(j.M - 1) : 1.f; a.relu = j.relu;
         m.start[i + 1] = m.start[i] + grid;
@@ -962,7 +1005,7 @@ extern "C" int danet_bn_forward_multi(const void* jobs_, int n, float momentum, 
     return DANET_OK;
 }
 
-extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
+extern "C" int NA_NAME(danet_bn_backward_multi)(const void* jobs_, int n, void* stream)
 {
     DANET_ENTER();
     const BnBwdJob* jobs = (const BnBwdJob*)jobs_;
@@ -979,8 +1022,8 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
         BnBwdOne& a = m.a[i];
         int grid;
         DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_backward_multi: job %d: C=%d unsupported", i, j.C);
-        a.dy = (const bf16_t*)j.dy; a.x = (const bf16_t*)j.x; a.y = (const bf16_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
-        a.dx = (bf16_t*)j.dx; a.dres = (bf16_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
+        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
+        a.dx = (elem_t*)j.dx; a.dres = (elem_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
         a.have_red = j.red_state == 2; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
         need_reduce = need_reduce || !a.have_red;
         m.start[i + 1] = m.start[i] + grid;
@@ -995,6 +1038,7 @@ extern "C" int danet_bn_backward_multi(const void* jobs_, int n, void* stream)
 }
 
 
+#ifndef NA_F32
 // ---------------------------------------------------------------------------------------------
 // One-pass form of danet_bn_backward_multi (bn_bwd_onepass_kernel).  `bar`: danet_bn_backward_onepass_bar_words() uints of device memory, zeroed ONCE by
 // the caller and then owned by these launches (barrier state + error flag), shared by all launches -- which must not
@@ -1036,8 +1080,8 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) 
         if (blocks < 1) blocks = 1;
         if (blocks > max_blocks) return 0;
         a.fm.rstep = (int)(rows_per_block * blocks);
-        a.dy = (const bf16_t*)j.dy; a.x = (const bf16_t*)j.x; a.y = (const bf16_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
-        a.dx = (bf16_t*)j.dx; a.dres = (bf16_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
+        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
+        a.dx = (elem_t*)j.dx; a.dres = (elem_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
         a.have_red = 0; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
         if (!m || m->start[m->n] + blocks > max_blocks) { m = &ms[nl++]; m->n = 0; m->start[0] = 0; }
         m->a[m->n] = a;
@@ -1079,3 +1123,4 @@ extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, voi
     }
     return DANET_OK;
 }
+#endif  // NA_F32

@@ -40,10 +40,23 @@ __device__ inline void store8(bf16_t* p, const V8& a) {
     *reinterpret_cast<uint4*>(p) = r;
 }
 
-// x [B,H,W,C] bf16, theta [B,P,2,3] f32 -> y [B,OH,OW,P*C] bf16.  C % 8 == 0.
-__global__ __launch_bounds__(256) void stn_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ theta,
+// fp32 tensors (BASELINE config C4's arithmetic type): the same eight channels per lane, two 16-byte accesses
+__device__ inline V8 load8(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    V8 o;
+    o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w; o.v[4] = b.x; o.v[5] = b.y; o.v[6] = b.z; o.v[7] = b.w;
+    return o;
+}
+__device__ inline void store8(float* p, const V8& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+// x [B,H,W,C] (T = bf16 or fp32), theta [B,P,2,3] f32 -> y [B,OH,OW,P*C].  C % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void stn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ theta,
                                                       int B, int H, int W, int C, int P, int OH, int OW, int align,
-                                                      bf16_t* __restrict__ y)
+                                                      T* __restrict__ y)
 {
     const int CV = C / 8;
     const long total = (long)B * OH * OW * P * CV;
@@ -95,10 +108,11 @@ __device__ inline void reach(float a, float b0, float target, int n_out, int* lo
     *hi = hf > (float)(n_out - 1) ? n_out - 1 : (hf < -1.0f ? -1 : (int)hf);
 }
 
-// dx [B,H,W,C] bf16 from dy [B,OH,OW,P*C] bf16; axis-aligned thetas only.
-__global__ __launch_bounds__(256) void stn_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ theta,
+// dx [B,H,W,C] from dy [B,OH,OW,P*C]; axis-aligned thetas only.
+template <typename T>
+__global__ __launch_bounds__(256) void stn_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ theta,
                                                       int B, int H, int W, int C, int P, int OH, int OW, int align,
-                                                      bf16_t* __restrict__ dx)
+                                                      T* __restrict__ dx)
 {
     const int CV = C / 8;
     const long total = (long)B * H * W * CV;
@@ -150,30 +164,44 @@ __global__ __launch_bounds__(256) void stn_bwd_kernel(const bf16_t* __restrict__
 
 }  // namespace
 
-extern "C" int danet_stn_gather_forward(const void* x, const float* theta, int B, int H, int W, int C, int P,
-                                        int OH, int OW, int align_corners, void* y, void* stream)
+template <typename T>
+int stn_forward(const void* x, const float* theta, int B, int H, int W, int C, int P, int OH, int OW, int align_corners, void* y, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && theta && y && B > 0 && H > 0 && W > 0 && P > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0,
                     "stn_gather_forward: bad arguments (C=%d must be a multiple of 8)", C);
     const long total = (long)B * OH * OW * P * (C / 8);
     long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(stn_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const danet_conv::bf16_t*)x,
-                       theta, B, H, W, C, P, OH, OW, align_corners, (danet_conv::bf16_t*)y);
+    hipLaunchKernelGGL(stn_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                       theta, B, H, W, C, P, OH, OW, align_corners, (T*)y);
     DANET_CHECK_LAUNCH("stn_fwd_kernel");
     return DANET_OK;
 }
 
-extern "C" int danet_stn_gather_backward(const void* dy, const float* theta, int B, int H, int W, int C, int P,
-                                         int OH, int OW, int align_corners, void* dx, void* stream)
+template <typename T>
+int stn_backward(const void* dy, const float* theta, int B, int H, int W, int C, int P, int OH, int OW, int align_corners, void* dx, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(dy && theta && dx && B > 0 && H > 0 && W > 0 && P > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0,
                     "stn_gather_backward: bad arguments");
     const long total = (long)B * H * W * (C / 8);
     long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(stn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const danet_conv::bf16_t*)dy,
-                       theta, B, H, W, C, P, OH, OW, align_corners, (danet_conv::bf16_t*)dx);
+    hipLaunchKernelGGL(stn_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                       theta, B, H, W, C, P, OH, OW, align_corners, (T*)dx);
     DANET_CHECK_LAUNCH("stn_bwd_kernel");
     return DANET_OK;
 }
+
+extern "C" int danet_stn_gather_forward(const void* x, const float* theta, int B, int H, int W, int C, int P,
+                                        int OH, int OW, int align_corners, void* y, void* stream)
+{ return stn_forward<danet_conv::bf16_t>(x, theta, B, H, W, C, P, OH, OW, align_corners, y, stream); }
+extern "C" int danet_stn_gather_backward(const void* dy, const float* theta, int B, int H, int W, int C, int P,
+                                         int OH, int OW, int align_corners, void* dx, void* stream)
+{ return stn_backward<danet_conv::bf16_t>(dy, theta, B, H, W, C, P, OH, OW, align_corners, dx, stream); }
+// fp32 NHWC tensors (conv.precision('fp32'))
+extern "C" int danet_stn_gather_forward_f32(const void* x, const float* theta, int B, int H, int W, int C, int P,
+                                            int OH, int OW, int align_corners, void* y, void* stream)
+{ return stn_forward<float>(x, theta, B, H, W, C, P, OH, OW, align_corners, y, stream); }
+extern "C" int danet_stn_gather_backward_f32(const void* dy, const float* theta, int B, int H, int W, int C, int P,
+                                             int OH, int OW, int align_corners, void* dx, void* stream)
+{ return stn_backward<float>(dy, theta, B, H, W, C, P, OH, OW, align_corners, dx, stream); }

@@ -10,7 +10,12 @@ import torch.nn.functional as F
 from . import _lib
 from . import conv as _conv
 from ._lib import ptr, check, stream
-from .conv import Conv2d, conv2d, nhwc_bf16, _empty_nhwc, ARENA  # noqa: F401
+from .conv import Conv2d, conv2d, nhwc_bf16, nhwc_as, nhwc_act, _empty_nhwc, ARENA  # noqa: F401
+
+
+def _k(L, name, dtype):
+    """The entry point `name` for activations of `dtype`: the fp32 instantiation (csrc/norm_act_f32.hip, stn.hip) or the bf16 one."""
+    return getattr(L, name + '_f32' if dtype == torch.float32 else name)
 
 
 RELU_MASK = bool(int(os.environ.get('DANET_BN_RELU_MASK', '1')))     # A/B knob: 0 = the backward gates on the saved output y
@@ -65,14 +70,15 @@ class BatchNormActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, fused_sums=None, link=None):
         L = _lib.lib()
-        x = nhwc_bf16(x)
+        x = nhwc_act(x)
+        dt = x.dtype
         B, C, H, W = x.shape
         M = B * H * W
         if res is not None:
-            res = nhwc_bf16(res)
+            res = nhwc_as(res, dt)
             if res.shape != x.shape:
                 raise ValueError('residual shape %s != %s' % (tuple(res.shape), tuple(x.shape)))
-        y = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
+        y = _empty_nhwc(B, C, H, W, dt, x.device)
         saved = torch.empty(2, C, dtype=torch.float32, device=x.device) if training else None
         sums, sums_zero = None, False
         if training and fused_sums is not None:
@@ -89,7 +95,7 @@ class BatchNormActFunction(torch.autograd.Function):
         # (without a residual the BatchNorm's own backward recomputes the gate; the mask then only serves conv._bn_gate)
         mask = torch.empty(M * C // 4, dtype=torch.uint8, device=x.device) \
             if (training and relu and RELU_MASK and (res is not None or _conv.FUSE_BN_BWD_REDUCE)) else None
-        check(L.danet_bn_forward(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
+        check(_k(L, 'danet_bn_forward', dt)(ptr(x.permute(0, 2, 3, 1)), None if res is None else ptr(res.permute(0, 2, 3, 1)),
                                  ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(b), ptr(running_mean), ptr(running_var),
                                  ptr(saved), ptr(sums), int(sums_zero), float(momentum), float(eps), int(training), int(relu),
                                  ptr(mask), stream()),
@@ -118,11 +124,12 @@ class BatchNormActFunction(torch.autograd.Function):
         L = _lib.lib()
         x, y, g, saved, b, mask = ctx.saved_tensors
         gy_in = gy
-        gy = nhwc_bf16(gy)
+        dt = x.dtype
+        gy = nhwc_as(gy, dt)
         B, C, H, W = x.shape
         M = B * H * W
-        dx = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device)
-        dres = _empty_nhwc(B, C, H, W, torch.bfloat16, x.device) if ctx.has_res else None
+        dx = _empty_nhwc(B, C, H, W, dt, x.device)
+        dres = _empty_nhwc(B, C, H, W, dt, x.device) if ctx.has_res else None
         red = getattr(gy_in, '_bn_red', None)        # reduced by the consumer conv's data-gradient epilogue (conv.py)
         _conv.FUSION['bn_bwd_reduce_fused' if red is not None else 'bn_bwd_reduce_own'] += 1
         if red is not None:
@@ -133,7 +140,7 @@ class BatchNormActFunction(torch.autograd.Function):
             if red is None:
                 red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)      # rows: d beta, d gamma
-        bar = _onepass_bar(x.device) if (red_zero != 2 and C <= 1024) else None
+        bar = _onepass_bar(x.device) if (red_zero != 2 and C <= 1024 and dt == torch.bfloat16) else None
         done = False
         if bar is not None:
             if red_zero is False:
@@ -150,7 +157,7 @@ class BatchNormActFunction(torch.autograd.Function):
                 _conv.FUSION['bn_bwd_onepass'] += 1
                 done = True
         if not done:
-            check(L.danet_bn_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
+            check(_k(L, 'danet_bn_backward', dt)(ptr(gy.permute(0, 2, 3, 1)), ptr(x.permute(0, 2, 3, 1)),
                                   None if y is None else ptr(y.permute(0, 2, 3, 1)), M, C, ptr(g), ptr(saved),
                                   int(ctx.relu), ptr(dx.permute(0, 2, 3, 1)),
                                   None if dres is None else ptr(dres.permute(0, 2, 3, 1)), ptr(dparam), ptr(red), int(red_zero),
@@ -185,13 +192,6 @@ class BatchNorm2d(nn.BatchNorm2d):
         training = self.training or not self.track_running_stats
         if training:
             self._count()
-        if _conv.PRECISION == 'fp32':                       # verification mode: fp32 tensor ops
-            y = F.batch_norm(x.float(), self.running_mean if self.track_running_stats else None,
-                             self.running_var if self.track_running_stats else None, self.weight, self.bias, training,
-                             0.1 if self.momentum is None else self.momentum, self.eps)
-            if res is not None:
-                y = y + res.float()
-            return F.relu(y) if relu else y
         momentum = 0.1 if self.momentum is None else self.momentum
         fused = getattr(x, '_bn_sums', None) if training else None
         if training:
@@ -211,8 +211,9 @@ class MultiBatchNormFunction(torch.autograd.Function):
     def forward(ctx, static, *tensors):
         L = _lib.lib()
         n, relu, momentum, eps, rms, rvs, fused, links = static
-        xs = [nhwc_bf16(t) for t in tensors[:n]]
-        ress = [None if t is None else nhwc_bf16(t) for t in tensors[n:2 * n]]
+        xs = [nhwc_act(t) for t in tensors[:n]]
+        dt = xs[0].dtype
+        ress = [None if t is None else nhwc_as(t, dt) for t in tensors[n:2 * n]]
         gammas = [t.detach().float().contiguous() for t in tensors[2 * n:3 * n]]
         betas = [t.detach().float().contiguous() for t in tensors[3 * n:4 * n]]
         jobs = (_lib.BnFwdJob * n)()
@@ -221,7 +222,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
             B, C, H, W = xs[i].shape
             if ress[i] is not None and ress[i].shape != xs[i].shape:
                 raise ValueError('residual shape %s != %s' % (tuple(ress[i].shape), tuple(xs[i].shape)))
-            y = _empty_nhwc(B, C, H, W, torch.bfloat16, xs[i].device)
+            y = _empty_nhwc(B, C, H, W, dt, xs[i].device)
             saved = torch.empty(2, C, dtype=torch.float32, device=xs[i].device)
             sums, state = fused[i], 2
             if sums is None:
@@ -242,7 +243,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
             j.M, j.C, j.sums_state, j.relu = B * H * W, C, state, int(relu)
             ys.append(y)
             saveds.append(saved)
-        check(L.danet_bn_forward_multi(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
+        check(_k(L, 'danet_bn_forward_multi', dt)(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
         modes = [((2 if r is None else (1 if m is not None else 0)) if RELU_MASK else 0) if relu else 0 for m, r in zip(masks, ress)]
         ctx.save_for_backward(*xs, *[y if (relu and md == 0) else None for y, md in zip(ys, modes)], *gammas, *saveds, *betas, *masks)
         ctx.cfg = (n, relu, [r is not None for r in ress], links, modes)
@@ -257,6 +258,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
         sv = ctx.saved_tensors
         xs, ys, gammas, saveds, betas, masks = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n], sv[4 * n:5 * n], sv[5 * n:6 * n]
         jobs = (_lib.BnBwdJob * n)()
+        dt = xs[0].dtype
         dxs, dress, dparams, keep = [], [], [], []
         for i in range(n):
             B, C, H, W = xs[i].shape
@@ -267,9 +269,9 @@ class MultiBatchNormFunction(torch.autograd.Function):
                 red, state = ARENA.alloc(L.danet_bn_ws_floats(C)), 1
                 if red is None:
                     red = torch.zeros(L.danet_bn_ws_floats(C), dtype=torch.float32, device=xs[i].device)
-            gy = nhwc_bf16(gys[i])
-            dx = _empty_nhwc(B, C, H, W, torch.bfloat16, xs[i].device)
-            dres = _empty_nhwc(B, C, H, W, torch.bfloat16, xs[i].device) if has_res[i] else None
+            gy = nhwc_as(gys[i], dt)
+            dx = _empty_nhwc(B, C, H, W, dt, xs[i].device)
+            dres = _empty_nhwc(B, C, H, W, dt, xs[i].device) if has_res[i] else None
             dparam = torch.empty(2, C, dtype=torch.float32, device=xs[i].device)
             keep += [red, gy]
             j = jobs[i]
@@ -281,12 +283,12 @@ class MultiBatchNormFunction(torch.autograd.Function):
             dxs.append(dx)
             dress.append(dres)
             dparams.append(dparam)
-        bar = _onepass_bar(xs[0].device) if all(jobs[i].red_state == 1 for i in range(n)) else None
+        bar = _onepass_bar(xs[0].device) if (dt == torch.bfloat16 and all(jobs[i].red_state == 1 for i in range(n))) else None
         if bar is not None and L.danet_bn_backward_onepass_ok(ctypes.addressof(jobs), n):
             check(L.danet_bn_backward_onepass(ctypes.addressof(jobs), n, ptr(bar), stream()), 'danet_bn_backward_onepass')
             _conv.FUSION['bn_bwd_onepass'] += n
         else:
-            check(L.danet_bn_backward_multi(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
+            check(_k(L, 'danet_bn_backward_multi', dt)(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
         if links is not None:
             for i, lk in enumerate(links):
                 if lk is not None and lk.armed and dress[i] is not None:
@@ -299,7 +301,7 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
     n = len(bns)
     ress = list(ress) if ress is not None else [None] * n
-    ok = _conv.PRECISION != 'fp32' and 1 <= n <= 8 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
+    ok = 1 <= n <= 8 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
     lks = list(links) if links is not None else [None] * n
     if not ok:
         return [b(x, r, relu, link=lk) for b, x, r, lk in zip(bns, xs, ress, lks)]
@@ -327,7 +329,8 @@ class SumReluFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, relu, shifts, *terms):
         L = _lib.lib()
-        terms = [nhwc_bf16(t) for t in terms]
+        terms = [nhwc_act(t) for t in terms]
+        dt = terms[0].dtype
         n = len(terms)
         B, C = terms[0].shape[0], terms[0].shape[1]
         H = max(t.shape[2] << s for t, s in zip(terms, shifts))
@@ -335,30 +338,30 @@ class SumReluFunction(torch.autograd.Function):
         for t, s in zip(terms, shifts):
             if t.shape[1] != C or (t.shape[2] << s) != H or (t.shape[3] << s) != W:
                 raise ValueError('sum_relu: term %s with shift %d does not match output %dx%dx%d' % (tuple(t.shape), s, C, H, W))
-        y = _empty_nhwc(B, C, H, W, torch.bfloat16, terms[0].device)
+        y = _empty_nhwc(B, C, H, W, dt, terms[0].device)
         ptrs = (ctypes.c_void_p * n)(*[ptr(t.permute(0, 2, 3, 1)) for t in terms])
         sh = (ctypes.c_int * n)(*shifts)
-        check(L.danet_sum_relu_forward(ptrs, sh, n, B, H, W, C, int(relu), ptr(y.permute(0, 2, 3, 1)), stream()),
+        check(_k(L, 'danet_sum_relu_forward', dt)(ptrs, sh, n, B, H, W, C, int(relu), ptr(y.permute(0, 2, 3, 1)), stream()),
               'danet_sum_relu_forward')
         ctx.save_for_backward(y if relu else None)
-        ctx.cfg = (relu, tuple(shifts), B, C, H, W)
+        ctx.cfg = (relu, tuple(shifts), B, C, H, W, dt)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
         (y,) = ctx.saved_tensors
-        relu, shifts, B, C, H, W = ctx.cfg
-        gy = nhwc_bf16(gy)
+        relu, shifts, B, C, H, W, dt = ctx.cfg
+        gy = nhwc_as(gy, dt)
         outs = []
         cache = {}
         need = sorted({s for i, s in enumerate(shifts) if ctx.needs_input_grad[2 + i]})
         if SUM_BWD_ALL and len(need) > 1 and need[-1] <= 3:
             # every shift in one launch: gy and y are read once (csrc/norm_act.hip sum_relu_bwd_all_kernel)
             for s in need:
-                cache[s] = _empty_nhwc(B, C, H >> s, W >> s, torch.bfloat16, gy.device)
+                cache[s] = _empty_nhwc(B, C, H >> s, W >> s, dt, gy.device)
             dp = [None if s not in cache else ptr(cache[s].permute(0, 2, 3, 1)) for s in range(4)]
-            check(L.danet_sum_relu_backward_all(ptr(gy.permute(0, 2, 3, 1)), None if y is None else ptr(y.permute(0, 2, 3, 1)),
+            check(_k(L, 'danet_sum_relu_backward_all', dt)(ptr(gy.permute(0, 2, 3, 1)), None if y is None else ptr(y.permute(0, 2, 3, 1)),
                                                 B, H, W, C, int(relu), dp[0], dp[1], dp[2], dp[3], stream()),
                   'danet_sum_relu_backward_all')
         for i, s in enumerate(shifts):
@@ -366,8 +369,8 @@ class SumReluFunction(torch.autograd.Function):
                 outs.append(None)
                 continue
             if s not in cache:
-                d = _empty_nhwc(B, C, H >> s, W >> s, torch.bfloat16, gy.device)
-                check(L.danet_sum_relu_backward(ptr(gy.permute(0, 2, 3, 1)), None if y is None else ptr(y.permute(0, 2, 3, 1)),
+                d = _empty_nhwc(B, C, H >> s, W >> s, dt, gy.device)
+                check(_k(L, 'danet_sum_relu_backward', dt)(ptr(gy.permute(0, 2, 3, 1)), None if y is None else ptr(y.permute(0, 2, 3, 1)),
                                                 B, H, W, C, s, int(relu), ptr(d.permute(0, 2, 3, 1)), stream()),
                       'danet_sum_relu_backward')
                 cache[s] = d
@@ -401,12 +404,13 @@ class FanOutFunction(torch.autograd.Function):
                 total = grp[0]
                 continue
             L = _lib.lib()
-            terms = [nhwc_bf16(t) for t in grp]
+            dt = torch.float32 if grp[0].dtype == torch.float32 else torch.bfloat16
+            terms = [nhwc_as(t, dt) for t in grp]
             B, C, H, W = terms[0].shape
-            y = _empty_nhwc(B, C, H, W, torch.bfloat16, terms[0].device)
+            y = _empty_nhwc(B, C, H, W, dt, terms[0].device)
             ptrs = (ctypes.c_void_p * len(terms))(*[ptr(t.permute(0, 2, 3, 1)) for t in terms])
             sh = (ctypes.c_int * len(terms))(*([0] * len(terms)))
-            check(L.danet_sum_relu_forward(ptrs, sh, len(terms), B, H, W, C, 0, ptr(y.permute(0, 2, 3, 1)), stream()),
+            check(_k(L, 'danet_sum_relu_forward', dt)(ptrs, sh, len(terms), B, H, W, C, 0, ptr(y.permute(0, 2, 3, 1)), stream()),
                   'danet_sum_relu_forward')
             total = y
         return total, None
@@ -416,9 +420,9 @@ FAN_OUT = bool(int(os.environ.get('DANET_FAN_OUT', '1')))
 
 
 def fan_out(x, n):
-    """n views of x whose gradients are summed by one kernel (CUDA bf16 NHWC tensors with channels % 4 == 0; plain
+    """n views of x whose gradients are summed by one kernel (CUDA NHWC tensors with channels % 4 == 0; plain
     aliases otherwise)."""
-    if not (FAN_OUT and n > 2 and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and _conv.PRECISION != 'fp32'
+    if not (FAN_OUT and n > 2 and x.is_cuda and x.requires_grad and torch.is_grad_enabled()
             and x.dim() == 4 and x.shape[1] % 4 == 0):
         return [x] * n
     return list(FanOutFunction.apply(x, n))
@@ -426,12 +430,6 @@ def fan_out(x, n):
 
 def sum_relu(terms, shifts=None, relu=True):
     shifts = [0] * len(terms) if shifts is None else list(shifts)
-    if _conv.PRECISION == 'fp32':                           # verification mode: fp32 tensor ops
-        y = None
-        for t, sh in zip(terms, shifts):
-            t = t.float() if sh == 0 else F.interpolate(t.float(), scale_factor=2 ** sh, mode='nearest')
-            y = t if y is None else y + t
-        return F.relu(y) if relu else y
     return SumReluFunction.apply(relu, shifts, *terms)
 
 
@@ -446,39 +444,33 @@ class StnGatherFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, theta, out_hw, align_corners):
         L = _lib.lib()
-        x = nhwc_bf16(x)
+        x = nhwc_act(x)
+        dt = x.dtype
         B, C, H, W = x.shape
         th = theta.detach().float().contiguous()
         P = th.shape[1]
         OH, OW = out_hw
-        y = _empty_nhwc(B, P * C, OH, OW, torch.bfloat16, x.device)
-        check(L.danet_stn_gather_forward(ptr(x.permute(0, 2, 3, 1)), ptr(th), B, H, W, C, P, OH, OW, int(align_corners),
+        y = _empty_nhwc(B, P * C, OH, OW, dt, x.device)
+        check(_k(L, 'danet_stn_gather_forward', dt)(ptr(x.permute(0, 2, 3, 1)), ptr(th), B, H, W, C, P, OH, OW, int(align_corners),
                                          ptr(y.permute(0, 2, 3, 1)), stream()), 'danet_stn_gather_forward')
         ctx.save_for_backward(th)
-        ctx.cfg = (B, C, H, W, P, OH, OW, int(align_corners))
+        ctx.cfg = (B, C, H, W, P, OH, OW, int(align_corners), dt)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
         (th,) = ctx.saved_tensors
-        B, C, H, W, P, OH, OW, align = ctx.cfg
-        gy = nhwc_bf16(gy)
-        dx = _empty_nhwc(B, C, H, W, torch.bfloat16, gy.device)
-        check(L.danet_stn_gather_backward(ptr(gy.permute(0, 2, 3, 1)), ptr(th), B, H, W, C, P, OH, OW, align,
+        B, C, H, W, P, OH, OW, align, dt = ctx.cfg
+        gy = nhwc_as(gy, dt)
+        dx = _empty_nhwc(B, C, H, W, dt, gy.device)
+        check(_k(L, 'danet_stn_gather_backward', dt)(ptr(gy.permute(0, 2, 3, 1)), ptr(th), B, H, W, C, P, OH, OW, align,
                                           ptr(dx.permute(0, 2, 3, 1)), stream()), 'danet_stn_gather_backward')
         return dx, None, None, None
 
 
 def stn_gather(x, theta, out_hw=None, align_corners=True):
     out_hw = (x.shape[2], x.shape[3]) if out_hw is None else out_hw
-    if _conv.PRECISION == 'fp32':                           # verification mode: the reference's own op sequence (iuv_estimator.py:193-204)
-        B, C = x.shape[0], x.shape[1]
-        outs = []
-        for i in range(theta.shape[1]):
-            grid = F.affine_grid(theta[:, i].detach().float(), [B, C, out_hw[0], out_hw[1]], align_corners=align_corners)
-            outs.append(F.grid_sample(x.float(), grid, mode='bilinear', padding_mode='zeros', align_corners=align_corners))
-        return torch.cat(outs, dim=1)
     return StnGatherFunction.apply(x, theta, out_hw, align_corners)
 
 

@@ -238,6 +238,27 @@ int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_
 int danet_conv_f32(int mode, const float* a, const float* b, const float* bias, float* out,
                    int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups,
                    void* stream);
+/* fp32 convolutions on the matrix cores (csrc/conv_f32m.hip; v_mfma_f32_16x16x4_f32, exact fp32 fmaf chains): the reference's
+ * own arithmetic type (nn.Conv2d in fp32, /root/reference/models/module/hr_module.py:188-378, res_module.py:27-97) as a
+ * performance path.  fp32 NHWC activations; weights repacked by danet_conv_f32m_pack_weights (mode 0 forward operand, mode 1
+ * data-gradient operand) with the channel counts the kernel runs with (Cout_gp >= Cout/groups, Cin_gp >= Cin_g, both
+ * multiples of 4; padding packs as zeros; groups > 1 allows no padding).  danet_conv_f32m_ok: 1 when _forward takes the
+ * problem.  _forward with transposed = 1 is the data gradient: (H, W, Cin) describe the tensor gathered FROM (dY).
+ * _wgrad: dW[Cout_real][Cin_g_real][R][S] in torch's layout; per-pixel-chunk partial blocks go to ws (_wgrad_ws_floats floats, 0 =
+ * unsupported) and are summed in a fixed order (deterministic, no atomics). */
+size_t danet_conv_f32m_packed_elems(int Cout_gp, int Cin_gp, int R, int S, int groups, int mode);
+int danet_conv_f32m_pack_weights(const float* w, float* wp, int Cout, int Cin_g, int R, int S, int groups, int mode,
+                                 int Cout_gp, int Cin_gp, void* stream);
+int danet_conv_f32m_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil,
+                       int groups, int transposed);
+int danet_conv_f32m_forward(const float* x, const float* wp, const float* bias, float* y,
+                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil,
+                            int groups, int transposed, int relu, void* stream);
+size_t danet_conv_f32m_wgrad_ws_floats(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad,
+                                       int dil, int groups, int Cout_real, int Cin_g_real);
+int danet_conv_f32m_wgrad(const float* x, const float* dy, float* dw, float* ws,
+                          int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups,
+                          int Cout_real, int Cin_g_real, void* stream);
 int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
 /* Run-time knobs of the LDS-tile 3x3 kernel (A-B timing, tests): enable 0/1 (-1 keeps); force_mt/force_kw = register
  * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps); want_tiles = tiles per
@@ -346,6 +367,26 @@ int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, 
 /* every requested shift in one launch: d0..d3 (NULL = not needed) <- [B, H >> s, W >> s, C]; gy and y are read once */
 int danet_sum_relu_backward_all(const void* gy, const void* y, int B, int H, int W, int C, int relu,
                                 void* d0, void* d1, void* d2, void* d3, void* stream);
+/* fp32 instantiation of the entry points above (csrc/norm_act_f32.hip: the same kernels with 4-byte elements; BASELINE
+ * config C4's arithmetic type -- the reference's nn.BatchNorm2d / ReLU / add / nn.Upsample in fp32,
+ * /root/reference/models/module/hr_module.py:111-177): activations fp32 NHWC, everything else as in the bf16 forms
+ * (masks: one byte per 4 channels; job structs identical).  The one-pass backward has no fp32 form. */
+int danet_bn_forward_f32(const void* x, const void* res, void* y, int64_t M, int C,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu,
+                         void* relu_mask, void* stream);
+int danet_bn_backward_f32(const void* dy, const void* x, const void* y, int64_t M, int C,
+                          const float* gamma, const float* saved, int relu,
+                          void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero,
+                          int mask_mode, const void* relu_mask, const float* beta, void* stream);
+int danet_bn_forward_multi_f32(const void* jobs, int n, float momentum, float eps, void* stream);
+int danet_bn_backward_multi_f32(const void* jobs, int n, void* stream);
+int danet_sum_relu_forward_f32(const void* const* terms, const int* shifts, int nterms,
+                               int B, int H, int W, int C, int relu, void* y, void* stream);
+int danet_sum_relu_backward_f32(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
+                                void* d_term, void* stream);
+int danet_sum_relu_backward_all_f32(const void* gy, const void* y, int B, int H, int W, int C, int relu,
+                                    void* d0, void* d1, void* d2, void* d3, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Joint-centric part decomposition (STN).  Replaces the 24 x (F.affine_grid + F.grid_sample) +
@@ -359,6 +400,11 @@ int danet_stn_gather_forward(const void* x, const float* theta, int B, int H, in
                              int OH, int OW, int align_corners, void* y, void* stream);
 int danet_stn_gather_backward(const void* dy, const float* theta, int B, int H, int W, int C, int P,
                               int OH, int OW, int align_corners, void* dx, void* stream);
+/* the same with fp32 NHWC tensors (conv.precision('fp32')) */
+int danet_stn_gather_forward_f32(const void* x, const float* theta, int B, int H, int W, int C, int P,
+                                 int OH, int OW, int align_corners, void* y, void* stream);
+int danet_stn_gather_backward_f32(const void* dy, const float* theta, int B, int H, int W, int C, int P,
+                                  int OH, int OW, int align_corners, void* dx, void* stream);
 
 #ifdef __cplusplus
 }
