@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (BASELINE: 32)')
     ap.add_argument('--size', type=int, default=256, help='input resolution (BASELINE: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 (BASELINE config C4) sub-record')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--dtype', choices=('bf16', 'fp32'), default='bf16',
@@ -151,41 +152,58 @@ def geometry_rooflines(tr, B, size, dev):
             mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 
-def fp32_line(args, tr, batch, world, rank, dev):
-    """BASELINE config C4 (full train step in fp32): the same model and step on the fp32 verification kernels."""
+def fp32_record(args, tr, batch, world, dev):
+    """BASELINE config C4 (the full train step in fp32, the reference's own arithmetic type): the same model and step with fp32
+    NHWC activations on the fp32 MFMA kernels (csrc/conv_f32m.hip, norm_act_f32.hip), replayed from a hipGraph when the
+    capture succeeds.  Returns the timing record (every rank must call it: the step holds the gradient all-reduces)."""
     from danet_densepose2smpl_amd import conv
+    from danet_densepose2smpl_amd import nn as _dnn
+    steps, warm = max(1, min(args.steps, 5)), 2
     with conv.precision('fp32'):
-        for _ in range(min(args.warmup, 1)):
-            tr.train_step(batch)
+        exec_mode = 'eager'
+        step = lambda: tr.train_step(batch)
+        if not args.no_graph:
+            try:
+                tr.capture(batch)
+                step, exec_mode = tr.train_step_graphed, 'hipgraph'
+            except Exception as e:
+                sys.stderr.write('fp32: hipGraph capture failed (%r); running eagerly\n' % (e,))
+        for _ in range(warm):
+            out = step()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         t0 = time.time()
-        steps = min(args.steps, 3)
         for _ in range(steps):
-            _, losses = tr.train_step(batch)
+            out = step()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         elapsed = time.time() - t0
-    from danet_densepose2smpl_amd import nn as _dnn
-    if _dnn.onepass_error(dev):                      # a grid barrier of the one-pass BatchNorm backward timed out: results are garbage
-        raise RuntimeError('bench: a one-pass BatchNorm launch gave up at its grid barrier (nn.onepass_error); '
-                           'run with DANET_BN_ONEPASS=0')
+    if _dnn.onepass_error(dev):
+        raise RuntimeError('bench: a one-pass BatchNorm launch gave up at its grid barrier (nn.onepass_error)')
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    losses = out[1] if isinstance(out, tuple) else out
+    finite = bool(all(torch.isfinite(v).all() for v in losses.values())) if isinstance(losses, dict) else None
+    return {'dtype': 'f32', 'value': round(world * args.batch * steps / elapsed, 2), 'unit': 'images/sec', 'ms_per_step': round(elapsed / steps * 1e3, 2),
+            'steps': steps, 'warmup': warm, 'exec': exec_mode, 'finite_losses': finite,
+            'workload': 'BASELINE config C4 arithmetic: the same full train step with fp32 NHWC activations; convolutions on '
+                        'v_mfma_f32_16x16x4_f32 (conv_f32m.hip), BatchNorm / fuse sums / STN on the fp32 instantiation of the HIP kernels'}
+
+
+def fp32_line(args, tr, batch, world, rank, dev):
+    rec = fp32_record(args, tr, batch, world, dev)
     if rank == 0:
         B = args.batch
-        print(json.dumps({'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(world * B * steps / elapsed, 3),
-                          'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': min(args.warmup, 1),
-                          'ms_per_step': round(elapsed / steps * 1e3, 1), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                          'dtype': 'f32', 'data': 'synthetic', 'exec': 'eager',
-                          'config': {'workload': 'BASELINE config C4 arithmetic: the full DaNet train step in fp32 on the verification kernels '
-                                                 '(direct fp32 convolutions, fp32 tensor-op glue) -- a correctness configuration, not tuned',
-                                     'global_batch': B * world, 'parallelism': 'dp%d' % world},
-                          'finite_losses': bool(all(torch.isfinite(v).all() for v in losses.values())), 'roofline': None}), flush=True)
+        print(json.dumps({'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': rec['value'],
+                          'unit': 'images/sec', 'n_gpus': world, 'steps': rec['steps'], 'warmup': rec['warmup'],
+                          'ms_per_step': rec['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'f32', 'data': 'synthetic', 'exec': rec['exec'],
+                          'config': {'workload': rec['workload'], 'global_batch': B * world, 'parallelism': 'dp%d' % world},
+                          'finite_losses': rec['finite_losses'], 'roofline': None}), flush=True)
 
 
 def main():
@@ -293,6 +311,12 @@ def main():
         except Exception as e:                                       # secondary figures must not take the bench line down
             extra = [{'error': repr(e)}]
 
+    fp32 = None
+    if not args.no_fp32:
+        try:                                                         # (after everything measured on the bf16 graph: this re-captures)
+            fp32 = fp32_record(args, tr, batch, world, dev)
+        except Exception as e:
+            fp32 = {'error': repr(e)}
     if rank == 0:
         ips = world * B * args.steps / elapsed
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
@@ -307,6 +331,8 @@ def main():
                                        'LBS/raster/losses fp32' % (args.size, args.size, B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world},
                 'roofline': roof, 'roofline_extra': extra}
+        if fp32 is not None:
+            line['fp32'] = fp32
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.size, args.cpu_batch)

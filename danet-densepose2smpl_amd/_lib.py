@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
+LIB_PATH = os.environ.get('DANET_LIB') or os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
 _lib = None
 
 c_f = ctypes.c_void_p      # device pointers travel as void*
@@ -65,6 +65,7 @@ _SIGNATURES = {
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),
+    'danet_bn_set_block_bytes': (ctypes.c_long, [ctypes.c_long]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_bn_backward_onepass_ok': (c_i, [c_f, c_i]),

@@ -145,13 +145,13 @@ def _pack_weight_f32(weight, w, groups, mode, Cout_gp, Cin_gp):
     """fp32 fragment-major operand of csrc/conv_f32m.hip for the fp32 weight `w` (= weight.detach()); cached per Parameter
     and version like pack_weight."""
     key = (id(weight), 10 + mode, groups, Cout_gp * 65536 + Cin_gp)
-    cacheable = isinstance(weight, nn.Parameter)
+    cacheable = weight is not None and isinstance(weight, nn.Parameter)
     if cacheable:
         hit = _PACK_CACHE.get(key)
         if hit is not None and hit[0] == weight._version and hit[2]() is weight:
             return hit[1]
     L = _lib.lib()
-    Cout, Cin_g, R, S = w.shape
+    Cout, Cin_g, R, S = w.shape                           # (a group-padded copy arrives with its padded Cout)
     wp = torch.empty(L.danet_conv_f32m_packed_elems(Cout_gp, Cin_gp, R, S, groups, mode), dtype=torch.float32, device=w.device)
     check(L.danet_conv_f32m_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, Cout_gp, Cin_gp, stream()), 'danet_conv_f32m_pack_weights')
     if cacheable:
@@ -166,9 +166,10 @@ def _pad_last(t, n):
 
 class Conv2dF32Function(torch.autograd.Function):
     """fp32 convolution: forward, data and weight gradient on the fp32 MFMA kernels (csrc/conv_f32m.hip) -- channel counts
-    zero-padded to multiples of 4 for its 16-byte operand loads --, or on the direct verification kernels
-    (csrc/conv_f32.hip) where that kernel family does not take the problem (grouped convolutions with odd channel counts,
-    strided data gradients whose channel count is no multiple of 16) or F32_MFMA is off."""
+    zero-padded to multiples of 4 for its 16-byte operand loads (for grouped convolutions: the output channels of every group,
+    through a padded copy of the weight) --, or on the direct verification kernels (csrc/conv_f32.hip) where that kernel family
+    does not take the problem (grouped convolutions with odd input channel counts, strided data gradients whose channel count is
+    no multiple of 16) or F32_MFMA is off."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, groups):
@@ -184,38 +185,46 @@ class Conv2dF32Function(torch.autograd.Function):
         Cout_g = Cout // groups
         Cin_gp, Cout_gp = (Cin_g + 3) // 4 * 4, (Cout_g + 3) // 4 * 4
         Cin_p, Cout_p = Cin_gp * groups, Cout_gp * groups
-        mfma = F32_MFMA and (groups == 1 or (Cin_gp == Cin_g and Cout_gp == Cout_g)) and \
+        gpad = groups > 1 and Cout_gp != Cout_g            # grouped: pad every group's output channels in a copy of the weight
+        mfma = F32_MFMA and (groups == 1 or Cin_gp == Cin_g) and \
             bool(L.danet_conv_f32m_ok(B, H, W, Cin_p, OH, OW, Cout_p, R, S, stride, pad, dil, groups, 0))
         if mfma:
             xh = _pad_last(xh, Cin_p)
-            wp = _pack_weight_f32(weight, w, groups, 0, Cout_gp, Cin_gp)
+            if gpad:
+                w = F.pad(w.view(groups, Cout_g, Cin_g, R, S), (0, 0, 0, 0, 0, 0, 0, Cout_gp - Cout_g)).reshape(Cout_p, Cin_g, R, S)
+                if b is not None:
+                    b = F.pad(b.view(groups, Cout_g), (0, Cout_gp - Cout_g)).reshape(-1)
+            wp = _pack_weight_f32(None if gpad else weight, w, groups, 0, Cout_gp, Cin_gp)
             y = torch.empty(B, OH, OW, Cout_p, dtype=torch.float32, device=x.device)
             tok = PROFILER.begin('conv_f32m_kernel', 2.0 * B * OH * OW * Cout * R * S * Cin_g, (B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
             check(L.danet_conv_f32m_forward(ptr(xh), ptr(wp), ptr(None if b is None else _pad_last(b, Cout_p)), ptr(y), B, H, W, Cin_p, OH, OW, Cout_p,
                                             R, S, stride, pad, dil, groups, 0, 0, stream()), 'danet_conv_f32m_forward')
             if tok is not None:
                 PROFILER.end(tok)
-            y = y[..., :Cout]
+            y = y.view(B, OH, OW, groups, Cout_gp)[..., :Cout_g].reshape(B, OH, OW, Cout) if gpad else y[..., :Cout]
         else:
             y = torch.empty(B, OH, OW, Cout, dtype=torch.float32, device=x.device)
             check(L.danet_conv_f32(0, ptr(xh), ptr(w), ptr(b), ptr(y), B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, stream()), 'danet_conv_f32')
         ctx.save_for_backward(xh, w)
-        ctx.weight = weight
-        ctx.cfg = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, bias is not None, mfma)
+        ctx.weight = None if gpad else weight
+        ctx.cfg = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, bias is not None, mfma, gpad)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
-        xh, w = ctx.saved_tensors
-        (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, has_bias, mfma) = ctx.cfg
+        xh, w = ctx.saved_tensors                           # (mfma: xh / w carry the padded channels)
+        (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, has_bias, mfma, gpad) = ctx.cfg
         g = gy.to(torch.float32).permute(0, 2, 3, 1).contiguous()
         gx = gw = gb = None
         dims = (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)
         Cin_g, Cout_g = Cin // groups, Cout // groups
         Cin_gp, Cout_gp = (Cin_g + 3) // 4 * 4, (Cout_g + 3) // 4 * 4
         Cin_p, Cout_p = Cin_gp * groups, Cout_gp * groups
-        gp = _pad_last(g, Cout_p) if mfma else g
+        if mfma and gpad:
+            gp = F.pad(g.view(B, OH, OW, groups, Cout_g), (0, Cout_gp - Cout_g)).reshape(B, OH, OW, Cout_p)
+        else:
+            gp = _pad_last(g, Cout_p) if mfma else g
         if ctx.needs_input_grad[0]:
             if mfma and L.danet_conv_f32m_ok(B, OH, OW, Cout_p, H, W, Cin_p, R, S, stride, pad, dil, groups, 1):
                 wp = _pack_weight_f32(ctx.weight, w, groups, 1, Cout_gp, Cin_gp)
@@ -224,16 +233,23 @@ class Conv2dF32Function(torch.autograd.Function):
                                                 stream()), 'danet_conv_f32m_forward')
                 gx = gx[..., :Cin]
             else:
+                wr = w.view(groups, Cout_gp, Cin_g, R, S)[:, :Cout_g].reshape(Cout, Cin_g, R, S) if (mfma and gpad) else w
+                xr = xh if xh.shape[-1] == Cin else xh[..., :Cin].contiguous()
                 gx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=g.device)
-                check(L.danet_conv_f32(1, ptr(g), ptr(w), None, ptr(gx), *dims, stream()), 'danet_conv_f32')
+                check(L.danet_conv_f32(1, ptr(g), ptr(wr.contiguous()), None, ptr(gx), *dims, stream()), 'danet_conv_f32')
+                del xr
             gx = gx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
             if mfma:
-                wdims = (B, H, W, Cin_p, OH, OW, Cout_p, R, S, stride, pad, dil, groups, Cout, Cin_g)
+                Co = Cout_p if gpad else Cout              # (grouped: the padded weight's gradient, sliced below)
+                gw = torch.empty(Co, Cin_g, R, S, dtype=torch.float32, device=g.device)
+                wdims = (B, H, W, Cin_p, OH, OW, Cout_p, R, S, stride, pad, dil, groups, Co, Cin_g)
                 ws = torch.empty(L.danet_conv_f32m_wgrad_ws_floats(*wdims), dtype=torch.float32, device=g.device)
                 check(L.danet_conv_f32m_wgrad(ptr(xh), ptr(gp), ptr(gw), ptr(ws), *wdims, stream()), 'danet_conv_f32m_wgrad')
+                if gpad:
+                    gw = gw.view(groups, Cout_gp, Cin_g, R, S)[:, :Cout_g].reshape(Cout, Cin_g, R, S)
             else:
+                gw = torch.empty_like(w)
                 check(L.danet_conv_f32(2, ptr(xh), ptr(g), None, ptr(gw), *dims, stream()), 'danet_conv_f32')
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=(0, 1, 2))

@@ -276,11 +276,26 @@ __global__ __launch_bounds__(256) void conv_f32m_wgrad_kernel(WgF p)
     const int ohw = p.OH * p.OW;
     const float rc_ohw = 1.0f / (float)ohw, rc_ow = 1.0f / (float)p.OW;
 
-    typedef __attribute__((ext_vector_type(BC))) float fvec;
+    // (components through __int_as_float: __builtin_bit_cast applied to a vector ELEMENT expression, bit_cast(float, q[k]),
+    //  read element 0 for every k with this compiler)
+    struct fvec { float v[BC]; };
     auto ldc = [&](__amdgpu_buffer_rsrc_t r, int off) -> fvec {
-        if constexpr (BC == 4) return __builtin_bit_cast(fvec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-        else if constexpr (BC == 2) return __builtin_bit_cast(fvec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
-        else return __builtin_bit_cast(fvec, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+        fvec o;
+        if constexpr (BC == 4) {
+            const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.v[k] = __int_as_float(q[k]);
+        } else if constexpr (BC == 3) {
+            const i32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+            const int q2 = (int)__builtin_amdgcn_raw_buffer_load_b32(r, off, 8, 0);
+            o.v[0] = __int_as_float(q[0]); o.v[1] = __int_as_float(q[1]); o.v[2] = __int_as_float(q2);
+        } else if constexpr (BC == 2) {
+            const i32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+            o.v[0] = __int_as_float(q[0]); o.v[1] = __int_as_float(q[1]);
+        } else {
+            o.v[0] = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+        }
+        return o;
     };
     auto load_step = [&](long mq, fvec& gv, fvec* xv) {
         const long m = mq + lg;
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_f32m_wgrad_kernel(WgF p)
             for (int i = 0; i < BC; ++i)
 #pragma unroll
                 for (int j = 0; j < BC; ++j)
-                    acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[i], xv[tp][j], acc[tp][i][j], 0, 0, 0);
+                    acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.v[i], xv[tp].v[j], acc[tp][i][j], 0, 0, 0);
     };
     // two-deep register ring over the 4-pixel steps
     fvec g0, g1, x0[NTAP], x1[NTAP];
@@ -328,30 +343,46 @@ __global__ __launch_bounds__(256) void conv_f32m_wgrad_kernel(WgF p)
                 for (int r = 0; r < 4; ++r) dst[(((tp * BC + i) * BC + j) * 4 + r) * 64] = acc[tp][i][j][r];
 }
 
-// dW[g][cout][cin][tap] = sum over chunks of the partial blocks (fixed order).
-__global__ void conv_f32m_wgrad_reduce_kernel(WgF p)
+// dW[g][cout][cin][tap] = sum over chunks of the partial blocks, in a fixed order.  A workgroup owns 32 consecutive
+// workspace elements (coalesced 128-byte reads) x 8 chunk groups: thread (cg, e) sums the chunks cg, cg + 8, ... of its
+// element, the eight partial sums meet in LDS, and the thread with cg == 0 writes the element to its place in dW.
+__global__ __launch_bounds__(256) void conv_f32m_wgrad_reduce_kernel(WgF p)
 {
-    const int RS = p.R * p.S;
-    const long total = (long)p.groups * p.Cout_gr * p.Cin_gr * RS;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int tap = (int)(idx % RS);
-    long q = idx / RS;
-    const int cin = (int)(q % p.Cin_gr); q /= p.Cin_gr;
-    const int cout = (int)(q % p.Cout_gr), g = (int)(q / p.Cout_gr);
-    const int BC = p.bc, NTAP = p.ntap, W16 = 16 * BC;
-    const int cb = cout / W16, cl = cout - cb * W16, rho = cl / BC, i = cl - rho * BC;
-    const int ib = cin / W16, il = cin - ib * W16, li = il / BC, j = il - li * BC;
-    const int tg = tap / NTAP, tp = tap - tg * NTAP;
-    const int blk = ((g * p.ncb + cb) * p.nib + ib) * p.ntg + tg;
+    __shared__ float sPart[8][32];
+    const int t = threadIdx.x, el = t & 31, cg = t >> 5;
+    const int BC = p.bc, NTAP = p.ntap;
     const size_t bsz = (size_t)NTAP * BC * BC * 256;
-    const float* src = p.ws + (size_t)blk * bsz + (((tp * BC + i) * BC + j) * 4 + (rho & 3)) * 64 + (rho >> 2) * 16 + li;
-    const size_t cstride = (size_t)p.nblk * bsz;
+    const size_t per_chunk = (size_t)p.nblk * bsz;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
     float s0 = 0.f, s1 = 0.f;
-    int c = 0;
-    for (; c + 1 < p.nchunk; c += 2) { s0 += src[(size_t)c * cstride]; s1 += src[(size_t)(c + 1) * cstride]; }
-    if (c < p.nchunk) s0 += src[(size_t)c * cstride];
-    p.dw[idx] = s0 + s1;
+    if (e < per_chunk) {
+        const float* src = p.ws + e;
+        int c = cg;
+        for (; c + 8 < p.nchunk; c += 16) { s0 += src[(size_t)c * per_chunk]; s1 += src[(size_t)(c + 8) * per_chunk]; }
+        if (c < p.nchunk) s0 += src[(size_t)c * per_chunk];
+    }
+    sPart[cg][el] = s0 + s1;
+    __syncthreads();
+    if (cg != 0 || e >= per_chunk) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += sPart[k][el];
+    // workspace element -> (block, tile (tp, i, j), r, lane) -> (g, cout, cin, tap)
+    const int blk = (int)(e / bsz);
+    int q = (int)(e - (size_t)blk * bsz);
+    const int lane = q & 63; q >>= 6;
+    const int r = q & 3; q >>= 2;
+    const int j = q % BC; q /= BC;
+    const int i = q % BC, tp = q / BC;
+    int id = blk;
+    const int tg = id % p.ntg; id /= p.ntg;
+    const int ib = id % p.nib; id /= p.nib;
+    const int cb = id % p.ncb, g = id / p.ncb;
+    const int RS = p.R * p.S;
+    const int tap = tg * NTAP + tp;
+    const int cout = cb * 16 * BC + ((lane >> 4) * 4 + r) * BC + i, cin = ib * 16 * BC + (lane & 15) * BC + j;
+    if (tap < RS && cout < p.Cout_gr && cin < p.Cin_gr)
+        p.dw[((size_t)(g * p.Cout_gr + cout) * p.Cin_gr + cin) * RS + tap] = s;
 }
 
 int f32m_mt(long M, int nt, int groups) {      // pixel tiles per wave: enough workgroups for the chip, then the larger register tile
@@ -420,7 +451,8 @@ bool wg_plan(WgF& p, int B, int H, int W, int Cin, int OH, int OW, int Cout, int
     // register tile: BC channels per lane on both sides, NTAP taps side by side (BC * BC * NTAP accumulator tiles <= 36)
     const bool c4 = p.Cin_g % 4 == 0 && p.Cout_g % 4 == 0, c2 = p.Cin_g % 2 == 0 && p.Cout_g % 2 == 0;
     int BC, NTAP;
-    if (RS == 9 && c2) { BC = 2; NTAP = 9; }                                  // 3x3: all taps at once, dY loaded once
+    if (RS == 9 && p.Cin_g % 48 == 0 && p.Cout_g % 48 == 0) { BC = 3; NTAP = 3; }       // HRNet-W48 widths: 48 x 48 blocks fit exactly (one filter row per wave)
+    else if (RS == 9 && c2) { BC = 2; NTAP = 9; }                             // 3x3: all taps at once, dY loaded once
     else if (c4 && p.Cin_g > 32 && p.Cout_g > 32) { BC = 4; NTAP = RS >= 2 ? 2 : 1; }
     else if (c2) { BC = 2; NTAP = S >= 7 ? 7 : (RS >= 3 ? 3 : 1); }
     else { BC = 1; NTAP = RS >= 9 ? 9 : (RS >= 3 ? 3 : 1); }
@@ -531,12 +563,12 @@ extern "C" int danet_conv_f32m_wgrad(const float* x, const float* dy, float* dw,
     const dim3 grid((unsigned)p.nchunk, (unsigned)((p.nblk + 3) / 4), 1);
     const int BC = p.bc, NTAP = p.ntap;
 #define WG_CASE(B_, T_) if (BC == B_ && NTAP == T_) { hipLaunchKernelGGL((conv_f32m_wgrad_kernel<B_, T_>), grid, dim3(256), 0, st, p); } else
-    WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 9) WG_CASE(2, 7) WG_CASE(2, 3) WG_CASE(2, 1) WG_CASE(1, 9) WG_CASE(1, 3) WG_CASE(1, 1)
+    WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(3, 3) WG_CASE(2, 9) WG_CASE(2, 7) WG_CASE(2, 3) WG_CASE(2, 1) WG_CASE(1, 9) WG_CASE(1, 3) WG_CASE(1, 1)
     return danet::fail(DANET_ERR_ARG, "conv_f32m_wgrad: no kernel for block %d taps %d", BC, NTAP);
 #undef WG_CASE
     DANET_CHECK_LAUNCH("conv_f32m_wgrad_kernel");
-    const long total = (long)groups * p.Cout_gr * p.Cin_gr * R * S;
-    hipLaunchKernelGGL(conv_f32m_wgrad_reduce_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, st, p);
+    const long per_chunk = (long)p.nblk * p.ntap * p.bc * p.bc * 256;
+    hipLaunchKernelGGL(conv_f32m_wgrad_reduce_kernel, dim3(danet::cdiv(per_chunk, 32)), dim3(256), 0, st, p);
     DANET_CHECK_LAUNCH("conv_f32m_wgrad_reduce_kernel");
     return DANET_OK;
 }

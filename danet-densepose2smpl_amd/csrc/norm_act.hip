@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict_
     if (t < fm.span) {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes);
         int cv; RowIter it; it.init(fm, blockIdx.x, t, cv);
+#ifdef NA_F32
+        // fp32 tensors: sums of x - k with k = the channel's value in row 0 (bn_apply_body adds it back), so that
+        // E[(x-k)^2] - E[x-k]^2 does not cancel for channels whose mean is large against their spread
+        const Vec k = ldv(xr, (fm.coff + cv) * VW * ES);
+#endif
         for (; it.more(); it.next()) {
             Vec a[UNR];
 #pragma unroll
@@ -181,7 +186,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict_
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                for (int j = 0; j < VW; ++j) { s.v[j] += a[u].v[j]; q.v[j] += a[u].v[j] * a[u].v[j]; }
+                for (int j = 0; j < VW; ++j) {
+#ifdef NA_F32
+                    const float d = it.offset(u) != OOB ? a[u].v[j] - k.v[j] : 0.f;       // (rows past the end load zeros)
+                    s.v[j] += d; q.v[j] += d * d;
+#else
+                    s.v[j] += a[u].v[j]; q.v[j] += a[u].v[j] * a[u].v[j];
+#endif
+                }
         }
     }
     float* dst = sums + (size_t)(blockIdx.x % danet_conv::bn_ncopy(Cst)) * 2 * Cst;
@@ -213,6 +225,10 @@ __device__ __forceinline__ void bn_apply_body(
         }
     };
     if (t < fm.span) fetch();                       // first rows are in flight while the statistics are reduced
+#ifdef NA_F32
+    Vec kshift;                                     // bn_stats_kernel's shift: the channel's value in row 0
+    if (t < fm.span && mode == 0) kshift = ldv(xr, (fm.coff + cv) * VW * ES);
+#endif
     if (mode == 0) reduce_replicas(sums, C, fm.CV * VW, t, sStat);
     if (t >= fm.span) return;
     const int c0 = cv * VW;
@@ -223,11 +239,18 @@ __device__ __forceinline__ void bn_apply_body(
         if (mode == 0) {
             mean = sStat[0][c0 + j] * inv_count;
             var = fmaxf(sStat[1][c0 + j] * inv_count - mean * mean, 0.f);
+#ifdef NA_F32
+            mean += kshift.v[j];
+#endif
         } else {
             mean = running_mean[c0 + j];
             var = running_var[c0 + j];
         }
+#ifdef NA_F32
+        const float invstd = 1.0f / sqrtf(var + eps);           // correctly rounded, as the reference's fp32 BatchNorm computes it
+#else
         const float invstd = rsqrtf(var + eps);
+#endif
         const float g = gamma ? gamma[c0 + j] : 1.f, b = beta ? beta[c0 + j] : 0.f;
         sc[j] = invstd * g;
         sh[j] = fmaf(-mean, sc[j], b);
@@ -264,12 +287,16 @@ __device__ __forceinline__ void bn_apply_body(
     }
 }
 
-__device__ __forceinline__ void bn_bwd_reduce_body(
+// GATE: where the ReLU gate comes from -- 0 / 1 / 2 = mask_mode (see ldmask), 3 = no ReLU.  A compile-time constant: with the
+// mode chosen per element through a run-time select chain the fp32 build lost the gated value altogether (the compiler
+// folded `on ? dy : 0` to 0 in bn_bwd_reduce_kernel), and the specialised loops are shorter anyway.
+template <int GATE>
+__device__ __forceinline__ void bn_bwd_reduce_body_g(
     const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */,
-    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
+    const float* __restrict__ saved, int Cst, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */,
+    const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta, float (*sm)[VW])
 {
-    __shared__ float sm[256][VW];
+    constexpr int relu = GATE != 3, mask_mode = GATE == 3 ? 0 : GATE;
     const int t = threadIdx.x;
     const int C = Cst;
     Vec s1, s2;
@@ -314,16 +341,30 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
 }
+__device__ __forceinline__ void bn_bwd_reduce_body(
+    const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
+    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red,
+    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
+{
+    __shared__ float sm[256][VW];
+    switch (relu ? mask_mode : 3) {
+        case 0: bn_bwd_reduce_body_g<0>(bid, dy, x, y, fm, saved, Cst, red, mask, gamma, beta, sm); break;
+        case 1: bn_bwd_reduce_body_g<1>(bid, dy, x, y, fm, saved, Cst, red, mask, gamma, beta, sm); break;
+        case 2: bn_bwd_reduce_body_g<2>(bid, dy, x, y, fm, saved, Cst, red, mask, gamma, beta, sm); break;
+        default: bn_bwd_reduce_body_g<3>(bid, dy, x, y, fm, saved, Cst, red, mask, gamma, beta, sm); break;
+    }
+}
 
-__device__ __forceinline__ void bn_bwd_apply_body(
+template <int GATE>
+__device__ __forceinline__ void bn_bwd_apply_body_g(
     const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
     const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
-    int Cst, float inv_count, int relu, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
-    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
+    int Cst, float inv_count, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
+    const unsigned char* __restrict__ mask, const float* __restrict__ beta, float (*sStat)[SLAB])
 {
+    constexpr int relu = GATE != 3, mask_mode = GATE == 3 ? 0 : GATE;
     const int t = threadIdx.x;
     const int C = Cst;
-    __shared__ float sStat[2][SLAB];
     const bool from_y = relu && mask_mode == 0;
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(dy, fm.bytes), xr = make_rsrc(x, fm.bytes), yr = make_rsrc(from_y ? y : x, fm.bytes);
     const __amdgpu_buffer_rsrc_t mr = make_rsrc(mask_mode == 1 ? (const void*)mask : (const void*)x, mask_mode == 1 ? fm.bytes >> MSH : 0);
@@ -378,6 +419,20 @@ __device__ __forceinline__ void bn_bwd_apply_body(
             if (dres) stv(drr, oo[u], gm[u]);
             stv(dxr, oo[u], d[u]);
         }
+    }
+}
+__device__ __forceinline__ void bn_bwd_apply_body(
+    const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
+    int Cst, float inv_count, int relu, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
+    int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
+{
+    __shared__ float sStat[2][SLAB];
+    switch (relu ? mask_mode : 3) {
+        case 0: bn_bwd_apply_body_g<0>(bid, dy, x, y, fm, saved, gamma, red, Cst, inv_count, dx, dres, dparam, mask, beta, sStat); break;
+        case 1: bn_bwd_apply_body_g<1>(bid, dy, x, y, fm, saved, gamma, red, Cst, inv_count, dx, dres, dparam, mask, beta, sStat); break;
+        case 2: bn_bwd_apply_body_g<2>(bid, dy, x, y, fm, saved, gamma, red, Cst, inv_count, dx, dres, dparam, mask, beta, sStat); break;
+        default: bn_bwd_apply_body_g<3>(bid, dy, x, y, fm, saved, gamma, red, Cst, inv_count, dx, dres, dparam, mask, beta, sStat); break;
     }
 }
 
@@ -815,6 +870,20 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const elem_t* __r
     }
 }
 
+}  // namespace
+// Bytes of the tensor a workgroup of the BatchNorm kernels handles at least (danet_bn_set_block_bytes; both instantiations
+// of this file share the one setting, which lives in the bf16 translation unit).
+#ifdef NA_F32
+long danet_bn_block_bytes();
+#else
+static long g_bn_block_bytes = getenv("DANET_BN_BLOCK_BYTES") ? atol(getenv("DANET_BN_BLOCK_BYTES")) : 24576;
+long danet_bn_block_bytes() { return g_bn_block_bytes; }
+// Run-time knob (A-B timing, tests): bytes <= 0 keeps; returns the previous value.  With a value above every tensor's size each
+// BatchNorm launch is ONE workgroup per tensor: its float sums then have a fixed order (the replicated atomics of larger grids
+// do not), which tests that compare two executions of a chaotic deep net need.
+extern "C" long danet_bn_set_block_bytes(long bytes) { const long prev = g_bn_block_bytes; if (bytes > 0) g_bn_block_bytes = bytes; return prev; }
+#endif
+namespace {
 // slab [c_begin, c_begin + Cs) of a [M, C] tensor; Cs <= 1024
 inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* grid) {
     if (C % VW != 0 || Cs % VW != 0 || c_begin % VW != 0 || Cs / VW > 256) return -1;
@@ -830,7 +899,7 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
     // a block reads the replicas of its slab's statistics before it can start (~8 KB): at least ~24 KB of the tensor each
     // (tools/experiments/bn_micro.cpp: the four-branch forward 24.7 -> 12.9 us, the two-kernel backward 81 -> 40 us together
     // with bn_ncopy; eight rows per trip instead of four measured slower: 14.8 / 62 us)
-    static const long per_block = getenv("DANET_BN_BLOCK_BYTES") ? atol(getenv("DANET_BN_BLOCK_BYTES")) : 24576;
+    const long per_block = danet_bn_block_bytes();
     const long by_bytes = (M * Cs * ES + per_block - 1) / per_block;
     if (blocks > by_bytes) blocks = by_bytes;
     if (blocks > 1024) blocks = 1024;
@@ -851,6 +920,9 @@ extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y
     DANET_CHECK_ARG(x && y && M > 0 && C > 0, "bn_forward: bad arguments");
     DANET_CHECK_ARG(training ? (saved && sums_ws) : (running_mean && running_var), "bn_forward: missing buffers");
     DANET_CHECK_ARG(C % VW == 0, "bn_forward: C=%d must be a multiple of %d", C, VW);
+#ifdef NA_F32
+    DANET_CHECK_ARG(!training || ws_is_zero != 2, "bn_forward_f32: the fp32 statistics are shifted sums (bn_stats_kernel): no pre-accumulated sums");
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (training && !ws_is_zero) {
         hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
@@ -988,6 +1060,9 @@ extern "C" int NA_NAME(danet_bn_forward_multi)(const void* jobs_, int n, float m
         const BnFwdJob& j = jobs[i];
         DANET_CHECK_ARG(j.x && j.y && j.saved && j.sums && j.M > 0 && j.C > 0 && j.C <= SLAB && (j.sums_state == 1 || j.sums_state == 2),
                         "bn_forward_multi: job %d: bad arguments (C <= %d, zeroed or pre-accumulated sums required)", i, SLAB);
+#ifdef NA_F32
+        DANET_CHECK_ARG(j.sums_state == 1, "bn_forward_multi_f32: job %d: the fp32 statistics are shifted sums (bn_stats_kernel): no pre-accumulated sums", i);
+#endif
         BnFwdOne& a = m.a[i];
         int grid;
         DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_forward_multi: job %d: C=%d unsupported", i, j.C);

@@ -349,6 +349,10 @@ int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, i
  *  backward job { const void* dy, *x, *y; const float* gamma, *saved; void* dx, *dres; float* dparam, *red; const float* beta;
  *                 const void* mask; int64_t M; int C, red_state, relu, mask_mode; }
  *                 red_state 1: zeroed scratch, 2: accumulated by the dgrad epilogue; mask / mask_mode as above */
+/* Run-time knob (A-B timing, tests): bytes of the tensor one workgroup of the BatchNorm kernels handles at least (default
+ * 24576, or DANET_BN_BLOCK_BYTES); <= 0 keeps; returns the previous value.  Above every tensor's size each launch is a single
+ * workgroup per tensor, whose float sums have a fixed order. */
+long danet_bn_set_block_bytes(long bytes);
 int danet_bn_forward_multi(const void* jobs, int n, float momentum, float eps, void* stream);
 int danet_bn_backward_multi(const void* jobs, int n, void* stream);
 /* One-pass form of danet_bn_backward_multi: every lane keeps its share of dy / x in registers across a grid-wide barrier,

@@ -16,7 +16,7 @@ SHAPES = [  # B, Cin, H, W, Cout, k, stride, pad, groups, bias
     (2, 48, 16, 16, 48, 3, 1, 1, 1, False), (2, 48, 16, 16, 96, 3, 2, 1, 1, False), (2, 96, 8, 8, 48, 1, 1, 0, 1, False),
     (2, 21, 24, 24, 64, 7, 2, 3, 1, False), (2, 48, 14, 14, 25, 1, 1, 0, 1, True), (3, 40, 9, 11, 24, 3, 1, 1, 1, True),
     (2, 96, 8, 8, 48, 1, 1, 0, 24, True), (2, 384, 8, 8, 384, 3, 1, 1, 1, False), (2, 18, 10, 10, 30, 3, 1, 1, 1, False),
-    (2, 32, 12, 12, 20, 3, 2, 1, 1, False),
+    (2, 32, 12, 12, 20, 3, 2, 1, 1, False), (2, 192, 8, 8, 84, 3, 1, 1, 4, True), (2, 48, 8, 8, 42, 1, 1, 0, 2, False),
 ]
 BIG = [(32, 48, 64, 64, 48, 3, 1, 1, 1, False), (32, 96, 32, 32, 96, 3, 1, 1, 1, False), (32, 192, 16, 16, 192, 3, 1, 1, 1, False),
        (32, 384, 8, 8, 384, 3, 1, 1, 1, False), (32, 64, 64, 64, 256, 1, 1, 0, 1, False), (32, 256, 64, 64, 64, 1, 1, 0, 1, False),
