@@ -31,7 +31,7 @@ def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, source description) from this round's committed PMC summary
     (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a 512 MiB copy
     in the same run), or (None, reason).  The file records the commit it was measured at."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             f = json.load(open(path))
@@ -94,9 +94,9 @@ def cpu_baseline(size, cpu_batch):
     t_geo = time.time() - t0
     return {'value': round(cpu_batch / (t_net + t_geo), 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port',
-            'sample': 'B=%d of the B=32 step: oracle/torch_ref.StepNets fwd+bwd+Adam fp32 (%.2fs; %.1f M parameters; 30.06 of the '
+            'sample': 'B=%d of the B=32 step (a batch this small under-uses the %d host threads: a port timed on a bounded sample, not a tuned CPU baseline): oracle/torch_ref.StepNets fwd+bwd+Adam fp32 (%.2fs; %.1f M parameters; 30.06 of the '
                       'step\'s 30.07 GMAC/img = 99.9 %% of its 5.77 TFLOP: only the GCN / 1x1 regressors and the loss glue are '
-                      'left out) + 2x C SMPL fwd, 1x C SMPL bwd, 1x C IUV raster (%.2fs)' % (cpu_batch, t_net, nparam / 1e6, t_geo)}
+                      'left out) + 2x C SMPL fwd, 1x C SMPL bwd, 1x C IUV raster (%.2fs)' % (cpu_batch, torch.get_num_threads(), t_net, nparam / 1e6, t_geo)}
 
 
 def geometry_rooflines(tr, B, size, dev):

@@ -47,6 +47,7 @@ _SIGNATURES = {
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, ctypes.c_long, c_f]),
     'danet_conv_pack_job_bricks': (ctypes.c_long, [c_i] * 7),
     'danet_conv_forward_multi_ok': (c_i, [c_f, c_i]),
+    'danet_conv_forward_multi_kernel': (c_i, [c_f, c_i]),
     'danet_conv_forward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_conv_forward_kernel': (c_i, [c_i] * 15),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6 + [c_i, c_f]),

@@ -384,9 +384,14 @@ def pack_weight(weight, groups, mode, chunk=0):
     return wp
 
 
-def _kernel_name(kid):
-    """Kernel symbol (as rocprofv3 prints it) for a danet_conv_forward_kernel id."""
+def _kernel_name(kid, stream_dims=None):
+    """Kernel symbol (as rocprofv3 prints it) for a danet_conv_forward_kernel id; stream_dims = (B, H, W, Cin, Cout) of a 3x3
+    problem without a fused BatchNorm-backward reduction: the streamed kernel (csrc/conv3x3s.hip) takes it when it has a plan."""
     if kid % 10 == 2:
+        if stream_dims is not None:
+            plan = _lib.lib().danet_conv3x3_stream_plan(*stream_dims, 1)
+            if plan > 0:
+                return 'conv3x3_stream_kernel<%d>' % (plan % 10)
         return 'conv3x3_tile_kernel'
     if kid % 10 == 1:
         return 'conv_fast_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10)
@@ -396,7 +401,10 @@ def _kernel_name(kid):
 def _multi_kernel_name(jobs, n, cout_g):
     import ctypes
     L = _lib.lib()
-    if L.danet_conv_forward_multi_ok(ctypes.addressof(jobs), n) == 2:
+    which = L.danet_conv_forward_multi_kernel(ctypes.addressof(jobs), n)
+    if which == 3:
+        return 'conv3x3_stream_kernel<%d>' % L.danet_conv_nt(cout_g)
+    if which == 2:
         return 'conv3x3_tile_kernel'
     return 'conv_fast_multi_kernel<%d>' % L.danet_conv_nt(cout_g)
 
@@ -414,7 +422,7 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     tok = None
     if PROFILER is not None:
         kid = L.danet_conv_forward_kernel(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, int(transposed), int(out_fp32))
-        name = _kernel_name(kid)
+        name = _kernel_name(kid, (B, H, W, Cin, Cout) if bn_bwd is None else None)
         tok = PROFILER.begin(name,
                              2.0 * B * OH * OW * Cout * (Cin // groups) * R * S,
                              ('dgrad' if transposed else 'fwd', B, H, W, Cin, Cout, R, stride, groups))

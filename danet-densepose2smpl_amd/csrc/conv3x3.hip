@@ -629,6 +629,8 @@ int conv3x3_config(const ConvP& p, bool vec8, int nprob) {
 
 // Launches n (<= 4) problems in one launch.  0 on launch, -1 when the set cannot run on this kernel (nothing is
 // launched then); dry = true only answers that question.
+bool conv3x3_stream_first() { return g_c3_on && g_force.mt == 0; }      // conv3x3_launch offers the problem set to the streamed kernel first
+
 int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
     if (n < 1 || n > C3_MAXP) return -1;
     if (g_c3_on && g_force.mt == 0 && conv3x3s_launch(ps, n, stream, dry) == 0) return 0;      // the streamed kernel takes what it can (no forced tiling)

@@ -55,6 +55,7 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry = false);     
 
 // conv3x3s.hip: the streamed successor (loader wave + two-deep LDS ring); conv3x3_launch tries it first.  0 = launched (or, dry, would be)
 int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry);
+bool conv3x3_stream_first();
 int* conv3x3_debug_buffer();        // danet_conv3x3_debug's buffer (NULL: off); the streamed kernel writes 16 ints per workgroup
 
 }  // namespace danet_conv

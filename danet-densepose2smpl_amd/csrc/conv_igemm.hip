@@ -726,6 +726,16 @@ extern "C" int danet_conv_forward_multi_ok(const void* jobs, int n)
     return all3 ? 2 : 1;                  // 2: one conv3x3_tile_kernel launch, 1: one conv_fast_multi_kernel launch
 }
 
+// Which kernel danet_conv_forward_multi launches for the set: 0 none (unsupported), 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel,
+// 3 conv3x3_stream_kernel (profilers label their records with it).
+extern "C" int danet_conv_forward_multi_kernel(const void* jobs, int n)
+{
+    ConvP ps[8]; int mts[8], nt; bool all3;
+    if (conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt, &all3) != 0) return 0;
+    if (!all3) return 1;
+    return conv3x3s_launch(ps, n, nullptr, true) == 0 && conv3x3_stream_first() ? 3 : 2;
+}
+
 extern "C" int danet_conv_forward_multi(const void* jobs, int n, void* stream)
 {
     DANET_ENTER();

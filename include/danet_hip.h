@@ -260,6 +260,8 @@ int danet_conv_f32m_wgrad(const float* x, const float* dy, float* dw, float* ws,
                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups,
                           int Cout_real, int Cin_g_real, void* stream);
 int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
+int danet_conv_forward_multi_kernel(const void* jobs, int n);      /* the kernel the set runs on: 0 none, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel,
+                                                                       3 conv3x3_stream_kernel (csrc/conv3x3s.hip) */
 /* Run-time knobs of the LDS-tile 3x3 kernel (A-B timing, tests): enable 0/1 (-1 keeps); force_mt/force_kw = register
  * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps); want_tiles = tiles per
  * problem the planner aims for (0 = 512 / problems of the launch; < 0 keeps). Returns the previous enable. */
