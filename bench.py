@@ -65,6 +65,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--dtype', choices=('bf16', 'fp32'), default='bf16',
                     help='fp32: BASELINE config C4\'s arithmetic on the verification kernels (csrc/conv_f32.hip, eager launches; a correctness configuration, not a performance one)')
+    ap.add_argument('--grad-wire', choices=('fp32', 'bf16'), default=None, help='N > 1: all-reduce the gradient buckets in this type (default: DANET_GRAD_WIRE or fp32)')
     ap.add_argument('--force-ddp', action='store_true', help='diagnostic: run the N > 1 code path (GradReducer + eager Adam) on a 1-rank group')
     return ap.parse_args()
 
@@ -233,7 +234,7 @@ def main():
     cfg_from_dict({'DANET.INIMG_SIZE': args.size, 'DANET.HEATMAP_SIZE': args.size // 4})
     torch.manual_seed(1234)
     B = args.batch
-    tr = Trainer(default_options(B), device=dev, distributed=world > 1 or args.force_ddp)
+    tr = Trainer(default_options(B), device=dev, distributed=world > 1 or args.force_ddp, grad_wire=args.grad_wire)
     batch = synthetic_in_dict(tr.model, B, dev, seed=1234 + rank)
     if args.dtype == 'fp32':
         fp32_line(args, tr, batch, world, rank, dev)
@@ -289,6 +290,7 @@ def main():
         step()
     sync()
     elapsed = time.time() - t0
+    elapsed_local = elapsed
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,14 +319,27 @@ def main():
             fp32 = fp32_record(args, tr, batch, world, dev)
         except Exception as e:
             fp32 = {'error': repr(e)}
+    allreduce_info = None
+    if world > 1 or args.force_ddp:
+        st = tr.store
+        issued, early = (tr.captured_collectives if use_graph and tr._reduce_in_graph else (st.issued, st.issued_early))
+        per_rank = [round(elapsed_local / args.steps * 1e3, 3)]
+        if world > 1:
+            gathered = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(gathered, torch.tensor([elapsed_local], device=dev, dtype=torch.float64))
+            per_rank = [round(float(g.item()) / args.steps * 1e3, 3) for g in gathered]
+        allreduce_info = {'mode': ('in-graph' if (use_graph and tr._reduce_in_graph) else 'after the graph replay' if use_graph else 'eager'),
+                          'buckets': len(st.buckets), 'bucket_mb': round(max(e - s0 for s0, e, _, _ in st.buckets) * 4 / 2**20, 1),
+                          'released_during_backward': int(early), 'wire_dtype': 'bf16' if st.wire is not None else 'f32',
+                          'bytes_per_step': int(st.flat.numel() * (2 if st.wire is not None else 4)),
+                          'ms_per_step_per_rank': per_rank}
     if rank == 0:
         ips = world * B * args.steps / elapsed
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                 'exec': 'hipgraph' if use_graph else 'eager',
-                'allreduce': ('in-graph, per bucket between the weight-gradient launches' if (use_graph and tr._reduce_in_graph) else
-                              'after the graph replay' if use_graph else 'eager, per bucket') if world > 1 or args.force_ddp else None,
+                'allreduce': allreduce_info,
                 'config': {'workload': 'full DaNet train step (HRNet-W48 + global and part-wise IUV heads + regressor nets + SMPL LBS '
                                        '(2 forward + 1 backward; the 2 label-side forwards belong to the untimed batch prologue) + IUV '
                                        'render + losses, fwd+bwd+Adam), %dx%d, %d img/GPU; convs bf16 MFMA fp32-acc, '

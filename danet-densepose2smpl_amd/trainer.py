@@ -23,6 +23,9 @@ from .geometry import perspective_projection, label_prologue
 
 DEFER_WGRAD = bool(int(os.environ.get('DANET_DEFER_WGRAD', '1')))
 USE_FUSED_ADAM = bool(int(os.environ.get('DANET_FUSED_ADAM', '1')))
+# N > 1: buckets are all-reduced from inside the backward pass as soon as they are complete (distributed.GradStore.arm_early);
+# 0 = all of them after the backward pass, interleaved with the weight-gradient launches only
+EARLY_BUCKETS = bool(int(os.environ.get('DANET_EARLY_BUCKETS', '1')))
 
 
 def default_options(batch_size=32):
@@ -71,7 +74,7 @@ class Trainer(object):
     """Single-process-per-GPU trainer.  Gradients live in one flat store (distributed.GradStore); with world_size > 1
     its buckets are all-reduced (RCCL) while the remaining weight gradients of the step are still being computed."""
 
-    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None, bucket_mb=None):
+    def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None, bucket_mb=None, grad_wire=None):
         self.options = options or default_options()
         self.device = device or torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.model = (model or DaNet(self.options, None, pretrained=False, smpl_model=smpl_model)).to(self.device)
@@ -90,8 +93,12 @@ class Trainer(object):
             from .optim import FusedAdam
             if bucket_mb is None:
                 bucket_mb = float(os.environ.get('DANET_BUCKET_MB', '32'))
+            wire = torch.bfloat16 if (grad_wire or os.environ.get('DANET_GRAD_WIRE', 'fp32')) == 'bf16' else torch.float32
             self.store = GradStore(params, bucket_mb=bucket_mb, device=self.device,
-                                   world=torch.distributed.get_world_size() if self.distributed else 1)
+                                   world=torch.distributed.get_world_size() if self.distributed else 1,
+                                   wire_dtype=wire if self.distributed else torch.float32)
+            if self.distributed and EARLY_BUCKETS:
+                self.store.arm_early(self._early_bucket)
             self.optimizer = FusedAdam(params, lr=lr0, grad_store=self.store)      # one HIP launch per step (csrc/adam.hip)
         else:
             if self.distributed:
@@ -254,9 +261,14 @@ class Trainer(object):
         self.optimizer.zero_grad(set_to_none=True)
         _conv.GRAD_STORE = st
         _conv.DEFER_WGRAD = DEFER_WGRAD
+        self._reduce_now = bool(self.distributed and reduce)
+        if st is not None:
+            st.backward_scope(self._reduce_now)
         try:
             loss_total.backward()
         finally:
+            if st is not None:
+                st.backward_scope(False)
             _conv.DEFER_WGRAD = False
             _conv.GRAD_STORE = None
         if st is None:
@@ -265,7 +277,7 @@ class Trainer(object):
             _conv.GRAD_STORE = st
             try:
                 if self.distributed and reduce:
-                    for bi in range(len(st.buckets)):
+                    for bi in range(st.next_bucket(), len(st.buckets)):      # what the backward pass did not release early
                         _conv.flush_wgrads(bucket=bi)
                         st.collect(bi)
                         st.reduce_bucket(bi)
@@ -282,6 +294,15 @@ class Trainer(object):
         if with_optimizer:
             self.optimizer.step()
         return out, losses
+
+    def _early_bucket(self, bi):
+        """GradStore's early-bucket callback (runs inside loss.backward(), on the step's stream): the bucket's queued weight
+        gradients are launched, its other gradients copied into the store, and its all-reduce started -- the rest of the
+        backward pass overlaps it."""
+        st = self.store
+        _conv.flush_wgrads(bucket=bi)
+        st.collect(bi)
+        st.reduce_bucket(bi)
 
     def train_step(self, in_dict):
         self.model.train()
@@ -332,6 +353,8 @@ class Trainer(object):
                     self._static_out = self._core(self._static, reduce=in_graph, with_optimizer=in_graph)
                 self._reduce_in_graph = in_graph
                 self.fusion_counts = dict(conv.FUSION)      # which attribute-carried fusions the captured step contains
+                # the collectives the capture recorded, in issue order, and how many of them from inside the backward pass
+                self.captured_collectives = (list(self.store.issued), self.store.issued_early) if (self.store is not None and in_graph) else ([], 0)
                 break
             except RuntimeError:
                 if not in_graph:

@@ -71,6 +71,34 @@ def _worker(rank, world, port, tmp):
     st.scale_()
     st.attach_all()
     torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(tmp, 'n%d.pt' % rank))
+    # early buckets: released from inside backward, strictly in bucket order, never-used parameters not waited for after the
+    # first step; and the bf16 wire format
+    for wire in (torch.float32, torch.bfloat16):
+        net2 = _Net()
+        st2 = GradStore(net2.parameters(), bucket_mb=0.0002, device=torch.device('cpu'), wire_dtype=wire)
+        st2.broadcast_parameters(net2)
+
+        def early(bi, st2=st2):
+            st2.collect(bi)
+            st2.reduce_bucket(bi)
+        st2.arm_early(early)
+        log = []
+        for step in range(3):
+            net2.zero_grad(set_to_none=True)
+            st2.begin_step()
+            st2.backward_scope(True)
+            net2(data[rank]).pow(2).mean().backward()
+            st2.backward_scope(False)
+            for bi in range(st2.next_bucket(), len(st2.buckets)):
+                st2.collect(bi)
+                st2.reduce_bucket(bi)
+            st2.wait()
+            st2.scale_()
+            st2.attach_all()
+            log.append((list(st2.issued), st2.issued_early))
+        torch.save({'log': log, 'nb': len(st2.buckets), 'grads': {k: p.grad.clone() for k, p in net2.named_parameters()},
+                    'params': {k: p.detach().clone() for k, p in net2.named_parameters()}},
+                   os.path.join(tmp, 'e%d_%s.pt' % (rank, 'bf16' if wire == torch.bfloat16 else 'fp32')))
     dist.destroy_process_group()
 
 
@@ -99,3 +127,24 @@ def test_two_rank_gradient_average_matches_single_process(tmp_path):
     n0 = torch.load(tmp_path / 'n0.pt')
     for k in n0:
         assert torch.allclose(n0[k], (grads[0][k] + grads[1][k]) / 2, atol=1e-6), k
+    # early buckets (fp32 and bf16 wire): every step issues all buckets in index order on both ranks; the first step cannot
+    # release past the never-used module, later steps release (nearly) every bucket from inside backward
+    for wire, tol in (('fp32', 1e-6), ('bf16', 2e-2)):
+        e0, e1 = torch.load(tmp_path / ('e0_%s.pt' % wire)), torch.load(tmp_path / ('e1_%s.pt' % wire))
+        nb = e0['nb']
+        for e in (e0, e1):
+            for issued, early in e['log']:
+                assert issued == list(range(nb))
+            assert e['log'][0][1] == 0 and e['log'][1][1] >= nb - 1 and e['log'][2][1] >= nb - 1
+        net = _Net()
+        net.load_state_dict({**net.state_dict(), **e0['params']})
+        ref = []
+        for r in range(world):
+            net.zero_grad(set_to_none=True)
+            net(data[r]).pow(2).mean().backward()
+            ref.append({k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in net.named_parameters()})
+        for k in e0['grads']:
+            mean = (ref[0][k] + ref[1][k]) / 2
+            assert torch.allclose(e0['grads'][k], mean, atol=tol * float(mean.abs().max() + 1e-6) if wire == 'bf16' else tol), (wire, k)
+            assert torch.equal(e0['grads'][k], e1['grads'][k]), (wire, k)
+
