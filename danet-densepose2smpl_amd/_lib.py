@@ -91,7 +91,7 @@ _SIGNATURES = {
     'danet_smpl_loss_forward': (c_i, [c_f] * 5),
     'danet_smpl_loss_backward': (c_i, [c_f] * 5),
     'danet_adam_chunk_bytes': (c_sz, []),
-    'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f]),
+    'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),

@@ -530,7 +530,9 @@ def new_wgrad(weight, shape, device):
     the all-reduce and the optimizer) when there is one and the parameter has no gradient yet, else a new tensor."""
     st = GRAD_STORE
     if st is not None and isinstance(weight, nn.Parameter) and weight.grad is None and st.has(weight) and tuple(shape) == tuple(weight.shape):
-        return st.view(weight)
+        v = st.take(weight)             # None: a second use of the same parameter in this backward pass (the slot is taken)
+        if v is not None:
+            return v
     return torch.empty(*shape, dtype=torch.float32, device=device)
 
 

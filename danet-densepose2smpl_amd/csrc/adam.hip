@@ -6,19 +6,30 @@
 // <= 32768-element chunks {param, grad, offset into the flat moment buffers, count} with one workgroup per
 // chunk.  The learning rate and the step count are read from device memory, so the step can sit inside a
 // captured hipGraph and the host can still decay the rate between replays.
+//
+// Per-parameter step counts, as torch.optim.Adam keeps them: a parameter that received no gradient in a step (gradient
+// pointer NULL, or used[param] == 0 where all gradients are views of one store) is skipped entirely -- moments untouched --
+// and idle[param] counts those steps; its bias corrections use step - idle[param], i.e. the number of steps it WAS updated
+// in.  (The reference pre-trains the IUV estimator alone for 5000 steps, /root/reference/train/base_trainer.py:74: the
+// regressor's first update must see step 1, not 5001.)
 #include "common.h"
 
 namespace {
 
-struct AdamChunk { float* p; const float* g; long off; int n; int pad; };
+struct AdamChunk { float* p; const float* g; long off; int n; int param; };     // param: 2 * parameter index + (1 for the parameter's first chunk)
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ lr_p, const float* __restrict__ step_p,
+                                                   const int* __restrict__ used, float* __restrict__ idle,
                                                    float beta1, float beta2, float eps, float gscale)
 {
     const AdamChunk c = table[blockIdx.x];
-    if (!c.g) return;                                              // parameter without a gradient this step
-    const float t = step_p[0];
+    const int pi = c.param >> 1;
+    if (!c.g || (used && !used[pi])) {                             // parameter without a gradient this step: skipped, and counted
+        if (idle && (c.param & 1) && threadIdx.x == 0) idle[pi] += 1.f;
+        return;
+    }
+    const float t = step_p[0] - (idle ? idle[pi] : 0.f);           // (nobody writes idle[pi] in a launch that reads it)
     const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
     const float step_size = lr_p[0] / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
     float* __restrict__ mp = m + c.off;
@@ -50,16 +61,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__
 
 extern "C" size_t danet_adam_chunk_bytes(void) { return sizeof(AdamChunk); }
 
-// table: nchunks entries { float* p; const float* g (NULL = skip); int64 off; int32 n; int32 pad } on the device; p, g and
-// the moment buffers m, v (+ off) must be 16-byte aligned for every chunk; lr and step (the 1-based step count, as a
-// float) live on the device.  grad_scale multiplies every gradient (1 / world size turns all-reduced sums into the
-// average without a pass of its own).
+// table: nchunks entries { float* p; const float* g (NULL = skip); int64 off; int32 n; int32 param } on the device (param = 2 *
+// parameter index + 1 for the parameter's first chunk); p, g and the moment buffers m, v (+ off) must be 16-byte aligned for
+// every chunk; lr and step (the 1-based GLOBAL step count, as a float) live on the device.  used (NULL = every parameter with a
+// gradient pointer): int per parameter, 0 = no gradient this step; idle (NULL = none): float per parameter, the steps it was
+// skipped in, maintained here.  grad_scale multiplies every gradient (1 / world size turns all-reduced sums into the average
+// without a pass of its own).
 extern "C" int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
-                               float beta1, float beta2, float eps, float grad_scale, void* stream)
+                               const int* used, float* idle, float beta1, float beta2, float eps, float grad_scale, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(table && nchunks > 0 && m && v && lr && step, "adam_step: bad arguments");
-    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, used, idle, beta1, beta2, eps, grad_scale);
     DANET_CHECK_LAUNCH("adam_kernel");
     return DANET_OK;
 }

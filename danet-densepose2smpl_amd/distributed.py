@@ -64,9 +64,19 @@ class GradStore(object):
         self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.wire_dtype = wire_dtype
         self.wire = None if wire_dtype == torch.float32 else torch.zeros(off, dtype=wire_dtype, device=self.device)
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        # which parameters received a gradient in the last backward pass (1 / 0, in self.params order): filled from the
+        # post-accumulate-grad hooks when the trainer leaves backward_scope; the optimizer skips the others (optim.FusedAdam)
+        self.used = torch.ones(len(self.params), dtype=torch.int32, device=self.device)
+        self._used_host = torch.ones(len(self.params), dtype=torch.int32)
+        if self.device.type == 'cuda':
+            self._used_host = self._used_host.pin_memory()
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
         self._works = []
         self.issued = []                    # bucket indices in the order their collectives were issued this step ...
         self.issued_early = 0               # ... and how many of them from inside the backward pass
+        self._handed = set()
         self._early_cb = None
         self._expected = None               # ids of the parameters that received a gradient in the previous step
         self._fired, self._late = set(), []
@@ -86,43 +96,64 @@ class GradStore(object):
     def grad_ptr(self, p):
         return self.flat.data_ptr() + 4 * self.offsets[id(p)]
 
+    def take(self, p):
+        """p's slot for a weight-gradient kernel to write (beta = 0) -- once per step: a parameter used twice in one backward
+        pass (shared weights) gets None the second time, the caller then writes a tensor of its own and autograd sums the two
+        (collect() copies the sum into the slot)."""
+        if id(p) in self._handed:
+            return None
+        self._handed.add(id(p))
+        return self.view(p)
+
     def begin_step(self):
         """Zero the storage (one memset): slots of parameters that receive no gradient this step stay zero."""
         self.flat.zero_()
         self.issued, self.issued_early, self._next = [], 0, 0
+        self._handed = set()
+        self._fired, self._late = set(), []
+        self._pending = None
         if self._early_cb is not None:
             exp = self._expected
             self._pending = [sum(1 for p in self.params[i0:i1] if exp is None or id(p) in exp) for (_, _, i0, i1) in self.buckets]
-            self._fired, self._late = set(), []
 
     # ---- early buckets -------------------------------------------------------------------------------------------
     def arm_early(self, callback):
         """callback(bucket_index) runs during backward once the next bucket in order is complete (see the module text)."""
-        if self._early_cb is None:
-            for p in self.params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
         self._early_cb = callback
 
-    def backward_scope(self, active):
-        """The trainer brackets loss.backward() with backward_scope(True) / (False): hooks outside it are ignored.  Leaving
-        the scope records which parameters received gradients (next step's expectation) and checks that none of them
+    def index_of(self, p):
+        return self.index[id(p)]
+
+    def backward_scope(self, active, early=True):
+        """The trainer brackets loss.backward() with backward_scope(True) / (False): hooks outside it are ignored; early =
+        False keeps the buckets for the caller's tail loop (steps whose all-reduces run elsewhere).  Leaving the scope
+        uploads which parameters received gradients (`used`; also the next step's expectation) and checks that none of them
         arrived after its bucket had been released."""
         was = self._in_backward
         self._in_backward = bool(active)
-        if was and not active and self._pending is not None:
+        if active and not early:
+            self._pending = None
+        if was and not active:
             late, self._late = self._late, []
             self._expected = set(self._fired)
+            self._used_host.zero_()
+            idx = [self.index[i] for i in self._fired]
+            if idx:
+                self._used_host[idx] = 1
+            self.used.copy_(self._used_host, non_blocking=True)
             if late:
                 raise RuntimeError('GradStore: %d parameter(s) received a gradient after their bucket had been all-reduced '
                                    '(the set of parameters in use changed between steps); the step is incomplete -- rerun it' % len(late))
 
     def _on_grad(self, p):
-        if not self._in_backward or self._pending is None:
+        if not self._in_backward:
             return
         b = self.bucket_of.get(id(p))
         if b is None:
             return
         self._fired.add(id(p))
+        if self._pending is None:
+            return
         if self._expected is not None and id(p) not in self._expected:
             if b < self._next:
                 self._late.append(p)

@@ -3,12 +3,20 @@ eps=1e-8) -- the reference's optimizer, /root/reference/train/trainer.py:42-44 -
 
 The moments live in two flat fp32 buffers; a device table of <= 32768-element chunks {param, grad, moment offset, n}
 drives the kernel.  With a `grad_store` (distributed.GradStore: every gradient is a view of one flat buffer) the
-table is written once and never changes -- parameters without a gradient in a step read their zeroed slot, which
-leaves parameter and moments of a never-used parameter untouched exactly like torch.optim.Adam's skip (a parameter
-that only sometimes receives gradients gets its moments decayed in the idle steps, torch would freeze them).
-Without a store the table is rebuilt (host side, double-buffered pinned copy) whenever a gradient tensor's address
-changed.  `param_groups[0]['lr']` is a device tensor, so a trainer can decay the rate between hipGraph replays.
-GPU only."""
+table is written once and never changes; which parameters received a gradient in the step comes from the store's
+per-parameter mask (GradStore.used, filled from its post-accumulate-grad hooks).  Without a store the table is
+rebuilt (host side, double-buffered pinned copy) whenever a gradient tensor's address changed, and a NULL gradient
+pointer marks the skip.
+
+Step counts are per parameter, as in torch.optim.Adam: a parameter without a gradient in a step is skipped entirely
+(moments untouched) and the kernel counts the step in `idle`; its bias corrections use step - idle.  The reference
+pre-trains the IUV estimator alone for 5000 steps (/root/reference/train/base_trainer.py:74): the regressor's first
+update then sees step 1 -- with one global count it would be ~3x too large.  state_dict / load_state_dict carry the
+per-parameter counts in torch's layout.
+
+With world_size > 1 the gradients in the store (and hence every p.grad) are the SUM over the ranks; the average is
+formed inside the update (grad_scale = 1 / world).  `param_groups[0]['lr']` is a device tensor, so a trainer can
+decay the rate between hipGraph replays.  GPU only."""
 import ctypes
 
 import numpy as np
@@ -38,7 +46,8 @@ class FusedAdam(object):
             tot += (p.numel() + 3) // 4 * 4                   # 16-byte aligned moment slices
         self.exp_avg = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)                 # global step count
+        self.idle = torch.zeros(len(self.params), dtype=torch.float32, device=dev)       # per parameter: steps without a gradient
         cb = int(_lib.lib().danet_adam_chunk_bytes())
         assert cb == 32
         self._dtype = np.dtype([('p', np.uint64), ('g', np.uint64), ('off', np.int64), ('n', np.int32), ('pad', np.int32)])
@@ -62,7 +71,7 @@ class FusedAdam(object):
             a['p'] = np.array([self.params[i].data_ptr() for i in pidx], dtype=np.uint64) + self._c0b
             a['off'] = np.array([r[3] for r in rows], dtype=np.int64)
             a['n'] = np.array([r[2] for r in rows], dtype=np.int32)
-            a['pad'] = 0
+            a['pad'] = np.array([2 * r[0] + (1 if r[1] == 0 else 0) for r in rows], dtype=np.int32)     # parameter index, first-chunk flag
             a['g'] = 0
         self._gptrs = None
         self.grad_store = grad_store
@@ -75,6 +84,9 @@ class FusedAdam(object):
             a = self._hosts[0].numpy().view(self._dtype)
             a['g'] = g[pidx] + self._c0b
             self._table.copy_(self._hosts[0])                 # synchronous, once
+            # the store's mask is in ITS parameter order: gathered into this optimizer's order every step (one tiny launch)
+            self._used_perm = torch.tensor([grad_store.index_of(p) for p in self.params], dtype=torch.long, device=dev)
+            self._used = torch.ones(len(self.params), dtype=torch.int32, device=dev)
 
     def state_dict(self):
         """torch.optim.Adam's layout (per-parameter step / exp_avg / exp_avg_sq + one param group), so the checkpoints of
@@ -82,7 +94,7 @@ class FusedAdam(object):
         state = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
-            state[i] = {'step': self.step_t.detach().clone(), 'exp_avg': self.exp_avg[o:o + n].view_as(p).clone(),
+            state[i] = {'step': (self.step_t - self.idle[i]).detach().clone(), 'exp_avg': self.exp_avg[o:o + n].view_as(p).clone(),
                         'exp_avg_sq': self.exp_avg_sq[o:o + n].view_as(p).clone()}
         group = {'lr': float(self.param_groups[0]['lr']), 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0,
                  'amsgrad': False, 'maximize': False, 'params': list(range(len(self.params)))}
@@ -93,16 +105,18 @@ class FusedAdam(object):
         ids = [i for g in groups for i in g['params']]
         if len(ids) != len(self.params):
             raise ValueError('FusedAdam.load_state_dict: %d parameters in the file, %d here' % (len(ids), len(self.params)))
-        step = 0.0
+        steps = [0.0] * len(self.params)
         for pos, (i, p, o) in enumerate(zip(ids, self.params, self.offsets)):
             st = sd['state'].get(i)
             if st is None:
-                continue
+                continue                    # (torch keeps no state for a parameter that never had a gradient: step 0, zero moments)
             n = p.numel()
             self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
             self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
-            step = max(step, float(st['step']))
-        self.step_t.fill_(step)             # one global step count (torch keeps one per parameter; they agree in training)
+            steps[pos] = float(st['step'])
+        top = max(steps)
+        self.step_t.fill_(top)              # global count = the most-updated parameter's; the others' deficits go to `idle`
+        self.idle.copy_(torch.tensor([top - s_ for s_ in steps], dtype=torch.float32))
         self.param_groups[0]['lr'].fill_(float(groups[0]['lr']))
         self.betas, self.eps = tuple(groups[0].get('betas', self.betas)), groups[0].get('eps', self.eps)
 
@@ -138,8 +152,12 @@ class FusedAdam(object):
     def step(self):
         self._refresh_table()
         self.step_t.add_(1.0)
+        used = None
+        if self.grad_store is not None:
+            torch.index_select(self.grad_store.used, 0, self._used_perm, out=self._used)
+            used = self._used
         check(_lib.lib().danet_adam_step(ptr(self._table), self.nchunks, ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                         ptr(self.param_groups[0]['lr']), ptr(self.step_t),
+                                         ptr(self.param_groups[0]['lr']), ptr(self.step_t), ptr(used), ptr(self.idle),
                                          float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale), stream()), 'danet_adam_step')
         # the kernel wrote the parameters through raw pointers: bump their version counters like an in-place op would
         # (the conv weight-pack cache and autograd's saved-tensor checks key on them)

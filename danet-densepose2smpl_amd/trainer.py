@@ -263,7 +263,7 @@ class Trainer(object):
         _conv.DEFER_WGRAD = DEFER_WGRAD
         self._reduce_now = bool(self.distributed and reduce)
         if st is not None:
-            st.backward_scope(self._reduce_now)
+            st.backward_scope(True, early=self._reduce_now)
         try:
             loss_total.backward()
         finally:

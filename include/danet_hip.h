@@ -147,12 +147,15 @@ int danet_smpl_loss_backward(const void* params, const float* gout, const float*
 
 /* ---------------------------------------------------------------------------------------
  * Optimizer (replaces torch.optim.Adam at /root/reference/train/trainer.py:42-44): one launch over a device table of
- * <= 32768-element chunks { float* p; const float* g (NULL = skip); int64 off (into m, v); int32 n; int32 pad }.
- * lr and step (1-based count, float) are read from device memory; p, g, m+off, v+off 16-byte aligned.  grad_scale
- * multiplies every gradient (1 / world size: all-reduced sums become the average without a pass of its own). */
+ * <= 32768-element chunks { float* p; const float* g (NULL = skip); int64 off (into m, v); int32 n; int32 param (2 * parameter
+ * index + 1 for the parameter's first chunk) }.  lr and step (1-based GLOBAL count, float) are read from device memory; p, g,
+ * m+off, v+off 16-byte aligned.  Per-parameter step counts as torch.optim.Adam keeps them: used (NULL = all): int per parameter,
+ * 0 = no gradient this step -> the parameter is skipped (moments untouched) and idle[param] (float per parameter, NULL = none,
+ * maintained by the kernel) counts it; bias corrections use step - idle[param].  grad_scale multiplies every gradient
+ * (1 / world size: all-reduced sums become the average without a pass of its own). */
 size_t danet_adam_chunk_bytes(void);
 int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
-                    float beta1, float beta2, float eps, float grad_scale, void* stream);
+                    const int* used, float* idle, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Partial-IUV ("limb") path glue (replaces /root/reference/models/danet/danet.py:264-283 and

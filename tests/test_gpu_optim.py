@@ -27,10 +27,76 @@ def test_fused_adam_matches_torch_adam():
             oa.param_groups[0]['lr'].mul_(0.1)                             # the manual decay of trainer.py:120-128
             ob.param_groups[0]['lr'] *= 0.1
     torch.cuda.synchronize()
-    for a, b in zip(pa, pb):
-        if a.numel() == 7:
-            continue          # torch keeps a per-parameter step count (the skipped step shifts its bias correction); ours is global
+    for a, b in zip(pa, pb):      # (the parameter that skipped a step included: step counts are per parameter, as in torch)
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a.shape, (a - b).abs().max().item())
+    sd = oa.state_dict()['state']
+    assert float(sd[1]['step']) == 4.0 and float(sd[0]['step']) == 5.0
+
+
+def test_fused_adam_late_starting_parameters_and_grad_store_mask():
+    """The reference pre-trains the IUV estimator alone for 5000 steps (base_trainer.py:74): parameters that start receiving
+    gradients later must see THEIR first step, not the global count -- through the NULL-gradient path and through the
+    gradient store's per-parameter mask (distributed.GradStore.used, filled by its hooks), against torch.optim.Adam; also a
+    convolution weight used twice in one backward pass (shared weights) with the store in place."""
+    from danet_densepose2smpl_amd.optim import FusedAdam
+    from danet_densepose2smpl_amd.distributed import GradStore
+    from danet_densepose2smpl_amd import conv
+    torch.manual_seed(2)
+    # (a) no store: gradient None for the first six steps
+    pa = [torch.nn.Parameter(torch.randn(300, device='cuda')), torch.nn.Parameter(torch.randn(70000, device='cuda'))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)
+    for step in range(9):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = torch.randn_like(a)
+            a.grad, b.grad = (None, None) if (i == 1 and step < 6) else (g.clone(), g.clone())
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max().item()
+    # (b) with a store: which parameters were used comes from the hooks; a module that joins in later
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 8)
+            self.late = torch.nn.Linear(8, 8)
+
+        def forward(self, x, use_late):
+            y = self.a(x)
+            return self.late(y) if use_late else y
+    na, nb = Net().cuda(), Net().cuda()
+    nb.load_state_dict(na.state_dict())
+    st = GradStore(na.parameters(), device=torch.device('cuda'))
+    oa, ob = FusedAdam(list(na.parameters()), lr=1e-2, grad_store=st), torch.optim.Adam(nb.parameters(), lr=1e-2)
+    for step in range(8):
+        x = torch.randn(4, 8, device='cuda')
+        oa.zero_grad(); ob.zero_grad()
+        st.begin_step()
+        st.backward_scope(True, early=False)
+        na(x, step >= 5).pow(2).mean().backward()
+        st.backward_scope(False)
+        st.collect()
+        nb(x, step >= 5).pow(2).mean().backward()
+        oa.step(); ob.step()
+    for (k, a), b in zip(na.named_parameters(), nb.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (k, (a - b).abs().max().item())
+    assert float(oa.state_dict()['state'][2]['step']) == 3.0          # `late.weight`: updated in steps 6..8 only
+    # (c) one conv weight, two uses in one backward pass, gradient store in place: the second use must not overwrite the first
+    w = torch.nn.Parameter(torch.randn(16, 16, 3, 3, device='cuda') * 0.1)
+    st2 = GradStore([w], device=torch.device('cuda'))
+    x = torch.randn(2, 16, 12, 12, device='cuda')
+    ref = torch.nn.functional.conv2d(torch.nn.functional.conv2d(x, w, None, 1, 1), w, None, 1, 1)
+    gy = torch.randn_like(ref)
+    gref, = torch.autograd.grad(ref, w, gy)
+    st2.begin_step()
+    conv.GRAD_STORE = st2
+    try:
+        y = conv.conv2d(conv.conv2d(x, w, None, 1, 1), w, None, 1, 1)
+        y.backward(gy.to(y.dtype))
+    finally:
+        conv.GRAD_STORE = None
+    st2.collect()
+    assert w.grad.data_ptr() == st2.grad_ptr(w)
+    assert ((w.grad - gref).norm() / gref.norm()).item() < 2e-2        # (bf16 convolutions)
 
 
 def test_fused_adam_state_dict_is_torch_adam_compatible():
