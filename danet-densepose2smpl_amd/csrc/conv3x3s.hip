@@ -49,6 +49,10 @@ constexpr int S3_FIXED = S3_SCR + 1536;
 constexpr int S3_LDS = 81920;                     // two workgroups per CU
 constexpr int S3_BUF = (S3_LDS - S3_FIXED) / 2;   // one ring slot: 37.5 KB
 constexpr int S3_D = 5;                           // weight-fragment ring: k-steps in flight
+#ifndef DANET_S3_WRAP
+#define DANET_S3_WRAP 0
+#endif
+constexpr bool S3_WRAP = DANET_S3_WRAP != 0;     // the ring carries over from a tile to the next (build knob; measured neutral: 40.1 vs 40.3 us on the four-branch launch, so off)
 constexpr int S3_THREADS = 256;
 
 struct S3Prob {
@@ -110,7 +114,8 @@ __device__ inline float row_sum16(float v) {
 // ---- the tap table of a problem (built once per signature, s3_table_for) ---------------------------------------------------
 // Entry j = one k-step (32 K values = two 16-channel blocks): {x, y} = LDS byte offsets of its two halves relative to a
 // lane's pixel cell, z = byte offset of its weight fragment (row block 0) in the packed operand, w = the next k-step of
-// the wave that owns entry j (its share of this stage, then of the following stages; the last one points at itself).
+// the wave that owns entry j (its share of this stage, then of the following stages; the last one points back at the wave's
+// first k-step: the ring's refills past the end of a tile fetch the first fragments of the next tile, see s3_problem).
 struct TabKey { int Wp, Sp, nc16, flip, kw, nst; unsigned c0w, ncw, j0w; };
 __global__ void s3_table_kernel(TabKey k, i32x4* __restrict__ out)
 {
@@ -155,10 +160,12 @@ __global__ void s3_table_kernel(TabKey k, i32x4* __restrict__ out)
         const int w = (t - a) / c;
         int jb, je;
         range_of(s, w, jb, je);
-        int nx = t;
+        int nx = -1;
         if (t + 1 < je) nx = t + 1;
         else for (int q = nst - 1; q > s; --q) { int nb2, ne2; range_of(q, w, nb2, ne2); if (nb2 < ne2) nx = nb2; }
-        e.w = nx;
+        if (nx < 0)                                   // the wave's last k-step of the tile: on to its first one (of the NEXT tile)
+            for (int q = nst - 1; q >= 0; --q) { int nb2, ne2; range_of(q, w, nb2, ne2); if (nb2 < ne2) nx = nb2; }
+        e.w = nx < 0 ? t : nx;
     }
     out[t] = e;
 }
@@ -515,13 +522,20 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
     for (int k = S3_MAXST - 1; k >= 0; --k) if (k < nst) { int a, b; range_of(k, kw, a, b); if (a < b) { jb0 = a; je0 = b; } }
 
     Pos cur{ii, first_tile_of(p.tile0m, bid, nblk), 0, true, true};
+    // The ring lives across the tiles of a problem visit: the refills issued during a tile's last D k-steps follow the table's
+    // wrap-around links and fetch the FIRST D k-steps of the next tile (same weights whenever the workgroup's next tile has the
+    // same channel block -- always for the grids used: the tile stride is a multiple of the channel-block count), so that tile
+    // starts with its fragments already in flight behind the previous epilogue instead of waiting ~2.7 k cycles for a refill.
+    bf16x8 A[D][NT];
+    i32x4 qn{};
+    int r0 = 0;                                       // ring slot of the next k-step
+    bool primed = false;                              // the ring already holds (or is fetching) this tile's first k-steps
     for (; cur.ii == ii && cur.valid;) {
         const int tau = cur.tau;
         int img0, y0, nb;
         tile_coords(p, tau, img0, y0, nb);
         const int n0 = nb * (16 * NT);
         const bf16_t* wblk = p.w + (size_t)(n0 / 16) * (size_t)nks * 512;
-        bf16x8 A[D][NT];
         // Weight-fragment loads are inline asm: the compiler's own vmcnt bookkeeping drains the whole ring at every loop
         // header (vmcnt(0) once per D k-steps, measured in the disassembly).  Invisible to it, they are counted by hand: the
         // ring is a FIFO, so whenever a slot is used exactly NT * (D - 1) younger fragment loads exist -- s_waitcnt
@@ -545,8 +559,10 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         // The ring runs over this wave's k-steps of the whole tile (stage after stage): k-step i sits in slot i % D and, once
         // used, the slot is refilled with k-step i + D.  The prefetch walks the table's successor links D k-steps ahead of
         // the MFMAs; the entry of the NEXT refill is read one k-step early.
-        i32x4 qn;
-        if (jb0 + D < je0) {                          // (the common case: the first D k-steps are consecutive entries)
+        if (primed) {
+            // (nothing to do: slots r0, r0 + 1, ... hold k-steps 0, 1, ... of this tile and qn the entry of the next refill)
+        } else if (jb0 + D < je0) {                   // (the common case: the first D k-steps are consecutive entries)
+            r0 = 0;
             i32x4 q[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) q[d] = sTab[jb0 + d];
@@ -554,6 +570,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
 #pragma unroll
             for (int d = 0; d < D; ++d) load_a(wlane + q[d].z, A[d]);
         } else {
+            r0 = 0;
             int pj = jb0;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -570,7 +587,6 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (dbg && t == 0 && g == 0) dbg[12] = (int)clock64();
 
-        int r0 = 0;                                   // ring slot of the next k-step
         for (int s = 0; s < nst; ++s) {
             // the stage after this one starts travelling into the slot the last barrier freed (after the ring's own loads
             // of this point: see the header)
@@ -619,13 +635,23 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             if (nsteps < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s + 1 < nst) { lds_barrier(); ++g; }          // slot consumed; the next stage's slot is complete
         }
-        // The ring's last refills fetched nothing anyone needs, but they are still in flight and the compiler knows nothing
-        // of them: it would hand their destination registers to the epilogue.  Every slot stays live up to a full wait.
+        // The ring's last refills are still in flight.  When the workgroup's next tile belongs to this problem and has the same
+        // channel block they are that tile's first k-steps: the slots simply stay live across the epilogue (loop-carried, so the
+        // compiler keeps the registers).  Otherwise nobody needs them, but the compiler knows nothing of them and would hand
+        // their destination registers to the epilogue: every slot stays live up to a full wait.
+        primed = false;
+        if (S3_WRAP && cur.valid && cur.ii == ii) {
+            int i2, y2, nb2;
+            tile_coords(p, cur.tau, i2, y2, nb2);
+            primed = nb2 == nb;
+        }
+        if (!primed) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]));
-            if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]));
-            if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]));
+            for (int d = 0; d < D; ++d) {
+                if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]));
+                if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]));
+                if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]));
+            }
         }
         int* const stamp = (dbg && t == 0 && g + 1 == nst) ? dbg : nullptr;       // the workgroup's first tile
         if (stamp) stamp[3] = (int)clock64();
