@@ -43,7 +43,8 @@ def main():
     L = _lib.lib()
     quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
     blocks = [int(b) for b in os.environ.get('C3S_BLOCKS', '512').split(',')]
-    for (Cin, Cout, H, W, B) in SHAPES[:4] if quick else SHAPES:
+    only_multi = len(sys.argv) > 1 and sys.argv[1] == 'multi'
+    for (Cin, Cout, H, W, B) in [] if only_multi else (SHAPES[:4] if quick else SHAPES):
         flops = 2.0 * B * H * W * Cout * Cin * 9
         x = conv.nhwc_bf16(torch.randn(B, Cin, H, W, device='cuda'))
         w = torch.nn.Parameter(torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.05)
