@@ -314,7 +314,7 @@ def main():
             extra = [{'error': repr(e)}]
 
     fp32 = None
-    if not args.no_fp32:
+    if not args.no_fp32 and world == 1:                             # (N > 1: one configuration per run; `--dtype fp32` measures C4 on N GPUs)
         try:                                                         # (after everything measured on the bf16 graph: this re-captures)
             fp32 = fp32_record(args, tr, batch, world, dev)
         except Exception as e:
