@@ -38,8 +38,20 @@ constexpr int CTX_JP = 360;        // [24][3] posed joints
 constexpr int CTX_RG = 432;        // [24][9] global rotations
 constexpr int CTX_STRIDE = 648;
 
-inline int bpad_of(int B) { return (B + NBG - 1) / NBG * NBG; }
-inline int ntiles_of(int V) { return (V + TV - 1) / TV; }
+// Forward main kernel: batch items per workgroup x vertices per tile = 512 (vertex, item) pairs.  Reading posedirs (17 MB) once
+// for all 32 items of a batch (32 items x 16 vertices per workgroup) was built and measured in round 3: SLOWER than four batch
+// groups of 8 (the re-reads hit the L2 / infinity cache; narrow tiles multiply the per-workgroup fixed cost: 37 KB of joint
+// transforms per workgroup, 192-byte row pieces), so 8 x 64 stays the default; DANET_LBS_NBG selects the other instantiations.
+inline int fwd_nbg_of(int B) {
+    static const int forced = getenv("DANET_LBS_NBG") ? atoi(getenv("DANET_LBS_NBG")) : 0;      // A-B timing knob: 8, 16 or 32
+    if (forced == 8 || forced == 16 || forced == 32) return forced;
+    (void)B;
+    return 8;      // measured at B = 32 (rocprofv3, main kernel): 8 items x 64 vertices 26.7 us, 16 x 32 39.4 us, 32 x 16 41.9 us
+}
+inline int fwd_tv_of(int B) { return 512 / fwd_nbg_of(B); }
+inline int bpad_of(int B) { const int g = fwd_nbg_of(B); return (B + g - 1) / g * g; }      // (a multiple of NBG = 8: the backward's groups)
+inline int ntiles_of(int V) { return (V + TV - 1) / TV; }                                   // backward tiles
+inline int fwd_ntiles_of(int V, int B) { const int tv = fwd_tv_of(B); return (V + tv - 1) / tv; }
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void smpl_prep_kernel(
@@ -111,6 +123,10 @@ __global__ __launch_bounds__(64) void smpl_prep_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+__device__ long long g_lbs_dbg[16];     // phase time stamps of workgroup (0, 0) (tools: danet_smpl_lbs_debug)
+#define LBS_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lbs_dbg[i] = clock64(); } while (0)
+
+template <int TV, int NBG>
 __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
     const float* __restrict__ v_template, const float* __restrict__ shapedirs,
     const float* __restrict__ posedirs, const float* __restrict__ lbs_weights,
@@ -119,13 +135,21 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
     int B, int Bpad, int V, int NB, int NE,
     float* __restrict__ verts, float* __restrict__ v_posed_out, float* __restrict__ jx_partial)
 {
+    constexpr int TC = TV * 3;                       // coordinates per tile
+    constexpr int NQ = (TC + 63) / 64;               // coordinates per lane in the blend-shape pass
     const int tile = blockIdx.x, b0 = blockIdx.y * NBG, t = threadIdx.x;
     const int v0 = tile * TV;
     const int C = V * 3;
-    __shared__ float sA[NBG][288];
+    __shared__ __attribute__((aligned(16))) float sA[NBG][288];
     __shared__ float sW[TV][WPAD];
     __shared__ float sVp[NBG][TC];
-    __shared__ float sPart[4][NBG][TC];
+    __shared__ float sPart[4][NBG][NQ * 64];
+    __shared__ float sB[NBG][NB_MAX];               // betas of the group (zero beyond NB / B)
+    __shared__ float sSd[TC][NB_MAX + 1];           // shapedirs rows of the tile's coordinates
+    __shared__ float sBase[TC];                     // v_template
+    __shared__ float sJx[NE_MAX][TV];               // extra-joint regressor columns of the tile
+    LBS_STAMP(8);
+    __shared__ __attribute__((aligned(16))) float sPf[NBG > 8 ? 4 : 1][NBG > 8 ? NPB_PAD / 4 : 1][NBG];      // per wave: its rows' pose features (NBG > 8)
 
 #pragma unroll
     for (int it_ = 0; it_ < (NBG * 288 + 255) / 256; ++it_) {
@@ -141,64 +165,108 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
         const int vv = i / NJ, j = i % NJ, v = v0 + vv;
         sW[vv][j] = v < V ? lbs_weights[(size_t)v * NJ + j] : 0.f;
     }
+    for (int i = t; i < NBG * NB_MAX; i += 256) {
+        const int bb = i / NB_MAX, l = i - bb * NB_MAX;
+        sB[bb][l] = (l < NB && b0 + bb < B) ? betas[(size_t)(b0 + bb) * NB + l] : 0.f;
+    }
+    for (int i = t; i < TC * NB_MAX; i += 256) {
+        const int cc = i / NB_MAX, l = i - cc * NB_MAX, c = v0 * 3 + cc;
+        sSd[cc][l] = (l < NB && c < C) ? shapedirs[(size_t)c * NB + l] : 0.f;
+    }
+    for (int i = t; i < TC; i += 256) { const int c = v0 * 3 + i; sBase[i] = v_template[c < C ? c : C - 1]; }
+    if (jx_partial)
+        for (int i = t; i < NE * TV; i += 256) {
+            const int e = i / TV, vv = i - e * TV;
+            sJx[e][vv] = v0 + vv < V ? Jx[(size_t)e * V + v0 + vv] : 0.f;
+        }
+    LBS_STAMP(9);
     {
         // pose blend-shapes: wave w owns 52 pose-basis rows, each lane 3 coordinates of the tile;
         // 39 independent 4-byte loads are in flight per unrolled batch, the pose feature arrives
         // through scalar loads (wave-uniform)
         const int w = t >> 6, lane = t & 63;
-        float acc[3][NBG];
+        float acc[NQ][NBG];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int bb = 0; bb < NBG; ++bb) acc[q][bb] = 0.f;
-        int cq[3];
+        int cq[NQ];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { const int c = v0 * 3 + lane + 64 * q; cq[q] = c < C ? c : C - 1; }
+        for (int q = 0; q < NQ; ++q) { const int c = v0 * 3 + lane + 64 * q; cq[q] = c < C ? c : C - 1; }    // (lanes past the tile's TC coordinates compute values nobody reads)
         const float* pf = pfT + b0;
         const int kbeg = w * (NPB_PAD / 4);
+        if constexpr (NBG <= 8) {
 #pragma unroll 13
-        for (int kk = 0; kk < NPB_PAD / 4; ++kk) {
-            const int k = kbeg + kk;                       // row 207 of pfT is zero padding
-            const int kr = k < NPB ? k : NPB - 1;
-            const float p0 = posedirs[(size_t)kr * C + cq[0]];
-            const float p1 = posedirs[(size_t)kr * C + cq[1]];
-            const float p2 = posedirs[(size_t)kr * C + cq[2]];
+            for (int kk = 0; kk < NPB_PAD / 4; ++kk) {
+                const int k = kbeg + kk;                       // row 207 of pfT is zero padding
+                const int kr = k < NPB ? k : NPB - 1;
+                float pq[NQ];
 #pragma unroll
-            for (int bb = 0; bb < NBG; ++bb) {
-                const float f = pf[(size_t)k * Bpad + bb];
-                acc[0][bb] += f * p0; acc[1][bb] += f * p1; acc[2][bb] += f * p2;
+                for (int q = 0; q < NQ; ++q) pq[q] = posedirs[(size_t)kr * C + cq[q]];
+#pragma unroll
+                for (int bb = 0; bb < NBG; ++bb) {
+                    const float f = pf[(size_t)k * Bpad + bb];      // wave-uniform: scalar loads
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q][bb] += f * pq[q];
+                }
+            }
+        } else {
+            // 16 / 32 items: the pose features of a row would need 16 / 32 SGPRs per row in flight (measured: 2x slower than the
+            // 8-item kernel).  The wave parks its 52 rows x NBG features in LDS and reads them back as broadcast ds_read_b128.
+            float* const myPf = &sPf[w][0][0];
+            for (int i = lane; i < (NPB_PAD / 4) * NBG; i += 64) {
+                const int kk = i / NBG, bb = i - kk * NBG;
+                myPf[i] = pf[(size_t)(kbeg + kk) * Bpad + bb];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            constexpr int UB = 26;                            // rows per batch: all of a batch's loads are issued before its arithmetic
+            static_assert((NPB_PAD / 4) % UB == 0, "UB");
+            for (int kk0 = 0; kk0 < NPB_PAD / 4; kk0 += UB) {
+                float pr[UB][NQ];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int k = kbeg + kk0 + u;
+                    const int kr = k < NPB ? k : NPB - 1;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) pr[u][q] = posedirs[(size_t)kr * C + cq[q]];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                    for (int b4 = 0; b4 < NBG; b4 += 4) {
+                        const float4 f = *reinterpret_cast<const float4*>(myPf + (kk0 + u) * NBG + b4);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            acc[q][b4 + 0] += f.x * pr[u][q]; acc[q][b4 + 1] += f.y * pr[u][q];
+                            acc[q][b4 + 2] += f.z * pr[u][q]; acc[q][b4 + 3] += f.w * pr[u][q];
+                        }
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int bb = 0; bb < NBG; ++bb) sPart[w][bb][lane + 64 * q] = acc[q][bb];
     }
     __syncthreads();
-    if (t < TC) {
-        const int c = v0 * 3 + t;
+    LBS_STAMP(10);
+    // shape blend-shapes + the four waves' pose partial sums (fixed order): (coordinate, item) pairs spread over all threads,
+    // the tile's shapedirs rows and the group's betas come from LDS
+    for (int o = t; o < TC * NBG; o += 256) {
+        const int bb = o / TC, cl_ = o - bb * TC;
+        const int c = v0 * 3 + cl_;
         const bool valid = c < C;
-        const int cl = valid ? c : C - 1;
-        float acc[NBG];
-        const float base = v_template[cl];
+        float a = sBase[cl_] + ((sPart[0][bb][cl_] + sPart[1][bb][cl_]) + (sPart[2][bb][cl_] + sPart[3][bb][cl_]));
 #pragma unroll
-        for (int bb = 0; bb < NBG; ++bb) acc[bb] = base + ((sPart[0][bb][t] + sPart[1][bb][t]) + (sPart[2][bb][t] + sPart[3][bb][t]));
-#pragma unroll
-        for (int l = 0; l < NB_MAX; ++l) {
-            const float sd = l < NB ? shapedirs[(size_t)cl * NB + l] : 0.f;
-#pragma unroll
-            for (int bb = 0; bb < NBG; ++bb) {
-                const int b = b0 + bb < B ? b0 + bb : B - 1;
-                acc[bb] += sd * (l < NB ? betas[(size_t)b * NB + l] : 0.f);
-            }
-        }
-#pragma unroll
-        for (int bb = 0; bb < NBG; ++bb) {
-            sVp[bb][t] = acc[bb];
-            if (v_posed_out && valid && b0 + bb < B) v_posed_out[(size_t)(b0 + bb) * C + c] = acc[bb];
-        }
+        for (int l = 0; l < NB_MAX; ++l) a += sSd[cl_][l] * sB[bb][l];            // (entries l >= NB are zero)
+        sVp[bb][cl_] = a;
+        if (v_posed_out && valid && b0 + bb < B) v_posed_out[(size_t)(b0 + bb) * C + c] = a;
     }
     __syncthreads();
+    LBS_STAMP(11);
     for (int pair = t; pair < TV * NBG; pair += 256) {
         const int vv = pair & (TV - 1), bb = pair / TV;
         float T[12];
@@ -206,8 +274,12 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
         for (int j = 0; j < NJ; ++j) {
             const float w = sW[vv][j];
+            const float4* a4 = reinterpret_cast<const float4*>(&sA[bb][j * 12]);       // (16-byte reads: with 16-vertex tiles a wave spans four items)
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] += w * sA[bb][j * 12 + e];
+            for (int e4 = 0; e4 < 3; ++e4) {
+                const float4 a = a4[e4];
+                T[e4 * 4 + 0] += w * a.x; T[e4 * 4 + 1] += w * a.y; T[e4 * 4 + 2] += w * a.z; T[e4 * 4 + 3] += w * a.w;
+            }
         }
         const float x = sVp[bb][vv * 3 + 0], y = sVp[bb][vv * 3 + 1], z = sVp[bb][vv * 3 + 2];
         float o[3];
@@ -222,19 +294,18 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
         }
     }
     __syncthreads();
+    LBS_STAMP(12);
     if (jx_partial) {
         const int NO = NE * 3;
         for (int o = t; o < NBG * NO; o += 256) {
             const int bb = o / NO, e = (o % NO) / 3, k = o % 3;
             float s = 0.f;
 #pragma unroll 16
-            for (int vv = 0; vv < TV; ++vv) {
-                const int v = v0 + vv;
-                s += (v < V ? Jx[(size_t)e * V + v] : 0.f) * sVp[bb][vv * 3 + k];
-            }
+            for (int vv = 0; vv < TV; ++vv) s += sJx[e][vv] * sVp[bb][vv * 3 + k];
             jx_partial[((size_t)tile * Bpad + b0 + bb) * NO + e * 3 + k] = s;
         }
     }
+    LBS_STAMP(13);
 }
 
 // sum over tiles of part[(tile*Bpad + b)*stride + o] in a FIXED order: 8 lanes own interleaved
@@ -279,8 +350,6 @@ __global__ __launch_bounds__(256) void smpl_finalize_kernel(
 //   gPf  [ntiles][Bpad][208]   d/d pose feature
 //   gBt  [ntiles][Bpad][NBmax] d/d beta through v_shaped
 
-__device__ long long g_lbs_dbg[16];     // phase time stamps of workgroup (0, 0) (tools: danet_smpl_lbs_debug)
-#define LBS_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lbs_dbg[i] = clock64(); } while (0)
 
 __global__ __launch_bounds__(256) void smpl_lbs_bwd_kernel(
     const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
@@ -559,7 +628,7 @@ extern "C" size_t danet_smpl_lbs_ctx_floats(int B) {
 }
 extern "C" size_t danet_smpl_lbs_fwd_ws_floats(int B, int V, int NE) {
     const size_t Bp = bpad_of(B);
-    return (size_t)NPB_PAD * Bp + (size_t)ntiles_of(V) * Bp * NE * 3;
+    return (size_t)NPB_PAD * Bp + (size_t)fwd_ntiles_of(V, B) * Bp * NE * 3;
 }
 extern "C" size_t danet_smpl_lbs_bwd_ws_floats(int B, int V, int NB) {
     (void)NB;
@@ -590,15 +659,16 @@ extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, 
         return danet::fail(DANET_ERR_WORKSPACE, "smpl_lbs_forward: workspace %zu < %zu floats", ws_floats,
                            danet_smpl_lbs_fwd_ws_floats(B, V, NE));
     hipStream_t s = (hipStream_t)stream;
-    const int Bp = bpad_of(B), nt = ntiles_of(V);
+    const int Bp = bpad_of(B), nt = fwd_ntiles_of(V, B), nbg = fwd_nbg_of(B);
     float* pfT = ws;
     float* jxp = ws + (size_t)NPB_PAD * Bp;
     hipLaunchKernelGGL(smpl_prep_kernel, dim3(Bp), dim3(64), 0, s, betas, rotmats, J_template, J_shapedirs, parents,
                        B, NB, Bp, NJ + NL + NE, ctx, pfT, joints54);
     DANET_CHECK_LAUNCH("smpl_prep_kernel");
-    hipLaunchKernelGGL(smpl_lbs_fwd_kernel, dim3(nt, Bp / NBG), dim3(256), 0, s, v_template, shapedirs, posedirs,
-                       lbs_weights, J_regressor_extra, betas, ctx, pfT, B, Bp, V, NB, NE, verts, v_posed,
-                       NE > 0 ? jxp : nullptr);
+#define LBS_FWD(TV_, NBG_) hipLaunchKernelGGL((smpl_lbs_fwd_kernel<TV_, NBG_>), dim3(nt, Bp / NBG_), dim3(256), 0, s, v_template, shapedirs, posedirs, \
+                       lbs_weights, J_regressor_extra, betas, ctx, pfT, B, Bp, V, NB, NE, verts, v_posed, NE > 0 ? jxp : nullptr)
+    if (nbg == 32) LBS_FWD(16, 32); else if (nbg == 16) LBS_FWD(32, 16); else LBS_FWD(64, 8);
+#undef LBS_FWD
     DANET_CHECK_LAUNCH("smpl_lbs_fwd_kernel");
     if (joints54 && (NL > 0 || NE > 0)) {
         hipLaunchKernelGGL(smpl_finalize_kernel, dim3(B), dim3(256), 0, s, verts, jxp, landmark_verts, Bp, V, NL, NE, nt,

@@ -24,3 +24,8 @@ names = ['load A/W/Jx', 'seeds', 'd v_posed', 'gA', 'd beta', 'pose-feature chun
 for i, n in enumerate(names):
     print('%-22s %8d cycles' % (n, st[i + 1] - st[i]))
 print('total %d cycles (100 MHz clock64 ticks? see ratio below)' % (st[6] - st[0]))
+fw = list(buf)[8:14]
+for i, n in enumerate(['forward: load A / W', 'forward: pose blend (incl. feature staging)', 'forward: shape blend', 'forward: skinning', 'forward: extra-joint partials']):
+    print('%-46s %8d ticks' % (n, fw[i + 1] - fw[i]))
+print('forward total %d ticks' % (fw[5] - fw[0]))
+
