@@ -504,8 +504,8 @@ class Conv2dFunction(torch.autograd.Function):
             addend = None
             if ctx.link is not None and ctx.link.dres is not None:
                 addend, ctx.link.dres = ctx.link.dres, None
-            fused_add = addend is not None and addend.shape == x.shape and \
-                L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 2
+            fused_add = addend is not None and addend.shape == x.shape and bn_bwd is None and \
+                L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2)
             gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
                                None, bn_bwd, addend if fused_add else None)
             if addend is not None:

@@ -40,7 +40,7 @@ struct ConvP {
     // (norm_act.hip; LDS-tile 3x3 kernel only: one byte per lane instead of eight).
     int bn_gate;
     long x_bytes, y_bytes;   // extents of the gathered / written tensors (buffer resources of conv_fast.hip)
-    const bf16_t* addend;    // optional (LDS-tile 3x3 kernel only): bf16 tensor shaped like y, added before rounding
+    const bf16_t* addend;    // optional (3x3 LDS kernels and conv_fast.hip; bf16 outputs): bf16 tensor shaped like y, added before rounding
 };
 
 // conv_fast.hip: the lean kernel for the common cases (conv_igemm.hip keeps the general one)

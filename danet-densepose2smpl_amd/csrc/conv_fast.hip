@@ -329,8 +329,14 @@ __device__ __forceinline__ void conv_fast_body(const ConvP& p, const int bx_, co
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x4 v = acc[mt][nt] + bv;
-            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             const bool ok = cok && outoff[mt] != OOB;
+            if (p.addend) {               // (bf16 outputs only, checked by the host) the residual branch's gradient, added before rounding
+                const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.addend), 0, (int)p.y_bytes, 0x00020000);
+                const i32x2 aq = __builtin_amdgcn_raw_buffer_load_b64(ar, ok ? outoff[mt] + cl * 2 : OOB, 0, 0);
+                v[0] += __uint_as_float((unsigned)aq.x << 16); v[1] += __uint_as_float((unsigned)aq.x & 0xffff0000u);
+                v[2] += __uint_as_float((unsigned)aq.y << 16); v[3] += __uint_as_float((unsigned)aq.y & 0xffff0000u);
+            }
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             if (p.out_fp32) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, ok ? outoff[mt] + cl * 4 : OOB, 0, 0);
             } else {

@@ -650,7 +650,8 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     const bool c3 = conv3x3_ok(p, vec8);
     DANET_CHECK_ARG(bn_gate == 0 || (bn_red && c3 && bn_gate == 2 && bn_y),
                     "conv_forward: bn_gate %d: only 2 (byte mask in bn_y, LDS-tile 3x3 kernel) is defined", bn_gate);
-    DANET_CHECK_ARG(!addend || (c3 && !out_fp32), "conv_forward: the fused addend needs the LDS-tile 3x3 kernel and a bf16 output (check danet_conv_forward_kernel)");
+    DANET_CHECK_ARG(!addend || (!out_fp32 && (c3 || (conv_fast_ok(p, vec8, mt) && !p.stats && !p.bn_red))),
+                    "conv_forward: the fused addend needs a bf16 output and the 3x3 LDS kernels, or the lean gather kernel without fused statistics (check danet_conv_forward_kernel)");
     DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && (c3 || conv_fast_ok(p, vec8, mt))),
                     "conv_forward: the fused BatchNorm-backward reduction needs the fast kernel and a plain bf16 output (check danet_conv_forward_kernel)");
     const int nt = danet_conv_nt(p.Cout_g);

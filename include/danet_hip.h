@@ -190,7 +190,7 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      LDS-tile kernel (csrc/conv3x3.hip: halo tile staged once in LDS, taps = LDS address offsets, K-split across
  *      the waves of a workgroup for small-M layers); danet_conv_forward / danet_conv_forward_multi pick it by
  *      themselves, danet_conv_forward_kernel reports it (last digit 2).
- *      addend (optional, LDS-tile 3x3 kernel with bf16 output only): a bf16 tensor shaped like y that is added before the
+ *      addend (optional; bf16 outputs on the 3x3 LDS kernels, or on the lean gather kernel without fused statistics): a bf16 tensor shaped like y that is added before the
  *      result is rounded -- a data-gradient launch thereby accumulates the residual branch's gradient (the `out += residual`
  *      of res_module.py:39-56 in backward) instead of leaving the sum to a separate pass.
  *  danet_conv_forward       y = conv(x, wp) (+bias[Cout])(ReLU); y is bf16 or fp32 NHWC.

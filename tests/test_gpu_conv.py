@@ -343,3 +343,21 @@ def test_transpose_read_wgrad_3x3_stride2(B, H, W, Cin, Cout, groups):
     assert (gw_m - t).abs().max().item() <= 2e-4 * scale
     t1 = torch.nn.grad.conv2d_weight(x1.float(), (Cout, Cin // groups, 3, 3), gy.float(), stride=1, padding=1, groups=groups)
     assert (gw_1 - t1).abs().max().item() <= 2e-4 * t1.abs().max().item()
+
+
+def test_fused_addend_on_the_gather_kernel():
+    """The residual-branch gradient added in the data-gradient epilogue of a 1x1 convolution (conv_fast.hip; the Bottleneck
+    blocks' first convolution): y = conv(x) + addend, rounded once."""
+    from danet_densepose2smpl_amd import conv, _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    B, H, W, Cin, Cout = 4, 24, 20, 64, 256
+    gy = conv.nhwc_bf16(torch.randn(B, Cin, H, W, device='cuda'))                 # dgrad of a 256 -> 64 1x1 conv: gathers 64, produces 256
+    w = torch.nn.Parameter(torch.randn(Cin, Cout, 1, 1, device='cuda') * 0.1)
+    add = conv.nhwc_bf16(torch.randn(B, Cout, H, W, device='cuda'))
+    wp1 = conv.pack_weight(w, 1, 1)
+    assert L.danet_conv_forward_kernel(B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, 1, 0) % 10 == 1
+    y = conv._conv_fwd_raw(gy, wp1, None, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, True, False, False, None, None, add)
+    ref = torch.nn.functional.conv_transpose2d(gy.float(), w.detach().bfloat16().float(), None, 1, 0) + add.float()
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 8e-3
+

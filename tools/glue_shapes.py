@@ -1,5 +1,6 @@
-"""aten ops of one eager train step by (op, input shapes): which tensors the copy / fill / add launches touch."""
-import collections, os, sys
+"""aten ops of one eager train step by (op, input shapes) with their device time (torch.profiler, CPU + device activities): which
+tensors the copy / fill / add launches touch, forward and backward.  python tools/glue_shapes.py [rows]"""
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from danet_densepose2smpl_amd.config import cfg_from_dict, reset_cfg
@@ -12,15 +13,17 @@ for _ in range(3):
     tr.train_step(batch)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.train_step(batch)
     torch.cuda.synchronize()
-want = ('aten::copy_', 'aten::clone', 'aten::fill_', 'aten::zero_', 'aten::add', 'aten::add_', 'aten::mul', 'aten::sum', 'aten::constant_pad_nd', 'aten::slice_backward',
-        'aten::cat', 'aten::contiguous', 'aten::_to_copy', 'aten::zeros', 'aten::zeros_like', 'aten::index', 'aten::select_backward', 'aten::max_pool2d_with_indices_backward')
-agg = collections.Counter()
-for e in prof.events():
-    if e.name in want:
-        shp = str([tuple(s) for s in (e.input_shapes or []) if s][:2])
-        agg[(e.name, shp)] += 1
-for (n, s), c in agg.most_common(int(sys.argv[1]) if len(sys.argv) > 1 else 70):
-    print('%4d  %-26s %s' % (c, n, s[:110]))
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    dt = getattr(e, 'self_device_time_total', None)
+    if dt is None:
+        dt = getattr(e, 'self_cuda_time_total', 0)
+    if dt > 0 and e.key.startswith('aten::'):
+        rows.append((dt, e.count, e.key, str(e.input_shapes)[:100]))
+rows.sort(reverse=True)
+print('aten ops with device time: %.2f ms in %d calls' % (sum(r[0] for r in rows) / 1e3, sum(r[1] for r in rows)))
+for dt, n, k, sh in rows[:int(sys.argv[1]) if len(sys.argv) > 1 else 60]:
+    print('%8.1f us %4d  %-28s %s' % (dt, n, k, sh))
