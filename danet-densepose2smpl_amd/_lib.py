@@ -76,6 +76,8 @@ _SIGNATURES = {
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward_all': (c_i, [c_f, c_f] + [c_i] * 5 + [c_f] * 5),
+    'danet_maxpool3x3s2_forward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'danet_maxpool3x3s2_backward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
     'danet_stn_gather_backward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
     'danet_part_clean_forward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
@@ -100,7 +102,8 @@ _SIGNATURES = {
 
 # fp32 instantiations (csrc/norm_act_f32.hip, stn.hip): same arguments, fp32 NHWC activations
 for _n in ('danet_bn_forward', 'danet_bn_backward', 'danet_bn_forward_multi', 'danet_bn_backward_multi', 'danet_sum_relu_forward',
-           'danet_sum_relu_backward', 'danet_sum_relu_backward_all', 'danet_stn_gather_forward', 'danet_stn_gather_backward'):
+           'danet_sum_relu_backward', 'danet_sum_relu_backward_all', 'danet_stn_gather_forward', 'danet_stn_gather_backward',
+           'danet_maxpool3x3s2_forward', 'danet_maxpool3x3s2_backward'):
     _SIGNATURES[_n + '_f32'] = _SIGNATURES[_n]
 
 

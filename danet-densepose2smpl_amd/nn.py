@@ -474,6 +474,44 @@ def stn_gather(x, theta, out_hw=None, align_corners=True):
     return StnGatherFunction.apply(x, theta, out_hw, align_corners)
 
 
+class MaxPool3x3S2Function(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the regressor stems (res_module.py:303) on NHWC tensors
+    (csrc/pool.hip): the forward records each maximum's window position (one byte per element), the backward gathers."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        x = nhwc_act(x)
+        dt = x.dtype
+        B, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = _empty_nhwc(B, C, OH, OW, dt, x.device)
+        idx = torch.empty(B * OH * OW * C, dtype=torch.uint8, device=x.device)
+        check(_k(L, 'danet_maxpool3x3s2_forward', dt)(ptr(x.permute(0, 2, 3, 1)), ptr(y.permute(0, 2, 3, 1)), ptr(idx), B, H, W, C, stream()),
+              'danet_maxpool3x3s2_forward')
+        ctx.save_for_backward(idx)
+        ctx.cfg = (B, C, H, W, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (idx,) = ctx.saved_tensors
+        B, C, H, W, dt = ctx.cfg
+        gy = nhwc_as(gy, dt)
+        dx = _empty_nhwc(B, C, H, W, dt, gy.device)
+        check(_k(L, 'danet_maxpool3x3s2_backward', dt)(ptr(gy.permute(0, 2, 3, 1)), ptr(idx), ptr(dx.permute(0, 2, 3, 1)), B, H, W, C, stream()),
+              'danet_maxpool3x3s2_backward')
+        return dx
+
+
+def maxpool3x3s2(x):
+    """F.max_pool2d(x, 3, 2, 1) on the HIP kernel for device tensors whose channel count fits its 16-byte lanes."""
+    if x.is_cuda and x.dim() == 4 and x.shape[1] % (4 if _conv.PRECISION == 'fp32' else 8) == 0:
+        return MaxPool3x3S2Function.apply(x)
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
 def bump_batch_counters(module=None):
     """num_batches_tracked += 1 for every BatchNorm2d that ran in training mode since the last call (with
     BatchNorm2d.count_batches switched off), as ONE multi-tensor launch -- the modules torch would have counted

@@ -120,8 +120,8 @@ class IUV_predict_layer(nn.Module):
 
 
 def _maxpool3x3s2(x):
-    # TODO(next): HIP kernel; torch's channels_last bf16 max-pool is used for the two regressor stems
-    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    from .nn import maxpool3x3s2
+    return maxpool3x3s2(x)
 
 
 class PoseResNet(nn.Module):

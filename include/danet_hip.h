@@ -415,6 +415,16 @@ int danet_stn_gather_forward_f32(const void* x, const float* theta, int B, int H
 int danet_stn_gather_backward_f32(const void* dy, const float* theta, int B, int H, int W, int C, int P,
                                   int OH, int OW, int align_corners, void* dx, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * 3x3 / stride-2 / pad-1 max pooling of the regressor stems (/root/reference/models/module/res_module.py:303) on NHWC tensors.
+ *  forward: x [B,H,W,C] -> y [B,OH,OW,C], OH = (H - 1) / 2 + 1, and idx (B*OH*OW*C bytes): the position 0..8 of each maximum
+ *  in its window (first maximum in row-major scan order, NaN wins: torch's rule); backward: dx as a gather over the <= 4 windows
+ *  of an input pixel (deterministic).  bf16 (C % 8 == 0) and fp32 (_f32, C % 4 == 0). */
+int danet_maxpool3x3s2_forward(const void* x, void* y, void* idx, int B, int H, int W, int C, void* stream);
+int danet_maxpool3x3s2_backward(const void* gy, const void* idx, void* dx, int B, int H, int W, int C, void* stream);
+int danet_maxpool3x3s2_forward_f32(const void* x, void* y, void* idx, int B, int H, int W, int C, void* stream);
+int danet_maxpool3x3s2_backward_f32(const void* gy, const void* idx, void* dx, int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,3 +306,30 @@ def test_onepass_backward_matches_two_kernel_backward(C, H, B, use_res):
         if use_res:
             assert torch.equal(a[1], b[1])
         _close(a[2], b[2], 1e-5, 'dgamma'); _close(a[3], b[3], 1e-5, 'dbeta')
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 32, 32), (2, 16, 9, 7), (5, 8, 1, 6), (2, 128, 16, 16)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('mode', ['bf16', 'fp32'])
+def test_maxpool3x3s2_vs_torch(shape, mode):
+    """csrc/pool.hip against F.max_pool2d(3, 2, 1): outputs exact; gradients exact where the window maxima are unique, and with
+    ties (bf16 inputs drawn from few values) the FIRST maximum in scan order gets the gradient, as torch's kernel does on the
+    same tensor."""
+    import torch.nn.functional as F
+    from danet_densepose2smpl_amd import conv, nn as dnn
+    torch.manual_seed(4)
+    B, C, H, W = shape
+    x = (torch.randn(B, C, H, W, device='cuda') * 4).round() / 4            # few distinct values: plenty of ties
+    if mode == 'bf16':
+        x = x.bfloat16()
+    gy = torch.randn(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device='cuda').to(x.dtype)
+    xr = x.float().clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gr, = torch.autograd.grad(yr, xr, gy.float())
+    xo = x.clone().requires_grad_(True)
+    with conv.precision(mode):
+        y = dnn.maxpool3x3s2(xo)
+        g, = torch.autograd.grad(y, xo, gy)
+    assert y.dtype == x.dtype and torch.equal(y.float(), yr)
+    tol = 0.0 if mode == 'fp32' else 2e-2                                    # bf16: the <= 4 gradient terms of a pixel are summed in fp32 and rounded once
+    assert float((g.float() - gr).abs().max()) <= tol * float(gr.abs().max()) + 1e-12
+
