@@ -202,6 +202,33 @@ class BatchNorm2d(nn.BatchNorm2d):
                                           training, momentum, self.eps, relu, fused, link if training else None)
 
 
+def _bn_forward_padded(self, x, d, relu=False, res=None):
+    """BatchNorm2d on a tensor that carries d extra, exactly-zero channels behind this module's num_features (resnet.Bottleneck.
+    _forward_padded): gamma / beta are padded with zeros, so the extra channels come out as zeros again; the running statistics
+    live in padded storage of which `running_mean` / `running_var` are views (state_dict keeps the reference's shapes)."""
+    C = self.num_features
+    training = self.training or not self.track_running_stats
+    if training:
+        self._count()
+    rm = rv = None
+    if self.track_running_stats:
+        pad = getattr(self, '_stat_pad', None)
+        if pad is None or pad[0].shape[0] != C + d or pad[0].device != x.device or self.running_mean.data_ptr() != pad[0].data_ptr():
+            rm, rv = torch.zeros(C + d, device=x.device), torch.ones(C + d, device=x.device)
+            rm[:C].copy_(self.running_mean); rv[:C].copy_(self.running_var)
+            self._stat_pad = (rm, rv)
+            self._buffers['running_mean'], self._buffers['running_var'] = rm[:C], rv[:C]        # views: updated in place by the kernel
+        rm, rv = self._stat_pad
+    momentum = 0.1 if self.momentum is None else self.momentum
+    fused = getattr(x, '_bn_sums', None) if training else None
+    if training:
+        _conv.FUSION['bn_stats_fused' if fused is not None else 'bn_stats_own'] += 1
+    return BatchNormActFunction.apply(x, res, F.pad(self.weight, (0, d)), F.pad(self.bias, (0, d)), rm, rv, training, momentum, self.eps, relu, fused, None)
+
+
+BatchNorm2d.forward_padded = _bn_forward_padded
+
+
 class MultiBatchNormFunction(torch.autograd.Function):
     """n (<= 4) independent training-mode BatchNorm(+residual)(+ReLU) ops in ONE launch per pass
     (csrc/norm_act.hip bn_*_multi_kernel).  Tensor arguments: xs[n], ress[n] (None allowed), gammas[n], betas[n];

@@ -12,10 +12,13 @@ import torch.nn.functional as F
 
 from .config import cfg
 from .nn import Conv2d, BatchNorm2d, relu as relu_op
-from .conv import ResLink
+from . import conv as _conv
+from .conv import ResLink, conv2d
 from .deconv import ConvTranspose2d
 
 BN_MOMENTUM = 0.1
+import os as _os
+PAD_NARROW_BLOCKS = bool(int(_os.environ.get('DANET_PAD_NARROW_BLOCKS', '1')))      # A-B knob, see Bottleneck._forward_padded
 
 
 class ConvBN(nn.Module):
@@ -71,9 +74,29 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
+        if PAD_NARROW_BLOCKS and self.conv1.groups == 1 and self.conv1.out_channels % 8 != 0 and x.is_cuda and not _conv.fp32_mode():
+            return self._forward_padded(x, residual)
         out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         return self.bn3(self.conv3(out), res=residual, relu=True)
+
+    def _forward_padded(self, x, residual):
+        """A block whose inner width is no multiple of 8 (the heat-map head's Bottleneck(48, 12), res_module.py:364) at the
+        next multiple of 8 THROUGHOUT: the weights are zero-padded (tiny tensors), the extra channels stay exactly zero through
+        conv -> BatchNorm (gamma = beta = 0) -> ReLU -> conv, and the 4 MB activations are no longer padded before and sliced
+        after every convolution (~40 copy / fill launches per step).  Parameters and buffers keep the reference's shapes."""
+        P = self.conv1.out_channels
+        d = (-P) % 8
+        tr = self.training
+        w1 = F.pad(self.conv1.weight, (0, 0, 0, 0, 0, 0, 0, d))
+        out = conv2d(x, w1, None, 1, 0, 1, 1, want_stats=tr)
+        out = self.bn1.forward_padded(out, d, relu=True)
+        w2 = F.pad(self.conv2.weight, (0, 0, 0, 0, 0, d, 0, d))
+        out = conv2d(out, w2, None, self.conv2.stride[0], 1, 1, 1, want_stats=tr)
+        out = self.bn2.forward_padded(out, d, relu=True)
+        w3 = F.pad(self.conv3.weight, (0, 0, 0, 0, 0, d))
+        out = conv2d(out, w3, None, 1, 0, 1, 1, want_stats=tr)
+        return self.bn3(out, res=residual, relu=True)
 
 
 resnet_spec = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),

@@ -144,3 +144,39 @@ def test_gcn_vs_reference_module_golden():
     _close(x.grad, g, 'x_grad', 1e-3, 'gcn')
     for k, p in net.named_parameters():
         _close(p.grad, g, 'grad__' + k.replace('.', '__'), 1e-3, 'gcn')
+
+
+def test_narrow_bottleneck_padded_path_equals_plain_path():
+    """resnet.Bottleneck(48, 12) (the heat-map head, res_module.py:364): the block run at width 16 throughout (zero-padded weights,
+    BatchNorm with gamma = beta = 0 on the extra channels) == the same block with the activations padded and sliced around every
+    convolution: outputs, input / weight / BatchNorm gradients and running statistics; state-dict shapes unchanged."""
+    from danet_densepose2smpl_amd import resnet
+    torch.manual_seed(7)
+    blk = resnet.Bottleneck(48, 12).cuda().train()
+    ref = resnet.Bottleneck(48, 12).cuda().train()
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(4, 48, 24, 20, device='cuda')
+    gy = torch.randn(4, 48, 24, 20, device='cuda')
+    outs = []
+    for m, flag in ((blk, True), (ref, False)):
+        resnet.PAD_NARROW_BLOCKS = flag
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            y.backward(gy.to(y.dtype))
+        finally:
+            resnet.PAD_NARROW_BLOCKS = True
+        outs.append((y.float(), xi.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()}))
+    (y0, g0, p0, b0), (y1, g1, p1, b1) = outs
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+    assert rel(y0, y1) < 2e-2 and rel(g0, g1) < 4e-2
+    for k in p1:
+        assert p0[k].shape == p1[k].shape and rel(p0[k], p1[k]) < 5e-2, k
+    for k in b1:
+        assert b0[k].shape == b1[k].shape
+        if b1[k].dtype.is_floating_point:
+            assert rel(b0[k].float(), b1[k].float()) < 1e-2, k
+    assert blk.bn1.running_mean.shape == (12,) and blk.state_dict()['bn1.running_var'].shape == (12,)
+
