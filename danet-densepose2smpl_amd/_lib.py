@@ -66,6 +66,7 @@ _SIGNATURES = {
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),
+    'danet_channel_sum': (c_i, [c_f, ctypes.c_int64, c_i, c_f, c_f]),
     'danet_bn_set_block_bytes': (ctypes.c_long, [ctypes.c_long]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
@@ -103,7 +104,7 @@ _SIGNATURES = {
 # fp32 instantiations (csrc/norm_act_f32.hip, stn.hip): same arguments, fp32 NHWC activations
 for _n in ('danet_bn_forward', 'danet_bn_backward', 'danet_bn_forward_multi', 'danet_bn_backward_multi', 'danet_sum_relu_forward',
            'danet_sum_relu_backward', 'danet_sum_relu_backward_all', 'danet_stn_gather_forward', 'danet_stn_gather_backward',
-           'danet_maxpool3x3s2_forward', 'danet_maxpool3x3s2_backward'):
+           'danet_maxpool3x3s2_forward', 'danet_maxpool3x3s2_backward', 'danet_channel_sum'):
     _SIGNATURES[_n + '_f32'] = _SIGNATURES[_n]
 
 

@@ -515,8 +515,20 @@ class Conv2dFunction(torch.autograd.Function):
             if bn_bwd is not None:
                 gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32)      # fp32 accumulation without a converted copy of gy
+            gb = channel_sum(gy)
         return gx, gw, gb, None, None, None, None, None, None, None, None
+
+
+def channel_sum(gy):
+    """gy.sum(dim=(0, 2, 3)) in fp32 for an NHWC bf16 / fp32 tensor (bias gradients) on csrc/norm_act.hip channel_sum_kernel."""
+    B, C, H, W = gy.shape
+    if not gy.is_cuda or C % 4 != 0 or gy.dtype not in (torch.bfloat16, torch.float32) or not gy.permute(0, 2, 3, 1).is_contiguous():
+        return gy.sum(dim=(0, 2, 3), dtype=torch.float32)
+    out = torch.empty(C, dtype=torch.float32, device=gy.device)
+    L = _lib.lib()
+    fn = L.danet_channel_sum_f32 if gy.dtype == torch.float32 else L.danet_channel_sum
+    check(fn(ptr(gy.permute(0, 2, 3, 1)), B * H * W, C, ptr(out), stream()), 'danet_channel_sum')
+    return out
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches

@@ -201,6 +201,30 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict_
     block_channel_reduce(sm, q, t, fm.CV, fm.span, dst + Cst);
 }
 
+// per-channel sums of a [M, C] tensor (bias gradients): one atomic per channel and block into out[C] (fp32, zeroed by the host)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restrict__ x, FlatMap fm, float* __restrict__ out)
+{
+    __shared__ float sm[256][VW];
+    const int t = threadIdx.x;
+    Vec s;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) s.v[j] = 0.f;
+    if (t < fm.span) {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, fm.bytes);
+        int cv; RowIter it; it.init(fm, blockIdx.x, t, cv);
+        for (; it.more(); it.next()) {
+            Vec a[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) a[u] = ldv(xr, it.offset(u));              // (rows past the end load zeros)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int j = 0; j < VW; ++j) s.v[j] += a[u].v[j];
+        }
+    }
+    block_channel_reduce(sm, s, t, fm.CV, fm.span, out);
+}
+
 // mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
 __device__ __forceinline__ void bn_apply_body(
     const int bid, const elem_t* __restrict__ x, const elem_t* __restrict__ res, elem_t* __restrict__ y, const FlatMap& fm,
@@ -981,6 +1005,25 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
                            fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (elem_t*)dx, (elem_t*)dres,
                            dparam ? dparam + c0 : nullptr, mask_mode, (const unsigned char*)relu_mask, beta ? beta + c0 : nullptr);
         DANET_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    }
+    return DANET_OK;
+}
+
+// out[C] (fp32) = sum over the M rows of x [M, C] (the bias gradient of a convolution: gy.sum(dim = (0, 2, 3))); out is zeroed
+// here (memset node) and accumulated with one atomic per channel and workgroup.  C % 4 == 0, C <= 1024 per launch slab.
+extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, float* out, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && out && M > 0 && C > 0 && C % VW == 0, "channel_sum: bad arguments (C=%d must be a multiple of %d)", C, VW);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+    if (err != hipSuccess) return danet::fail(DANET_ERR_HIP, "channel_sum: memset: %s", hipGetErrorString(err));
+    for (int c0 = 0; c0 < C; c0 += SLAB) {
+        const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
+        FlatMap fm; int grid;
+        DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "channel_sum: C=%d (M=%ld) unsupported", C, (long)M);
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, out + c0);
+        DANET_CHECK_LAUNCH("channel_sum_kernel");
     }
     return DANET_OK;
 }

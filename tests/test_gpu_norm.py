@@ -333,3 +333,15 @@ def test_maxpool3x3s2_vs_torch(shape, mode):
     tol = 0.0 if mode == 'fp32' else 2e-2                                    # bf16: the <= 4 gradient terms of a pixel are summed in fp32 and rounded once
     assert float((g.float() - gr).abs().max()) <= tol * float(gr.abs().max()) + 1e-12
 
+
+@pytest.mark.parametrize('shape', [(32, 576, 16, 16), (3, 24, 9, 7), (2, 2048, 4, 4), (5, 32, 33, 17)], ids=lambda s: 'x'.join(map(str, s)))
+def test_channel_sum_vs_torch(shape):
+    """danet_channel_sum (bias gradients) == gy.sum(dim=(0, 2, 3)) in fp32, for bf16 and fp32 NHWC tensors."""
+    from danet_densepose2smpl_amd import conv
+    torch.manual_seed(5)
+    for dt in (torch.bfloat16, torch.float32):
+        gy = conv.nhwc_as(torch.randn(*shape, device='cuda'), dt)
+        ref = gy.float().sum(dim=(0, 2, 3))
+        got = conv.channel_sum(gy)
+        assert got.dtype == torch.float32 and float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-3
+
