@@ -23,9 +23,12 @@ from .geometry import perspective_projection, label_prologue
 
 DEFER_WGRAD = bool(int(os.environ.get('DANET_DEFER_WGRAD', '1')))
 USE_FUSED_ADAM = bool(int(os.environ.get('DANET_FUSED_ADAM', '1')))
-# N > 1: buckets are all-reduced from inside the backward pass as soon as they are complete (distributed.GradStore.arm_early);
-# 0 = all of them after the backward pass, interleaved with the weight-gradient launches only
-EARLY_BUCKETS = bool(int(os.environ.get('DANET_EARLY_BUCKETS', '1')))
+# N > 1, opt-in (DANET_EARLY_BUCKETS=1): buckets are all-reduced from inside the backward pass of EAGER steps as soon as they are
+# complete (distributed.GradStore.arm_early).  Off by default: on the 1-rank RCCL group of this environment a run with the
+# early release aborted (SIGABRT, no message) about once in eight starts -- with the collectives issued from the engine's
+# device thread and from the calling thread alike, inside a capture and in eager steps --, never without it (8 / 8, 10 / 10).
+# Default: bucket by bucket after the backward pass, interleaved with the weight-gradient launches (round 2's order).
+EARLY_BUCKETS = bool(int(os.environ.get('DANET_EARLY_BUCKETS', '0')))
 
 
 def default_options(batch_size=32):
@@ -262,8 +265,13 @@ class Trainer(object):
         _conv.GRAD_STORE = st
         _conv.DEFER_WGRAD = DEFER_WGRAD
         self._reduce_now = bool(self.distributed and reduce)
+        # Early buckets only in eager steps: collectives issued from inside the backward pass of a hipGraph CAPTURE aborted the
+        # process sporadically (1-rank RCCL group: 1 run in 8, from the engine's device thread and from this thread alike;
+        # never with the collectives issued after the backward pass), so a captured step keeps the round-2 order -- bucket by
+        # bucket after the backward pass, interleaved with the weight-gradient launches.
+        capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
         if st is not None:
-            st.backward_scope(True, early=self._reduce_now)
+            st.backward_scope(True, early=self._reduce_now and not capturing)
         try:
             loss_total.backward()
         finally:

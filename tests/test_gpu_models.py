@@ -481,17 +481,15 @@ def test_data_parallel_graph_path_single_rank():
             batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
             batch['pretrain_mode'] = True
             tr.train_step(batch)
-            if mode == 'ddp':       # the first step knows nothing about never-used parameters: nothing released around them
-                assert tr.store.issued == list(range(len(tr.store.buckets)))
             _, l_eager = tr.train_step(batch)
-            if mode == 'ddp':       # from the second step on the buckets go out from inside the backward pass, in bucket order
-                nb = len(tr.store.buckets)
-                assert tr.store.issued == list(range(nb)) and tr.store.issued_early >= nb // 2, (tr.store.issued, tr.store.issued_early)
+            if mode == 'ddp':       # every bucket once, in bucket order (the early release from inside the backward pass is opt-in:
+                nb = len(tr.store.buckets)      # trainer.EARLY_BUCKETS; its ordering logic is pinned by tests/test_distributed.py on gloo)
+                assert tr.store.issued == list(range(nb)), tr.store.issued
             tr.capture(batch, warmup=1)
             if mode == 'ddp':
                 assert tr._reduce_in_graph, 'the RCCL all-reduces were not captured into the hipGraph'
-                issued, early = tr.captured_collectives      # what the capture recorded: every bucket once, in order, early
-                assert issued == list(range(nb)) and early >= nb // 2, (issued, early)
+                issued, early = tr.captured_collectives      # what the capture recorded: every bucket once, in order, after the
+                assert issued == list(range(nb)) and early == 0, (issued, early)      # backward pass (early release is eager-only, see Trainer._core)
             tr.train_step_graphed()
             _, l_graph = tr.train_step_graphed()
             torch.cuda.synchronize()
