@@ -437,7 +437,13 @@ def test_lockstep_branches_match_per_branch_execution(lds_tile):
 
 def test_graphed_full_step_losses_match_eager():
     """The full model (regressor included) through hipGraph replay: every loss term equals the eager step's
-    (learning rate ~0; gradients of this path are not compared at test batch sizes, see the test above)."""
+    (learning rate ~0; gradients of this path are not compared at test batch sizes, see the test above).
+    BatchNorm sums in fixed order: see _fixed_order_bn."""
+    with _fixed_order_bn():
+        _graphed_full_step_losses_match_eager()
+
+
+def _graphed_full_step_losses_match_eager():
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
     from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
