@@ -148,3 +148,27 @@ def test_two_rank_gradient_average_matches_single_process(tmp_path):
             assert torch.allclose(e0['grads'][k], mean, atol=tol * float(mean.abs().max() + 1e-6) if wire == 'bf16' else tol), (wire, k)
             assert torch.equal(e0['grads'][k], e1['grads'][k]), (wire, k)
 
+
+def test_grad_store_usage_mask_and_single_handout():
+    """GradStore on CPU tensors (no process group): `used` marks the parameters that received a gradient in the last backward
+    pass (the optimizer skips the others, optim.FusedAdam), `take` hands a parameter's slot out once per step (shared weights)."""
+    sys.path.insert(0, ROOT)
+    from danet_densepose2smpl_amd.distributed import GradStore
+    net = _Net()
+    st = GradStore(net.parameters(), device=torch.device('cpu'), world=1)
+    names = {id(p): k for k, p in net.named_parameters()}
+    for step in range(2):
+        net.zero_grad(set_to_none=True)
+        st.begin_step()
+        st.backward_scope(True, early=False)
+        net(torch.randn(6, 8)).pow(2).mean().backward()
+        st.backward_scope(False)
+        used = {names[id(p)]: int(st.used[st.index_of(p)]) for p in st.params}
+        assert used['unused.weight'] == 0 and used['unused.bias'] == 0
+        assert all(v == 1 for k, v in used.items() if not k.startswith('unused')), used
+        w = net.a.weight
+        v = st.take(w)
+        assert v is not None and v.data_ptr() == st.grad_ptr(w) and st.take(w) is None      # the second request of a step gets no slot
+    st.begin_step()
+    assert st.take(net.a.weight) is not None                                              # ... a new step does
+
