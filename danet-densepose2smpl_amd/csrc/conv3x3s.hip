@@ -49,6 +49,10 @@ constexpr int S3_FIXED = S3_SCR + 1536;
 constexpr int S3_LDS = 81920;                     // two workgroups per CU
 constexpr int S3_BUF = (S3_LDS - S3_FIXED) / 2;   // one ring slot: 37.5 KB
 constexpr int S3_D = 5;                           // weight-fragment ring: k-steps in flight
+#ifndef DANET_S3_PLAIN_EPI
+#define DANET_S3_PLAIN_EPI 1
+#endif
+constexpr bool S3_PLAIN_EPI = DANET_S3_PLAIN_EPI != 0;      // specialised epilogue for the option-free case (build knob)
 #ifndef DANET_S3_WRAP
 #define DANET_S3_WRAP 0
 #endif
@@ -345,7 +349,9 @@ __device__ inline void issue_pos(int nprob, int rot, const Pos& q, unsigned char
 }
 
 // ---- a tile's end: K-split exchange, epilogue, statistics ---------------------------------------------------------------
-template <int NT, int KW>
+// PLAIN: no bias, addend, ReLU, fp32 output or idle lanes -- the common case (every BasicBlock convolution), instantiated without the
+// per-value tests of those options (12 accumulator tiles x 5 uniform branches per tile otherwise).
+template <int NT, int KW, bool PLAIN>
 __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], float (*s1)[4], float (*s2)[4], const int* outoff, unsigned char* sR,
                                           float* sScr, int img0, int y0, int n0, bool flush, int bid, int* dbg_stamp)
 {
@@ -355,7 +361,9 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
     const int li = lane & 15, lg = lane >> 4;
     const int pw = wave % PW, kw = wave / PW;
     const int H = p.H, W = p.W;
-    const int osz = p.out_fp32 ? 4 : 2;
+    const bool has_bias = PLAIN ? false : p.bias != nullptr, has_add = PLAIN ? false : p.addend != nullptr;
+    const bool relu = PLAIN ? false : (bool)p.relu, out_fp32 = PLAIN ? false : (bool)p.out_fp32, has_idle = PLAIN ? false : (bool)p.has_idle;
+    const int osz = out_fp32 ? 4 : 2;
     // ---- K-split: partial sums meet in the consumed slot; wave kw finishes accumulator tiles [kw*MO, (kw+1)*MO) ----------
     if constexpr (KW > 1) {
         lds_barrier();                                          // every wave is done reading the tile
@@ -403,7 +411,7 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                 const bool cok = cl < p.Cout;
                 const int so = tile_out + (n0 + nt * 16) * osz;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
+                if (has_bias) {
                     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.Cout * 4, 0x00020000);
                     bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(br, cok ? cl * 4 : OOB, 0, 0));
                 }
@@ -412,21 +420,21 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                     const int mt = qq * MO + m;
                     const int off = (cok && outoff[mt] != OOB) ? outoff[mt] : OOB;
                     f32x4 v = acc[mt][nt];
-                    if (p.bias) v += bv;
-                    if (p.addend) {
+                    if (has_bias) v += bv;
+                    if (has_add) {
                         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.addend), 0, p.y_bytes, 0x00020000);
                         const i32x2 aq = __builtin_amdgcn_raw_buffer_load_b64(ar, off, so, 0);
                         v[0] += __uint_as_float((unsigned)aq.x << 16); v[1] += __uint_as_float((unsigned)aq.x & 0xffff0000u);
                         v[2] += __uint_as_float((unsigned)aq.y << 16); v[3] += __uint_as_float((unsigned)aq.y & 0xffff0000u);
                     }
-                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    if (p.out_fp32) {
+                    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (out_fp32) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, off, so, 0);
                     } else {
                         const i32x2 pk = {(int)f2bf_pk(v[0], v[1]), (int)f2bf_pk(v[2], v[3])};
                         __builtin_amdgcn_raw_buffer_store_b64(pk, yr, off, so, 0);
                         if (p.stats) {           // BatchNorm statistics from the fp32 accumulators (see conv3x3.hip), two values per instruction
-                            if (p.has_idle) { const float msk = off != OOB ? 1.f : 0.f; v *= msk; }
+                            if (has_idle) { const float msk = off != OOB ? 1.f : 0.f; v *= msk; }
                             f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
                             f32x2_& a0 = *reinterpret_cast<f32x2_*>(&s1[nt][0]); f32x2_& a1 = *reinterpret_cast<f32x2_*>(&s1[nt][2]);
                             f32x2_& q0 = *reinterpret_cast<f32x2_*>(&s2[nt][0]); f32x2_& q1 = *reinterpret_cast<f32x2_*>(&s2[nt][2]);
@@ -657,10 +665,18 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         if (stamp) stamp[3] = (int)clock64();
         unsigned char* const sR = ring + (g & 1) * S3_BUF;
         const bool flush = flush_after(p, tau, nblk);
-        switch (KW) {
-            case 1: s3_finish<NT, 1>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
-            case 2: s3_finish<NT, 2>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
-            default: s3_finish<NT, 4>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+        if (S3_PLAIN_EPI && !p.bias && !p.addend && !p.relu && !p.out_fp32 && !p.has_idle) {
+            switch (KW) {
+                case 1: s3_finish<NT, 1, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+                case 2: s3_finish<NT, 2, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+                default: s3_finish<NT, 4, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+            }
+        } else {
+            switch (KW) {
+                case 1: s3_finish<NT, 1, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+                case 2: s3_finish<NT, 2, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+                default: s3_finish<NT, 4, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+            }
         }
         lds_barrier();                                              // the last stage's slot is consumed
         if (stamp) stamp[6] = (int)clock64();
