@@ -48,7 +48,7 @@ constexpr int S3_SCR = 2 * S3_TABB;               // statistics scratch behind t
 constexpr int S3_FIXED = S3_SCR + 1536;
 constexpr int S3_LDS = 81920;                     // two workgroups per CU
 constexpr int S3_BUF = (S3_LDS - S3_FIXED) / 2;   // one ring slot: 37.5 KB
-constexpr int S3_D = 5;                           // weight-fragment ring: k-steps in flight
+constexpr int S3_D = 4;                           // weight-fragment ring: k-steps in flight (even: ring slot d uses pixel-fragment buffer d & 1)
 #ifndef DANET_S3_PLAIN_EPI
 #define DANET_S3_PLAIN_EPI 1
 #endif
@@ -78,6 +78,11 @@ __host__ __device__ inline int st_nc(const S3Prob& p, int s) { return (int)((p.s
 __host__ __device__ inline int st_end(const S3Prob& p, int s) { return (int)((p.st_j0w >> (8 * s)) & 255u); }
 __host__ __device__ inline int st_begin(const S3Prob& p, int s) { return s == 0 ? 0 : st_end(p, s - 1); }
 static_assert(S3_TAB < 256 && sizeof(S3Prob) % 4 == 0, "S3Prob");
+// The debug stamps are GLOBAL-address-space stores: through a generic pointer they are FLAT instructions, and a pending FLAT access
+// makes the compiler's waitcnt pass force lgkmcnt(0) at every LDS dependency for the rest of the kernel (it never sees a vmcnt
+// wait here -- those are hand-counted inline asm -- so the FLAT access stays "pending" for it): the pixel-fragment prefetch of the
+// k-loop was serialised by exactly that.
+typedef __attribute__((address_space(1))) int* dbg_ptr;
 struct S3Launch { S3Prob p[S3_MAXP]; int n; int total; int* dbg; };     // dbg: optional [blocks][16] timestamps (tools/c3s_diag.py)
 
 // The kernel argument is indexed with run-time problem numbers.  Done on the by-value argument the compiler copies the
@@ -353,7 +358,7 @@ __device__ inline void issue_pos(int nprob, int rot, const Pos& q, unsigned char
 // per-value tests of those options (12 accumulator tiles x 5 uniform branches per tile otherwise).
 template <int NT, int KW, bool PLAIN>
 __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], float (*s1)[4], float (*s2)[4], const int* outoff, unsigned char* sR,
-                                          float* sScr, int img0, int y0, int n0, bool flush, int bid, int* dbg_stamp)
+                                          float* sScr, int img0, int y0, int n0, bool flush, int bid, dbg_ptr dbg_stamp)
 {
     constexpr int MT = 4, PW = 4 / KW, MO = MT / KW;
     const int t = threadIdx.x, lane = t & 63;
@@ -462,7 +467,10 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
             const int which = t / (NT * 16), c = t - which * (NT * 16);
             const float v = (sScr[(0 * 2 + which) * (NT * 16) + c] + sScr[(1 * 2 + which) * (NT * 16) + c]) +
                             (sScr[(2 * 2 + which) * (NT * 16) + c] + sScr[(3 * 2 + which) * (NT * 16) + c]);
-            if (n0 + c < p.Cout) atomicAdd(p.stats + ((size_t)(bid % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + n0 + c, v);
+            // (a GLOBAL atomic: see dbg_ptr -- a FLAT one would serialise every later LDS wait of the kernel)
+            if (n0 + c < p.Cout)
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(p.stats + ((size_t)(bid % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + n0 + c), v,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -473,7 +481,7 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
 // later has been requested.
 template <int NT>
 __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const int rot, const int bid, const int nblk, int& g, const int np,
-                                           unsigned char* smem, int* dbg)
+                                           unsigned char* smem, dbg_ptr dbg, int (&dsum)[3])
 {
     constexpr int MT = 4, D = S3_D;
     const S3Prob p = desc_prob(wrap_idx(ii + rot, nprob));
@@ -484,6 +492,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
     const int PW = 4 >> lkw;
     const int pw = wave & (PW - 1), kw = wave >> (2 - lkw);
     const i32x4* const sTab = reinterpret_cast<const i32x4*>(smem + ((np - 1) & 1) * S3_TABB);
+    const unsigned char* const tabB = reinterpret_cast<const unsigned char*>(sTab) + ((threadIdx.x & 32) ? 4 : 0);     // a lane's LDS-offset word of an entry
     float* const sScr = reinterpret_cast<float*>(smem + S3_SCR);
     unsigned char* const ring = smem + S3_FIXED;
     const int Wp = p.Wp, Sp = p.Sp, W = p.W, H = p.H, TH = p.TH, NI = p.NI, nst = p.nst;
@@ -534,8 +543,10 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
     // wrap-around links and fetch the FIRST D k-steps of the next tile (same weights whenever the workgroup's next tile has the
     // same channel block -- always for the grids used: the tile stride is a multiple of the channel-block count), so that tile
     // starts with its fragments already in flight behind the previous epilogue instead of waiting ~2.7 k cycles for a refill.
+    static_assert(D % 2 == 0, "ring slot d pairs with pixel-fragment buffer d & 1");
     bf16x8 A[D][NT];
-    i32x4 qn{};
+    bf16x8 Bq[2][MT];
+    i32x2 qn{};                                       // {z, w} of the table entry of the next refill
     int r0 = 0;                                       // ring slot of the next k-step
     bool primed = false;                              // the ring already holds (or is fetching) this tile's first k-steps
     for (; cur.ii == ii && cur.valid;) {
@@ -574,7 +585,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             i32x4 q[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) q[d] = sTab[jb0 + d];
-            qn = sTab[jb0 + D];
+            qn = i32x2{sTab[jb0 + D].z, sTab[jb0 + D].w};
 #pragma unroll
             for (int d = 0; d < D; ++d) load_a(wlane + q[d].z, A[d]);
         } else {
@@ -586,7 +597,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
                 load_a(wlane + q.z, A[d]);
                 pj = __builtin_amdgcn_readfirstlane(q.w);
             }
-            qn = sTab[pj];
+            qn = i32x2{sTab[pj].z, sTab[pj].w};
         }
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -598,48 +609,87 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         for (int s = 0; s < nst; ++s) {
             // the stage after this one starts travelling into the slot the last barrier freed (after the ring's own loads
             // of this point: see the header)
+            const int tq0 = dbg ? (int)clock64() : 0;      // (debug launches only: per-workgroup sums over ALL stages -- copy issue, k-steps, tile end)
             const Pos nxt = pos_next(nprob, bid, nblk, rot, cur);
             issue_pos(nprob, rot, nxt, smem, ring + ((g + 1) & 1) * S3_BUF, np, wave, lane);
             if (dbg && t == 0 && g == 0) dbg[2] = (int)clock64();
+            const int tq1 = dbg ? (int)clock64() : 0;
             const unsigned char* const sX = ring + (g & 1) * S3_BUF;
             int j, je;
             range_of(s, kw, j, je);
             const int nsteps = je - j;
-            i32x4 e = sTab[min(j, p.nent - 1)];
-            // one k-step on ring slot `a`: MT pixel fragments from the LDS tile, MT * NT MFMAs, the slot refilled
-            auto kstep = [&](const int jj, bf16x8* a) {
-                const int koff = lg >= 2 ? e.y : e.x;
-                bf16x8 b[MT];
+            // Pixel fragments are double-buffered in registers: k-step jj issues the LDS reads of k-step jj + 1 BEFORE its own MFMAs
+            // (a wave alone on its SIMD measured ~590 cycles per k-step against 192 of MFMA work: the ds_read latency of every
+            // k-step sat in front of its MFMAs).  Ring slot d pairs with buffer d & 1 (D is even), so all indices stay static.
+            // The first k-step of a stage reads its fragments unpipelined (the slot was published by the last barrier); the
+            // last one pre-reads a clamped entry nobody uses.
+            // Table reads are slim and come FIRST in a k-step (a lane reads the one LDS offset it needs: .x for lanes 0-31, .y for
+            // 32-63; the refill entry only its {z, w} half): LDS returns in order, so the MFMAs' wait for the current fragments
+            // and the next k-step's wait for its table words both leave the four younger fragment reads in flight.
+            int ek = *reinterpret_cast<const int*>(tabB + min(j, p.nent - 1) * 16);
+            {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const bf16x8*>(sX + lanebase[mt] + koff);
-                e = sTab[min(jj + 1, je - 1)];
-                const int voffn = wlane + qn.z;
-                qn = sTab[__builtin_amdgcn_readfirstlane(qn.w)];
+                for (int mt = 0; mt < MT; ++mt) { Bq[0][mt] = *reinterpret_cast<const bf16x8*>(sX + lanebase[mt] + ek); Bq[1][mt] = Bq[0][mt]; }
+                ek = *reinterpret_cast<const int*>(tabB + min(j + 1, max(je - 1, 0)) * 16);
+            }
+            // One k-step on ring slot `a`: MT * NT MFMAs with everything else of the k-step slotted BETWEEN them, one small group
+            // per MFMA (sched_barrier(0) pins the order).  A wave issues in order: with the ~28 other instructions of a k-step
+            // in front of its MFMA block a wave alone on its SIMD needed ~500 cycles per k-step for 192 cycles of MFMA work;
+            // behind an MFMA (4 cycles to issue, 16 in the pipe) three more instructions issue for free.  Slots, by MFMA index
+            // i = nt * MT + mt: i < MT: the NEXT k-step's pixel fragment i (LDS); after the last MFMA that reads a[nt]: that
+            // fragment's refill; i = MT, MT + 1 (NT = 1: MT - 1): the table words of the k-step after the next.
+            auto kstep = [&](const int jj, bf16x8* a, const bf16x8* bc, bf16x8* bn) {
+                const int koff = ek;
+                int voffn = 0;
+                auto table_next = [&](int part) {
+#if defined(DANET_S3_X_NOT)               // (timing experiment: no table reads)
+                    if (part == 0) voffn = wlane + qn.x;
+                    return;
+#endif
+                    if (part == 0) {
+                        voffn = wlane + qn.x;
+                        qn = *reinterpret_cast<const i32x2*>(reinterpret_cast<const unsigned char*>(sTab) + __builtin_amdgcn_readfirstlane(qn.y) * 16 + 8);
+                    } else {
+                        ek = *reinterpret_cast<const int*>(tabB + min(jj + 2, je - 1) * 16);
+                    }
+                };
                 ring_wait(a);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], b[mt], acc[mt][nt], 0, 0, 0);
-                load_a(voffn, a);
-                __builtin_amdgcn_sched_barrier(0);          // k-steps stay in order: every slot's loads are D k-steps ahead of their use
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bc[mt], acc[mt][nt], 0, 0, 0);
+#if !defined(DANET_S3_X_NOB)
+                        if (nt == 0) bn[mt] = *reinterpret_cast<const bf16x8*>(sX + lanebase[mt] + koff);
+#endif
+                        if (nt == 0 && mt == MT - 1) table_next(0);
+                        if (NT == 1 ? (mt == MT - 1) : (nt == 1 && mt == 0)) table_next(1);
+#if defined(DANET_S3_X_NOA)              // (timing experiment: no refill; the wait count of ring_wait is then trivially met)
+                        if (mt == MT - 1) asm volatile("" : "+v"(a[nt]) : "v"(voffn));
+#else
+                        if (mt == MT - 1)
+                            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a[nt]) : "v"(voffn), "s"(wdesc), "s"(wso[nt]) : "memory");
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
             };
             // head: up to D - 1 k-steps that bring the ring back to slot 0; groups of D without any condition inside; tail
 #pragma unroll
             for (int d = 1; d < D; ++d)
-                if (r0 == d && j < je) { kstep(j, A[d]); ++j; r0 = (d + 1) % D; }
+                if (r0 == d && j < je) { kstep(j, A[d], Bq[d & 1], Bq[(d + 1) & 1]); ++j; r0 = (d + 1) % D; }
             if (r0 == 0) {
                 for (; j + D <= je; j += D) {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) kstep(j + d, A[d]);
+                    for (int d = 0; d < D; ++d) kstep(j + d, A[d], Bq[d & 1], Bq[(d + 1) & 1]);
                 }
 #pragma unroll
                 for (int d = 0; d < D - 1; ++d)
-                    if (r0 == d && j < je) { kstep(j, A[d]); ++j; r0 = d + 1; }
+                    if (r0 == d && j < je) { kstep(j, A[d], Bq[d & 1], Bq[(d + 1) & 1]); ++j; r0 = d + 1; }
             }
             cur = nxt;
             // the copies requested at this stage's start are older than the refills of its k-steps: D - 1 k-steps later a
             // ring_wait has covered them; a shorter stage waits explicitly
+            if (dbg) { const int tq2 = (int)clock64(); dsum[0] += tq1 - tq0; dsum[1] += tq2 - tq1; }
             if (nsteps < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s + 1 < nst) { lds_barrier(); ++g; }          // slot consumed; the next stage's slot is complete
         }
@@ -661,8 +711,9 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
                 if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]));
             }
         }
-        int* const stamp = (dbg && t == 0 && g + 1 == nst) ? dbg : nullptr;       // the workgroup's first tile
+        const dbg_ptr stamp = (dbg && t == 0 && g + 1 == nst) ? dbg : nullptr;       // the workgroup's first tile
         if (stamp) stamp[3] = (int)clock64();
+        const int tq3 = dbg ? (int)clock64() : 0;
         unsigned char* const sR = ring + (g & 1) * S3_BUF;
         const bool flush = flush_after(p, tau, nblk);
         if (S3_PLAIN_EPI && !p.bias && !p.addend && !p.relu && !p.out_fp32 && !p.has_idle) {
@@ -680,6 +731,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         }
         lds_barrier();                                              // the last stage's slot is consumed
         if (stamp) stamp[6] = (int)clock64();
+        if (dbg) dsum[2] += (int)clock64() - tq3;
         ++g;
     }
 }
@@ -695,7 +747,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch 
     const int rot = __builtin_amdgcn_readfirstlane((int)(rv - (unsigned)nprob * udiv24(rv, (unsigned)nprob, 1.0f / (float)nprob)));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int* const dbg0 = s3_args()->dbg;
-    int* const dbg = dbg0 ? dbg0 + bid * 16 : nullptr;
+    const dbg_ptr dbg = dbg0 ? (dbg_ptr)(dbg0 + bid * 16) : nullptr;
     if (dbg && threadIdx.x == 0) {
         dbg[0] = (int)clock64();
         dbg[15] = (int)((__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xff00u) | ((__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 16));   // CU: HW_ID cu / sh / se, XCC_ID
@@ -708,13 +760,14 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch 
     lds_barrier();                                                                  // ... published
     if (dbg && threadIdx.x == 0) dbg[10] = (int)clock64();
     int g = 0, np = 0;
+    int dsum[3] = {0, 0, 0};
     for (int ii = first.ii; ii < nprob; ++ii) {
         const int idx = wrap_idx(ii + rot, nprob);
         if (first_tile_of(S3_FIELD(idx, tile0m), bid, nblk) >= S3_FIELD(idx, ntiles)) continue;
         ++np;
-        s3_problem<NT>(nprob, ii, rot, bid, nblk, g, np, s3_smem, dbg);
+        s3_problem<NT>(nprob, ii, rot, bid, nblk, g, np, s3_smem, dbg, dsum);
     }
-    if (dbg && threadIdx.x == 0) dbg[7] = (int)clock64();
+    if (dbg && threadIdx.x == 0) { dbg[7] = (int)clock64(); dbg[1] = dsum[0]; dbg[13] = dsum[1]; dbg[14] = dsum[2]; }
 }
 
 bool g_s3_on = getenv("DANET_NO_C3_STREAM") == nullptr;

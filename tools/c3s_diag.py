@@ -98,9 +98,52 @@ def multi_subsets():
             print(json.dumps({'multi_subset': [chans[i] for i in sub], 'plans': plans, 'err': errs}), flush=True)
 
 
+
+def multi_phases():
+    """Workgroup timelines of the four-branch launch: start / end stamps of every workgroup, phases of its first tile."""
+    import ctypes
+    L = _lib.lib()
+    chans, sizes = (48, 96, 192, 384), (64, 32, 16, 8)
+    B = 32
+    xs = [conv.nhwc_bf16(torch.randn(B, c, s, s, device='cuda')) for c, s in zip(chans, sizes)]
+    wps = [conv.pack_weight(torch.nn.Parameter(torch.randn(c, c, 3, 3, device='cuda') * 0.05), 1, 0) for c in chans]
+    ys = [torch.empty_like(x) for x in xs]
+    jobs = (_lib.ConvJob * 4)()
+    for j, x, wp, y, c, s in zip(jobs, xs, wps, ys, chans, sizes):
+        conv._conv_job(j, x, wp, y, (B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1), False, None)
+    L.danet_conv3x3_set(1, 0, 0, 512, 0)
+    L.danet_conv3x3_stream_set(1, 512, -1, 0)
+
+    def multi():
+        conv.check(L.danet_conv_forward_multi(ctypes.addressof(jobs), 4, _lib.stream()), 'multi')
+    for _ in range(3):
+        multi()
+    nb = 1024
+    dbg = torch.zeros(nb * 16, dtype=torch.int32, device='cuda')
+    L.danet_conv3x3_debug(dbg.data_ptr())
+    multi()
+    torch.cuda.synchronize()
+    L.danet_conv3x3_debug(None)
+    d = dbg.view(nb, 16).cpu().numpy().astype('int64')
+    d = d[d[:, 0] != 0]
+    t0 = d[:, 0].min()
+    start = (d[:, 0] - t0) & 0xffffffff
+    end = (d[:, 7] - t0) & 0xffffffff
+
+    def q(a):
+        return [int(v) for v in np.percentile(a, [0, 10, 50, 90, 100])]
+
+    def ph(a, b):
+        return q((d[:, b] - d[:, a]) & 0xffffffff)
+    print(json.dumps({'multi4_wgs': int(d.shape[0]), 'life': q(end - start), 'sum_issue': q(d[:, 1]), 'sum_ksteps': q(d[:, 13]), 'sum_tile_end': q(d[:, 14]),
+                      'first_tile': {'issue0': ph(0, 9), 'wait0': ph(9, 10), 'desc+lanebase+fill': ph(10, 12), 'issue1': ph(12, 2), 'kloop': ph(2, 3),
+                                     'ksplit': ph(3, 4), 'epilogue': ph(4, 5), 'flush+bar': ph(5, 6)}, 'us': round(timeit(multi) * 1e6, 2)}), flush=True)
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'multi':
         multi_subsets()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'phases':
+        multi_phases()
     else:
         main()
         multi_subsets()
