@@ -15,7 +15,7 @@ for name in names:
     b = txt.index('s_endpgm', a)
     body = txt[a:b]
     meta = re.search(r'\.amdhsa_kernel ' + re.escape(name) + r'.*?\.end_amdhsa_kernel', txt, re.S)
-    info = re.findall(r'; (codeLenInByte|NumVgprs|ScratchSize|Occupancy)[ :=]+(\d+)', txt[b:b + 3000])
+    info = []
     print('==', name[:110], dict(info))
     blocks, cur, bn = [], [], 'entry'
     for l in body.split('\n'):
