@@ -541,6 +541,79 @@ def g14_augment():
 ALL.update({'g14': g14_augment, 'g13': g13_eval_metrics, 'g12': g12_label_prologue, 'g6': g6_backbones, 'g7': g7_estimator, 'g9': g9_predictor, 'g10': g10_losses, 'g11': g11_dp_losses})
 
 
+def g15_dp_producer():
+    """DensePose-COCO dp_dict producer (utils/dp_utils.py:12-140) and the mirror-symmetry labels
+    (utils/densepose_methods.py:31-59), run on SYNTHETIC symmetry tables and annotations.  The reference module needs three
+    things this image lacks: the licensed UV_*.mat tables (written here as synthetic .mat files into a scratch directory the
+    reference loads them from), pycocotools' mask decode and cv2.remap (both third-party; this repo's restatements
+    dp_utils.rle_decode / remap_nearest are plugged in for them) -- so the fixture pins the reference's own arithmetic around
+    those two primitives, not the primitives."""
+    import tempfile
+    from scipy.io import savemat
+    ref_env()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from danet_densepose2smpl_amd import dp_utils as ours
+    rng = np.random.default_rng(15)
+    u_tab, v_tab = ours.synthetic_symmetry_tables()      # closed-form lookup images: the test re-creates them
+    obj = lambda t: np.array([[t[i] for i in range(24)]], dtype=object)
+    scratch = tempfile.mkdtemp()
+    os.makedirs(os.path.join(scratch, 'data/UV_data'))
+    savemat(os.path.join(scratch, 'data/UV_data/UV_symmetry_transforms.mat'), {'U_transforms': obj(u_tab), 'V_transforms': obj(v_tab)})
+    savemat(os.path.join(scratch, 'data/UV_data/UV_Processed.mat'),
+            {'All_FaceIndices': np.zeros((4, 1)), 'All_Faces': np.ones((4, 3)), 'All_U_norm': np.zeros((6, 1)), 'All_V_norm': np.zeros((6, 1)),
+             'All_vertices': np.zeros((1, 6))})
+    cv2 = sys.modules['cv2']
+    cv2.INTER_NEAREST, cv2.BORDER_CONSTANT = 0, 0
+    cv2.remap = lambda img, mx, my, interpolation=None, borderMode=None, borderValue=None: ours.remap_nearest(img, mx, my)
+    pm = types.ModuleType('pycocotools')
+    pmm = types.ModuleType('pycocotools.mask')
+    pmm.decode = ours.rle_decode
+    pm.mask = pmm
+    sys.modules.update({'pycocotools': pm, 'pycocotools.mask': pmm})
+    os.chdir(scratch)
+    import utils.dp_utils as ref_dp                     # (instantiates DensePoseMethods from the scratch directory's tables)
+    out = {}
+    yy, xx = np.mgrid[0:256, 0:256]
+    for case in range(4):
+        # 14 overlapping part blobs (some parts absent), up to 120 annotated points
+        masks, polys = [], []
+        for i in range(14):
+            if (case + i) % 5 == 0:
+                polys.append([])
+                masks.append(np.zeros((256, 256), np.uint8))
+                continue
+            cx, cy, r = rng.uniform(40, 216), rng.uniform(40, 216), rng.uniform(12, 60)
+            m = (((xx - cx) ** 2 + (yy - cy) ** 2) < r * r).astype(np.uint8)
+            masks.append(m)
+            polys.append(ours.rle_encode(m))
+        n = int(rng.integers(20, 120))
+        ann = {'bbox': [float(rng.uniform(20, 120)), float(rng.uniform(20, 120)), float(rng.uniform(90, 260)), float(rng.uniform(120, 300))],
+               'dp_masks': polys, 'dp_I': rng.integers(1, 25, n).astype(np.float64).tolist(), 'dp_U': rng.uniform(0, 1, n).tolist(),
+               'dp_V': rng.uniform(0, 1, n).tolist(), 'dp_x': rng.uniform(0, 255, n).tolist(), 'dp_y': rng.uniform(0, 255, n).tolist()}
+        center = [ann['bbox'][0] + ann['bbox'][2] / 2 + float(rng.uniform(-15, 15)), ann['bbox'][1] + ann['bbox'][3] / 2 + float(rng.uniform(-15, 15))]
+        scale = float(max(ann['bbox'][2], ann['bbox'][3]) / 200. * rng.uniform(0.9, 1.3))
+        flipped = case % 2
+        d = ref_dp.dp_annot_process(ann, 56, 224, center, scale, flipped)
+        out['c%d_counts' % case] = np.array([p['counts'] if p else b'' for p in polys], dtype=object).astype('S')
+        for k in ('bbox', 'dp_I', 'dp_U', 'dp_V', 'dp_x', 'dp_y'):
+            out['c%d_%s' % (case, k)] = np.asarray(ann[k], dtype=np.float64)
+        out['c%d_center' % case], out['c%d_scale' % case], out['c%d_flipped' % case] = np.asarray(center), np.asarray(scale), np.asarray(flipped)
+        for k, v in d.items():
+            out['c%d_out_%s' % (case, k)] = v
+        if case == 0:                                      # the symmetry function on its own
+            I, U, V = np.asarray(ann['dp_I']), np.asarray(ann['dp_U']), np.asarray(ann['dp_V'])
+            lab = ours.get_densepose_mask(polys)
+            res = ref_dp.DP.get_symmetric_densepose(I, U, V, np.asarray(ann['dp_x']), np.asarray(ann['dp_y']), lab)
+            for name, r_ in zip(('I', 'U', 'V', 'x', 'y', 'mask'), res):
+                out['sym_' + name] = np.asarray(r_)
+            out['sym_in_mask'] = lab
+    os.chdir(REF)
+    save('g15_dp_producer', **out)
+
+
+ALL['g15'] = g15_dp_producer
+
+
 def _main():
     names = sys.argv[1:] or list(ALL)
     for n in names:

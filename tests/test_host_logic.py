@@ -287,6 +287,48 @@ def test_dp_dict_producer_construction():
     assert df['body_uv_I_points'][:3].tolist() != [] and df['body_uv_ann_labels'].shape == (M * M,)
 
 
+def test_dp_dict_producer_matches_reference_golden():
+    """Golden g15 (tests/golden/make_golden.py g15_dp_producer): the reference's dp_annot_process and get_symmetric_densepose run
+    on synthetic symmetry tables and RLE annotations (with this repo's RLE decode / nearest remap standing in for pycocotools /
+    cv2 inside the reference) -- every entry of the dp_dict, flipped and unflipped samples, absent parts, points falling
+    outside the crop; plus known answers of the RLE string format."""
+    from danet_densepose2smpl_amd import dp_utils
+    g = golden('g15_dp_producer')
+    sym = dp_utils.DensePoseSymmetry(dict(zip(('U_transforms', 'V_transforms'), dp_utils.synthetic_symmetry_tables())))
+    for case in range(4):
+        polys = [{'size': [256, 256], 'counts': bytes(c)} if len(c) else [] for c in g['c%d_counts' % case]]
+        ann = {'bbox': g['c%d_bbox' % case].tolist(), 'dp_masks': polys}
+        for k in ('dp_I', 'dp_U', 'dp_V', 'dp_x', 'dp_y'):
+            ann[k] = g['c%d_%s' % (case, k)].tolist()
+        d = dp_utils.dp_annot_process(ann, 56, 224, g['c%d_center' % case].tolist(), float(g['c%d_scale' % case]), int(g['c%d_flipped' % case]), symmetric=sym)
+        for k, v in d.items():
+            want = g['c%d_out_%s' % (case, k)]
+            assert v.shape == want.shape and v.dtype == want.dtype, (case, k, v.dtype, want.dtype)
+            np.testing.assert_allclose(v, want, rtol=0, atol=1e-5, err_msg='case %d %s' % (case, k))
+        assert int(g['c%d_flipped' % case]) == case % 2 and (d['body_uv_I_points'] > 0).sum() > 5
+    I, U, V = g['c0_dp_I'], g['c0_dp_U'], g['c0_dp_V']
+    res = sym.get_symmetric_densepose(I, U, V, g['c0_dp_x'], g['c0_dp_y'], g['sym_in_mask'])
+    for name, r in zip(('I', 'U', 'V', 'x', 'y', 'mask'), res):
+        np.testing.assert_allclose(np.asarray(r), g['sym_' + name], rtol=0, atol=1e-6, err_msg=name)
+    # the tables as scipy.io.loadmat returns them (object array [1, 24]) give the same object
+    u, v = dp_utils.synthetic_symmetry_tables()
+    obj = lambda t: np.array([[t[i] for i in range(24)]], dtype=object)
+    sym2 = dp_utils.DensePoseSymmetry({'U_transforms': obj(u), 'V_transforms': obj(v)})
+    np.testing.assert_array_equal(sym2.get_symmetric_densepose(I, U, V, g['c0_dp_x'], g['c0_dp_y'], g['sym_in_mask'])[1], res[1])
+    # COCO RLE strings (maskApi.c): 5-bit groups + 48, 0x20 = continuation, differences to the count two back from the fourth on
+    assert dp_utils.rle_encode(np.ones((3, 2), np.uint8))['counts'] == b'06'
+    assert dp_utils.rle_decode({'size': [10, 10], 'counts': b'T3'}).sum() == 0            # one run of 100 zeros: 100 = 4 + 3 * 32
+    m = dp_utils.rle_decode({'size': [4, 3], 'counts': [2, 3, 4, 3]})                     # uncompressed list form, column-major runs
+    np.testing.assert_array_equal(m, np.array([[0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 0, 1]], np.uint8))
+    rng = np.random.default_rng(3)
+    for t in range(50):
+        h, w = rng.integers(1, 70, 2)
+        mk = (rng.uniform(size=(h, w)) < rng.uniform()).astype(np.uint8)
+        np.testing.assert_array_equal(dp_utils.rle_decode(dp_utils.rle_encode(mk)), mk)
+    with pytest.raises(ValueError):
+        dp_utils.rle_decode({'size': [4, 4], 'counts': [3, 3]})
+
+
 def test_trainer_save_and_resume(tmp_path):
     """Trainer.save / Trainer.resume: parameters, optimizer state and the step count that drives the LR decay survive a
     round trip through a reference-format checkpoint (utils/saver.py, base_trainer.py:37-51)."""
