@@ -236,6 +236,61 @@ def load_smpl_npz(path):
     return out
 
 
+class _PickledArray(object):
+    """Stand-in for a chumpy array inside an SMPL .pkl (chumpy is not installed here and not needed): keeps the pickled state,
+    whose 'x' entry is the ndarray of a leaf `chumpy.ch.Ch` (what the official SMPL files store for v_template, shapedirs,
+    posedirs, weights and J)."""
+    def __init__(self, *args, **kwargs):
+        self.state = {}
+
+    def __setstate__(self, state):
+        self.state = state if isinstance(state, dict) else {'x': state}
+
+    def __array__(self, dtype=None, copy=None):
+        for k in ('x', 'r', 'a'):
+            if k in self.state:
+                return np.asarray(self.state[k], dtype=dtype)
+        raise ValueError('SMPL .pkl: a chumpy object without a stored array (keys %s)' % sorted(self.state))
+
+
+def load_smpl_pkl(path, extra_regressor=None, num_betas=NUM_BETAS):
+    """The official SMPL model file (SMPL_NEUTRAL.pkl, what `smplx.SMPL(model_path)` reads in
+    /root/reference/models/smpl.py:15-19 with path_config.SMPL_MODEL_DIR) -> the dict of arrays smpl.SMPL takes, following
+    smplx.body_models.SMPL.__init__: latin-1 unpickling, shapedirs cut to `num_betas`, posedirs [V, 3, 207] -> [207, V * 3],
+    J_regressor densified, parents = kintree_table[0] with the root set to -1.  chumpy objects and the old scipy.sparse module
+    paths inside the file are resolved without either package's pickling support.  extra_regressor: path of the reference's
+    J_regressor_extra.npy (path_config.JOINT_REGRESSOR_TRAIN_EXTRA) or the [9, V] array; zeros when absent."""
+    import pickle
+    import scipy.sparse as sp
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split('.')[0] == 'chumpy':
+                return _PickledArray
+            if module.startswith('scipy.sparse') and hasattr(sp, name):
+                return getattr(sp, name)
+            return super().find_class(module, name)
+
+    with open(path, 'rb') as f:
+        d = _Unpickler(f, encoding='latin1').load()
+    if not isinstance(d, dict):
+        d = dict(vars(d))
+    dense = lambda a: np.asarray(a.todense()) if sp.issparse(a) else np.asarray(a)
+    v_template = np.asarray(dense(d['v_template']), np.float32)
+    V = v_template.shape[0]
+    shapedirs = np.asarray(dense(d['shapedirs']), np.float32)[:, :, :num_betas]
+    posedirs = np.asarray(dense(d['posedirs']), np.float32).reshape(V * 3, -1).T
+    parents = np.asarray(d['kintree_table'])[0].astype(np.int64)
+    parents[0] = -1
+    if extra_regressor is None:
+        extra = np.zeros((9, V), np.float32)
+    else:
+        extra = np.asarray(np.load(extra_regressor) if isinstance(extra_regressor, str) else extra_regressor, np.float32)
+    return {'v_template': v_template, 'faces': np.asarray(d['f']).astype(np.int32), 'shapedirs': shapedirs, 'posedirs': np.ascontiguousarray(posedirs),
+            'J_regressor': np.asarray(dense(d['J_regressor']), np.float32), 'lbs_weights': np.asarray(dense(d['weights']), np.float32),
+            'parents': parents.astype(np.int32), 'J_regressor_extra': extra, 'landmark_verts': SMPL_LANDMARK_VERTS.copy()}
+
+
 def load_densepose_mat(path):
     """Load the real UV_Processed.mat (user-supplied)."""
     from scipy.io import loadmat

@@ -20,13 +20,18 @@ ModelOutput_.__new__.__defaults__ = (None,) * len(ModelOutput_._fields)
 
 class SMPL(nn.Module):
     def __init__(self, model=None, batch_size=1, gender='neutral', create_transl=False, **kwargs):
-        """model: dict of numpy arrays (see assets.make_synthetic_smpl), a path to a converted
-        .npz (assets.load_smpl_npz), or None for the seeded synthetic model."""
+        """model: dict of numpy arrays (see assets.make_synthetic_smpl), a path -- the official SMPL_*.pkl or a directory holding
+        SMPL_<GENDER>.pkl like smplx's model_path (assets.load_smpl_pkl; `joint_regressor_extra` = the reference's
+        J_regressor_extra.npy), or a converted .npz (assets.load_smpl_npz) --, or None for the seeded synthetic model."""
         super().__init__()
         if model is None:
             model = assets.make_synthetic_smpl(0)
         elif isinstance(model, str):
-            model = assets.load_smpl_npz(model)
+            import os
+            if os.path.isdir(model):
+                model = os.path.join(model, 'SMPL_%s.pkl' % gender.upper())
+            model = (assets.load_smpl_npz(model) if model.endswith('.npz')
+                     else assets.load_smpl_pkl(model, kwargs.get('joint_regressor_extra')))
         self.batch_size = batch_size
         self.gender = gender
         f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))

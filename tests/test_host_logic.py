@@ -329,6 +329,50 @@ def test_dp_dict_producer_matches_reference_golden():
         dp_utils.rle_decode({'size': [4, 4], 'counts': [3, 3]})
 
 
+def test_smpl_pkl_loader_reads_the_official_file_layout(tmp_path):
+    """assets.load_smpl_pkl (/root/reference/models/smpl.py:15-19 -> smplx.SMPL(model_path)): a file with the official layout --
+    chumpy leaves for v_template / shapedirs / posedirs / weights, a scipy.sparse J_regressor, uint32 kintree_table with the
+    2^32 - 1 root, 300 shape components, python-2 style protocol-2 pickle -- loads without chumpy into the arrays the synthetic
+    model was built from.  (The file is written here with a throw-away `chumpy` module in sys.modules: parity with a real
+    SMPL_NEUTRAL.pkl is unpinned, the model is licence-gated.)"""
+    import pickle
+    import sys
+    import types
+    import scipy.sparse as sp
+    from danet_densepose2smpl_amd import assets
+    m = assets.make_synthetic_smpl(0)
+    V = m['v_template'].shape[0]
+    ch_mod, pkg = types.ModuleType('chumpy.ch'), types.ModuleType('chumpy')
+
+    class Ch(object):
+        def __init__(self, x):
+            self.x = np.asarray(x, np.float64)
+    Ch.__module__, Ch.__qualname__ = 'chumpy.ch', 'Ch'
+    ch_mod.Ch, pkg.ch = Ch, ch_mod
+    sys.modules.update({'chumpy': pkg, 'chumpy.ch': ch_mod})
+    try:
+        shapedirs300 = np.concatenate([m['shapedirs'], np.zeros((V, 3, 290), np.float32)], -1)
+        kt = np.stack([m['parents'].astype(np.int64) % (1 << 32), np.arange(24)]).astype(np.uint32)
+        d = {'v_template': Ch(m['v_template']), 'f': m['faces'].astype(np.uint32), 'shapedirs': Ch(shapedirs300),
+             'posedirs': Ch(m['posedirs'].T.reshape(V, 3, 207)), 'J_regressor': sp.csc_matrix(m['J_regressor'].astype(np.float64)),
+             'weights': Ch(m['lbs_weights']), 'kintree_table': kt, 'J': Ch(np.zeros((24, 3))), 'bs_style': 'lbs', 'bs_type': 'lrotmin'}
+        path = tmp_path / 'SMPL_NEUTRAL.pkl'
+        with open(path, 'wb') as f:
+            pickle.dump(d, f, protocol=2)
+    finally:
+        del sys.modules['chumpy'], sys.modules['chumpy.ch']
+    got = assets.load_smpl_pkl(str(path), extra_regressor=m['J_regressor_extra'])
+    for k in ('v_template', 'faces', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'parents', 'J_regressor_extra', 'landmark_verts'):
+        assert got[k].shape == m[k].shape and got[k].dtype == m[k].dtype, (k, got[k].shape, got[k].dtype, m[k].dtype)
+        np.testing.assert_allclose(got[k], m[k], rtol=0, atol=1e-7, err_msg=k)
+    assert np.abs(assets.load_smpl_pkl(str(path))['J_regressor_extra']).sum() == 0
+    from danet_densepose2smpl_amd.smpl import SMPL                 # smplx's model_path convention: a directory holding SMPL_<GENDER>.pkl
+    layer = SMPL(str(tmp_path), joint_regressor_extra=m['J_regressor_extra'])
+    ref = SMPL(m)
+    for (ka, a), (kb, b) in zip(layer.named_buffers(), ref.named_buffers()):
+        assert ka == kb and torch.equal(a, b), ka
+
+
 def test_trainer_save_and_resume(tmp_path):
     """Trainer.save / Trainer.resume: parameters, optimizer state and the step count that drives the LR decay survive a
     round trip through a reference-format checkpoint (utils/saver.py, base_trainer.py:37-51)."""
