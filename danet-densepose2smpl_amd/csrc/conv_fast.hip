@@ -225,14 +225,23 @@ __device__ __forceinline__ void conv_fast_body(const ConvP& p, const int bx_, co
                     *reinterpret_cast<bf16x8*>(buf + ((2 * wave + j) * NT + nt) * 1024 + lane * 16) = Areg[j][nt];
             __syncthreads();                  // round r's fragments visible; everyone is done with round r-1 (other buffer)
             if (r + 1 < nrounds) load_round(r + 1, bnxt);
+            // the weight fragments of k-step q + 1 are read from LDS before the MFMAs of k-step q (two register sets; left to the
+            // compiler every MFMA waited for a ds_read issued one MFMA earlier: lgkmcnt(1) in front of each of them)
+            bf16x8 a[2][NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a[0][nt] = *reinterpret_cast<const bf16x8*>(buf + nt * 1024 + lane * 16);
 #pragma unroll
             for (int q = 0; q < G; ++q) {
-                bf16x8 a[NT];
+                if (q + 1 < G) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const bf16x8*>(buf + (q * NT + nt) * 1024 + lane * 16);
+                    for (int nt = 0; nt < NT; ++nt)
+                        a[(q + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(buf + ((q + 1) * NT + nt) * 1024 + lane * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bcur[q], acc[0][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q & 1][nt], bcur[q], acc[0][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (nrounds > 0) load_round(0, Bq2[0]);

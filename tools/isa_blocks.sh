@@ -14,9 +14,9 @@ for name in names:
     a = txt.index('\n' + name + ':')
     b = txt.index('s_endpgm', a)
     body = txt[a:b]
-    meta = re.search(r'\.amdhsa_kernel ' + re.escape(name) + r'.*?\.end_amdhsa_kernel', txt, re.S)
-    info = []
-    print('==', name[:110], dict(info))
+    meta = re.search(r'\.amdhsa_kernel ' + re.escape(name) + r'\n.*?\.end_amdhsa_kernel', txt, re.S)
+    vg = re.search(r'next_free_vgpr (\d+)', meta.group(0)).group(1) if meta else '?'
+    print('==', name[:110], 'vgprs', vg)
     blocks, cur, bn = [], [], 'entry'
     for l in body.split('\n'):
         if re.match(r'^\.LBB\d+_\d+:', l):
@@ -25,7 +25,7 @@ for name in names:
             cur.append(l)
     blocks.append((bn, cur))
     for n, bl in blocks:
-        ins = [x.strip().split()[0] for x in bl if x.startswith('\t') and not x.strip().startswith(('.', ';'))]
+        ins = [x.strip().split()[0] for x in bl if x.startswith('\t') and x.strip() and not x.strip().startswith(('.', ';'))]
         m = sum(i.startswith('v_mfma') for i in ins)
         if m >= 4:
             print('  ', n, len(ins), 'mfma', m, 'ds', sum(i.startswith('ds_') for i in ins), 'vmem', sum(i.startswith(('buffer', 'global', 'flat')) for i in ins),
