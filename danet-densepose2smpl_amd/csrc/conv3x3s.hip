@@ -642,10 +642,6 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
                 const int koff = ek;
                 int voffn = 0;
                 auto table_next = [&](int part) {
-#if defined(DANET_S3_X_NOT)               // (timing experiment: no table reads)
-                    if (part == 0) voffn = wlane + qn.x;
-                    return;
-#endif
                     if (part == 0) {
                         voffn = wlane + qn.x;
                         qn = *reinterpret_cast<const i32x2*>(reinterpret_cast<const unsigned char*>(sTab) + __builtin_amdgcn_readfirstlane(qn.y) * 16 + 8);
@@ -659,17 +655,11 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], bc[mt], acc[mt][nt], 0, 0, 0);
-#if !defined(DANET_S3_X_NOB)
                         if (nt == 0) bn[mt] = *reinterpret_cast<const bf16x8*>(sX + lanebase[mt] + koff);
-#endif
                         if (nt == 0 && mt == MT - 1) table_next(0);
                         if (NT == 1 ? (mt == MT - 1) : (nt == 1 && mt == 0)) table_next(1);
-#if defined(DANET_S3_X_NOA)              // (timing experiment: no refill; the wait count of ring_wait is then trivially met)
-                        if (mt == MT - 1) asm volatile("" : "+v"(a[nt]) : "v"(voffn));
-#else
                         if (mt == MT - 1)
                             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a[nt]) : "v"(voffn), "s"(wdesc), "s"(wso[nt]) : "memory");
-#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
             };
