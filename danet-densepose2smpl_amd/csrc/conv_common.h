@@ -53,7 +53,7 @@ bool conv3x3_ok(const ConvP& p, bool vec8);
 int conv3x3_config(const ConvP& p, bool vec8, int nprob);      // MT*100 + NT*10 + KW, 0 = not supported
 int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry = false);      // n <= 4 problems in one launch; dry: only check
 
-// conv3x3s.hip: the streamed successor (loader wave + two-deep LDS ring); conv3x3_launch tries it first.  0 = launched (or, dry, would be)
+// conv3x3s.hip: the streamed successor (LDS-DMA stage copies into a two-slot LDS ring); conv3x3_launch tries it first.  0 = launched (or, dry, would be)
 int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry);
 bool conv3x3_stream_first();
 int* conv3x3_debug_buffer();        // danet_conv3x3_debug's buffer (NULL: off); the streamed kernel writes 16 ints per workgroup

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 // fragment-major (see the kernel).
 //  mode 0 (forward):  rows = cout within group, k = (r*S+s)*Cin_g + cin
 //  mode 1 (dgrad):    rows = cin  within group, k = (r*S+s)*Cout_g + cout   (used with the transposed gather)
-// With chunk > 0 (conv3x3_lds.hip) the K order is (channel chunk, tap, channel within chunk) and every chunk is
+// With chunk > 0 (a reserved packing: the C-ABI requires chunk = 0 today) the K order is (channel chunk, tap, channel within chunk) and every chunk is
 // zero-padded to KpC = roundup(R*S*chunk, 32).
 __device__ inline bool pack_decode(int k, int inner, int RS, int chunk, int& tap, int& ch) {
     if (chunk <= 0) { tap = k / inner; ch = k - tap * inner; return k < RS * inner; }
