@@ -66,7 +66,10 @@ def parse():
     ap.add_argument('--dtype', choices=('bf16', 'fp32'), default='bf16',
                     help='fp32: BASELINE config C4\'s arithmetic on the verification kernels (csrc/conv_f32.hip, eager launches; a correctness configuration, not a performance one)')
     ap.add_argument('--grad-wire', choices=('fp32', 'bf16'), default=None, help='N > 1: all-reduce the gradient buckets in this type (default: DANET_GRAD_WIRE or fp32)')
-    ap.add_argument('--force-ddp', action='store_true', help='diagnostic: run the N > 1 code path (GradReducer + eager Adam) on a 1-rank group')
+    ap.add_argument('--force-ddp', action='store_true', help='diagnostic: run the N > 1 code path (GradStore buckets, segmented backward, in-graph all-reduces) on a 1-rank group')
+    ap.add_argument('--dry', action='store_true',
+                    help='launch-line check: build the trainer, capture, run ONE step and print the line (allreduce record included) without the '
+                         'roofline / geometry / fp32 / CPU legs -- what a multi-GPU launch does first, cheap enough for a test')
     return ap.parse_args()
 
 
@@ -207,6 +210,34 @@ def fp32_line(args, tr, batch, world, rank, dev):
                           'finite_losses': rec['finite_losses'], 'roofline': None}), flush=True)
 
 
+def _dnn_blocks():
+    from danet_densepose2smpl_amd import nn as _dnn
+    return _dnn.ONEPASS_MAX_BLOCKS
+
+
+def profile_step(tr, batch, dev):
+    """One eager step with every conv launch bracketed by HIP events: (summary, dominant kernel)."""
+    from danet_densepose2smpl_amd import conv
+    # The host needs ~3x longer to enqueue an eager step than the GPU needs to run it; ~0.4 s of queued matmuls in
+    # front let the host run ahead, so that the bracketed kernels execute back to back and an event pair measures
+    # the kernel, not the host's launch latency.
+    fa = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    fb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    torch.mm(fa, fb)
+    torch.cuda.synchronize(dev)
+    for _ in range(240):
+        torch.mm(fa, fb)
+    conv.PROFILER = conv.KernelProfiler()
+    tr.train_step(batch)
+    torch.cuda.synchronize(dev)
+    summ = conv.PROFILER.summary()
+    conv.PROFILER = None
+    del fa, fb
+    dominant = max(((k, v) for k, v in summ.items() if v[2] > 0), key=lambda kv: kv[1][1])[0] if summ else None
+
+    return summ, dominant
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -220,6 +251,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1 or args.force_ddp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # the communicator must see the channel limit the one-pass BatchNorm barrier is sized against (trainer.reserve_comm_channels)
+        from danet_densepose2smpl_amd.trainer import reserve_comm_channels
+        reserve_comm_channels()
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
@@ -248,29 +282,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if args.dry:
+        args.steps, args.warmup, args.no_fp32, args.no_cpu_baseline = 1, 0, True, True
     # One eager step with every conv launch bracketed by HIP events (on the launch stream) finds the
     # dominant kernel instance and gives its per-launch durations -- the same kernels, shapes and
     # data as the timed steps (which replay them from a hipGraph, where events cannot be recorded).
     tr.train_step(batch)
     tr.train_step(batch)
     torch.cuda.synchronize(dev)
-    # The host needs ~3x longer to enqueue an eager step than the GPU needs to run it; ~0.4 s of queued matmuls in
-    # front let the host run ahead, so that the bracketed kernels execute back to back and an event pair measures
-    # the kernel, not the host's launch latency.
-    fa = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
-    fb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
-    torch.mm(fa, fb)
-    torch.cuda.synchronize(dev)
-    for _ in range(240):
-        torch.mm(fa, fb)
-    conv.PROFILER = conv.KernelProfiler()
-    tr.train_step(batch)
-    torch.cuda.synchronize(dev)
-    summ = conv.PROFILER.summary()
-    conv.PROFILER = None
-    del fa, fb
-    dominant = max(((k, v) for k, v in summ.items() if v[2] > 0), key=lambda kv: kv[1][1])[0] if summ else None
-
+    summ, dominant = {}, None
+    if not args.dry:
+        summ, dominant = profile_step(tr, batch, dev)
     use_graph = not args.no_graph
     if use_graph:
         try:
@@ -307,7 +329,7 @@ def main():
                     'launches': n, 'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3),
                     'traffic_source': tsrc}
     extra = None
-    if rank == 0:
+    if rank == 0 and not args.dry:
         try:
             extra = geometry_rooflines(tr, B, args.size, dev)
         except Exception as e:                                       # secondary figures must not take the bench line down
@@ -332,13 +354,17 @@ def main():
                           'buckets': len(st.buckets), 'bucket_mb': round(max(e - s0 for s0, e, _, _ in st.buckets) * 4 / 2**20, 1),
                           'released_during_backward': int(early), 'wire_dtype': 'bf16' if st.wire is not None else 'f32',
                           'bytes_per_step': int(st.flat.numel() * (2 if st.wire is not None else 4)),
-                          'ms_per_step_per_rank': per_rank}
+                          'ms_per_step_per_rank': per_rank,
+                          # compute units left to the communication library while the backward pass runs (NCCL_MAX_NCHANNELS) and the
+                          # workgroup budget of the one-pass BatchNorm backward's grid barrier that follows from it
+                          'comm_channels_reserved': int(os.environ.get('NCCL_MAX_NCHANNELS', 0)), 'onepass_max_blocks': int(_dnn_blocks())}
     if rank == 0:
         ips = world * B * args.steps / elapsed
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                 'exec': 'hipgraph' if use_graph else 'eager',
+                'dry': bool(args.dry),
                 'allreduce': allreduce_info,
                 'config': {'workload': 'full DaNet train step (HRNet-W48 + global and part-wise IUV heads + regressor nets + SMPL LBS '
                                        '(2 forward + 1 backward; the 2 label-side forwards belong to the untimed batch prologue) + IUV '

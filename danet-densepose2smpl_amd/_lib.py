@@ -44,6 +44,8 @@ _SIGNATURES = {
     'danet_conv3x3_debug': (None, [c_f]),
     'danet_conv3x3_stream_set': (c_i, [c_i, c_i, c_i, c_i]),
     'danet_conv3x3_stream_plan': (c_i, [c_i] * 6),
+    'danet_conv3x3_stream_table_bytes': (c_sz, []),
+    'danet_conv3x3_stream_tables': (c_i, [c_f, c_sz]),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, ctypes.c_long, c_f]),
     'danet_conv_pack_job_bricks': (ctypes.c_long, [c_i] * 7),
     'danet_conv_forward_multi_ok': (c_i, [c_f, c_i]),
@@ -70,9 +72,9 @@ _SIGNATURES = {
     'danet_bn_set_block_bytes': (ctypes.c_long, [ctypes.c_long]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
-    'danet_bn_backward_onepass_ok': (c_i, [c_f, c_i]),
+    'danet_bn_backward_onepass_ok': (c_i, [c_f, c_i, c_i]),
     'danet_bn_backward_onepass_bar_words': (c_i, []),
-    'danet_bn_backward_onepass': (c_i, [c_f, c_i, c_f, c_f]),
+    'danet_bn_backward_onepass': (c_i, [c_f, c_i, c_f, c_i, c_f]),
     'danet_bn_backward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f]),
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
@@ -94,7 +96,7 @@ _SIGNATURES = {
     'danet_smpl_loss_forward': (c_i, [c_f] * 5),
     'danet_smpl_loss_backward': (c_i, [c_f] * 5),
     'danet_adam_chunk_bytes': (c_sz, []),
-    'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f]),
+    'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),

@@ -413,11 +413,31 @@ def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+_S3_TABLES = {}          # device index -> the tensor the streamed 3x3 kernel's tap tables live in (csrc/conv3x3s.hip)
+S3_TABLE_SLOTS = 512
+
+
+def stream_tables(device):
+    """The library allocates no device memory: the tap-table cache of the streamed 3x3 kernel lives in a buffer this side owns,
+    registered once per device (danet_conv3x3_stream_tables; without it the kernel refuses and the tile kernel runs)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _S3_TABLES.get(idx)
+    if t is None:
+        L = _lib.lib()
+        with torch.cuda.device(idx):
+            t = torch.empty(S3_TABLE_SLOTS * int(L.danet_conv3x3_stream_table_bytes()), dtype=torch.uint8, device=torch.device('cuda', idx))
+            if L.danet_conv3x3_stream_tables(ptr(t), t.numel()) != S3_TABLE_SLOTS:
+                raise RuntimeError('danet_conv3x3_stream_tables: workspace not accepted')
+        _S3_TABLES[idx] = t
+    return t
+
+
 def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, relu, out_fp32,
                   bn_sums=None, bn_bwd=None, addend=None):
     """bn_bwd = (bn_x, gate tensor or None, saved, red, bn_gate) (see _bn_gate): data-gradient launches also reduce the
     BatchNorm-backward sums of the BN that produced the conv's input (see include/danet_hip.h)."""
     L = _lib.lib()
+    stream_tables(x.device)
     y = _empty_nhwc(B, Cout, OH, OW, torch.float32 if out_fp32 else torch.bfloat16, x.device)
     tok = None
     if PROFILER is not None:
@@ -736,6 +756,7 @@ def _bn_gate(bn_ctx, x, c3):
 
 def _conv_job(job, x, wp, y, dims, transposed, bn_sums=None, bn_bwd=None, addend=None):
     (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims
+    stream_tables(x.device)
     job.x, job.wp, job.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     job.bn_sums = None if bn_sums is None else bn_sums.data_ptr()
     job.addend = None if addend is None else addend.data_ptr()

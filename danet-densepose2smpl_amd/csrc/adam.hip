@@ -8,10 +8,16 @@
 // captured hipGraph and the host can still decay the rate between replays.
 //
 // Per-parameter step counts, as torch.optim.Adam keeps them: a parameter that received no gradient in a step (gradient
-// pointer NULL, or used[param] == 0 where all gradients are views of one store) is skipped entirely -- moments untouched --
+// pointer NULL, or used[param] == 0 where all gradients are views of one store; `used` is the number of RANKS in which the
+// parameter received a gradient, all-reduced with the gradients, so every replica decides alike) is skipped entirely -- moments untouched --
 // and idle[param] counts those steps; its bias corrections use step - idle[param], i.e. the number of steps it WAS updated
 // in.  (The reference pre-trains the IUV estimator alone for 5000 steps, /root/reference/train/base_trainer.py:74: the
 // regressor's first update must see step 1, not 5001.)
+//
+// Poison guard: `poison` points at the error word of the one-pass BatchNorm backward's grid barrier (norm_act.hip, bar[2]).
+// A barrier that timed out in this step left garbage gradients; with the word set EVERY parameter is skipped (and counted
+// in idle, so the bias corrections stay those of the updates that were applied): a poisoned step can never reach the
+// weights or the moments, whatever the host does or does not check (Trainer.check_onepass reports it).
 #include "common.h"
 
 namespace {
@@ -20,12 +26,12 @@ struct AdamChunk { float* p; const float* g; long off; int n; int param; };     
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ lr_p, const float* __restrict__ step_p,
-                                                   const int* __restrict__ used, float* __restrict__ idle,
-                                                   float beta1, float beta2, float eps, float gscale)
+                                                   const float* __restrict__ used, float* __restrict__ idle,
+                                                   float beta1, float beta2, float eps, float gscale, const int* __restrict__ poison)
 {
     const AdamChunk c = table[blockIdx.x];
     const int pi = c.param >> 1;
-    if (!c.g || (used && !used[pi])) {                             // parameter without a gradient this step: skipped, and counted
+    if (!c.g || (used && !(used[pi] > 0.f)) || (poison && poison[0] != 0)) {                             // parameter without a gradient this step: skipped, and counted
         if (idle && (c.param & 1) && threadIdx.x == 0) idle[pi] += 1.f;
         return;
     }
@@ -64,15 +70,17 @@ extern "C" size_t danet_adam_chunk_bytes(void) { return sizeof(AdamChunk); }
 // table: nchunks entries { float* p; const float* g (NULL = skip); int64 off; int32 n; int32 param } on the device (param = 2 *
 // parameter index + 1 for the parameter's first chunk); p, g and the moment buffers m, v (+ off) must be 16-byte aligned for
 // every chunk; lr and step (the 1-based GLOBAL step count, as a float) live on the device.  used (NULL = every parameter with a
-// gradient pointer): int per parameter, 0 = no gradient this step; idle (NULL = none): float per parameter, the steps it was
-// skipped in, maintained here.  grad_scale multiplies every gradient (1 / world size turns all-reduced sums into the average
-// without a pass of its own).
+// gradient pointer): float per parameter, > 0 = some rank produced a gradient this step; idle (NULL = none): float per
+// parameter, the steps it was skipped in, maintained here.  grad_scale multiplies every gradient (1 / world size turns
+// all-reduced sums into the average without a pass of its own).  poison (NULL = none): device int; non-zero = skip the
+// whole step (see the header).
 extern "C" int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
-                               const int* used, float* idle, float beta1, float beta2, float eps, float grad_scale, void* stream)
+                               const float* used, float* idle, float beta1, float beta2, float eps, float grad_scale,
+                               const int* poison, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(table && nchunks > 0 && m && v && lr && step, "adam_step: bad arguments");
-    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, used, idle, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, used, idle, beta1, beta2, eps, grad_scale, poison);
     DANET_CHECK_LAUNCH("adam_kernel");
     return DANET_OK;
 }

@@ -18,8 +18,8 @@
 //   * fragment loads and copies are inline asm, counted by hand (s_waitcnt vmcnt(NT * (D - 1)) before a slot's use): the
 //     compiler's own bookkeeping drained the whole ring at every loop header.
 //   * what a workgroup needs once per problem is kept off its serial path (measured: ~7 k cycles of table / address set-up
-//     per tile in the first version, as much as the k-loop): the tap table is built ONCE per problem signature by a tiny
-//     kernel into a device-side cache and arrives by LDS-DMA together with the problem's first stage; per-lane pixel
+//     per tile in the first version, as much as the k-loop): the tap table is built ONCE per problem signature (on the
+//     host, uploaded into a caller-provided cache) and arrives by LDS-DMA together with the problem's first stage; per-lane pixel
 //     addresses use shifts when the sizes are powers of two; the launch descriptor is read with scalar loads.
 // A stage is a halo tile restricted to a range of input channels; a tile whose input does not fit one ring slot
 // (96 / 192 / 384 channels) is a sequence of stages that share the accumulators -- the (tap, channel) k-steps of the
@@ -28,6 +28,7 @@
 // branch's tile is computed, the first stage of the next branch's tile is already arriving.
 #include "common.h"
 #include "conv_common.h"
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -61,7 +62,7 @@ constexpr int S3_THREADS = 256;
 
 struct S3Prob {
     const bf16_t* x; const bf16_t* w; void* y; const float* bias; float* stats; const bf16_t* addend;
-    const i32x4* tab;                                    // the problem's tap table (device cache, see s3_table_kernel)
+    const i32x4* tab;                                    // the problem's tap table (device cache, see s3_table_for)
     int B, H, W, Cin, Cout;
     int x_bytes, y_bytes;
     int TH, NI, Wp, Sp, tiles_h, nnb, nks, nc16;
@@ -126,64 +127,70 @@ __device__ inline float row_sum16(float v) {
 // the wave that owns entry j (its share of this stage, then of the following stages; the last one points back at the wave's
 // first k-step: the ring's refills past the end of a tile fetch the first fragments of the next tile, see s3_problem).
 struct TabKey { int Wp, Sp, nc16, flip, kw, nst; unsigned c0w, ncw, j0w; };
-__global__ void s3_table_kernel(TabKey k, i32x4* __restrict__ out)
+struct TabEntry { int x, y, z, w; };
+static_assert(sizeof(TabEntry) == sizeof(i32x4), "TabEntry");
+
+// Host side: the table is a pure function of the key (<= 112 entries), computed here and uploaded once per key.
+void s3_table_host(const TabKey& k, TabEntry* out /* [S3_TAB] */)
 {
-    const int t = threadIdx.x;
     const int nst = k.nst, KW = k.kw, nc16 = k.nc16;
     auto sbeg = [&](int s) { return s == 0 ? 0 : (int)((k.j0w >> (8 * (s - 1))) & 255u); };
     auto send = [&](int s) { return (int)((k.j0w >> (8 * s)) & 255u); };
     auto range_of = [&](int s, int w, int& jb, int& je) {
         const int a = sbeg(s), b = send(s);
         const int c = (b - a + KW - 1) / KW;
-        jb = min(b, a + w * c); je = min(b, jb + c);
+        jb = std::min(b, a + w * c); je = std::min(b, jb + c);
     };
-    const int nent = send(nst - 1);
-    if (t >= nent) return;
-    int s = 0;
-    while (s + 1 < nst && t >= send(s)) ++s;
-    const int jl = t - sbeg(s);
     auto tapoff = [&](int tap) {
         const int r = tap / 3, sx = tap - 3 * r;
         const int off = ((r - 1) * k.Wp + (sx - 1)) * k.Sp * 16;
         return k.flip ? -off : off;
     };
-    i32x4 e = {0, 0, 0, 0};
-    if (nst == 1) {                               // (tap, 16-channel block) order; a k-step may straddle two taps when nc16 is odd
-        for (int half = 0; half < 2; ++half) {
-            int h = 2 * jl + half;
-            if (h > 9 * nc16 - 1) h = 9 * nc16 - 1;                 // zero-weight tail of the last k-step: any valid cell
-            const int tap = h / nc16, c16 = h - tap * nc16;
-            const int off = tapoff(tap) + c16 * 32;
-            if (half == 0) e.x = off; else e.y = off;
+    const int nent = send(nst - 1);
+    for (int t = 0; t < S3_TAB; ++t) {
+        TabEntry e{0, 0, 0, 0};
+        if (t < nent) {
+            int s = 0;
+            while (s + 1 < nst && t >= send(s)) ++s;
+            const int jl = t - sbeg(s);
+            if (nst == 1) {                           // (tap, 16-channel block) order; a k-step may straddle two taps when nc16 is odd
+                for (int half = 0; half < 2; ++half) {
+                    int h = 2 * jl + half;
+                    if (h > 9 * nc16 - 1) h = 9 * nc16 - 1;             // zero-weight tail of the last k-step: any valid cell
+                    const int tap = h / nc16, c16 = h - tap * nc16;
+                    const int off = tapoff(tap) + c16 * 32;
+                    if (half == 0) e.x = off; else e.y = off;
+                }
+                e.z = jl * 1024;
+            } else {                                  // an even number of blocks per stage: both halves of a k-step share the tap
+                const int hn = (int)((k.ncw >> (8 * s)) & 255u) >> 1;
+                const int tap = jl / hn, cl = 2 * (jl - tap * hn);
+                e.x = tapoff(tap) + cl * 32; e.y = e.x + 32;
+                e.z = ((tap * nc16 + (int)((k.c0w >> (8 * s)) & 255u) + cl) >> 1) * 1024;
+            }
+            const int a = sbeg(s), b = send(s);
+            const int c = (b - a + KW - 1) / KW;
+            const int w = (t - a) / c;
+            int jb, je;
+            range_of(s, w, jb, je);
+            int nx = -1;
+            if (t + 1 < je) nx = t + 1;
+            else for (int q = nst - 1; q > s; --q) { int nb2, ne2; range_of(q, w, nb2, ne2); if (nb2 < ne2) nx = nb2; }
+            if (nx < 0)                                   // the wave's last k-step of the tile: on to its first one (of the NEXT tile)
+                for (int q = nst - 1; q >= 0; --q) { int nb2, ne2; range_of(q, w, nb2, ne2); if (nb2 < ne2) nx = nb2; }
+            e.w = nx < 0 ? t : nx;
         }
-        e.z = jl * 1024;
-    } else {                                      // an even number of blocks per stage: both halves of a k-step share the tap
-        const int hn = (int)((k.ncw >> (8 * s)) & 255u) >> 1;
-        const int tap = jl / hn, cl = 2 * (jl - tap * hn);
-        e.x = tapoff(tap) + cl * 32; e.y = e.x + 32;
-        e.z = ((tap * nc16 + (int)((k.c0w >> (8 * s)) & 255u) + cl) >> 1) * 1024;
+        out[t] = e;
     }
-    {
-        const int a = sbeg(s), b = send(s);
-        const int c = (b - a + KW - 1) / KW;
-        const int w = (t - a) / c;
-        int jb, je;
-        range_of(s, w, jb, je);
-        int nx = -1;
-        if (t + 1 < je) nx = t + 1;
-        else for (int q = nst - 1; q > s; --q) { int nb2, ne2; range_of(q, w, nb2, ne2); if (nb2 < ne2) nx = nb2; }
-        if (nx < 0)                                   // the wave's last k-step of the tile: on to its first one (of the NEXT tile)
-            for (int q = nst - 1; q >= 0; --q) { int nb2, ne2; range_of(q, w, nb2, ne2); if (nb2 < ne2) nx = nb2; }
-        e.w = nx < 0 ? t : nx;
-    }
-    out[t] = e;
 }
 
-// Device-side cache of tap tables: one pool per device, a table per signature, built by s3_table_kernel on the stream of
-// the launch that needs it first (a later launch on the same stream finds it complete; graph capture records the builder
-// with the launch).  nullptr when the pool cannot be set up (e.g. first use inside a capture): the caller falls back.
-constexpr int S3_POOL_TABLES = 512;
-struct TabPool { i32x4* base = nullptr; int used = 0; std::map<std::tuple<int, int, int, int, int, int, unsigned, unsigned, unsigned>, int> index; };
+// Cache of tap tables in CALLER-PROVIDED device memory (danet_conv3x3_stream_tables: one workspace per device, registered by
+// the host side before the first launch; without one the streamed kernel refuses and conv3x3.hip's tile kernel runs).  A
+// table is a pure function of its key: computed on the host and uploaded with a synchronous copy the first time a key is
+// seen, so it is complete before ANY stream can launch a kernel that reads it (a builder kernel on the launching stream
+// would be unordered against other streams and only recorded, not run, under a capture).  New keys are refused while the
+// launching stream is capturing (a synchronous copy is illegal there): the caller falls back for that launch.
+struct TabPool { i32x4* base = nullptr; int cap = 0, used = 0; std::map<std::tuple<int, int, int, int, int, int, unsigned, unsigned, unsigned>, int> index; };
 std::mutex g_tab_mutex;
 std::map<int, TabPool> g_tab_pools;
 
@@ -192,21 +199,23 @@ const i32x4* s3_table_for(const S3Prob& q, hipStream_t st, bool dry)
     std::lock_guard<std::mutex> lock(g_tab_mutex);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    TabPool& pool = g_tab_pools[dev];
-    if (!pool.base) {
-        if (dry) return reinterpret_cast<const i32x4*>(1);           // (a dry run only asks whether the problem qualifies)
-        void* mem = nullptr;
-        if (hipMalloc(&mem, (size_t)S3_POOL_TABLES * S3_TABB) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        pool.base = (i32x4*)mem;
-    }
+    auto pit = g_tab_pools.find(dev);
+    if (pit == g_tab_pools.end() || !pit->second.base) return nullptr;       // no workspace registered for this device
+    TabPool& pool = pit->second;
     const auto key = std::make_tuple(q.Wp, q.Sp, q.nc16, q.flip, q.kw, q.nst, q.st_c0w, q.st_ncw, q.st_j0w);
     auto it = pool.index.find(key);
     if (it != pool.index.end()) return pool.base + (size_t)it->second * S3_TAB;
-    if (dry) return reinterpret_cast<const i32x4*>(1);
-    if (pool.used >= S3_POOL_TABLES) return nullptr;
-    const int slot = pool.used++;
+    if (dry) return reinterpret_cast<const i32x4*>(1);                       // (a dry run only asks whether the problem qualifies)
+    if (pool.used >= pool.cap) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     TabKey k{q.Wp, q.Sp, q.nc16, q.flip, q.kw, q.nst, q.st_c0w, q.st_ncw, q.st_j0w};
-    hipLaunchKernelGGL(s3_table_kernel, dim3(1), dim3(128), 0, st, k, pool.base + (size_t)slot * S3_TAB);
+    TabEntry host[S3_TAB];
+    s3_table_host(k, host);
+    const int slot = pool.used;
+    if (hipMemcpy(pool.base + (size_t)slot * S3_TAB, host, S3_TABB, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ++pool.used;
     pool.index[key] = slot;
     return pool.base + (size_t)slot * S3_TAB;
 }
@@ -918,6 +927,21 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
 // enable: 0 / 1 (-1 keeps); blocks: workgroup cap of a launch (<= 0 keeps); kw: forced K split 1 / 2 / 4 (0: the planner's
 // choice, < 0 keeps); want_tiles: tiles per problem the planner aims for (0: 512 / problems of the launch, < 0 keeps).
 // Returns the previous `enable`.
+// The device memory the tap tables of the CURRENT device live in (caller-owned, must outlive every launch; the library
+// never allocates device memory).  bytes / danet_conv3x3_stream_table_bytes() tables fit; registering again (another
+// buffer, or NULL to withdraw it) forgets the cached tables.  Returns the number of tables the workspace holds.
+extern "C" size_t danet_conv3x3_stream_table_bytes(void) { return (size_t)S3_TABB; }
+extern "C" int danet_conv3x3_stream_tables(void* ws, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    TabPool& pool = g_tab_pools[dev];
+    pool.base = (i32x4*)ws;
+    pool.cap = ws ? (int)(bytes / S3_TABB) : 0;
+    pool.used = 0;
+    pool.index.clear();
+    return pool.cap;
+}
 extern "C" int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want_tiles) {
     const int prev = g_s3_on ? 1 : 0;
     if (enable >= 0) g_s3_on = enable != 0;

@@ -1179,9 +1179,13 @@ static int onepass_max_blocks() {
     return cached;
 }
 
-static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) {
+// cap (> 0): the caller's co-residency budget -- fewer workgroups than the device could hold when other kernels may occupy
+// compute units while these launches run (a data-parallel trainer reserves the communication library's channels, see
+// danet_hip.h); <= 0: the whole device.
+static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */, int cap) {
     if (!jobs || n < 1 || n > NBM || getenv("DANET_NO_BN_ONEPASS")) return 0;
-    const int max_blocks = onepass_max_blocks();
+    int max_blocks = onepass_max_blocks();
+    if (cap > 0 && cap < max_blocks) max_blocks = cap;
     int nl = 0;
     long total = 0;
     BnOnePass* m = nullptr;
@@ -1216,13 +1220,13 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */) 
 
 extern "C" int danet_bn_backward_onepass_bar_words(void) { return OP_BAR_WORDS; }
 
-extern "C" int danet_bn_backward_onepass_ok(const void* jobs, int n)
+extern "C" int danet_bn_backward_onepass_ok(const void* jobs, int n, int max_blocks)
 {
     BnOnePass ms[NBM];
-    return onepass_plan((const BnBwdJob*)jobs, n, ms) > 0 ? 1 : 0;
+    return onepass_plan((const BnBwdJob*)jobs, n, ms, max_blocks) > 0 ? 1 : 0;
 }
 
-extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, void* stream)
+extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, int max_blocks, void* stream)
 {
     DANET_ENTER();
     BnOnePass ms[NBM];
@@ -1231,7 +1235,7 @@ extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, voi
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OP_NL * 256 * 17);
         attr_set = true;
     }
-    const int nl = onepass_plan((const BnBwdJob*)jobs, n, ms);
+    const int nl = onepass_plan((const BnBwdJob*)jobs, n, ms, max_blocks);
     DANET_CHECK_ARG(bar && nl > 0, "bn_backward_onepass: the job set does not qualify (see danet_bn_backward_onepass_ok)");
     for (int l = 0; l < nl; ++l) {
         ms[l].bar = (unsigned*)bar;

@@ -10,6 +10,7 @@ from .geometry import batch_rodrigues
 from .iuv_estimator import IUV_Estimator, DP2SMPL_MAPPING
 from .iuvmap import iuvmap_clean
 from . import part_ops
+from . import segments
 
 FUSED_PART_OPS = True       # part drop + per-part iuvmap_clean in one HIP kernel (False: the tensor-op formulation)
 from .renderer import IUV_Renderer
@@ -96,6 +97,7 @@ class DaNet(nn.Module):
         uv = self.img2iuv(image, uv_image_gt, target_smpl_kps, uvia_dp_gt=in_dict.get('dp_dict'), has_iuv=has_iuv, has_dp=has_dp,
                           keep25=keep25)
         u_pred, v_pred, index_pred, ann_pred = uv['uvia_pred']
+        segments.note_losses(uv.get('losses', {}).keys())            # the estimator's losses hang off the segment open now
 
         if 'iuv_map' in uv:
             # the fused global-IUV op (csrc/iuv_ops.hip) already dropped, cleaned and concatenated: [U | V | I | 5 zeros] bf16
@@ -123,13 +125,17 @@ class DaNet(nn.Module):
             if keep is not None:                                              # danet.py:264-274
                 pk = keep25[:, self._partial_src]                            # [B,24,7]
             from . import conv as _conv
+            # the IUV -> SMPL regressor is a backward-pass segment of its own (segments.py: its gradient buckets are on the wire
+            # while the estimator's and the backbone's backward run); identity unless a data-parallel trainer asked for cuts
             if FUSED_PART_OPS and part_pred.is_cuda and _conv.PRECISION != 'fp32':
-                part_iuv_map, x24 = part_ops.part_clean(part_pred, pk)        # one kernel; bf16 view of the padded operand
+                _, x24 = part_ops.part_clean(part_pred, pk)                   # one kernel; bf16, channels 21..23 zero
+                iuv_map, x24 = segments.cut([iuv_map, x24])
+                part_iuv_map = part_ops.padded_part_view(x24)                 # the [B,24,3,7,H,W] view of the padded operand
                 part_iuv_map._nhwc_padded = x24
             else:
                 if pk is not None:
                     part_pred = part_pred * pk.view(B, 24, 1, 7, 1, 1)
-                part_iuv_map = self._clean_partial(part_pred)
+                iuv_map, part_iuv_map = segments.cut([iuv_map, self._clean_partial(part_pred)])
             rd['visualization']['part_iuv_pred'] = part_iuv_map
             smpl_rd = self.iuv2smpl({'iuv_map': iuv_map, 'part_iuv_map': part_iuv_map, 'target': target,
                                      'target_kps': target_kps, 'target_verts': target_verts, 'target_kps3d': target_kps3d,

@@ -18,16 +18,22 @@ graph nodes with the same dependencies, so the replayed step overlaps them the s
 The sum is not divided: `grad_scale` = 1 / world is folded into the optimizer's update (FusedAdam) or applied
 by `scale_()` for other optimizers.
 
-Early buckets.  With `arm_early(callback)` every parameter carries a post-accumulate-grad hook; as soon as all
-parameters of the next bucket IN ORDER have their gradient (written, or queued as a deferred weight-gradient job) the
-callback runs for that bucket from inside the backward pass -- the trainer's callback launches the bucket's weight
-gradients and starts its all-reduce, so the regressor / limb-net buckets are on the wire while the HRNet backward is
-still running.  Buckets are released strictly in index order (a bucket that completes before its predecessor waits
-for it), so every rank issues the same sequence of collectives; buckets that do not complete during backward are
-finished by the trainer's tail loop, in order as well.  Parameters that received no gradient in the previous step
-(never-used modules: rot2pos / pos2rot, a skipped regressor) are not waited for -- the first step, which knows
-nothing yet, releases nothing early around them; should such a parameter receive a gradient after its bucket has
-gone out, end_backward() raises instead of training on an incomplete sum.
+Overlap with the backward pass.  The trainer runs the backward pass in SEGMENTS (segments.py: the autograd graph is cut at
+the HRNet module boundaries and at the estimator -> regressor interface) and calls `release_ready(fn)` between two
+segments: every bucket whose parameters all have their gradient (written, or queued as a deferred weight-gradient job) is
+handed to fn -- the trainer launches the bucket's weight gradients and starts its all-reduce -- strictly in index order (a
+bucket that completes before its predecessor waits for it), so every rank issues the same sequence of collectives from
+its main thread; the regressor / limb-net buckets are on the wire while the HRNet backward is still running, and buckets
+that do not complete before the last segment are finished by the trainer's tail loop, in order as well.  (Rounds 2-3
+released buckets from post-accumulate-grad hooks inside one loss.backward(): collectives issued from autograd's device
+thread aborted the process sporadically and could not be captured; the hooks now only count.)  Parameters that received no
+gradient in the previous step (never-used modules: rot2pos / pos2rot, a skipped regressor) are not waited for -- the first
+step, which knows nothing yet, releases nothing early around them; should such a parameter receive a gradient after its
+bucket has gone out, backward_scope(False) raises instead of training on an incomplete sum.
+
+Which parameters are in use is a GLOBAL fact: the flat buffer ends in one float per parameter ("fired on this rank"), which
+travels with the last bucket's all-reduce; the optimizer skips a parameter only if no rank produced a gradient for it
+(`used`), so replicas cannot diverge on data-dependent branches.
 
 bf16 wire format (`wire_dtype=torch.bfloat16`, BASELINE config C5's 204.5 MB instead of 409 MB per step): a bucket is
 rounded into a bf16 staging buffer, summed over the ranks in bf16, and widened back into the fp32 store when the
@@ -60,29 +66,46 @@ class GradStore(object):
             self.offsets[id(p)] = off
             self.bucket_of[id(p)] = len(self.buckets)
             off += n
-        self.buckets.append((start, off, first, len(self.params)))
-        self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # the last bucket ends in one float per parameter: "received a gradient on this rank in this step" (see `used`)
+        npad = (len(self.params) + 3) // 4 * 4
+        self.buckets.append((start, off + npad, first, len(self.params)))
+        self.flat = torch.zeros(off + npad, dtype=torch.float32, device=self.device)
         self.wire_dtype = wire_dtype
-        self.wire = None if wire_dtype == torch.float32 else torch.zeros(off, dtype=wire_dtype, device=self.device)
+        self.wire = None if wire_dtype == torch.float32 else torch.zeros(off + npad, dtype=wire_dtype, device=self.device)
         self.index = {id(p): i for i, p in enumerate(self.params)}
-        # which parameters received a gradient in the last backward pass (1 / 0, in self.params order): filled from the
-        # post-accumulate-grad hooks when the trainer leaves backward_scope; the optimizer skips the others (optim.FusedAdam)
-        self.used = torch.ones(len(self.params), dtype=torch.int32, device=self.device)
-        self._used_host = torch.ones(len(self.params), dtype=torch.int32)
+        # In how many ranks each parameter (self.params order) received a gradient in the last backward pass: written from
+        # the post-accumulate-grad hooks when the trainer leaves backward_scope, summed over the ranks by the last bucket's
+        # all-reduce; the optimizer skips a parameter only where this is 0 (optim.FusedAdam), on every rank alike.
+        self.used = self.flat[off:off + len(self.params)]
+        self.used.fill_(1.0)
+        self._grads = self.flat[:off]
+        self._mask_fresh = False            # this step's mask has been uploaded (backward_scope); else every parameter counts as in use
+        # two pinned host copies of the mask, used alternately and rewritten only when the set of parameters in use changes:
+        # the asynchronous upload of one step (and the memcpy node of a captured graph, which re-reads its buffer on every
+        # replay) never sees a half-written mask
+        self._mask_host = [torch.ones(len(self.params), dtype=torch.float32) for _ in range(2)]
         if self.device.type == 'cuda':
-            self._used_host = self._used_host.pin_memory()
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+            self._mask_host = [m.pin_memory() for m in self._mask_host]
+        self._mask_set = [None, None]
+        self._mask_event = [None, None]
+        self._mask_turn = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._works = []
         self.issued = []                    # bucket indices in the order their collectives were issued this step ...
-        self.issued_early = 0               # ... and how many of them from inside the backward pass
+        self.issued_early = 0               # ... and how many of them before the backward pass had finished
         self._handed = set()
-        self._early_cb = None
         self._expected = None               # ids of the parameters that received a gradient in the previous step
         self._fired, self._late = set(), []
         self._pending = None
         self._next = 0
         self._in_backward = False
+
+    def close(self):
+        """Detach from the parameters (hooks) -- call when a trainer replaces its store; the flat buffer is freed with the
+        last reference."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     # ---- storage -------------------------------------------------------------------------------------------------
     def has(self, p):
@@ -107,26 +130,21 @@ class GradStore(object):
 
     def begin_step(self):
         """Zero the storage (one memset): slots of parameters that receive no gradient this step stay zero."""
-        self.flat.zero_()
+        self._grads.zero_()
+        self._mask_fresh = False
         self.issued, self.issued_early, self._next = [], 0, 0
         self._handed = set()
         self._fired, self._late = set(), []
-        self._pending = None
-        if self._early_cb is not None:
-            exp = self._expected
-            self._pending = [sum(1 for p in self.params[i0:i1] if exp is None or id(p) in exp) for (_, _, i0, i1) in self.buckets]
-
-    # ---- early buckets -------------------------------------------------------------------------------------------
-    def arm_early(self, callback):
-        """callback(bucket_index) runs during backward once the next bucket in order is complete (see the module text)."""
-        self._early_cb = callback
+        exp = self._expected
+        self._pending = [sum(1 for p in self.params[i0:i1] if exp is None or id(p) in exp) for (_, _, i0, i1) in self.buckets]
 
     def index_of(self, p):
         return self.index[id(p)]
 
+    # ---- the backward pass ---------------------------------------------------------------------------------------
     def backward_scope(self, active, early=True):
-        """The trainer brackets loss.backward() with backward_scope(True) / (False): hooks outside it are ignored; early =
-        False keeps the buckets for the caller's tail loop (steps whose all-reduces run elsewhere).  Leaving the scope
+        """The trainer brackets the backward pass with backward_scope(True) / (False): hooks outside it are ignored; early =
+        False keeps every bucket for the caller's tail loop (steps whose all-reduces run elsewhere).  Leaving the scope
         uploads which parameters received gradients (`used`; also the next step's expectation) and checks that none of them
         arrived after its bucket had been released."""
         was = self._in_backward
@@ -136,14 +154,31 @@ class GradStore(object):
         if was and not active:
             late, self._late = self._late, []
             self._expected = set(self._fired)
-            self._used_host.zero_()
-            idx = [self.index[i] for i in self._fired]
-            if idx:
-                self._used_host[idx] = 1
-            self.used.copy_(self._used_host, non_blocking=True)
+            self._upload_mask()
             if late:
                 raise RuntimeError('GradStore: %d parameter(s) received a gradient after their bucket had been all-reduced '
                                    '(the set of parameters in use changed between steps); the step is incomplete -- rerun it' % len(late))
+
+    def _upload_mask(self):
+        fired = frozenset(self.index[i] for i in self._fired)
+        k = self._mask_turn
+        if self._mask_set[k] != fired:
+            k ^= 1
+            if self._mask_set[k] != fired:
+                if self._mask_event[k] is not None:
+                    self._mask_event[k].synchronize()          # the upload that last read this buffer has finished
+                m = torch.zeros(len(self.params), dtype=torch.float32)
+                if fired:
+                    m[sorted(fired)] = 1.0
+                self._mask_host[k].copy_(m)                    # (one pass over a complete mask, never a zeroed intermediate)
+                self._mask_set[k] = fired
+            self._mask_turn = k
+        self.used.copy_(self._mask_host[k], non_blocking=True)
+        self._mask_fresh = True
+        if self.device.type == 'cuda':
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._mask_event[k] = ev
 
     def _on_grad(self, p):
         if not self._in_backward:
@@ -159,11 +194,21 @@ class GradStore(object):
                 self._late.append(p)
             return
         self._pending[b] -= 1
-        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+
+    def release_ready(self, fn):
+        """Between two segments of the backward pass (main thread): fn(bucket) for every bucket that is complete, strictly in
+        index order.  The last bucket is never released here: it carries the usage mask, which is only known once the
+        backward pass has finished.  Returns the number of buckets released."""
+        n = 0
+        if self._pending is None or not self._in_backward:
+            return n
+        while self._next < len(self.buckets) - 1 and self._pending[self._next] == 0:
             bi = self._next
             self._next += 1
             self.issued_early += 1
-            self._early_cb(bi)
+            fn(bi)
+            n += 1
+        return n
 
     def next_bucket(self):
         """First bucket the backward pass did not release (the trainer's tail loop continues from here)."""
@@ -206,6 +251,8 @@ class GradStore(object):
             return
         s, e, _, _ = self.buckets[bi]
         self.issued.append(bi)
+        if bi == len(self.buckets) - 1 and not self._mask_fresh:
+            self.used.fill_(1.0)            # a step outside backward_scope: no mask, every parameter with a gradient pointer is updated
         if self.wire is None:
             work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -231,9 +278,26 @@ class GradStore(object):
         if self.world > 1:
             self.flat.mul_(self.grad_scale)
 
-    def broadcast_parameters(self, module, src=0):
-        """One-time broadcast of parameters and buffers (BatchNorm statistics) from rank `src`."""
+    def broadcast_parameters(self, module, src=0, chunk_mb=64.0):
+        """One-time broadcast of parameters and buffers (BatchNorm statistics) from rank `src`: tensors of one dtype are
+        packed into chunks of ~chunk_mb MB -- about a dozen collectives for the whole model instead of one per tensor."""
+        by_dtype = {}
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+                by_dtype.setdefault(t.dtype, []).append(t.data)
         with torch.no_grad():
-            for t in list(module.parameters()) + list(module.buffers()):
-                if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
-                    dist.broadcast(t.data, src=src, group=self.group)
+            for dt, ts in by_dtype.items():
+                cap = max(1, int(chunk_mb * 1024 * 1024 / ts[0].element_size()))
+                grp, n = [], 0
+                for t in ts + [None]:
+                    if t is None or (grp and n + t.numel() > cap):
+                        flat = torch.cat([g.reshape(-1) for g in grp])
+                        dist.broadcast(flat, src=src, group=self.group)
+                        o = 0
+                        for g in grp:
+                            g.copy_(flat[o:o + g.numel()].view_as(g))
+                            o += g.numel()
+                        grp, n = [], 0
+                    if t is not None:
+                        grp.append(t)
+                        n += t.numel()

@@ -10,6 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import segments
 from .config import cfg
 from .nn import fan_out, sum_relu, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
@@ -240,7 +241,8 @@ class PoseHighResolutionNet(nn.Module):
 
     def _run_stage(self, stage, xs):
         for m in stage:
-            xs = m(xs)
+            # a backward-pass segment per module (segments.py): identity unless a data-parallel trainer asked for cuts
+            xs = m(segments.cut(xs))
         return xs
 
     def forward(self, x):

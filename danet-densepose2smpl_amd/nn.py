@@ -26,6 +26,11 @@ RELU_MASK = bool(int(os.environ.get('DANET_BN_RELU_MASK', '1')))     # A/B knob:
 # trainer names in ONEPASS_STREAM (its capture stream); BatchNorms running on other (side) streams take the two-kernel path.
 ONEPASS = bool(int(os.environ.get('DANET_BN_ONEPASS', '1')))
 ONEPASS_STREAM = None
+# Co-residency budget of a one-pass launch (workgroups; 0 = the whole device, two per compute unit).  A data-parallel trainer
+# lowers it to 2 * (compute units - communication channels): the all-reduce kernels of the step's earlier gradient buckets run
+# on the communication stream WHILE the backward pass continues, and a grid barrier over more workgroups than fit beside them
+# could wait for ever (include/danet_hip.h, danet_bn_backward_onepass).
+ONEPASS_MAX_BLOCKS = 0
 _ONEPASS_BAR = {}
 
 
@@ -37,15 +42,36 @@ def _onepass_bar(device):
     cur = torch.cuda.current_stream(device)
     if cur != (ONEPASS_STREAM if ONEPASS_STREAM is not None else torch.cuda.default_stream(device)):
         return None
+    return _onepass_state(device)
+
+
+def _onepass_state(device):
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
     bar = _ONEPASS_BAR.get(device)
     if bar is None:
         bar = _ONEPASS_BAR[device] = torch.zeros(_lib.lib().danet_bn_backward_onepass_bar_words(), dtype=torch.int32, device=device)
     return bar
 
 
+def onepass_poison(device):
+    """The barrier's error word as a one-element int32 tensor: what optim.FusedAdam hands the Adam kernel as `poison`, so that a
+    step whose one-pass launch timed out is never applied."""
+    return _onepass_state(device)[2:3]
+
+
+def _on_device(d, device):
+    """d (a key of _ONEPASS_BAR, always with an index) is `device` (None = any; 'cuda' without an index = any GPU)."""
+    if device is None:
+        return True
+    device = torch.device(device)
+    return d.type == device.type and (device.index is None or d.index == device.index)
+
+
 def onepass_error(device=None):
     """True if a one-pass launch gave up waiting at its barrier (its results are garbage)."""
-    return any(int(b[2]) != 0 for d, b in _ONEPASS_BAR.items() if device is None or d == device)
+    return any(int(b[2]) != 0 for d, b in _ONEPASS_BAR.items() if _on_device(d, device))
 
 
 def onepass_recover(device=None):
@@ -58,7 +84,7 @@ def onepass_recover(device=None):
         return False
     torch.cuda.synchronize()
     for d, b in _ONEPASS_BAR.items():
-        if device is None or d == device:
+        if _on_device(d, device):
             b.zero_()
     ONEPASS = False
     return True
@@ -152,8 +178,8 @@ class BatchNormActFunction(torch.autograd.Function):
             j.dx, j.dres, j.dparam, j.red = dx.data_ptr(), None if dres is None else dres.data_ptr(), dparam.data_ptr(), red.data_ptr()
             j.beta, j.mask, j.mask_mode = None if b is None else b.data_ptr(), None if mask is None else mask.data_ptr(), int(ctx.mask_mode)
             j.M, j.C, j.red_state, j.relu = M, C, 1, int(ctx.relu)
-            if L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1):
-                check(L.danet_bn_backward_onepass(ctypes.addressof(job), 1, ptr(bar), stream()), 'danet_bn_backward_onepass')
+            if L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1, ONEPASS_MAX_BLOCKS):
+                check(L.danet_bn_backward_onepass(ctypes.addressof(job), 1, ptr(bar), ONEPASS_MAX_BLOCKS, stream()), 'danet_bn_backward_onepass')
                 _conv.FUSION['bn_bwd_onepass'] += 1
                 done = True
         if not done:
@@ -311,8 +337,8 @@ class MultiBatchNormFunction(torch.autograd.Function):
             dress.append(dres)
             dparams.append(dparam)
         bar = _onepass_bar(xs[0].device) if (dt == torch.bfloat16 and all(jobs[i].red_state == 1 for i in range(n))) else None
-        if bar is not None and L.danet_bn_backward_onepass_ok(ctypes.addressof(jobs), n):
-            check(L.danet_bn_backward_onepass(ctypes.addressof(jobs), n, ptr(bar), stream()), 'danet_bn_backward_onepass')
+        if bar is not None and L.danet_bn_backward_onepass_ok(ctypes.addressof(jobs), n, ONEPASS_MAX_BLOCKS):
+            check(L.danet_bn_backward_onepass(ctypes.addressof(jobs), n, ptr(bar), ONEPASS_MAX_BLOCKS, stream()), 'danet_bn_backward_onepass')
             _conv.FUSION['bn_bwd_onepass'] += n
         else:
             check(_k(L, 'danet_bn_backward_multi', dt)(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')

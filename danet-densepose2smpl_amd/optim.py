@@ -4,7 +4,8 @@ eps=1e-8) -- the reference's optimizer, /root/reference/train/trainer.py:42-44 -
 The moments live in two flat fp32 buffers; a device table of <= 32768-element chunks {param, grad, moment offset, n}
 drives the kernel.  With a `grad_store` (distributed.GradStore: every gradient is a view of one flat buffer) the
 table is written once and never changes; which parameters received a gradient in the step comes from the store's
-per-parameter mask (GradStore.used, filled from its post-accumulate-grad hooks).  Without a store the table is
+per-parameter mask (GradStore.used: filled from its post-accumulate-grad hooks and, with N > 1, summed over the ranks with
+the last gradient bucket -- a parameter is skipped only if NO rank produced a gradient for it, so replicas stay identical).  Without a store the table is
 rebuilt (host side, double-buffered pinned copy) whenever a gradient tensor's address changed, and a NULL gradient
 pointer marks the skip.
 
@@ -86,7 +87,10 @@ class FusedAdam(object):
             self._table.copy_(self._hosts[0])                 # synchronous, once
             # the store's mask is in ITS parameter order: gathered into this optimizer's order every step (one tiny launch)
             self._used_perm = torch.tensor([grad_store.index_of(p) for p in self.params], dtype=torch.long, device=dev)
-            self._used = torch.ones(len(self.params), dtype=torch.int32, device=dev)
+            self._used = torch.ones(len(self.params), dtype=torch.float32, device=dev)
+        # device int the kernel tests before it touches anything: non-zero = this step's gradients are invalid (set by the trainer
+        # to the one-pass BatchNorm backward's barrier error word, nn.onepass_poison)
+        self.poison = None
 
     def state_dict(self):
         """torch.optim.Adam's layout (per-parameter step / exp_avg / exp_avg_sq + one param group), so the checkpoints of
@@ -158,7 +162,8 @@ class FusedAdam(object):
             used = self._used
         check(_lib.lib().danet_adam_step(ptr(self._table), self.nchunks, ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                          ptr(self.param_groups[0]['lr']), ptr(self.step_t), ptr(used), ptr(self.idle),
-                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale), stream()), 'danet_adam_step')
+                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale),
+                                         ptr(self.poison), stream()), 'danet_adam_step')
         # the kernel wrote the parameters through raw pointers: bump their version counters like an in-place op would
         # (the conv weight-pack cache and autograd's saved-tensor checks key on them)
         upd = self.params if self.grad_store is not None else [p for p in self.params if p.grad is not None]

@@ -61,10 +61,14 @@ def part_clean(pred, keep=None):
     if pred.dim() == 6:
         B, J, T, K, H, W = pred.shape
         pred = getattr(pred, '_padded', None) if getattr(pred, '_padded', None) is not None else pred.reshape(B, J * T * K, H, W)
-    B, _, H, W = pred.shape
     x24 = PartCleanFunction.apply(pred, keep)
-    view = x24[:, :21].reshape(B, NJ, 3, NC, H, W)          # strided view of the padded buffer, no copy
-    return view, x24
+    return padded_part_view(x24), x24
+
+
+def padded_part_view(x24):
+    """x24 [B*24, 24, H, W] (channels 21..23 zero) -> its [B,24,3,7,H,W] strided view (no copy)."""
+    BJ, _, H, W = x24.shape
+    return x24[:, :21].reshape(BJ // NJ, NJ, 3, NC, H, W)
 
 
 class PartLossFunction(torch.autograd.Function):

@@ -23,12 +23,25 @@ from .geometry import perspective_projection, label_prologue
 
 DEFER_WGRAD = bool(int(os.environ.get('DANET_DEFER_WGRAD', '1')))
 USE_FUSED_ADAM = bool(int(os.environ.get('DANET_FUSED_ADAM', '1')))
-# N > 1, opt-in (DANET_EARLY_BUCKETS=1): buckets are all-reduced from inside the backward pass of EAGER steps as soon as they are
-# complete (distributed.GradStore.arm_early).  Off by default: on the 1-rank RCCL group of this environment a run with the
-# early release aborted (SIGABRT, no message) about once in eight starts -- with the collectives issued from the engine's
-# device thread and from the calling thread alike, inside a capture and in eager steps --, never without it (8 / 8, 10 / 10).
-# Default: bucket by bucket after the backward pass, interleaved with the weight-gradient launches (round 2's order).
-EARLY_BUCKETS = bool(int(os.environ.get('DANET_EARLY_BUCKETS', '0')))
+# Data-parallel steps run the backward pass in segments (segments.py) and release complete gradient buckets between them:
+# all-reduces overlap the backward pass proper, issued by this thread in program order (eager and captured alike).
+# DANET_SEGMENTS=0 switches the cuts off (every bucket after the backward pass: round 2's order); DANET_SEGMENTS=1 forces them
+# on in a single-process trainer (tests, A/B timing).
+SEGMENTS = os.environ.get('DANET_SEGMENTS', '')
+# Compute units the communication library may occupy while the backward pass runs (one workgroup per channel): the one-pass
+# BatchNorm backward's grid barrier is sized to fit beside them (nn.ONEPASS_MAX_BLOCKS).  The trainer exports it as
+# NCCL_MAX_NCHANNELS unless the environment already names a limit (must happen before the first collective creates the
+# communicator; bench.py sets it before init_process_group).
+COMM_CHANNELS = int(os.environ.get('DANET_COMM_CHANNELS', '24'))
+
+
+def reserve_comm_channels():
+    """Export the channel limit (if none is set) and return the number of compute units to keep free for collectives."""
+    cur = os.environ.get('NCCL_MAX_NCHANNELS')
+    if cur is None:
+        os.environ['NCCL_MAX_NCHANNELS'] = str(COMM_CHANNELS)
+        return COMM_CHANNELS
+    return max(1, int(cur))
 
 
 def default_options(batch_size=32):
@@ -75,7 +88,8 @@ def synthetic_in_dict(model, B, device, seed=1234, img_size=None, with_dp=False)
 
 class Trainer(object):
     """Single-process-per-GPU trainer.  Gradients live in one flat store (distributed.GradStore); with world_size > 1
-    its buckets are all-reduced (RCCL) while the remaining weight gradients of the step are still being computed."""
+    its buckets are all-reduced (RCCL) while the rest of the backward pass and the remaining weight gradients of the step
+    are still being computed (segments.py)."""
 
     def __init__(self, options=None, model=None, device=None, lr=None, distributed=None, smpl_model=None, bucket_mb=None, grad_wire=None):
         self.options = options or default_options()
@@ -100,8 +114,6 @@ class Trainer(object):
             self.store = GradStore(params, bucket_mb=bucket_mb, device=self.device,
                                    world=torch.distributed.get_world_size() if self.distributed else 1,
                                    wire_dtype=wire if self.distributed else torch.float32)
-            if self.distributed and EARLY_BUCKETS:
-                self.store.arm_early(self._early_bucket)
             self.optimizer = FusedAdam(params, lr=lr0, grad_store=self.store)      # one HIP launch per step (csrc/adam.hip)
         else:
             if self.distributed:
@@ -114,10 +126,18 @@ class Trainer(object):
         # gradient-accumulation node to the stream it was created on, and a node created on the default
         # stream would pull that (non-capturing) stream into a later hipGraph capture.
         self.stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+        self.segmented = (self.distributed and SEGMENTS != '0') or SEGMENTS == '1'
         if on_gpu:
             _conv.ARENA.enable(self.device)
             from . import nn as _nn
             _nn.ONEPASS_STREAM = self.stream        # the one-pass BatchNorm backward is confined to the step's own stream
+            if isinstance(self.optimizer, torch.optim.Optimizer) is False:
+                # a step whose one-pass BatchNorm backward timed out at its grid barrier is skipped by the Adam kernel itself
+                self.optimizer.poison = _nn.onepass_poison(self.device)
+            if self.distributed:
+                # all-reduce kernels of earlier buckets run beside the backward pass: size the grid barrier to fit next to them
+                cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+                _nn.ONEPASS_MAX_BLOCKS = max(2, 2 * (cus - reserve_comm_channels()))
         self._graph = None
         self._static = None
         self._reduce_in_graph = True
@@ -169,16 +189,20 @@ class Trainer(object):
 
     def check_onepass(self):
         """The one-pass BatchNorm backward (csrc/norm_act.hip) spins at a grid-wide barrier with a bound; a time-out -- a GPU
-        shared with another process, a partitioned device -- leaves garbage gradients and a stale barrier.  Called every
-        ONEPASS_CHECK_EVERY steps and before a checkpoint is written: on an error the barrier is reset, the one-pass path
-        switched off (two-kernel BatchNorm backward from here on), a captured graph dropped, and the caller told: the
-        parameters have been updated with garbage since the time-out, so training must resume from a checkpoint."""
+        shared with another process, a partitioned device -- leaves garbage gradients and a stale barrier.  The Adam kernel
+        reads the barrier's error word and skips such a step on the device (csrc/adam.hip `poison`), so nothing is ever
+        applied; this host-side check (every ONEPASS_CHECK_EVERY steps and before a checkpoint is written) is for reporting and
+        recovery: the barrier is reset, the one-pass path switched off (two-kernel BatchNorm backward from here on), a
+        captured graph dropped, and the caller told."""
         from . import nn as dnn
         if self.device.type == 'cuda' and dnn.onepass_recover(self.device):
             self._graph = None
-            raise RuntimeError('a one-pass BatchNorm launch timed out at its grid barrier: gradients since then are invalid. '
-                               'The barrier was reset and the one-pass path switched off (nn.ONEPASS = False); resume from the '
-                               'last checkpoint (and capture() again if you replay a graph)')
+            guarded = getattr(self.optimizer, 'poison', None) is not None
+            raise RuntimeError('a one-pass BatchNorm launch timed out at its grid barrier: gradients since then are invalid'
+                               + (' -- the optimizer skipped those steps (device-side guard), parameters and moments are intact. '
+                                  if guarded else ' and were applied: resume from the last checkpoint. ') +
+                               'The barrier was reset and the one-pass path switched off (nn.ONEPASS = False); capture() again if you '
+                               'replay a graph')
 
     def save(self, path, epoch=0, batch_idx=0, batch_size=0, dataset_perm=None):
         """A training checkpoint in the reference's format (utils/saver.py:24-50): model, optimizer, bookkeeping with
@@ -245,50 +269,60 @@ class Trainer(object):
         cur.wait_stream(self.stream)
 
     def _core(self, batch, reduce=True, with_optimizer=True):
-        """One optimisation step on the current stream: forward, backward with the weight gradients queued, then bucket
-        by bucket: the bucket's weight-gradient launches, its small gradients copied into the store, its all-reduce
-        (N > 1, asynchronous: the next bucket's launches overlap it); Adam waits for the last all-reduce."""
+        """One optimisation step on the current stream: forward; backward with the weight gradients queued -- in segments
+        when data-parallel (segments.py), releasing every complete gradient bucket between two segments: the bucket's
+        weight-gradient launches, its small gradients copied into the store, its all-reduce (asynchronous, on the
+        communication stream: the next segment's backward kernels overlap it); then the remaining buckets the same way; Adam
+        waits for the last all-reduce."""
+        from . import segments
         st = self.store
         self._begin_step()
         if st is not None:
             st.begin_step()
         BatchNorm2d.count_batches = False
+        reduce_now = bool(self.distributed and reduce)
+        segments.begin(self.segmented and st is not None)
         try:
-            out = self.model(batch)
-        finally:
-            BatchNorm2d.count_batches = True
-        bump_batch_counters(self.model)
-        losses = out['losses']
-        # (every loss is a 1-element tensor, models/danet/danet.py:359-364: views + one cat + one sum)
-        loss_total = torch.cat([v.reshape(-1) for v in losses.values()]).sum()
-        self.optimizer.zero_grad(set_to_none=True)
-        _conv.GRAD_STORE = st
-        _conv.DEFER_WGRAD = DEFER_WGRAD
-        self._reduce_now = bool(self.distributed and reduce)
-        # Early buckets only in eager steps: collectives issued from inside the backward pass of a hipGraph CAPTURE aborted the
-        # process sporadically (1-rank RCCL group: 1 run in 8, from the engine's device thread and from this thread alike;
-        # never with the collectives issued after the backward pass), so a captured step keeps the round-2 order -- bucket by
-        # bucket after the backward pass, interleaved with the weight-gradient launches.
-        capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
-        if st is not None:
-            st.backward_scope(True, early=self._reduce_now and not capturing)
-        try:
-            loss_total.backward()
-        finally:
+            try:
+                out = self.model(batch)
+            finally:
+                BatchNorm2d.count_batches = True
+            bump_batch_counters(self.model)
+            losses = out['losses']
+            self.optimizer.zero_grad(set_to_none=True)
+            _conv.GRAD_STORE = st
+            _conv.DEFER_WGRAD = DEFER_WGRAD
             if st is not None:
-                st.backward_scope(False)
-            _conv.DEFER_WGRAD = False
-            _conv.GRAD_STORE = None
+                st.backward_scope(True, early=reduce_now)
+            try:
+                if segments.level() > 0:
+                    segments.backward(losses, (lambda k: st.release_ready(self._release_bucket)) if reduce_now else None)
+                else:
+                    # (every loss is a 1-element tensor, models/danet/danet.py:359-364: views + one cat + one sum)
+                    torch.cat([v.reshape(-1) for v in losses.values()]).sum().backward()
+            finally:
+                # first disarm the module globals, then close the scope (which may raise on a late gradient): an aborted step
+                # must not leave queued weight-gradient jobs or pending collectives behind for the rerun
+                _conv.DEFER_WGRAD = False
+                _conv.GRAD_STORE = None
+                if st is not None:
+                    try:
+                        st.backward_scope(False)
+                    except RuntimeError:
+                        _conv._WQ.clear()
+                        _conv._WQG.clear()
+                        st._works = []
+                        raise
+        finally:
+            segments.end()
         if st is None:
             _conv.flush_wgrads()
         else:
             _conv.GRAD_STORE = st
             try:
-                if self.distributed and reduce:
-                    for bi in range(st.next_bucket(), len(st.buckets)):      # what the backward pass did not release early
-                        _conv.flush_wgrads(bucket=bi)
-                        st.collect(bi)
-                        st.reduce_bucket(bi)
+                if reduce_now:
+                    for bi in range(st.next_bucket(), len(st.buckets)):      # what the backward pass did not release
+                        self._release_bucket(bi)
                 else:
                     # one process: no all-reduce to overlap with, so all queued weight gradients go out in the fewest, largest
                     # multi-problem launches (-0.15 ms against 13 bucket-sized flushes)
@@ -297,18 +331,21 @@ class Trainer(object):
                 _conv.flush_wgrads()                     # (nothing left: every parameter belongs to a bucket)
             finally:
                 _conv.GRAD_STORE = None
-            if self.distributed and reduce:
+            if reduce_now:
                 st.wait()
         if with_optimizer:
             self.optimizer.step()
         return out, losses
 
-    def _early_bucket(self, bi):
-        """GradStore's early-bucket callback (runs inside loss.backward(), on the step's stream): the bucket's queued weight
-        gradients are launched, its other gradients copied into the store, and its all-reduce started -- the rest of the
-        backward pass overlaps it."""
+    def _release_bucket(self, bi):
+        """A complete gradient bucket: its queued weight gradients are launched, its other gradients copied into the store, and
+        its all-reduce started (GradStore.release_ready between two backward segments, or the tail loop)."""
         st = self.store
-        _conv.flush_wgrads(bucket=bi)
+        prev, _conv.GRAD_STORE = _conv.GRAD_STORE, st
+        try:
+            _conv.flush_wgrads(bucket=bi)
+        finally:
+            _conv.GRAD_STORE = prev
         st.collect(bi)
         st.reduce_bucket(bi)
 

@@ -149,13 +149,16 @@ int danet_smpl_loss_backward(const void* params, const float* gout, const float*
  * Optimizer (replaces torch.optim.Adam at /root/reference/train/trainer.py:42-44): one launch over a device table of
  * <= 32768-element chunks { float* p; const float* g (NULL = skip); int64 off (into m, v); int32 n; int32 param (2 * parameter
  * index + 1 for the parameter's first chunk) }.  lr and step (1-based GLOBAL count, float) are read from device memory; p, g,
- * m+off, v+off 16-byte aligned.  Per-parameter step counts as torch.optim.Adam keeps them: used (NULL = all): int per parameter,
- * 0 = no gradient this step -> the parameter is skipped (moments untouched) and idle[param] (float per parameter, NULL = none,
- * maintained by the kernel) counts it; bias corrections use step - idle[param].  grad_scale multiplies every gradient
- * (1 / world size: all-reduced sums become the average without a pass of its own). */
+ * m+off, v+off 16-byte aligned.  Per-parameter step counts as torch.optim.Adam keeps them: used (NULL = all): float per
+ * parameter, the number of ranks in which it received a gradient this step (summed with the gradients), 0 -> the parameter is
+ * skipped (moments untouched) and idle[param] (float per parameter, NULL = none, maintained by the kernel) counts it; bias
+ * corrections use step - idle[param].  grad_scale multiplies every gradient (1 / world size: all-reduced sums become the
+ * average without a pass of its own).  poison (NULL = none): device int, non-zero = the step's gradients are invalid (the
+ * one-pass BatchNorm backward's barrier error word, danet_bn_backward_onepass): every parameter is skipped and counted idle. */
 size_t danet_adam_chunk_bytes(void);
 int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
-                    const int* used, float* idle, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                    const float* used, float* idle, float beta1, float beta2, float eps, float grad_scale,
+                    const int* poison, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Partial-IUV ("limb") path glue (replaces /root/reference/models/danet/danet.py:264-283 and
@@ -278,6 +281,14 @@ int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks, int wa
  * problems (0: not taken). */
 int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want_tiles);
 int danet_conv3x3_stream_plan(int B, int H, int W, int Cin, int Cout, int nprob);
+/* The streamed kernel reads a per-shape tap table (<= 112 k-step entries, danet_conv3x3_stream_table_bytes() bytes each) from
+ * device memory.  The library allocates none: the caller registers a workspace for the CURRENT device once (it must outlive
+ * every launch; registering again, or NULL, forgets the cached tables) and gets back the number of tables it holds.  A
+ * table is computed on the host and uploaded with a synchronous copy the first time its shape is seen -- complete before any
+ * stream can launch a reader; a new shape first seen while the launching stream is capturing, or with no workspace / a full
+ * one, runs on conv3x3_tile_kernel instead (danet_conv_forward_multi_kernel / danet_conv_forward_kernel say which). */
+size_t danet_conv3x3_stream_table_bytes(void);
+int danet_conv3x3_stream_tables(void* workspace, size_t bytes);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);
@@ -365,10 +376,17 @@ int danet_bn_backward_multi(const void* jobs, int n, void* stream);
  * a ReLU gate that does not need y (mask_mode 1 or 2), C <= 1024 and at most 512 x 256 x 16 channel vectors.  bar:
  * danet_bn_backward_onepass_bar_words() uints of device memory, zeroed once, shared by all such launches, which must not overlap
  * (issue them on one stream).  The barrier (two levels: eight arrival groups, then one) spin is bounded: after a timeout
- * bar[2] != 0, the results of that launch are garbage and the state must be zeroed again before another launch. */
+ * bar[2] != 0, the results of that launch are garbage and the state must be zeroed again before another launch (pass bar + 2
+ * to danet_adam_step as `poison`: such a step is then never applied).
+ * max_blocks (<= 0: two workgroups per compute unit of the device, at most 512): the caller's co-residency budget.  The
+ * barrier needs every workgroup of a launch resident at once; a kernel of ANOTHER stream that occupies compute units while
+ * these launches run (the communication library's all-reduce kernels of a data-parallel step: one workgroup per channel)
+ * can keep the last workgroups out until it finishes -- and if that kernel is itself only partly resident, for ever.  With
+ * max_blocks = 2 * (compute units - channels) every launch fits beside the other kernel's worst case, so neither can wait
+ * for the other; job sets are split into more launches, a single job that needs more takes the two-kernel path. */
 int danet_bn_backward_onepass_bar_words(void);
-int danet_bn_backward_onepass_ok(const void* jobs, int n);
-int danet_bn_backward_onepass(const void* jobs, int n, void* bar, void* stream);
+int danet_bn_backward_onepass_ok(const void* jobs, int n, int max_blocks);
+int danet_bn_backward_onepass(const void* jobs, int n, void* bar, int max_blocks, void* stream);
 /* out[C] (fp32) = sum over the M rows of x [M, C] (bf16; _f32: fp32): the bias gradient of a convolution,
  * gy.sum(dim = (0, 2, 3)) in /root/reference's autograd.  out is zeroed here; C % 4 == 0. */
 int danet_channel_sum(const void* x, int64_t M, int C, float* out, void* stream);

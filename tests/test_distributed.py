@@ -71,34 +71,56 @@ def _worker(rank, world, port, tmp):
     st.scale_()
     st.attach_all()
     torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(tmp, 'n%d.pt' % rank))
-    # early buckets: released from inside backward, strictly in bucket order, never-used parameters not waited for after the
-    # first step; and the bf16 wire format
+    # segmented backward (segments.py): complete buckets are released BETWEEN two segments, strictly in bucket order, from this
+    # thread; never-used parameters are not waited for after the first step; the last bucket (it carries the usage mask) always
+    # goes out in the tail; and the bf16 wire format
+    from danet_densepose2smpl_amd import segments
     for wire in (torch.float32, torch.bfloat16):
         net2 = _Net()
         st2 = GradStore(net2.parameters(), bucket_mb=0.0002, device=torch.device('cpu'), wire_dtype=wire)
         st2.broadcast_parameters(net2)
 
-        def early(bi, st2=st2):
+        def release(bi, st2=st2):
             st2.collect(bi)
             st2.reduce_bucket(bi)
-        st2.arm_early(early)
         log = []
         for step in range(3):
             net2.zero_grad(set_to_none=True)
             st2.begin_step()
+            segments.begin(True)
+            h = segments.cut(torch.relu(net2.bn(net2.a(data[rank]))))           # segment 0: a, bn | segment 1: b
+            loss = {'l': net2.b(h).pow(2).mean()}
+            assert segments.level() == 1
             st2.backward_scope(True)
-            net2(data[rank]).pow(2).mean().backward()
+            segments.backward(loss, lambda k: st2.release_ready(release))
             st2.backward_scope(False)
+            segments.end()
             for bi in range(st2.next_bucket(), len(st2.buckets)):
-                st2.collect(bi)
-                st2.reduce_bucket(bi)
+                release(bi)
             st2.wait()
+            used = st2.used.clone()
             st2.scale_()
             st2.attach_all()
-            log.append((list(st2.issued), st2.issued_early))
+            log.append((list(st2.issued), st2.issued_early, used))
         torch.save({'log': log, 'nb': len(st2.buckets), 'grads': {k: p.grad.clone() for k, p in net2.named_parameters()},
-                    'params': {k: p.detach().clone() for k, p in net2.named_parameters()}},
+                    'params': {k: p.detach().clone() for k, p in net2.named_parameters()},
+                    'order': [k for p in st2.params for k, q in net2.named_parameters() if q is p]},
                    os.path.join(tmp, 'e%d_%s.pt' % (rank, 'bf16' if wire == torch.bfloat16 else 'fp32')))
+    # a parameter that receives a gradient on ONE rank only: the mask is summed with the last bucket, so both ranks see it in use
+    net3 = _Net()
+    st3 = GradStore(net3.parameters(), bucket_mb=0.0002, device=torch.device('cpu'))
+    st3.broadcast_parameters(net3)
+    net3.zero_grad(set_to_none=True)
+    st3.begin_step()
+    st3.backward_scope(True, early=False)
+    y = net3(data[rank]).pow(2).mean()
+    if rank == 1:
+        y = y + net3.unused(torch.ones(2, 3)).sum()
+    y.backward()
+    st3.backward_scope(False)
+    st3.reduce_all()
+    torch.save({'used': st3.used.clone(), 'order': [k for p in st3.params for k, q in net3.named_parameters() if q is p]},
+               os.path.join(tmp, 'u%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -124,18 +146,26 @@ def test_two_rank_gradient_average_matches_single_process(tmp_path):
         assert torch.allclose(r0['grads'][k], mean, atol=1e-6), k
         assert torch.allclose(r1['grads'][k], mean, atol=1e-6), k
     assert r0['grads']['unused.weight'].abs().max() == 0               # unused parameters reduced as zeros
+    for r in (0, 1):                                                   # in use on rank 1 only -> in use everywhere (count 1), the rest count 2
+        u = torch.load(tmp_path / ('u%d.pt' % r))
+        for name, c in zip(u['order'], u['used'].tolist()):
+            assert c == (1.0 if name.startswith('unused') else 2.0), (r, name, c)
     n0 = torch.load(tmp_path / 'n0.pt')
     for k in n0:
         assert torch.allclose(n0[k], (grads[0][k] + grads[1][k]) / 2, atol=1e-6), k
-    # early buckets (fp32 and bf16 wire): every step issues all buckets in index order on both ranks; the first step cannot
-    # release past the never-used module, later steps release (nearly) every bucket from inside backward
+    # segmented backward (fp32 and bf16 wire): every step issues all buckets in index order on both ranks; the first step cannot
+    # release past the never-used module, later steps release the buckets of segment 1 (the layer behind the cut) between the
+    # segments; the usage mask counts the ranks
     for wire, tol in (('fp32', 1e-6), ('bf16', 2e-2)):
         e0, e1 = torch.load(tmp_path / ('e0_%s.pt' % wire)), torch.load(tmp_path / ('e1_%s.pt' % wire))
         nb = e0['nb']
         for e in (e0, e1):
-            for issued, early in e['log']:
+            for issued, early, used in e['log']:
                 assert issued == list(range(nb))
-            assert e['log'][0][1] == 0 and e['log'][1][1] >= nb - 1 and e['log'][2][1] >= nb - 1
+                for name, u in zip(e['order'], used.tolist()):
+                    assert u == (0.0 if name.startswith('unused') else 2.0), (name, u)
+            assert e['log'][0][1] == 0 and 1 <= e['log'][1][1] < nb and e['log'][2][1] == e['log'][1][1]
+        assert e0['log'][1][1] == e1['log'][1][1]
         net = _Net()
         net.load_state_dict({**net.state_dict(), **e0['params']})
         ref = []

@@ -361,3 +361,71 @@ def test_fused_addend_on_the_gather_kernel():
     ref = torch.nn.functional.conv_transpose2d(gy.float(), w.detach().bfloat16().float(), None, 1, 0) + add.float()
     assert float((y.float() - ref).abs().max() / ref.abs().max()) < 8e-3
 
+
+
+def test_production_launches_run_on_the_streamed_kernel_and_match_torch_fp32():
+    """What the benched step launches, at ITS size: the four HRNet-W48 branch shapes at B = 32 -- each
+    alone and the four-branch lockstep launch -- must be taken by conv3x3_stream_kernel (plan != 0, kernel id 3: no silent
+    fall-back to the tile or gather kernels), and that exact launch -- forward with the fused BatchNorm statistics, and the
+    data gradient -- must match F.conv2d in fp32 on the same bf16-rounded operands at 1e-2 of scale."""
+    import ctypes
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    B = 32
+    chans, sizes = (48, 96, 192, 384), (64, 32, 16, 8)
+    g = torch.Generator().manual_seed(77)
+    xs = [torch.randn(B, c, s, s, generator=g).bfloat16().cuda() for c, s in zip(chans, sizes)]
+    ws = [(torch.randn(c, c, 3, 3, generator=g) / np.sqrt(9 * c)).bfloat16().float().cuda() for c in chans]
+    gys = [torch.randn(B, c, s, s, generator=g).bfloat16().cuda() for c, s in zip(chans, sizes)]
+    refs = []
+    for x, w, gy in zip(xs, ws, gys):
+        xr = x.float().requires_grad_(True)
+        yr = F.conv2d(xr, w, None, 1, 1)
+        yr.backward(gy.float())
+        refs.append((yr.detach(), xr.grad))
+
+    def close(a, r, rel, what):
+        scale = r.abs().max().item() + 1e-6
+        err = (a.float() - r).abs().max().item()
+        assert err <= rel * scale, '%s: max err %g vs scale %g' % (what, err, scale)
+
+    xn = [dconv.nhwc_bf16(x) for x in xs]
+    gn = [dconv.nhwc_bf16(gy) for gy in gys]
+    wp0 = [dconv.pack_weight(torch.nn.Parameter(w), 1, 0) for w in ws]
+    wp1 = [dconv.pack_weight(torch.nn.Parameter(w), 1, 1) for w in ws]
+    for nprob in (1, 4):
+        for c, s in zip(chans, sizes):
+            plan = L.danet_conv3x3_stream_plan(B, s, s, c, c, nprob)
+            assert plan != 0 and plan % 10 == 3, (c, s, nprob, plan)          # taken, NT = 3 (48-channel N-blocks)
+    # single launches through the entry point every Conv2d uses
+    for i, (c, s) in enumerate(zip(chans, sizes)):
+        dims = (B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1)
+        for tr_, xin, wpk in ((False, xn[i], wp0[i]), (True, gn[i], wp1[i])):
+            one = (_lib.ConvJob * 1)()
+            dconv._conv_job(one[0], xin, wpk, xin, dims, tr_)
+            assert L.danet_conv_forward_multi_kernel(ctypes.addressof(one), 1) == 3, (c, s, tr_)       # 3 = conv3x3_stream_kernel
+        sums = torch.zeros(L.danet_bn_ws_floats(c), device='cuda')
+        y = dconv._conv_fwd_raw(xn[i], wp0[i], None, B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1, False, False, False, sums)
+        gx = dconv._conv_fwd_raw(gn[i], wp1[i], None, B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1, True, False, False)
+        close(y, refs[i][0], 1e-2, 'forward %d' % c)
+        close(gx, refs[i][1], 1e-2, 'dgrad %d' % c)
+        st = sums.view(-1, 2, c).sum(0)
+        close(st[0], refs[i][0].sum(dim=(0, 2, 3)), 5e-3, 'statistics: sum %d' % c)
+        close(st[1], (refs[i][0] ** 2).sum(dim=(0, 2, 3)), 2e-3, 'statistics: squares %d' % c)
+    # the four-branch lockstep launch (forward + statistics, then the data gradients)
+    for transposed in (False, True):
+        jobs = (_lib.ConvJob * 4)()
+        ys = [torch.empty_like(x) for x in xn]
+        sums = [torch.zeros(L.danet_bn_ws_floats(c), device='cuda') for c in chans]
+        for j, x, gy, a, b, y, c, s, sm in zip(jobs, xn, gn, wp0, wp1, ys, chans, sizes, sums):
+            dconv._conv_job(j, gy if transposed else x, b if transposed else a, y, (B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1), transposed,
+                            None if transposed else sm)
+        assert L.danet_conv_forward_multi_kernel(ctypes.addressof(jobs), 4) == 3          # conv3x3_stream_kernel
+        dconv.check(L.danet_conv_forward_multi(ctypes.addressof(jobs), 4, _lib.stream()), 'multi')
+        torch.cuda.synchronize()
+        for i, c in enumerate(chans):
+            close(ys[i], refs[i][1 if transposed else 0], 1e-2, 'four-branch %s %d' % ('dgrad' if transposed else 'forward', c))
+            if not transposed:
+                st = sums[i].view(-1, 2, c).sum(0)
+                close(st[0], refs[i][0].sum(dim=(0, 2, 3)), 5e-3, 'four-branch statistics: sum %d' % c)
+                close(st[1], (refs[i][0] ** 2).sum(dim=(0, 2, 3)), 2e-3, 'four-branch statistics: squares %d' % c)

@@ -466,9 +466,10 @@ def _graphed_full_step_losses_match_eager():
 
 
 def test_data_parallel_graph_path_single_rank():
-    """The N > 1 execution path of bench.py on a 1-rank RCCL group: eager steps with the bucketed all-reduces
-    interleaved with the weight-gradient launches, then the hipGraph capture with the all-reduces and Adam INSIDE the
-    graph.  It must run and agree with the single-process trainer (a sum over one rank is the identity)."""
+    """The N > 1 execution path of bench.py on a 1-rank RCCL group: eager steps with the backward pass in segments
+    (segments.py) and the bucketed all-reduces released between them, then the hipGraph capture with the all-reduces and
+    Adam INSIDE the graph.  It must run and agree with the single-process trainer, whose backward pass is ONE autograd call (a
+    sum over one rank is the identity, and cutting the graph changes no arithmetic)."""
     import torch.distributed as dist
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
@@ -488,14 +489,16 @@ def test_data_parallel_graph_path_single_rank():
             batch['pretrain_mode'] = True
             tr.train_step(batch)
             _, l_eager = tr.train_step(batch)
-            if mode == 'ddp':       # every bucket once, in bucket order (the early release from inside the backward pass is opt-in:
-                nb = len(tr.store.buckets)      # trainer.EARLY_BUCKETS; its ordering logic is pinned by tests/test_distributed.py on gloo)
-                assert tr.store.issued == list(range(nb)), tr.store.issued
+            if mode == 'ddp':       # every bucket once, in bucket order; from the second step on (the first one learns which parameters
+                nb = len(tr.store.buckets)      # are in use) the backward pass runs in segments and releases complete buckets between them
+                assert tr.segmented and tr.store.issued == list(range(nb)), tr.store.issued
+                assert 1 <= tr.store.issued_early < nb, (tr.store.issued_early, nb)
+                eager_early = tr.store.issued_early
             tr.capture(batch, warmup=1)
             if mode == 'ddp':
                 assert tr._reduce_in_graph, 'the RCCL all-reduces were not captured into the hipGraph'
-                issued, early = tr.captured_collectives      # what the capture recorded: every bucket once, in order, after the
-                assert issued == list(range(nb)) and early == 0, (issued, early)      # backward pass (early release is eager-only, see Trainer._core)
+                issued, early = tr.captured_collectives      # what the capture recorded: every bucket once, in order, the same ones
+                assert issued == list(range(nb)) and early == eager_early, (issued, early)      # between the backward segments as in the eager step
             tr.train_step_graphed()
             _, l_graph = tr.train_step_graphed()
             torch.cuda.synchronize()
@@ -513,6 +516,65 @@ def test_data_parallel_graph_path_single_rank():
     finally:
         fixed.__exit__(None, None, None)
         dist.destroy_process_group()
+
+
+def test_segmented_backward_equals_one_autograd_call():
+    """segments.py: cutting the autograd graph at the HRNet module boundaries and at the estimator -> regressor interface
+    changes no arithmetic -- the same trainer, same batch, same weights, backward as ONE call and in segments: every loss is
+    identical and the gradients agree to the noise floor of two identical runs (weight-gradient atomics)."""
+    _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
+            'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    from danet_densepose2smpl_amd import segments
+    dev = torch.device('cuda')
+    with _fixed_order_bn():
+        torch.manual_seed(0)
+        tr = Trainer(default_options(2), device=dev, distributed=False, lr=1e-30)
+        batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
+        tr.train_step(batch)                                   # (BatchNorm running statistics, weight bank)
+        runs = []
+        for seg in (False, False, True):
+            tr.segmented = seg
+            levels = []
+            orig = segments.backward
+
+            def spy(losses, between=None, _o=orig, _l=levels):
+                _l.append(segments.level())
+                return _o(losses, between)
+            segments.backward = spy
+            try:
+                _, l = tr.train_step(batch)
+            finally:
+                segments.backward = orig
+            torch.cuda.synchronize()
+            assert (levels == [9]) if seg else (levels == []), levels        # 8 HRNet modules + the regressor
+            runs.append(({k: float(v.sum()) for k, v in l.items()},
+                         {n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None}))
+        (la, ga), (lb, gb), (ls, gs) = runs
+        assert set(gs) == set(ga)
+        for k in la:
+            assert abs(ls[k] - la[k]) <= 2 * abs(lb[k] - la[k]) + 1e-5 * abs(la[k]) + 1e-7, (k, la[k], lb[k], ls[k])
+        rel = lambda x, y: ((x - y).norm() / (y.norm() + 1e-20)).item()       # noqa: E731
+        noise = sorted(rel(gb[n], ga[n]) for n in ga)
+        diff = sorted(rel(gs[n], ga[n]) for n in ga)
+        assert diff[len(diff) // 2] <= 2 * noise[len(noise) // 2] + 1e-6 and diff[-1] <= 4 * noise[-1] + 1e-3, (diff[-3:], noise[-3:])
+
+
+def test_bench_dry_launch_line_on_a_one_rank_group():
+    """`bench.py --dry --force-ddp`: the launch line of a multi-GPU run (process group, trainer, capture with the in-graph
+    all-reduces, one step, the JSON line with its `allreduce` record) end to end on one GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + (os.getpid() + 777) % 2000), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-ddp', '--dry', '--batch', '4'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    ar = line['allreduce']
+    assert line['dry'] and line['exec'] == 'hipgraph' and ar['mode'] == 'in-graph', line
+    assert ar['buckets'] >= 10 and 1 <= ar['released_during_backward'] < ar['buckets'], ar
+    assert ar['comm_channels_reserved'] >= 1 and ar['onepass_max_blocks'] == 2 * (256 - ar['comm_channels_reserved']), ar
 
 
 def _two_proc_worker(rank, world, port, tmp):

@@ -345,3 +345,49 @@ def test_channel_sum_vs_torch(shape):
         got = conv.channel_sum(gy)
         assert got.dtype == torch.float32 and float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-3
 
+
+
+def test_onepass_backward_with_a_co_residency_budget():
+    """nn.ONEPASS_MAX_BLOCKS (danet_bn_backward_onepass max_blocks): a data-parallel trainer keeps compute units free for the
+    communication library's kernels.  A four-tensor job set that fills the device in one launch is split into launches that
+    fit the budget -- same results --, and a single tensor that needs more workgroups than the budget takes the two-kernel
+    path instead of a barrier that could not be met."""
+    import ctypes
+    from danet_densepose2smpl_amd import nn as dnn, conv as dconv, _lib
+    g = torch.Generator().manual_seed(11)
+    shapes = [(32, 48, 64, 64), (32, 96, 32, 32), (32, 192, 16, 16), (32, 384, 8, 8)]
+    xs = [(torch.randn(*s, generator=g) * 1.5 + 0.3).cuda() for s in shapes]
+    gys = [torch.randn(*s, generator=g).bfloat16().cuda() for s in shapes]
+    dnn.ONEPASS_STREAM = None
+    out = {}
+    prev = dnn.ONEPASS_MAX_BLOCKS
+    try:
+        for cap in (0, 464, 300):
+            dnn.ONEPASS_MAX_BLOCKS = cap
+            bns = [dnn.BatchNorm2d(s[1]).cuda().train() for s in shapes]
+            xt = [x.clone().requires_grad_(True) for x in xs]
+            dconv.FUSION.clear()
+            ys = dnn.multi_batch_norm(bns, xt, None, relu=True)
+            torch.autograd.backward(ys, gys)
+            assert dconv.FUSION.get('bn_bwd_onepass', 0) == 4, (cap, dict(dconv.FUSION))
+            out[cap] = [t.grad.float() for t in xt] + [b.weight.grad.clone() for b in bns]
+        torch.cuda.synchronize()
+        assert not dnn.onepass_error()
+        for cap in (464, 300):
+            for a, b in zip(out[cap][:4], out[0][:4]):
+                _close(a, b, 4e-3, 'dx at budget %d' % cap)
+            for a, b in zip(out[cap][4:], out[0][4:]):
+                _close(a, b, 1e-4, 'dgamma at budget %d' % cap)
+        # the planner itself: the 48-channel tensor alone needs > 100 workgroups
+        L = _lib.lib()
+        job = (_lib.BnBwdJob * 1)()
+        j = job[0]
+        x, gy = xs[0].bfloat16(), gys[0]
+        scratch = torch.zeros(4 * L.danet_bn_ws_floats(48), device='cuda')
+        j.dy, j.x, j.y, j.gamma, j.saved = gy.data_ptr(), x.data_ptr(), None, None, scratch.data_ptr()
+        j.dx, j.dres, j.dparam, j.red = x.data_ptr(), None, scratch.data_ptr(), scratch.data_ptr()
+        j.beta, j.mask, j.mask_mode, j.M, j.C, j.red_state, j.relu = None, None, 0, 32 * 64 * 64, 48, 1, 0
+        assert L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1, 0) == 1
+        assert L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1, 100) == 0
+    finally:
+        dnn.ONEPASS_MAX_BLOCKS = prev

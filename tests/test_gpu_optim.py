@@ -125,3 +125,38 @@ def test_fused_adam_state_dict_is_torch_adam_compatible():
     torch.cuda.synchronize()
     for a, b, c in zip(pa, pb, pc):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6) and torch.allclose(a, c, rtol=1e-6, atol=1e-7)
+
+
+def test_adam_poison_guard_skips_the_whole_step_on_the_device():
+    """csrc/adam.hip `poison`: with the one-pass BatchNorm barrier's error word set, the kernel updates NOTHING -- neither
+    parameters nor moments -- and counts the step as idle for every parameter, so the bias corrections of later steps are
+    those of the updates that were applied; with the word clear again the optimizer continues exactly like torch's Adam
+    that never saw the poisoned step."""
+    from danet_densepose2smpl_amd.optim import FusedAdam
+    torch.manual_seed(4)
+    shapes = [(33, 5), (70001,), (12, 12, 3, 3)]
+    pa = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+    oa.poison = word
+    for step in range(6):
+        gs = [torch.randn(s, device='cuda') for s in shapes]
+        poisoned = step in (2, 3)
+        word.fill_(1 if poisoned else 0)
+        before = [p.detach().clone() for p in pa]
+        m0, v0 = oa.exp_avg.clone(), oa.exp_avg_sq.clone()
+        for a, b, g in zip(pa, pb, gs):
+            a.grad = (g * 1e6).clone() if poisoned else g.clone()       # garbage that must never arrive
+            b.grad = g.clone()
+        oa.step()
+        if poisoned:
+            torch.cuda.synchronize()
+            assert all(torch.equal(p, q) for p, q in zip(pa, before))
+            assert torch.equal(oa.exp_avg, m0) and torch.equal(oa.exp_avg_sq, v0)
+        else:
+            ob.step()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max().item()
+    assert all(float(s['step']) == 4.0 for s in oa.state_dict()['state'].values())

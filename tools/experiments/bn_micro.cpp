@@ -74,8 +74,8 @@ int main()
                 const double ta = time_us([&] { DK(danet_bn_backward_multi(aj.data(), n, nullptr)); });
                 printf("n=%d res=%d   of which apply     %7.2f us  (reduce %.2f us)\n", n, with_res, ta, tb - ta);
             }
-            if (danet_bn_backward_onepass_ok(bj.data(), n)) {
-                const double to = time_us([&] { DK(danet_bn_backward_onepass(bj.data(), n, bar, nullptr)); });
+            if (danet_bn_backward_onepass_ok(bj.data(), n, 0)) {
+                const double to = time_us([&] { DK(danet_bn_backward_onepass(bj.data(), n, bar, 0, nullptr)); });
                 printf("n=%d res=%d backward one-pass   %7.2f us  (%.1f MB moved: %.2f TB/s)\n", n, with_res, to, b * (3 + with_res) / 1e6, b * (3 + with_res) / to / 1e6);
             } else printf("n=%d res=%d one-pass: not taken\n", n, with_res);
         }
