@@ -308,6 +308,237 @@ __global__ __launch_bounds__(256) void smpl_lbs_fwd_kernel(
     LBS_STAMP(13);
 }
 
+// ------------------------------------------------------------------------------------------
+// The forward as ONE launch (/root/reference/models/smpl.py:27-46 is one call; prep -> main -> finalize above are three
+// launches with two hand-overs through memory, 43 us back to back but 66 us inside the train step's hipGraph).  Grid as the
+// main kernel (vertex tiles of 64 x batch groups of 8); what the other two kernels did moves into it:
+//   * every workgroup recomputes its eight items' kinematic chain in LDS (8 items x 12 lanes, a barrier per joint, the parent
+//     table in LDS); the workgroups of tile 0 write the posed joints and the context rows the backward pass reads;
+//   * the group's pose features (R - I) sit in LDS and are read back as two broadcast ds_read_b128 per posedirs row (eight
+//     one-dword scalar loads per row from `rotmats` measured 56 us: SMEM returns out of order, every batch of rows ends in
+//     lgkmcnt(0));
+//   * landmark vertices are written by the tile that owns them; the regressed extra joints are reduced by the LAST workgroup of
+//     a batch group to arrive: partials leave as returning agent-scope atomic exchanges (complete at the memory side when the
+//     old value is back -- the XCDs' L2s are not coherent for plain stores inside a kernel), an agent-scope ticket counts
+//     arrivals, the last workgroup sums the tiles in a fixed order (deterministic) with agent-scope loads, twelve in flight per
+//     lane, and resets the ticket for the next launch.
+// `ticket`: one uint per batch group, zeroed ONCE by the caller and owned by these launches, which must not overlap (one stream).
+__global__ __launch_bounds__(256) void smpl_fused_fwd_kernel(
+    const float* __restrict__ betas, const float* __restrict__ rot,
+    const float* __restrict__ v_template, const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
+    const float* __restrict__ J_template, const float* __restrict__ J_dirs, const float* __restrict__ lbs_weights,
+    const int* __restrict__ parents, const float* __restrict__ Jx, const int* __restrict__ landmark_verts,
+    int B, int Bpad, int V, int NB, int NL, int NE, int ntiles,
+    float* __restrict__ verts, float* __restrict__ joints54, float* __restrict__ ctx, float* __restrict__ v_posed_out,
+    float* jx_partial, unsigned* ticket)
+{
+    constexpr int NQ = 3;
+    const int tile = blockIdx.x, b0 = blockIdx.y * NBG, t = threadIdx.x;
+    const int v0 = tile * TV, C = V * 3, NJ54 = NJ + NL + NE;
+    // the chain's arrays are dead once sA is built: they share their storage with the pose pass's partial sums
+    __shared__ __attribute__((aligned(16))) float sUnion[4 * NBG * NQ * 64];
+    float (*sR)[216] = reinterpret_cast<float (*)[216]>(sUnion);
+    float (*sRg)[216] = reinterpret_cast<float (*)[216]>(sUnion + NBG * 216);
+    float (*sJ)[72] = reinterpret_cast<float (*)[72]>(sUnion + 2 * NBG * 216);
+    float (*sJp)[72] = reinterpret_cast<float (*)[72]>(sUnion + 2 * NBG * 216 + NBG * 72);
+    float (*sPart)[NBG][NQ * 64] = reinterpret_cast<float (*)[NBG][NQ * 64]>(sUnion);
+    static_assert(2 * NBG * 216 + 2 * NBG * 72 <= 4 * NBG * NQ * 64, "union");
+    __shared__ __attribute__((aligned(16))) float sA[NBG][288];
+    __shared__ float sW[TV][WPAD];
+    __shared__ float sVp[NBG][TC];
+    __shared__ float sB[NBG][NB_MAX];
+    __shared__ float sSd[TC][NB_MAX + 1];
+    __shared__ float sBase[TC];
+    __shared__ float sJx[NE_MAX][TV];
+    __shared__ int sLast;
+    __shared__ int sPar[NJ];
+    __shared__ __attribute__((aligned(16))) float sPf[NPB_PAD][NBG];      // the group's pose features, read back as broadcast ds_read_b128
+
+    // ---- phase 0: inputs of the group, tile constants, the chain ------------------------------------------------------------
+    for (int i = t; i < NBG * 216; i += 256) {           // (padding items of the last group: identity rotations)
+        const int bb = i / 216, e = i - bb * 216;
+        sR[bb][e] = b0 + bb < B ? rot[(size_t)(b0 + bb) * 216 + e] : (e % 9 % 4 == 0 ? 1.f : 0.f);
+    }
+    for (int i = t; i < NBG * NB_MAX; i += 256) { const int bb = i / NB_MAX, l = i - bb * NB_MAX; sB[bb][l] = (l < NB && b0 + bb < B) ? betas[(size_t)(b0 + bb) * NB + l] : 0.f; }
+    for (int i = t; i < TV * NJ; i += 256) { const int vv = i / NJ, j = i - vv * NJ, v = v0 + vv; sW[vv][j] = v < V ? lbs_weights[(size_t)v * NJ + j] : 0.f; }
+    for (int i = t; i < TC * NB_MAX; i += 256) { const int cc = i / NB_MAX, l = i - cc * NB_MAX, c = v0 * 3 + cc; sSd[cc][l] = (l < NB && c < C) ? shapedirs[(size_t)c * NB + l] : 0.f; }
+    for (int i = t; i < TC; i += 256) { const int c = v0 * 3 + i; sBase[i] = v_template[c < C ? c : C - 1]; }
+    if (t < NJ) sPar[t] = parents[t];                               // (the chain below would otherwise wait for one dependent scalar load per joint)
+    for (int i = t; i < NE * TV; i += 256) { const int e = i / TV, vv = i - e * TV; sJx[e][vv] = v0 + vv < V ? Jx[(size_t)e * V + v0 + vv] : 0.f; }
+    __syncthreads();
+    for (int i = t; i < NBG * 72; i += 256) {
+        const int bb = i / 72, e = i - bb * 72;
+        float s = J_template[e];
+        for (int l = 0; l < NB; ++l) s += J_dirs[e * NB + l] * sB[bb][l];
+        sJ[bb][e] = s;
+    }
+    __syncthreads();
+    {
+        const int bb = t / 12, e = t - bb * 12;              // threads 0..95: item bb, entry e (9 rotation, 3 translation)
+        const bool act = t < NBG * 12;
+        for (int i = 0; i < NJ; ++i) {
+            const int p = sPar[i];
+            if (act) {
+                if (e < 9) {
+                    const int r = e / 3, cc = e - r * 3;
+                    sRg[bb][i * 9 + e] = p < 0 ? sR[bb][i * 9 + e]
+                                                : sRg[bb][p * 9 + r * 3 + 0] * sR[bb][i * 9 + 0 + cc] + sRg[bb][p * 9 + r * 3 + 1] * sR[bb][i * 9 + 3 + cc] +
+                                                  sRg[bb][p * 9 + r * 3 + 2] * sR[bb][i * 9 + 6 + cc];
+                } else {
+                    const int r = e - 9;
+                    float s;
+                    if (p < 0) s = sJ[bb][i * 3 + r];
+                    else {
+                        s = sJp[bb][p * 3 + r];
+                        for (int m = 0; m < 3; ++m) s += sRg[bb][p * 9 + r * 3 + m] * (sJ[bb][i * 3 + m] - sJ[bb][p * 3 + m]);
+                    }
+                    sJp[bb][i * 3 + r] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = t; idx < NBG * 288; idx += 256) {
+        const int bb = idx / 288, q = idx - bb * 288, j = q / 12, e = q - j * 12, r = e / 4, cc = e - r * 4;
+        float v;
+        if (cc < 3) v = sRg[bb][j * 9 + r * 3 + cc];
+        else {
+            v = sJp[bb][j * 3 + r];
+            for (int m = 0; m < 3; ++m) v -= sRg[bb][j * 9 + r * 3 + m] * sJ[bb][j * 3 + m];
+        }
+        sA[bb][q] = v;
+    }
+    for (int i = t; i < NPB_PAD * NBG; i += 256) {
+        const int k = i / NBG, bb = i - k * NBG, e = k % 9;
+        sPf[k][bb] = k < NPB ? sR[bb][9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f) : 0.f;
+    }
+    if (tile == 0) {                                                // posed joints, and what the backward pass reads (zeros for padding items)
+        for (int i = t; i < NBG * 72; i += 256) {
+            const int bb = i / 72, e = i - bb * 72;
+            const bool live = b0 + bb < B;
+            float* c = ctx + (size_t)(b0 + bb) * CTX_STRIDE;
+            c[CTX_J + e] = live ? sJ[bb][e] : 0.f;
+            c[CTX_JP + e] = live ? sJp[bb][e] : 0.f;
+            if (live && joints54) joints54[(size_t)(b0 + bb) * NJ54 * 3 + e] = sJp[bb][e];
+        }
+        for (int i = t; i < NBG * 216; i += 256) { const int bb = i / 216, e = i - bb * 216; ctx[(size_t)(b0 + bb) * CTX_STRIDE + CTX_RG + e] = b0 + bb < B ? sRg[bb][e] : 0.f; }
+    }
+    __syncthreads();                                                // sA / sPf complete; the chain's arrays are free from here on (sPart)
+    if (tile == 0)
+        for (int i = t; i < NBG * 288; i += 256) { const int bb = i / 288, e = i - bb * 288; ctx[(size_t)(b0 + bb) * CTX_STRIDE + CTX_A + e] = b0 + bb < B ? sA[bb][e] : 0.f; }
+
+    // ---- phase 1: pose blend-shapes: wave w owns 52 pose-basis rows, a lane three coordinates of the tile ---------------------
+    {
+        const int w = t >> 6, lane = t & 63;
+        float acc[NQ][NBG];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) acc[q][bb] = 0.f;
+        int cq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const int c = v0 * 3 + lane + 64 * q; cq[q] = c < C ? c : C - 1; }
+        const int kbeg = w * (NPB_PAD / 4);
+#pragma unroll 13
+        for (int kk = 0; kk < NPB_PAD / 4; ++kk) {
+            const int k = kbeg + kk;
+            const int kr = k < NPB ? k : NPB - 1;
+            float pq[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) pq[q] = posedirs[(size_t)kr * C + cq[q]];          // (row 207 of sPf is zero)
+            const float4 f0 = *reinterpret_cast<const float4*>(&sPf[k][0]), f1 = *reinterpret_cast<const float4*>(&sPf[k][4]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                acc[q][0] += f0.x * pq[q]; acc[q][1] += f0.y * pq[q]; acc[q][2] += f0.z * pq[q]; acc[q][3] += f0.w * pq[q];
+                acc[q][4] += f1.x * pq[q]; acc[q][5] += f1.y * pq[q]; acc[q][6] += f1.z * pq[q]; acc[q][7] += f1.w * pq[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int bb = 0; bb < NBG; ++bb) sPart[w][bb][lane + 64 * q] = acc[q][bb];
+    }
+    __syncthreads();
+    // ---- phase 2: shape blend-shapes + the four waves' partial sums (fixed order), then skinning --------------------------------
+    for (int o = t; o < TC * NBG; o += 256) {
+        const int bb = o / TC, cl_ = o - bb * TC;
+        const int c = v0 * 3 + cl_;
+        float a = sBase[cl_] + ((sPart[0][bb][cl_] + sPart[1][bb][cl_]) + (sPart[2][bb][cl_] + sPart[3][bb][cl_]));
+#pragma unroll
+        for (int l = 0; l < NB_MAX; ++l) a += sSd[cl_][l] * sB[bb][l];
+        sVp[bb][cl_] = a;
+        if (v_posed_out && c < C && b0 + bb < B) v_posed_out[(size_t)(b0 + bb) * C + c] = a;
+    }
+    __syncthreads();
+    for (int pair = t; pair < TV * NBG; pair += 256) {
+        const int vv = pair & (TV - 1), bb = pair / TV;
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = sW[vv][j];
+            const float4* a4 = reinterpret_cast<const float4*>(&sA[bb][j * 12]);
+#pragma unroll
+            for (int e4 = 0; e4 < 3; ++e4) {
+                const float4 a = a4[e4];
+                T[e4 * 4 + 0] += w * a.x; T[e4 * 4 + 1] += w * a.y; T[e4 * 4 + 2] += w * a.z; T[e4 * 4 + 3] += w * a.w;
+            }
+        }
+        const float x = sVp[bb][vv * 3 + 0], y = sVp[bb][vv * 3 + 1], z = sVp[bb][vv * 3 + 2];
+        float o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = T[r * 4 + 0] * x + T[r * 4 + 1] * y + T[r * 4 + 2] * z + T[r * 4 + 3];
+        const int v = v0 + vv, b = b0 + bb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sVp[bb][vv * 3 + r] = o[r];
+        if (v < V && b < B) { float* dst = verts + ((size_t)b * V + v) * 3; dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; }
+    }
+    __syncthreads();
+    // ---- phase 3: landmarks of this tile, extra-joint partials, the last workgroup of the group reduces them ------------------
+    if (joints54) {
+        for (int i = t; i < NBG * NL; i += 256) {
+            const int bb = i / NL, l = i - bb * NL, lv = landmark_verts[l];
+            if (lv >= v0 && lv < v0 + TV && b0 + bb < B)
+                for (int k = 0; k < 3; ++k) joints54[((size_t)(b0 + bb) * NJ54 + NJ + l) * 3 + k] = sVp[bb][(lv - v0) * 3 + k];
+        }
+    }
+    if (NE > 0 && joints54) {
+        const int NO = NE * 3;
+        for (int o = t; o < NBG * NO; o += 256) {
+            const int bb = o / NO, q = o - bb * NO, e = q / 3, k = q - e * 3;
+            float s = 0.f;
+#pragma unroll 16
+            for (int vv = 0; vv < TV; ++vv) s += sJx[e][vv] * sVp[bb][vv * 3 + k];
+            // performed at the memory side and complete when the old value has returned
+            const float old = __hip_atomic_exchange(&jx_partial[((size_t)tile * Bpad + b0 + bb) * NO + q], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" :: "v"(old));                        // (keeps it a RETURNING atomic: the wave waits for it)
+        }
+        __syncthreads();                                            // (every thread's exchanges have returned)
+        if (t == 0) sLast = __hip_atomic_fetch_add(&ticket[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ntiles - 1);
+        __syncthreads();
+        if (sLast) {
+            // a few lanes per output would be 14 dependent load batches (+24 us measured); one lane per output, the tiles in a
+            // fixed order, twelve agent-scope loads in flight
+            for (int o = t; o < NBG * NO; o += 256) {
+                const int bb = o / NO, q = o - bb * NO;
+                const float* src = &jx_partial[((size_t)0 * Bpad + b0 + bb) * NO + q];
+                const size_t tstride = (size_t)Bpad * NO;
+                float s = 0.f;
+                for (int t0 = 0; t0 < ntiles; t0 += 12) {
+                    float v[12];
+#pragma unroll
+                    for (int u = 0; u < 12; ++u)
+                        v[u] = t0 + u < ntiles ? __hip_atomic_load(src + (size_t)(t0 + u) * tstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 12; ++u) s += v[u];
+                }
+                if (b0 + bb < B) joints54[((size_t)(b0 + bb) * NJ54 + NJ + NL) * 3 + q] = s;
+            }
+            if (t == 0) __hip_atomic_store(&ticket[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
+    }
+}
+
 // sum over tiles of part[(tile*Bpad + b)*stride + o] in a FIXED order: 8 lanes own interleaved
 // tile subsets (loads batched 4 deep), then a 3-step butterfly -> deterministic.
 __device__ inline float tile_sum8(const float* __restrict__ part, size_t tile_stride, int ntiles, int sub) {
@@ -630,6 +861,7 @@ extern "C" size_t danet_smpl_lbs_fwd_ws_floats(int B, int V, int NE) {
     const size_t Bp = bpad_of(B);
     return (size_t)NPB_PAD * Bp + (size_t)fwd_ntiles_of(V, B) * Bp * NE * 3;
 }
+extern "C" size_t danet_smpl_lbs_ticket_words(int B) { return (size_t)bpad_of(B) / NBG; }
 extern "C" size_t danet_smpl_lbs_bwd_ws_floats(int B, int V, int NB) {
     (void)NB;
     const size_t Bp = bpad_of(B);
@@ -644,7 +876,7 @@ extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, 
                                       const float* J_regressor_extra, const int32_t* landmark_verts,
                                       int V, int NB, int NL, int NE,
                                       float* verts, float* joints54, float* ctx, float* v_posed,
-                                      float* ws, size_t ws_floats, void* stream)
+                                      float* ws, size_t ws_floats, void* ticket, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(B > 0 && V > 0, "smpl_lbs_forward: B=%d V=%d", B, V);
@@ -662,6 +894,14 @@ extern "C" int danet_smpl_lbs_forward(const float* betas, const float* rotmats, 
     const int Bp = bpad_of(B), nt = fwd_ntiles_of(V, B), nbg = fwd_nbg_of(B);
     float* pfT = ws;
     float* jxp = ws + (size_t)NPB_PAD * Bp;
+    static const bool no_fused = getenv("DANET_LBS_NO_FUSED") != nullptr;      // A-B timing knob
+    if (ticket && nbg == 8 && !no_fused) {                        // ONE launch (smpl_fused_fwd_kernel)
+        hipLaunchKernelGGL(smpl_fused_fwd_kernel, dim3(nt, Bp / NBG), dim3(256), 0, s, betas, rotmats, v_template, shapedirs, posedirs,
+                           J_template, J_shapedirs, lbs_weights, parents, J_regressor_extra, landmark_verts, B, Bp, V, NB, NL, NE, nt,
+                           verts, joints54, ctx, v_posed, jxp, (unsigned*)ticket);
+        DANET_CHECK_LAUNCH("smpl_fused_fwd_kernel");
+        return DANET_OK;
+    }
     hipLaunchKernelGGL(smpl_prep_kernel, dim3(Bp), dim3(64), 0, s, betas, rotmats, J_template, J_shapedirs, parents,
                        B, NB, Bp, NJ + NL + NE, ctx, pfT, joints54);
     DANET_CHECK_LAUNCH("smpl_prep_kernel");

@@ -9,6 +9,23 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+LBS_ONE_LAUNCH = True       # the SMPL forward as one kernel launch (csrc/smpl_lbs.hip smpl_fused_fwd_kernel); False: prep -> main -> finalize
+_LBS_TICKETS = {}
+
+
+def lbs_ticket(device, words):
+    """The fused forward's arrival counters: zeroed once, then owned (and reset) by the launches on ONE stream -- a buffer
+    per (device, stream), so launches that could overlap never share one."""
+    if not LBS_ONE_LAUNCH or device.type != 'cuda':          # (CPU tensors: the C-ABI call below refuses them -- there is no CPU path)
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    t = _LBS_TICKETS.get(key)
+    if t is None or t.numel() < words:
+        with torch.cuda.device(key[0]):
+            t = _LBS_TICKETS[key] = torch.zeros(max(1024, int(words)), dtype=torch.int32, device=device)
+    return t
+
+
 class SmplLbsFunction(torch.autograd.Function):
     """(betas [B,NB], rotmats [B,24,3,3], model buffers) -> (vertices [B,V,3], joints54 [B,54,3]).
     Gradients flow to betas and rotmats (/root/reference/models/danet/smpl_regressor.py:176)."""
@@ -28,11 +45,12 @@ class SmplLbsFunction(torch.autograd.Function):
         vposed = torch.empty(B, V, 3, device=dev, dtype=torch.float32) if need_grad else None
         nws = L.danet_smpl_lbs_fwd_ws_floats(B, V, NE)
         ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        ticket = lbs_ticket(dev, L.danet_smpl_lbs_ticket_words(B))
         check(L.danet_smpl_lbs_forward(
             ptr(betas_c), ptr(rot_c), B, ptr(m.v_template), ptr(m.shapedirs), ptr(m.posedirs),
             ptr(m.J_template), ptr(m.J_shapedirs), ptr(m.lbs_weights), ptr(m.parents),
             ptr(m.J_regressor_extra), ptr(m.landmark_verts), V, NB, NL, NE,
-            ptr(verts), ptr(j54), ptr(cbuf), ptr(vposed), ptr(ws), nws, stream()), 'danet_smpl_lbs_forward')
+            ptr(verts), ptr(j54), ptr(cbuf), ptr(vposed), ptr(ws), nws, ptr(ticket), stream()), 'danet_smpl_lbs_forward')
         if need_grad:
             ctx.m = m
             ctx.save_for_backward(betas_c, rot_c, cbuf, vposed)

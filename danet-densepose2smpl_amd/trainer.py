@@ -384,6 +384,8 @@ class Trainer(object):
             for _ in range(warmup):
                 self._core(self._static)
         torch.cuda.synchronize(self.device)
+        if self.store is not None:
+            self.store.quiesce()                  # no collective of the eager steps may still be on the watchdog's list (see there)
         from . import hrnet
         for in_graph in ((True, False) if self.distributed else (True,)):
             conv._PACK_CACHE.clear()              # weight packing must be part of the captured work

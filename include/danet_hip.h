@@ -46,10 +46,16 @@ const char* danet_last_error(void);
  *         NE extra regressed joints; ctx [danet_smpl_lbs_ctx_floats(B)] and
  *         v_posed [B,V,3] are saved for the backward (v_posed may be NULL for inference).
  * ws      scratch of danet_smpl_lbs_fwd_ws_floats(B,V,NE) floats.
+ * ticket  danet_smpl_lbs_ticket_words(B) uints of device memory, zeroed ONCE by the caller and from then on owned by these
+ *         launches (arrival counters, reset by the kernel itself), which must not overlap -- one buffer per stream.  With a
+ *         ticket the forward is ONE kernel launch (smpl_fused_fwd_kernel: chain, blend shapes, skinning, landmarks and the
+ *         regressed joints, the last workgroup of a batch group to arrive sums the per-tile partials in a fixed order);
+ *         NULL runs the three-launch form (prep -> main -> finalize).  Both give the same results.
  */
 size_t danet_smpl_lbs_ctx_floats(int B);
 size_t danet_smpl_lbs_fwd_ws_floats(int B, int V, int NE);
 size_t danet_smpl_lbs_bwd_ws_floats(int B, int V, int NB);
+size_t danet_smpl_lbs_ticket_words(int B);
 
 int danet_smpl_lbs_forward(const float* betas, const float* rotmats, int B,
                            const float* v_template, const float* shapedirs, const float* posedirs,
@@ -58,7 +64,7 @@ int danet_smpl_lbs_forward(const float* betas, const float* rotmats, int B,
                            const float* J_regressor_extra, const int32_t* landmark_verts,
                            int V, int NB, int NL, int NE,
                            float* verts, float* joints54, float* ctx, float* v_posed,
-                           float* ws, size_t ws_floats, void* stream);
+                           float* ws, size_t ws_floats, void* ticket, void* stream);
 
 /* Gradient w.r.t. betas and rotmats (the reference's differentiable call site is
  * /root/reference/models/danet/smpl_regressor.py:176).  g_verts [B,V,3] and

@@ -110,3 +110,61 @@ def test_geometry_helpers_vs_reference_goldens():
     np.testing.assert_allclose(x6.grad.cpu().numpy(), g['x6_grad'], atol=1e-4, rtol=1e-3)
     th = rand_pose_shape(4)[1].reshape(-1, 3)
     np.testing.assert_allclose(ops.rodrigues_smplx(_t(th)).cpu().numpy(), R.batch_rodrigues(th), atol=1e-5)
+
+
+@pytest.mark.parametrize('B', [1, 4, 7, 32, 33])
+def test_one_launch_forward_equals_three_launch_forward(smpl, smpl_model, B):
+    """csrc/smpl_lbs.hip: the forward as ONE kernel (smpl_fused_fwd_kernel, the default) against prep -> main -> finalize
+    (ticket = NULL) on the same inputs: vertices, all 54 joints, and everything the backward pass reads (context rows,
+    v_posed) -- so the gradients of the one-launch path are the three-launch path's.  Twice in a row: the arrival tickets
+    are reset by the kernel itself."""
+    from danet_densepose2smpl_amd import ops
+    betas, pose = rand_pose_shape(B, 300 + B, pose_sigma=0.4)
+    rot = R.batch_rodrigues(pose.reshape(-1, 3)).reshape(B, 24, 3, 3)
+    rng = np.random.default_rng(B)
+    gv, gj = _t(rng.normal(0, 1, (B, 6890, 3)) * 1e-2), _t(rng.normal(0, 1, (B, 54, 3)))
+    res = {}
+    for one in (True, False, True):
+        ops.LBS_ONE_LAUNCH = one
+        try:
+            tb, tr = _t(betas).requires_grad_(True), _t(rot).requires_grad_(True)
+            verts, j54 = ops.smpl_lbs(tb, tr, smpl)
+            ((verts * gv).sum() + (j54 * gj).sum()).backward()
+            torch.cuda.synchronize()
+            res.setdefault(one, []).append((verts.detach().clone(), j54.detach().clone(), tb.grad.clone(), tr.grad.clone()))
+        finally:
+            ops.LBS_ONE_LAUNCH = True
+    a, b, a2 = res[True][0], res[False][0], res[True][1]
+    for x, y in zip(a, a2):
+        assert torch.equal(x, y)                                   # (deterministic, ticket reset included)
+    assert (a[0] - b[0]).abs().max().item() <= 2e-6 and (a[1] - b[1]).abs().max().item() <= 2e-6
+    for x, y in zip(a[2:], b[2:]):
+        assert (x - y).abs().max().item() <= 1e-5 * (y.abs().max().item() + 1e-6)
+    v_ref, j_ref = oracle.lbs_forward(smpl_model, betas.astype(np.float32), rot.astype(np.float32), True)
+    np.testing.assert_allclose(a[0].cpu().numpy(), v_ref, atol=TOL)
+    np.testing.assert_allclose(a[1].cpu().numpy(), j_ref, atol=TOL)
+
+
+def test_one_launch_forward_replays_from_a_graph(smpl, smpl_model):
+    """The SMPL forward inside a hipGraph (as in the captured train step): replays give the eager result, again and again
+    (the tickets end every launch at zero).  (That it is ONE kernel is visible in the kernel statistics, profiles/r04_*.)"""
+    B = 32
+    betas, pose = rand_pose_shape(B, 77)
+    tb, tp = _t(betas), _t(pose)
+    eager = smpl(betas=tb, body_pose=tp[:, 3:], global_orient=tp[:, :3])
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        from danet_densepose2smpl_amd import ops
+        rotm = ops.rodrigues_smplx(tp.reshape(-1, 3)).reshape(B, 24, 3, 3)
+        ops.smpl_lbs(tb, rotm, smpl)                               # (this stream's ticket buffer exists before the capture)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            verts, j54 = ops.smpl_lbs(tb, rotm, smpl)
+        for _ in range(3):
+            verts.zero_(); j54.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(verts, eager.vertices)
+            assert (j54[:, :24] - eager.smpl_joints).abs().max().item() == 0
