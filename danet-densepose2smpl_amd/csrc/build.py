@@ -29,6 +29,7 @@ UNITS = {
     'conv3x3.hip': MFMA_VGPR,
     'conv3x3s.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
+    'conv_pw.hip': MFMA_VGPR,
     'conv_f32.hip': ['-ffp-contract=off'],
     'conv_f32m.hip': MFMA_VGPR,
     'part_ops.hip': [],

@@ -58,6 +58,10 @@ constexpr bool S3_PLAIN_EPI = DANET_S3_PLAIN_EPI != 0;      // specialised epilo
 #define DANET_S3_WRAP 0
 #endif
 constexpr bool S3_WRAP = DANET_S3_WRAP != 0;     // the ring carries over from a tile to the next (build knob; measured neutral: 40.1 vs 40.3 us on the four-branch launch, so off)
+#ifndef DANET_S3_WIDE_STORES
+#define DANET_S3_WIDE_STORES 0
+#endif
+constexpr bool S3_WIDE_STORES = DANET_S3_WIDE_STORES != 0;  // 16-byte epilogue stores through v_permlane16_swap (build knob; measured neutral on the four-branch launch: 39.5 / 39.6 / 40.4 / 38.2 us with, 40.9 / 37.2 / 39.2 / 37.4 without -- the epilogue is not store-issue bound --, so off)
 constexpr int S3_THREADS = 256;
 
 struct S3Prob {
@@ -416,11 +420,39 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
     // ---- epilogue on the wave's own tiles ----------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const int tile_out = ((img0 * H + y0) * W) * p.Cout * osz;
+    auto add_stats = [&](int nt, f32x4 v) {                 // BatchNorm statistics from the fp32 accumulators (see conv3x3.hip), two values per instruction
+        f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        f32x2_& a0 = *reinterpret_cast<f32x2_*>(&s1[nt][0]); f32x2_& a1 = *reinterpret_cast<f32x2_*>(&s1[nt][2]);
+        f32x2_& q0 = *reinterpret_cast<f32x2_*>(&s2[nt][0]); f32x2_& q1 = *reinterpret_cast<f32x2_*>(&s2[nt][2]);
+        a0 += lo; a1 += hi;
+        q0 = __builtin_elementwise_fma(lo, lo, q0); q1 = __builtin_elementwise_fma(hi, hi, q1);
+    };
+    // PLAIN, two channel blocks at a time: v_permlane16_swap trades lane rows 1 <-> 0 and 3 <-> 2 between the packed registers of
+    // blocks a and b, after which a lane owns EIGHT consecutive channels (rows 0 / 2: block a's channels 0-7 / 8-15, rows 1 / 3:
+    // block b's) and stores 16 bytes -- 8 instead of 12 store instructions per pixel fragment row at NT = 3 (csrc/conv_pw.hip measured
+    // the same exchange: 8-byte pieces 32 bytes apart cost the write path twice the instructions for the same lines).
+    constexpr int NPAIR = (PLAIN && S3_WIDE_STORES) ? NT / 2 : 0;
 #pragma unroll
     for (int qq = 0; qq < KW; ++qq) {
         if (qq == kw) {
+            if constexpr (NPAIR > 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+                for (int np = 0; np < NPAIR; ++np)
+#pragma unroll
+                    for (int m = 0; m < MO; ++m) {
+                        const int mt = qq * MO + m;
+                        const f32x4 va = acc[mt][2 * np], vb = acc[mt][2 * np + 1];
+                        if (p.stats) { add_stats(2 * np, va); add_stats(2 * np + 1, vb); }
+                        const auto sx = __builtin_amdgcn_permlane16_swap(f2bf_pk(va[0], va[1]), f2bf_pk(vb[0], vb[1]), false, false);
+                        const auto sy = __builtin_amdgcn_permlane16_swap(f2bf_pk(va[2], va[3]), f2bf_pk(vb[2], vb[3]), false, false);
+                        const i32x4 q = {(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
+                        // outoff holds the lane's 4-channel run (lg * 8 bytes); the 8-channel run starts at block (lg & 1), channel (lg >> 1) * 8
+                        const int off = outoff[mt] != OOB ? outoff[mt] - lg * 8 + (lg & 1) * 32 + (lg >> 1) * 16 : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(q, yr, off, tile_out + (n0 + 2 * np * 16) * 2, 0);
+                    }
+            }
+#pragma unroll
+            for (int nt = 2 * NPAIR; nt < NT; ++nt) {
                 const int cl = n0 + nt * 16 + lg * 4;
                 const bool cok = cl < p.Cout;
                 const int so = tile_out + (n0 + nt * 16) * osz;
@@ -447,13 +479,9 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                     } else {
                         const i32x2 pk = {(int)f2bf_pk(v[0], v[1]), (int)f2bf_pk(v[2], v[3])};
                         __builtin_amdgcn_raw_buffer_store_b64(pk, yr, off, so, 0);
-                        if (p.stats) {           // BatchNorm statistics from the fp32 accumulators (see conv3x3.hip), two values per instruction
+                        if (p.stats) {
                             if (has_idle) { const float msk = off != OOB ? 1.f : 0.f; v *= msk; }
-                            f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
-                            f32x2_& a0 = *reinterpret_cast<f32x2_*>(&s1[nt][0]); f32x2_& a1 = *reinterpret_cast<f32x2_*>(&s1[nt][2]);
-                            f32x2_& q0 = *reinterpret_cast<f32x2_*>(&s2[nt][0]); f32x2_& q1 = *reinterpret_cast<f32x2_*>(&s2[nt][2]);
-                            a0 += lo; a1 += hi;
-                            q0 = __builtin_elementwise_fma(lo, lo, q0); q1 = __builtin_elementwise_fma(hi, hi, q1);
+                            add_stats(nt, v);
                         }
                     }
                 }

@@ -48,6 +48,11 @@ bool conv_fast_ok(const ConvP& p, bool vec8, int mt);
 int conv_fast_launch(const ConvP& p, int mt, int nt, void* stream);
 int conv_fast_launch_multi(const ConvP* ps, const int* mts, int n, int nt, void* stream);
 
+// conv_pw.hip: 1x1 / stride-1 layers with the whole weight operand in LDS and persistent workgroups (X read once, Y written once)
+bool conv_pw_ok(const ConvP& p, bool vec8);
+int conv_pw_config(const ConvP& p);                  // NKS * 10 + NTB of the instantiation, 0 = not supported
+int conv_pw_launch(const ConvP& p, void* stream);
+
 // conv3x3.hip: 3x3 / stride-1 / pad-1 forward and data gradient on an LDS-resident halo tile (persistent workgroups)
 bool conv3x3_ok(const ConvP& p, bool vec8);
 int conv3x3_config(const ConvP& p, bool vec8, int nprob);      // MT*100 + NT*10 + KW, 0 = not supported

@@ -614,7 +614,8 @@ static bool fill_conv_params(ConvP& p, bool& vec8, int B, int H, int W, int Cin,
 }
 
 // Which kernel danet_conv_forward launches for a problem: MT*1000 + NT*100 + vec8*10 + fast
-// (fast = 1: conv_fast_kernel<MT, NT>, 0: conv_igemm_kernel<MT, NT, vec8>); -1 for invalid sizes.
+// (fast = 1: conv_fast_kernel<MT, NT>, 0: conv_igemm_kernel<MT, NT, vec8>, 2: the LDS-tile 3x3 kernels (MT, NT, KW in the other
+// digits), 3: conv_pw_kernel<NKS, NTB> (NKS, NTB in the first two)); -1 for invalid sizes.
 extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
                                          int stride, int pad, int dil, int groups, int transposed, int out_fp32)
 {
@@ -623,6 +624,7 @@ extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, i
     if (!fill_conv_params(p, vec8, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, 0, out_fp32)) return -1;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
     if (conv3x3_ok(p, vec8)) { const int c = conv3x3_config(p, vec8, 1); return (c / 100) * 1000 + ((c / 10) % 10) * 100 + (c % 10) * 10 + 2; }
+    if (conv_pw_ok(p, vec8)) { const int c = conv_pw_config(p); return (c / 10) * 1000 + (c % 10) * 100 + 10 + 3; }      // conv_pw_kernel<NKS, NTB>
     return mt * 1000 + danet_conv_nt(p.Cout_g) * 100 + (vec8 ? 10 : 0) + (conv_fast_ok(p, vec8, mt) ? 1 : 0);
 }
 
@@ -650,7 +652,8 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     const bool c3 = conv3x3_ok(p, vec8);
     DANET_CHECK_ARG(bn_gate == 0 || (bn_red && c3 && bn_gate == 2 && bn_y),
                     "conv_forward: bn_gate %d: only 2 (byte mask in bn_y, LDS-tile 3x3 kernel) is defined", bn_gate);
-    DANET_CHECK_ARG(!addend || (!out_fp32 && (c3 || (conv_fast_ok(p, vec8, mt) && !p.stats && !p.bn_red))),
+    const bool pw = !c3 && conv_pw_ok(p, vec8);
+    DANET_CHECK_ARG(!addend || (!out_fp32 && (c3 || pw || (conv_fast_ok(p, vec8, mt) && !p.stats && !p.bn_red))),
                     "conv_forward: the fused addend needs a bf16 output and the 3x3 LDS kernels, or the lean gather kernel without fused statistics (check danet_conv_forward_kernel)");
     DANET_CHECK_ARG(!bn_red || (bn_x && bn_saved && !bias && !relu && !out_fp32 && (c3 || conv_fast_ok(p, vec8, mt))),
                     "conv_forward: the fused BatchNorm-backward reduction needs the fast kernel and a plain bf16 output (check danet_conv_forward_kernel)");
@@ -661,6 +664,11 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     if (c3) {
         if (conv3x3_launch(&p, 1, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no 3x3 tiling");
         DANET_CHECK_LAUNCH("conv3x3_tile_kernel");
+        return DANET_OK;
+    }
+    if (pw) {
+        if (conv_pw_launch(p, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no pointwise instantiation");
+        DANET_CHECK_LAUNCH("conv_pw_kernel");
         return DANET_OK;
     }
     if (conv_fast_ok(p, vec8, mt)) {

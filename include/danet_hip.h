@@ -295,6 +295,10 @@ int danet_conv3x3_stream_plan(int B, int H, int W, int Cin, int Cout, int nprob)
  * one, runs on conv3x3_tile_kernel instead (danet_conv_forward_multi_kernel / danet_conv_forward_kernel say which). */
 size_t danet_conv3x3_stream_table_bytes(void);
 int danet_conv3x3_stream_tables(void* workspace, size_t bytes);
+/* The pointwise kernel (csrc/conv_pw.hip: 1x1 / stride-1 layers with <= 64 KB of packed weights and >= 8192 pixels; the layer's
+ * weights in LDS, persistent workgroups, X read once and Y written once) takes such problems ahead of the gather kernel in
+ * danet_conv_forward (danet_conv_forward_kernel: last digit 3).  enable 0/1 (-1 keeps); returns the previous setting. */
+int danet_conv_pw_set(int enable);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);

@@ -429,3 +429,62 @@ def test_production_launches_run_on_the_streamed_kernel_and_match_torch_fp32():
                 st = sums[i].view(-1, 2, c).sum(0)
                 close(st[0], refs[i][0].sum(dim=(0, 2, 3)), 5e-3, 'four-branch statistics: sum %d' % c)
                 close(st[1], (refs[i][0] ** 2).sum(dim=(0, 2, 3)), 2e-3, 'four-branch statistics: squares %d' % c)
+
+
+PW_SHAPES = [  # (Cin, Cout, H, W, B): Bottleneck projections, the limb regressor's input projection, the narrow head bottlenecks, ragged sizes
+    (64, 256, 64, 64, 32), (256, 64, 64, 64, 32), (24, 64, 64, 64, 96), (64, 24, 64, 64, 96), (48, 16, 64, 64, 32), (16, 48, 64, 64, 32),
+    (96, 192, 24, 20, 19), (128, 128, 33, 31, 9), (40, 72, 50, 50, 4), (256, 48, 32, 32, 10)]
+
+
+@pytest.mark.parametrize('shape', PW_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_pointwise_kernel_vs_torch_fp32(shape):
+    """csrc/conv_pw.hip (1x1 / stride-1 layers: the layer's weights in LDS, persistent workgroups) is what danet_conv_forward
+    launches for these problems (kernel id ...3), forward and data gradient; against F.conv2d in fp32 on the bf16-rounded
+    operands at 1e-2 of scale, fused BatchNorm statistics included; and against the gather kernel (danet_conv_pw_set(0)) on the
+    same operands, with bias + ReLU + fp32 output and with the fused bf16 addend."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    Cin, Cout, H, W, B = shape
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float().cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)).bfloat16().float().cuda()
+    gy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float().cuda()
+    assert L.danet_conv_forward_kernel(B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, 0, 0) % 10 == 3
+    assert L.danet_conv_forward_kernel(B, H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1, 1, 1, 0) % 10 == 3      # the data gradient
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w)
+    yr.backward(gy)
+
+    def close(a, r, rel, what):
+        scale = r.abs().max().item() + 1e-6
+        err = (a.float() - r.float()).abs().max().item()
+        assert err <= rel * scale, '%s: max err %g vs scale %g (%s)' % (what, err, scale, shape)
+    res = {}
+    b = torch.randn(Cout, generator=g).cuda()
+    add = dconv.nhwc_bf16(torch.randn(B, Cout, H, W, generator=g).cuda())
+    for on in (1, 0):
+        prev = L.danet_conv_pw_set(on)
+        try:
+            xt = x.clone().requires_grad_(True)
+            wt = w.clone().requires_grad_(True)
+            y = dconv.conv2d(xt, wt, None, 1, 0, want_stats=True)
+            sums = getattr(y, '_bn_sums', None)
+            y.backward(gy.bfloat16())
+            xn, wp = dconv.nhwc_bf16(x), dconv.pack_weight(torch.nn.Parameter(w), 1, 0)
+            y32 = dconv._conv_fwd_raw(xn, wp, b, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, False, True, True)
+            yadd = dconv._conv_fwd_raw(xn, wp, None, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, False, False, False, None, None, add)
+            torch.cuda.synchronize()
+            res[on] = (y.detach(), xt.grad, None if sums is None else sums.view(-1, 2, Cout).sum(0), y32, yadd, add)
+        finally:
+            L.danet_conv_pw_set(prev)
+    y, gx, st, y32, yadd, add = res[1]
+    close(y, yr, 1e-2, 'forward')
+    close(gx, xr.grad, 1e-2, 'dgrad')
+    if Cout % 8 == 0:
+        assert st is not None
+        yb = y.float()
+        close(st[0], yb.sum(dim=(0, 2, 3)), 2e-3, 'statistics: sum')
+        close(st[1], (yb * yb).sum(dim=(0, 2, 3)), 2e-3, 'statistics: sum of squares')
+    for k, tol, what in ((0, 1e-2, 'forward vs gather kernel'), (1, 1e-2, 'dgrad vs gather kernel'), (3, 2e-3, 'bias + ReLU + fp32'), (4, 1e-2, 'addend')):
+        close(res[1][k], res[0][k], tol, what)
+    close(yadd, yr.detach() + add.float(), 1.5e-2, 'addend vs fp32')
