@@ -25,13 +25,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP32_MFMA_TFLOPS = 157.0         # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD (no reduced-precision path for fp32 inputs on gfx950)
 
 
 def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, source description) from this round's committed PMC summary
     (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a 512 MiB copy
     in the same run), or (None, reason).  The file records the commit it was measured at."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             f = json.load(open(path))
@@ -42,6 +43,21 @@ def pmc_traffic(kernel):
         except (OSError, ValueError, KeyError):
             pass
     return None, 'no PMC summary for this kernel under profiles/'
+
+
+def rocprof_avg_us(kernel):
+    """(average duration of `kernel` in us, source) from this round's committed `rocprofv3 --kernel-trace --stats` summary of the same
+    command (profiles/r04_bench_kernel_stats.csv), to sit beside the live HIP-event figure; (None, reason) without one."""
+    import csv
+    for name in ('r04_bench_kernel_stats.csv', 'r03_bench_bf16_only_kernel_stats.csv'):
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            for row in csv.DictReader(open(path)):
+                if kernel and kernel in row['Name']:
+                    return round(float(row['AverageNs']) / 1e3, 2), 'profiles/' + name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, 'no rocprofv3 summary for this kernel under profiles/'
 
 
 def _flush_c_stdio():
@@ -62,7 +78,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 (BASELINE config C4) sub-record')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--dtype', choices=('bf16', 'fp32'), default='bf16',
                     help='fp32: BASELINE config C4\'s arithmetic on the verification kernels (csrc/conv_f32.hip, eager launches; a correctness configuration, not a performance one)')
     ap.add_argument('--grad-wire', choices=('fp32', 'bf16'), default=None, help='N > 1: all-reduce the gradient buckets in this type (default: DANET_GRAD_WIRE or fp32)')
@@ -73,16 +89,30 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(size, cpu_batch):
     """The oracle timed on the host cores on a bounded sample of the same workload: every convolutional net of the step
     (oracle/torch_ref.StepNets: HRNet-W48 + global and partial IUV heads + body / limb regressor nets) forward + backward
     + Adam in fp32, plus the C restatements of the SMPL layer (2 forward, 1 backward -- what the timed GPU step holds)
-    and of the IUV raster."""
+    and of the IUV raster.  The thread count is swept (all host threads, a half, a quarter: small batches do not scale to
+    every core) and the best setting reported."""
     import numpy as np
     import oracle
     from oracle import torch_ref
     from danet_densepose2smpl_amd import assets
-    t_net, nparam = torch_ref.train_step_cpu(cpu_batch, size, 1)
+    nthr = torch.get_num_threads()
+    counts = sorted({max(1, nthr), max(1, nthr // 2), max(1, nthr // 4)}, reverse=True)
+    sweep, nparam = torch_ref.train_step_cpu_sweep(cpu_batch, size, counts)
+    best_thr, t_net = min(sweep, key=lambda r: r[1])
     model = assets.make_synthetic_smpl(0)
     vm, faces, tex = assets.densepose_render_tables(assets.make_synthetic_densepose(model, 0))
     rng = np.random.default_rng(0)
@@ -96,11 +126,13 @@ def cpu_baseline(size, cpu_batch):
     cam = np.tile(np.array([[0.9, 0.0, 0.0]], np.float32), (cpu_batch, 1))
     oracle.raster_forward(verts, cam, vm, faces, tex, 5000.0, float(size), size // 4)
     t_geo = time.time() - t0
-    return {'value': round(cpu_batch / (t_net + t_geo), 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': 'B=%d of the B=32 step (a batch this small under-uses the %d host threads: a port timed on a bounded sample, not a tuned CPU baseline): oracle/torch_ref.StepNets fwd+bwd+Adam fp32 (%.2fs; %.1f M parameters; 30.06 of the '
-                      'step\'s 30.07 GMAC/img = 99.9 %% of its 5.77 TFLOP: only the GCN / 1x1 regressors and the loss glue are '
-                      'left out) + 2x C SMPL fwd, 1x C SMPL bwd, 1x C IUV raster (%.2fs)' % (cpu_batch, torch.get_num_threads(), t_net, nparam / 1e6, t_geo)}
+    return {'value': round(cpu_batch / (t_net + t_geo), 4), 'unit': 'images/sec', 'cores': best_thr,
+            'kind': 'port', 'cpu': _cpu_model(), 'host_threads': nthr,
+            'thread_sweep': [{'threads': n, 'images_per_sec': round(cpu_batch / (t + t_geo), 4)} for n, t in sweep],
+            'sample': 'B=%d of the B=32 step, one timed step per thread count after one warm-up step, best of %s threads reported: '
+                      'oracle/torch_ref.StepNets fwd+bwd+Adam fp32 (%.2fs; %.1f M parameters; 30.06 of the step\'s 30.07 GMAC/img = 99.9 %% of its '
+                      '5.77 TFLOP: only the GCN / 1x1 regressors and the loss glue are left out) + 2x C SMPL fwd, 1x C SMPL bwd, 1x C IUV '
+                      'raster on one thread (%.2fs)' % (cpu_batch, counts, t_net, nparam / 1e6, t_geo)}
 
 
 def geometry_rooflines(tr, B, size, dev):
@@ -162,9 +194,20 @@ def fp32_record(args, tr, batch, world, dev):
     capture succeeds.  Returns the timing record (every rank must call it: the step holds the gradient all-reduces)."""
     from danet_densepose2smpl_amd import conv
     from danet_densepose2smpl_amd import nn as _dnn
-    steps, warm = max(1, min(args.steps, 5)), 2
+    steps, warm = (1 if args.dry else max(10, min(args.steps, 20))), 2
+    roof = None
     with conv.precision('fp32'):
         exec_mode = 'eager'
+        if not args.dry:
+            # the fp32 step's own roofline: the conv launches of one eager step bracketed by HIP events, against the fp32 MFMA peak
+            tr.train_step(batch)
+            summ, dominant = profile_step(tr, batch, dev)
+            if dominant is not None:
+                n, secs, flops = summ[dominant]
+                ach = flops / secs / 1e12
+                roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                        'traffic': None, 'kernel': dominant + ' (forward + data-gradient launches of the step, all shapes)', 'launches': n,
+                        'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3)}
         step = lambda: tr.train_step(batch)
         if not args.no_graph:
             try:
@@ -193,7 +236,7 @@ def fp32_record(args, tr, batch, world, dev):
     losses = out[1] if isinstance(out, tuple) else out
     finite = bool(all(torch.isfinite(v).all() for v in losses.values())) if isinstance(losses, dict) else None
     return {'dtype': 'f32', 'value': round(world * args.batch * steps / elapsed, 2), 'unit': 'images/sec', 'ms_per_step': round(elapsed / steps * 1e3, 2),
-            'steps': steps, 'warmup': warm, 'exec': exec_mode, 'finite_losses': finite,
+            'steps': steps, 'warmup': warm, 'exec': exec_mode, 'finite_losses': finite, 'roofline': roof,
             'workload': 'BASELINE config C4 arithmetic: the same full train step with fp32 NHWC activations; convolutions on '
                         'v_mfma_f32_16x16x4_f32 (conv_f32m.hip), BatchNorm / fuse sums / STN on the fp32 instantiation of the HIP kernels'}
 
@@ -207,7 +250,7 @@ def fp32_line(args, tr, batch, world, rank, dev):
                           'ms_per_step': rec['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                           'dtype': 'f32', 'data': 'synthetic', 'exec': rec['exec'],
                           'config': {'workload': rec['workload'], 'global_batch': B * world, 'parallelism': 'dp%d' % world},
-                          'finite_losses': rec['finite_losses'], 'roofline': None}), flush=True)
+                          'finite_losses': rec['finite_losses'], 'roofline': rec.get('roofline')}), flush=True)
 
 
 def _dnn_blocks():
@@ -324,10 +367,15 @@ def main():
             n, secs, flops = summ[dominant]
             ach = flops / secs / 1e12
             traffic, tsrc = pmc_traffic(dominant)
+            rp_us, rp_src = rocprof_avg_us(dominant)
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': traffic, 'kernel': dominant,
                     'launches': n, 'avg_us': round(secs / n * 1e6, 2), 'alg_gflop_per_launch': round(flops / n / 1e9, 3),
-                    'traffic_source': tsrc}
+                    'traffic_source': tsrc,
+                    # the same kernel's average under rocprofv3 --kernel-trace --stats (graph replays, committed summary) beside the
+                    # live event brackets of one eager step: the brackets include the launch gaps of eager execution
+                    'rocprof_avg_us': rp_us, 'rocprof_frac': None if rp_us is None else round(flops / n / (rp_us * 1e-6) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
+                    'rocprof_source': rp_src}
     extra = None
     if rank == 0 and not args.dry:
         try:

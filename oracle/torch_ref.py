@@ -338,3 +338,32 @@ def train_step_cpu(B, size, reps=1):
     for _ in range(reps):
         step()
     return (time.time() - t0) / reps, sum(p.numel() for p in net.parameters())
+
+
+def train_step_cpu_sweep(B, size, thread_counts):
+    """[(threads, seconds per fwd + bwd + Adam step of StepNets)] for every thread count: ONE network and one warm-up step, then
+    one timed step per setting (bench.py's cpu_baseline reports the best); restores the thread count."""
+    import time
+    torch.manual_seed(0)
+    net = StepNets().train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    img = torch.randn(B, 3, size, size)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, part, cam_shape, rot = net(img)
+        loss = sum(out[k].float().mean() for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm'))
+        (loss + part.mean() + cam_shape.mean() + rot.mean()).backward()
+        opt.step()
+    prev = torch.get_num_threads()
+    res = []
+    try:
+        step()                                                                           # warm-up (allocator, thread pool)
+        for n in thread_counts:
+            torch.set_num_threads(int(n))
+            t0 = time.time()
+            step()
+            res.append((int(n), time.time() - t0))
+    finally:
+        torch.set_num_threads(prev)
+    return res, sum(p.numel() for p in net.parameters())
