@@ -67,6 +67,8 @@ _SIGNATURES = {
     'danet_conv_wgrad3x3_kernel_id': (c_i, [c_i] * 7),
     'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 7 + [c_fl, c_i, c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
+    'danet_conv_wgrad_ws_floats_for': (c_sz, [c_i] * 13),
+    'danet_conv_pw_wgrad_set': (c_i, [c_i]),
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),

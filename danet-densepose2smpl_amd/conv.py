@@ -664,7 +664,7 @@ def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad,
             check(L.danet_conv_wgrad3x3(*args, 2, stream()), 'danet_conv_wgrad3x3')
             PROFILER.end(tok)
         return
-    nws = L.danet_conv_wgrad_ws_floats(Cout, Cin_g, R, S)
+    nws = L.danet_conv_wgrad_ws_floats_for(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)
     ws = ARENA.alloc(nws)
     ws_zero = ws is not None
     if ws is None:

@@ -30,6 +30,7 @@ UNITS = {
     'conv3x3s.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
     'conv_pw.hip': MFMA_VGPR,
+    'conv_pw_wgrad.hip': MFMA_VGPR,
     'conv_f32.hip': ['-ffp-contract=off'],
     'conv_f32m.hip': MFMA_VGPR,
     'part_ops.hip': [],

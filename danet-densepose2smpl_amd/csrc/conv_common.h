@@ -53,6 +53,13 @@ bool conv_pw_ok(const ConvP& p, bool vec8);
 int conv_pw_config(const ConvP& p);                  // NKS * 10 + NTB of the instantiation, 0 = not supported
 int conv_pw_launch(const ConvP& p, void* stream);
 
+// One problem of the multi-problem weight-gradient entry points (include/danet_hip.h danet_conv_wgrad_multi)
+struct WgJob { const void* x; const void* dy; float* dw; int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; };
+// conv_pw_wgrad.hip: weight gradients of 1x1 / stride-1 layers (chunks staged as they lie, LDS transpose reads, deterministic partials)
+bool conv_pw_wgrad_ok(const WgJob& j);
+size_t conv_pw_wgrad_ws_floats(const WgJob* jobs, const int* idx, int cnt, long target);
+int conv_pw_wgrad_launch(const WgJob* jobs, const int* idx, int cnt, float* ws, float beta, long target, void* stream);
+
 // conv3x3.hip: 3x3 / stride-1 / pad-1 forward and data gradient on an LDS-resident halo tile (persistent workgroups)
 bool conv3x3_ok(const ConvP& p, bool vec8);
 int conv3x3_config(const ConvP& p, bool vec8, int nprob);      // MT*100 + NT*10 + KW, 0 = not supported

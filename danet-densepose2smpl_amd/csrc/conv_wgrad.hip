@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p)
 
 // Several independent problems of one kernel instance in one launch (see conv_wgrad3x3.hip: weight gradients are
 // queued during the backward pass and flushed in batches).
+constexpr long PW_WGRAD_BLOCKS = 768;       // workgroups of a pointwise weight-gradient launch (three 45 KB workgroups per compute unit)
 constexpr int NPM = 16;
 struct WgradMulti { WgradP p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; };
 
@@ -299,6 +300,16 @@ extern "C" size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S) 
     return (size_t)Cout * Cin_g * R * S + 16;            // + a zero block the kernel reads for out-of-range runs
 }
 
+// Workspace of danet_conv_wgrad for a given problem: the packed accumulator of danet_conv_wgrad_ws_floats, or -- 1x1 / stride-1 layers
+// on csrc/conv_pw_wgrad.hip -- that kernel's partial sums, whichever is larger.
+extern "C" size_t danet_conv_wgrad_ws_floats_for(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups) {
+    size_t need = groups > 0 ? danet_conv_wgrad_ws_floats(Cout, Cin / groups, R, S) : 0;
+    const WgJob job{nullptr, nullptr, nullptr, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups};
+    const int one = 0;
+    if (conv_pw_wgrad_ok(job)) { const size_t n2 = conv_pw_wgrad_ws_floats(&job, &one, 1, PW_WGRAD_BLOCKS); if (n2 > need) need = n2; }
+    return need;
+}
+
 // dW[Cout][Cin_g][R][S] (fp32, torch layout) = beta * dW + conv_wgrad(x, dy).
 // ws: danet_conv_wgrad_ws_floats() floats of scratch (zeroed and filled here).
 extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
@@ -313,6 +324,15 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
                     (long)B * H * W * Cin < 1073741823L && (long)B * OH * OW * Cout < 1073741823L && (long)B * OH * OW < (1L << 24),
                     "conv_wgrad: channels per group must be multiples of 8 (Cin_g=%d, Cout_g=%d); the host pads them",
                     Cin / groups, Cout / groups);
+    {
+        const WgJob job{x, dy, dw, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups};
+        const int one = 0;
+        if (conv_pw_wgrad_ok(job) && conv_pw_wgrad_ws_floats(&job, &one, 1, PW_WGRAD_BLOCKS) <= ws_floats) {
+            // (a workspace sized by danet_conv_wgrad_ws_floats_for: the pointwise kernel's partial sums; need not be zeroed)
+            if (conv_pw_wgrad_launch(&job, &one, 1, ws, beta, PW_WGRAD_BLOCKS, stream) != 0) return danet::fail(DANET_ERR_HIP, "conv_wgrad: pointwise launch failed");
+            return DANET_OK;
+        }
+    }
     WgradP p;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dwp = ws;
     p.zero = ws + (danet_conv_wgrad_ws_floats(Cout, Cin / groups, R, S) - 16);
@@ -365,7 +385,7 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
 // ---------------------------------------------------------------------------------------------
 // Batched form: n independent problems, grouped by kernel instance, up to 16 per launch.  ws: zeroed by the
 // caller (danet_conv_wgrad_multi_ws_floats floats; every problem's packed accumulator lives there).
-struct WgJob { const void* x; const void* dy; float* dw; int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; };
+// (WgJob: conv_common.h)
 
 static bool wg_job_ok(const WgJob& j) {
     return j.x && j.dy && j.dw && j.B > 0 && j.H > 0 && j.W > 0 && j.Cin > 0 && j.OH > 0 && j.OW > 0 && j.Cout > 0 && j.R > 0 && j.S > 0 &&
@@ -380,6 +400,20 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
     bool done[4096];
     for (int i = 0; i < n; ++i) done[i] = false;
     size_t used = 0;
+    {
+        // 1x1 / stride-1 problems: csrc/conv_pw_wgrad.hip (its partial sums need no zeroed workspace)
+        static int idx[4096];
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) if (conv_pw_wgrad_ok(jobs[i])) { idx[cnt++] = i; done[i] = true; }
+        if (cnt > 0) {
+            const size_t need = conv_pw_wgrad_ws_floats(jobs, idx, cnt, PW_WGRAD_BLOCKS);
+            if (ws) {
+                if (need > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad_multi: workspace too small");
+                if (conv_pw_wgrad_launch(jobs, idx, cnt, ws, beta, PW_WGRAD_BLOCKS, st) != 0) return danet::fail(DANET_ERR_HIP, "conv_wgrad_multi: pointwise launch failed");
+            }
+            used += need;
+        }
+    }
     long target = 1024;     // swept on MI355X (512 / 768 / 1024 / 1536 / 2048: 33.04 / 32.82 / 32.67 / 32.81 / 32.89 ms per step once
                             // the 7x7 stem has its own kernel and one process flushes all problems at once)
     if (const char* e = getenv("DANET_WGRAD_MULTI_BLOCKS")) target = atol(e);

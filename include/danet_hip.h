@@ -337,6 +337,13 @@ int danet_conv_wgrad_rows(const void* x, const void* dy, float* dw, float* ws, s
                           int B, int H, int W, int Cin, int OH, int OW, int Cout,
                           int R, int S, int stride, int pad, int groups, float beta, void* stream);
 size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
+/* The workspace danet_conv_wgrad needs for THIS problem: as above, or more for 1x1 / stride-1 layers, which run on the pointwise
+ * weight-gradient kernel (csrc/conv_pw_wgrad.hip: 32-pixel chunks of dY and X staged as they lie in memory, LDS transpose reads,
+ * per-workgroup partial sums reduced in a fixed order -- deterministic, no atomics) when the workspace has room for its partial
+ * sums; with the smaller workspace the generic kernel runs.  danet_conv_wgrad_multi sizes its own (danet_conv_wgrad_multi_ws_floats).
+ * danet_conv_pw_wgrad_set: run-time switch (A-B timing, tests): 0 / 1 (-1 keeps); returns the previous setting. */
+size_t danet_conv_wgrad_ws_floats_for(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+int danet_conv_pw_wgrad_set(int enable);
 int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,
                      int R, int S, int stride, int pad, int dil, int groups, float beta, int ws_is_zero, void* stream);

@@ -474,12 +474,15 @@ def test_pointwise_kernel_vs_torch_fp32(shape):
             y32 = dconv._conv_fwd_raw(xn, wp, b, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, False, True, True)
             yadd = dconv._conv_fwd_raw(xn, wp, None, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, False, False, False, None, None, add)
             torch.cuda.synchronize()
-            res[on] = (y.detach(), xt.grad, None if sums is None else sums.view(-1, 2, Cout).sum(0), y32, yadd, add)
+            res[on] = (y.detach(), xt.grad, None if sums is None else sums.view(-1, 2, Cout).sum(0), y32, yadd, add, wt.grad.clone())
         finally:
             L.danet_conv_pw_set(prev)
-    y, gx, st, y32, yadd, add = res[1]
+    y, gx, st, y32, yadd, add, gw = res[1]
     close(y, yr, 1e-2, 'forward')
     close(gx, xr.grad, 1e-2, 'dgrad')
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr).backward(gy)
+    close(gw, wr.grad, 3e-3, 'wgrad (csrc/conv_pw_wgrad.hip)')
     if Cout % 8 == 0:
         assert st is not None
         yb = y.float()
@@ -488,3 +491,49 @@ def test_pointwise_kernel_vs_torch_fp32(shape):
     for k, tol, what in ((0, 1e-2, 'forward vs gather kernel'), (1, 1e-2, 'dgrad vs gather kernel'), (3, 2e-3, 'bias + ReLU + fp32'), (4, 1e-2, 'addend')):
         close(res[1][k], res[0][k], tol, what)
     close(yadd, yr.detach() + add.float(), 1.5e-2, 'addend vs fp32')
+
+
+def test_pointwise_wgrad_kernel_multi_problem_and_switch():
+    """csrc/conv_pw_wgrad.hip through danet_conv_wgrad_multi (the trainer's deferred, multi-problem path): several 1x1 layers of
+    different widths in one call, with a 3x3 problem mixed in (it stays on the generic kernel), against torch's fp32 weight
+    gradient; deterministic (two calls agree bit for bit); and with the kernel switched off the generic path gives the same
+    numbers up to summation order.  beta = 1 accumulates."""
+    import ctypes
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    from danet_densepose2smpl_amd._lib import ptr, stream, check
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    specs = [(64, 256, 1, 8, 64), (256, 64, 1, 8, 64), (24, 64, 1, 40, 64), (64, 24, 1, 40, 64), (48, 16, 1, 4, 64), (16, 48, 1, 4, 64), (32, 32, 3, 4, 32), (96, 192, 1, 6, 30)]
+    xs, gys, refs = [], [], []
+    for cin, cout, k, B, H in specs:
+        x = torch.randn(B, cin, H, H, generator=g).bfloat16().float().cuda()
+        gy = torch.randn(B, cout, H, H, generator=g).bfloat16().float().cuda()
+        refs.append(torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), gy, padding=k // 2))
+        xs.append(dconv.nhwc_bf16(x)); gys.append(dconv.nhwc_bf16(gy))
+
+    def run(beta=0.0, init=None):
+        dws = [torch.full((cout, cin, k, k), float('nan'), device='cuda') if init is None else init[i].clone() for i, (cin, cout, k, B, H) in enumerate(specs)]
+        jobs = (_lib.WgJob * len(specs))()
+        for j, x, gy, dw, (cin, cout, k, B, H) in zip(jobs, xs, gys, dws, specs):
+            j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), dw.data_ptr()
+            (j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups) = (B, H, H, cin, H, H, cout, k, k, 1, k // 2, 1, 1)
+        need = L.danet_conv_wgrad_multi_ws_floats(ctypes.addressof(jobs), len(specs))
+        ws = torch.zeros(need, device='cuda')
+        check(L.danet_conv_wgrad_multi(ctypes.addressof(jobs), len(specs), ptr(ws), need, beta, stream()), 'wgrad_multi')
+        torch.cuda.synchronize()
+        return dws
+    a, b = run(), run()
+    prev = L.danet_conv_pw_wgrad_set(0)
+    try:
+        c = run()
+    finally:
+        L.danet_conv_pw_wgrad_set(prev)
+    acc = run(beta=1.0, init=[r.clone() for r in refs])
+    for (cin, cout, k, B, H), x1, x2, x3, x4, r in zip(specs, a, b, c, acc, refs):
+        scale = r.abs().max().item()
+        assert torch.isfinite(x1).all(), (cin, cout)
+        if k == 1 and (cin, cout) != (96, 192):                                  # (96 -> 192: 12 x 6 blocks exceed a wave's 16 accumulator tiles: generic kernel)
+            assert torch.equal(x1, x2), (cin, cout)                             # deterministic (the generic kernel's atomics are not)
+        assert (x1 - r).abs().max().item() <= 3e-3 * scale, (cin, cout, k)
+        assert (x1 - x3).abs().max().item() <= 1e-3 * scale, (cin, cout, k)     # == the generic kernel up to order
+        assert (x4 - 2 * r).abs().max().item() <= 6e-3 * scale, (cin, cout, k)

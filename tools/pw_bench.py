@@ -38,6 +38,26 @@ def main():
                 rec['err'] = round(float((y - yref).abs().max() / yref.abs().max()), 5)
             else:
                 yref = y
+        # weight gradient: dY and X read once
+        gy = conv.nhwc_bf16(torch.randn(B, Cout, H, W, device='cuda'))
+        gw = torch.empty(Cout, Cin, 1, 1, device='cuda')
+        nws = L.danet_conv_wgrad_ws_floats_for(B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1)
+        ws = torch.zeros(nws, device='cuda')
+
+        def wgrad():
+            conv.check(L.danet_conv_wgrad(_lib.ptr(x.permute(0, 2, 3, 1)), _lib.ptr(gy.permute(0, 2, 3, 1)), _lib.ptr(gw), _lib.ptr(ws), nws,
+                                          B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, 0.0, 0, _lib.stream()), 'wgrad')
+        for on in (0, 1):
+            prev = L.danet_conv_pw_wgrad_set(on)
+            wgrad()
+            g = gw.clone()
+            t = timeit(wgrad)
+            L.danet_conv_pw_wgrad_set(prev)
+            rec['wgrad_pw' if on else 'wgrad_generic'] = {'us': round(t * 1e6, 1), 'TBps': round(mb / t / 1e6, 2)}
+            if on:
+                rec['wgrad_err'] = round(float((g - gref).abs().max() / gref.abs().max()), 6)
+            else:
+                gref = g
         print(json.dumps(rec), flush=True)
 
 
