@@ -395,6 +395,8 @@ def _kernel_name(kid, stream_dims=None):
         return 'conv3x3_tile_kernel'
     if kid % 10 == 3:
         return 'conv_pw_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10)
+    if kid % 10 == 4:
+        return 'conv3x3_stream_kernel<%d>' % ((kid // 100) % 10)
     if kid % 10 == 1:
         return 'conv_fast_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10)
     return 'conv_igemm_kernel<%d, %d, %s>' % (kid // 1000, (kid // 100) % 10, 'true' if (kid // 10) % 10 else 'false')

@@ -67,7 +67,9 @@ constexpr int S3_THREADS = 256;
 struct S3Prob {
     const bf16_t* x; const bf16_t* w; void* y; const float* bias; float* stats; const bf16_t* addend;
     const i32x4* tab;                                    // the problem's tap table (device cache, see s3_table_for)
-    int B, H, W, Cin, Cout;
+    int B, H, W, Cin, Cout;                              // Cin, Cout: channels PER GROUP
+    int groups, nnbg, pixb_in, Cout_tot;                 // grouped layers: N-blocks per group, bytes per input pixel, output channels of all groups
+    float rc_nnbg;
     int x_bytes, y_bytes;
     int TH, NI, Wp, Sp, tiles_h, nnb, nks, nc16;
     int tile0, ntiles, tile0m;                           // tile0m = tile0 % grid (filled at launch)
@@ -276,11 +278,11 @@ __device__ inline i32x4 raw_desc(const void* base, int bytes) {           // raw
 }
 
 template <int NIR>
-__device__ __forceinline__ void s3_rows(const S3Prob& p, int s, int img0, int y0, unsigned char* buf, int wave, int lane)
+__device__ __forceinline__ void s3_rows(const S3Prob& p, int s, int img0, int y0, int gofs, unsigned char* buf, int wave, int lane)
 {
     const int Sp = p.Sp, Wp = p.Wp, W = p.W, H = p.H, TH2 = p.TH + 2, NI = p.NI;
-    const int S_s = 2 * st_nc(p, s), ch0 = st_c0(p, s) * 32;
-    const int pixb = p.Cin * 2, rowb = W * pixb;
+    const int S_s = 2 * st_nc(p, s), ch0 = st_c0(p, s) * 32 + gofs;        // gofs: byte offset of the tile's group within a pixel
+    const int pixb = p.pixb_in, rowb = W * pixb;
     const i32x4 desc = raw_desc(p.x, p.x_bytes);
     const int rowcells = Wp * Sp;
     int voff[NIR];
@@ -322,15 +324,16 @@ __device__ inline void s3_issue(const S3Prob& p, int tau, int s, unsigned char* 
     }
     int img0, y0, nb;
     tile_coords(p, tau, img0, y0, nb);
+    const int gofs = p.groups > 1 ? __builtin_amdgcn_readfirstlane((int)udiv24((unsigned)nb, (unsigned)p.nnbg, p.rc_nnbg) * p.Cin * 2) : 0;
     switch ((p.Wp * p.Sp + 63) >> 6) {
-        case 1: s3_rows<1>(p, s, img0, y0, buf, wave, lane); break;
-        case 2: s3_rows<2>(p, s, img0, y0, buf, wave, lane); break;
-        case 3: s3_rows<3>(p, s, img0, y0, buf, wave, lane); break;
-        case 4: s3_rows<4>(p, s, img0, y0, buf, wave, lane); break;
-        case 5: s3_rows<5>(p, s, img0, y0, buf, wave, lane); break;
-        case 6: s3_rows<6>(p, s, img0, y0, buf, wave, lane); break;
-        case 7: s3_rows<7>(p, s, img0, y0, buf, wave, lane); break;
-        default: s3_rows<8>(p, s, img0, y0, buf, wave, lane); break;
+        case 1: s3_rows<1>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 2: s3_rows<2>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 3: s3_rows<3>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 4: s3_rows<4>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 5: s3_rows<5>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 6: s3_rows<6>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 7: s3_rows<7>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        default: s3_rows<8>(p, s, img0, y0, gofs, buf, wave, lane); break;
     }
 }
 
@@ -371,7 +374,7 @@ __device__ inline void issue_pos(int nprob, int rot, const Pos& q, unsigned char
 // per-value tests of those options (12 accumulator tiles x 5 uniform branches per tile otherwise).
 template <int NT, int KW, bool PLAIN>
 __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], float (*s1)[4], float (*s2)[4], const int* outoff, unsigned char* sR,
-                                          float* sScr, int img0, int y0, int n0, bool flush, int bid, dbg_ptr dbg_stamp)
+                                          float* sScr, int img0, int y0, int n0, int climit, bool flush, int bid, dbg_ptr dbg_stamp)
 {
     constexpr int MT = 4, PW = 4 / KW, MO = MT / KW;
     const int t = threadIdx.x, lane = t & 63;
@@ -419,7 +422,8 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
     if (dbg_stamp) dbg_stamp[4] = (int)clock64();
     // ---- epilogue on the wave's own tiles ----------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const int tile_out = ((img0 * H + y0) * W) * p.Cout * osz;
+    // n0: first output channel of the tile's block among ALL groups' channels, climit: end of its group's channels
+    const int tile_out = ((img0 * H + y0) * W) * p.Cout_tot * osz;
     auto add_stats = [&](int nt, f32x4 v) {                 // BatchNorm statistics from the fp32 accumulators (see conv3x3.hip), two values per instruction
         f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
         f32x2_& a0 = *reinterpret_cast<f32x2_*>(&s1[nt][0]); f32x2_& a1 = *reinterpret_cast<f32x2_*>(&s1[nt][2]);
@@ -454,7 +458,7 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
 #pragma unroll
             for (int nt = 2 * NPAIR; nt < NT; ++nt) {
                 const int cl = n0 + nt * 16 + lg * 4;
-                const bool cok = cl < p.Cout;
+                const bool cok = cl < climit;
                 const int so = tile_out + (n0 + nt * 16) * osz;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (has_bias) {
@@ -505,8 +509,8 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
             const float v = (sScr[(0 * 2 + which) * (NT * 16) + c] + sScr[(1 * 2 + which) * (NT * 16) + c]) +
                             (sScr[(2 * 2 + which) * (NT * 16) + c] + sScr[(3 * 2 + which) * (NT * 16) + c]);
             // (a GLOBAL atomic: see dbg_ptr -- a FLAT one would serialise every later LDS wait of the kernel)
-            if (n0 + c < p.Cout)
-                __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(p.stats + ((size_t)(bid % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + n0 + c), v,
+            if (n0 + c < climit)
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(p.stats + ((size_t)(bid % bn_ncopy(p.Cout_tot)) * 2 + which) * p.Cout_tot + n0 + c), v,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -558,7 +562,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             r = (int)udiv24((unsigned)rem, (unsigned)W, 1.0f / (float)W); xx = rem - r * W;
         }
         lanebase[mt] = ((sl * (TH + 2) + r + 1) * Wp + xx + 1) * Sp * 16 + (lg & 1) * 16;
-        outoff[mt] = valid ? (((sl * H + r) * W + xx) * p.Cout + lg * 4) * osz : OOB;
+        outoff[mt] = valid ? (((sl * H + r) * W + xx) * p.Cout_tot + lg * 4) * osz : OOB;
     }
     if (dbg && t == 0 && g == 0) dbg[11] = (int)clock64();
     const int nks = p.nks;
@@ -590,8 +594,13 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         const int tau = cur.tau;
         int img0, y0, nb;
         tile_coords(p, tau, img0, y0, nb);
-        const int n0 = nb * (16 * NT);
+        const int n0 = nb * (16 * NT);                               // row of the packed weights ([group][rows_pad / 16][k-step] fragments)
         const bf16_t* wblk = p.w + (size_t)(n0 / 16) * (size_t)nks * 512;
+        int cb = n0, clim = p.Cout;                                  // the block's first output channel / the end of its group's channels
+        if (p.groups > 1) {
+            const int gq = __builtin_amdgcn_readfirstlane((int)udiv24((unsigned)nb, (unsigned)p.nnbg, p.rc_nnbg));
+            cb = gq * p.Cout + (nb - gq * p.nnbg) * (16 * NT); clim = (gq + 1) * p.Cout;
+        }
         // Weight-fragment loads are inline asm: the compiler's own vmcnt bookkeeping drains the whole ring at every loop
         // header (vmcnt(0) once per D k-steps, measured in the disassembly).  Invisible to it, they are counted by hand: the
         // ring is a FIFO, so whenever a slot is used exactly NT * (D - 1) younger fragment loads exist -- s_waitcnt
@@ -745,15 +754,15 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         const bool flush = flush_after(p, tau, nblk);
         if (S3_PLAIN_EPI && !p.bias && !p.addend && !p.relu && !p.out_fp32 && !p.has_idle) {
             switch (KW) {
-                case 1: s3_finish<NT, 1, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
-                case 2: s3_finish<NT, 2, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
-                default: s3_finish<NT, 4, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+                case 1: s3_finish<NT, 1, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, cb, clim, flush, bid, stamp); break;
+                case 2: s3_finish<NT, 2, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, cb, clim, flush, bid, stamp); break;
+                default: s3_finish<NT, 4, true>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, cb, clim, flush, bid, stamp); break;
             }
         } else {
             switch (KW) {
-                case 1: s3_finish<NT, 1, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
-                case 2: s3_finish<NT, 2, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
-                default: s3_finish<NT, 4, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, n0, flush, bid, stamp); break;
+                case 1: s3_finish<NT, 1, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, cb, clim, flush, bid, stamp); break;
+                case 2: s3_finish<NT, 2, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, cb, clim, flush, bid, stamp); break;
+                default: s3_finish<NT, 4, false>(p, acc, s1, s2, outoff, sR, sScr, img0, y0, cb, clim, flush, bid, stamp); break;
             }
         }
         lds_barrier();                                              // the last stage's slot is consumed
@@ -818,7 +827,7 @@ bool s3_plan_one(const ConvP& p, S3Prob& q, int NT, int KW) {
         if (TH == 0) return false;
     }
     if ((long)NI * TH * W * 4 < (long)TP * 3) return false;             // < 75 % of the register tile in use
-    const int nc16 = p.Cin / 16, nrows = NI * (TH + 2), Wp = W + 2;
+    const int nc16 = p.Cin_g / 16, nrows = NI * (TH + 2), Wp = W + 2;
     const int nks = p.Kp / 32;
     if (nks > S3_TAB) return false;
     if (KW > 1 && 4 * (MT - MT / KW) * NT * 1024 > S3_BUF) return false;
@@ -845,7 +854,8 @@ bool s3_plan_one(const ConvP& p, S3Prob& q, int NT, int KW) {
     if (j0 != nks) return false;
     q.nent = j0;
     q.TH = TH; q.NI = NI; q.Wp = Wp; q.Sp = Sp;
-    q.tiles_h = H / TH; q.nnb = p.Cout_pad / (16 * NT); q.nks = nks; q.nc16 = nc16;
+    q.tiles_h = H / TH; q.nnbg = p.Cout_pad / (16 * NT); q.nnb = q.nnbg * p.groups; q.nks = nks; q.nc16 = nc16;
+    q.rc_nnbg = 1.0f / (float)q.nnbg;
     q.rc_nnb = 1.0f / (float)q.nnb; q.rc_th = 1.0f / (float)q.tiles_h;
     q.lw = ilog2_exact(W); q.lthw = ilog2_exact(TH * W);
     if (q.lw < 0 || q.lthw < 0) q.lw = q.lthw = -1;
@@ -853,26 +863,29 @@ bool s3_plan_one(const ConvP& p, S3Prob& q, int NT, int KW) {
     q.ntiles = npt * q.nnb;
     q.kw = KW; q.nt = NT;
     q.swz = (npt % 8 == 0 && q.nnb > 1) ? 1 : 0;
-    q.has_idle = (NI * TH * W != TP || p.Cout != p.Cout_pad) ? 1 : 0;
+    q.has_idle = (NI * TH * W != TP || p.Cout_g != p.Cout_pad) ? 1 : 0;
     return true;
 }
 
 bool s3_shape_ok(const ConvP& p) {
     if (!g_s3_on) return false;
-    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.dil != 1 || p.groups != 1) return false;
-    if (p.H != p.OH || p.W != p.OW || p.Cin % 16 != 0 || p.Cout % 4 != 0) return false;
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.dil != 1) return false;
+    // grouped layers (the 24-group partial-IUV head, /root/reference/models/danet/iuv_estimator.py:193-206): a tile = one group's
+    // channels of a pixel tile; forward only (the data gradient's 24 channels per group are no multiple of 16)
+    if (p.groups != 1 && (p.transposed || p.bias || p.addend)) return false;
+    if (p.H != p.OH || p.W != p.OW || p.Cin_g % 16 != 0 || p.Cout_g % 4 != 0) return false;
     if (p.x_bytes >= (1L << 30) || p.y_bytes >= (1L << 31)) return false;       // (rows outside the image add 2^30 to their offsets: see s3_rows)
-    if ((long)p.Cout_pad * p.Kp * 2 >= (1L << 31)) return false;
+    if ((long)p.groups * p.Cout_pad * p.Kp * 2 >= (1L << 31)) return false;
     if ((long)p.B * p.H * p.W >= (1L << 24)) return false;
     if (p.bn_red) return false;                     // (the fused BatchNorm-backward reduction stays on conv3x3.hip)
-    return danet_conv_nt(p.Cout) <= 3;
+    return danet_conv_nt(p.Cout_g) <= 3;
 }
 
 // The first K split that gives a launch of nprob problems enough tiles, else the one with the most tiles: fewer, larger tiles
 // with less K splitting win as long as every workgroup gets work (measured on the four HRNet branches, tools/c3s_bench.py:
 // 39.2 us with 512 + 3 x 256 tiles, 42.6 us with the per-workgroup load balanced through smaller tiles, 43.1 us with 512 each).
 bool s3_plan(const ConvP& p, S3Prob& q, int nprob) {
-    const int NT = danet_conv_nt(p.Cout);
+    const int NT = danet_conv_nt(p.Cout_g);
     static const int cand[3] = {1, 2, 4};
     const int want = g_s3_want > 0 ? g_s3_want : (2 * 256 + nprob - 1) / nprob;
     int best = -1;
@@ -916,7 +929,8 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
         if (!s3_shape_ok(p)) return -1;
         S3Prob& q = L.p[i];
         q.x = p.x; q.w = p.w; q.y = p.y; q.bias = p.bias; q.stats = p.stats; q.addend = p.addend;
-        q.B = p.B; q.H = p.OH; q.W = p.OW; q.Cin = p.Cin; q.Cout = p.Cout;
+        q.B = p.B; q.H = p.OH; q.W = p.OW; q.Cin = p.Cin_g; q.Cout = p.Cout_g;
+        q.groups = p.groups; q.pixb_in = p.Cin * 2; q.Cout_tot = p.Cout;
         q.flip = p.transposed ? 1 : 0; q.relu = p.relu ? 1 : 0; q.out_fp32 = p.out_fp32 ? 1 : 0;
         q.x_bytes = (int)p.x_bytes; q.y_bytes = (int)p.y_bytes;
     }
@@ -982,6 +996,7 @@ extern "C" int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want
 extern "C" int danet_conv3x3_stream_plan(int B, int H, int W, int Cin, int Cout, int nprob) {
     ConvP p{};
     p.B = B; p.H = p.OH = H; p.W = p.OW = W; p.Cin = Cin; p.Cout = Cout; p.R = p.S = 3; p.stride = p.pad = p.dil = p.groups = 1;
+    p.Cin_g = Cin; p.Cout_g = Cout;
     p.K = 9 * Cin; p.Kp = (p.K + 31) / 32 * 32;
     const int nt = danet_conv_nt(Cout);
     p.Cout_pad = (Cout + 16 * nt - 1) / (16 * nt) * (16 * nt);

@@ -489,8 +489,13 @@ extern "C" int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, in
     const long M = (long)B * OH * OW;
     // pixel tiles per wave: the largest of 4/2/1 that still gives the 256 CUs two workgroups each
     const long nb = (long)(Cout_pad / (16 * nt)) * groups;
-    const int mt = (M + 255) / 256 * nb >= 512 ? 4 : ((M + 127) / 128 * nb >= 512 ? 2 : 1);
+    int mt = (M + 255) / 256 * nb >= 512 ? 4 : ((M + 127) / 128 * nb >= 512 ? 2 : 1);
     const int vec8 = (Cin_g % 8 == 0) && (Cin % 8 == 0);
+    // 128-pixel wave tiles (conv_fast_kernel<8, 4>: the accumulators spill into AGPRs, one wave per SIMD) for the very large 64-channel
+    // layers -- the regressors' 7x7 stems over the 768 part crops: every wave streams the layer's whole weight slab (401 KB) through L2
+    // per pixel tile, so twice the pixels per wave halve the step's largest operand stream
+    static const bool mt8 = getenv("DANET_CONV_MT8") != nullptr;
+    if (mt8 && mt == 4 && nt == 4 && groups == 1 && vec8 && Cin_g >= 64 && M >= 500000) mt = 8;
     return mt * 100 + nt * 10 + vec8;
 }
 
@@ -615,7 +620,7 @@ static bool fill_conv_params(ConvP& p, bool& vec8, int B, int H, int W, int Cin,
 
 // Which kernel danet_conv_forward launches for a problem: MT*1000 + NT*100 + vec8*10 + fast
 // (fast = 1: conv_fast_kernel<MT, NT>, 0: conv_igemm_kernel<MT, NT, vec8>, 2: the LDS-tile 3x3 kernels (MT, NT, KW in the other
-// digits), 3: conv_pw_kernel<NKS, NTB> (NKS, NTB in the first two)); -1 for invalid sizes.
+// digits), 3: conv_pw_kernel<NKS, NTB> (NKS, NTB in the first two), 4: a grouped 3x3 layer on conv3x3_stream_kernel<NT>); -1 for invalid sizes.
 extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
                                          int stride, int pad, int dil, int groups, int transposed, int out_fp32)
 {
@@ -625,6 +630,8 @@ extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, i
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
     if (conv3x3_ok(p, vec8)) { const int c = conv3x3_config(p, vec8, 1); return (c / 100) * 1000 + ((c / 10) % 10) * 100 + (c % 10) * 10 + 2; }
     if (conv_pw_ok(p, vec8)) { const int c = conv_pw_config(p); return (c / 10) * 1000 + (c % 10) * 100 + 10 + 3; }      // conv_pw_kernel<NKS, NTB>
+    if (p.groups > 1 && vec8 && conv3x3_stream_first() && conv3x3s_launch(&p, 1, nullptr, true) == 0)                       // grouped 3x3 on conv3x3_stream_kernel<NT>
+        return 4000 + danet_conv_nt(p.Cout_g) * 100 + 10 + 4;
     return mt * 1000 + danet_conv_nt(p.Cout_g) * 100 + (vec8 ? 10 : 0) + (conv_fast_ok(p, vec8, mt) ? 1 : 0);
 }
 
@@ -669,6 +676,11 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     if (pw) {
         if (conv_pw_launch(p, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no pointwise instantiation");
         DANET_CHECK_LAUNCH("conv_pw_kernel");
+        return DANET_OK;
+    }
+    if (p.groups > 1 && vec8 && !p.bn_red && conv3x3_stream_first() && conv3x3s_launch(&p, 1, stream, false) == 0) {
+        // grouped 3x3 / stride-1 layers (the 24-group partial-IUV head): one group's channels of a pixel tile per tile of the streamed kernel
+        DANET_CHECK_LAUNCH("conv3x3_stream_kernel");
         return DANET_OK;
     }
     if (conv_fast_ok(p, vec8, mt)) {

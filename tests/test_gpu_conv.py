@@ -537,3 +537,37 @@ def test_pointwise_wgrad_kernel_multi_problem_and_switch():
         assert (x1 - r).abs().max().item() <= 3e-3 * scale, (cin, cout, k)
         assert (x1 - x3).abs().max().item() <= 1e-3 * scale, (cin, cout, k)     # == the generic kernel up to order
         assert (x4 - 2 * r).abs().max().item() <= 6e-3 * scale, (cin, cout, k)
+
+
+@pytest.mark.parametrize('B,H', [(32, 64), (3, 32)])
+def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
+    """The 24-group partial-IUV head (/root/reference/models/danet/iuv_estimator.py:193-206: 24 x (48 -> 21, padded 24) channels, 3x3) is
+    a problem of conv3x3_stream_kernel (kernel id ...4: one group's channels of a pixel tile per tile, the group's 96-byte slice of every
+    2304-byte pixel row staged by LDS-DMA) instead of the gather kernel; forward against F.conv2d(groups = 24) in fp32 on the bf16-rounded
+    operands, with the fused BatchNorm statistics of all 576 channels, and against the gather kernel itself (stream switched off)."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    G, Cg, Ng = 24, 48, 24
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, G * Cg, H, H, generator=g).bfloat16().cuda()
+    w = (torch.randn(G * Ng, Cg, 3, 3, generator=g) / np.sqrt(9 * Cg)).bfloat16().float().cuda()
+    dconv.stream_tables(x.device)
+    assert L.danet_conv_forward_kernel(B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, 0, 0) % 10 == 4
+    yr = F.conv2d(x.float(), w, None, 1, 1, 1, G)
+    xn, wp = dconv.nhwc_bf16(x), dconv.pack_weight(torch.nn.Parameter(w), G, 0)
+    res = {}
+    for on in (1, 0):
+        prev = L.danet_conv3x3_stream_set(on, -1, -1, -1)
+        try:
+            sums = torch.zeros(L.danet_bn_ws_floats(G * Ng), device='cuda')
+            y = dconv._conv_fwd_raw(xn, wp, None, B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, False, False, False, sums)
+            torch.cuda.synchronize()
+            res[on] = (y.float(), sums.view(-1, 2, G * Ng).sum(0))
+        finally:
+            L.danet_conv3x3_stream_set(prev, -1, -1, -1)
+    scale = yr.abs().max().item()
+    assert (res[1][0] - yr).abs().max().item() <= 1e-2 * scale
+    assert (res[1][0] - res[0][0]).abs().max().item() <= 1e-2 * scale
+    st = res[1][1]
+    assert (st[0] - yr.sum(dim=(0, 2, 3))).abs().max().item() <= 5e-3 * yr.sum(dim=(0, 2, 3)).abs().max().item() + 1e-3 * scale * B * H
+    assert (st[1] - (yr * yr).sum(dim=(0, 2, 3))).abs().max().item() <= 3e-3 * (yr * yr).sum(dim=(0, 2, 3)).abs().max().item()

@@ -1,0 +1,58 @@
+"""The regressors' 7x7 / stride-2 stem over the 768 part crops (the step's largest single layer: 315 GFLOP forward, the same again
+for the data gradient): time per launch from hipGraph replays.  python tools/stem_bench.py   (DANET_CONV_MT8=1 for 128-pixel wave tiles)"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from danet_densepose2smpl_amd import conv, _lib          # noqa: E402
+from c3s_bench import timeit                             # noqa: E402
+
+L = _lib.lib()
+B, C, H = 768, 64, 64
+x = conv.nhwc_bf16(torch.randn(B, C, H, H, device='cuda'))
+w = torch.nn.Parameter(torch.randn(C, C, 7, 7, device='cuda') * 0.02)
+gy = conv.nhwc_bf16(torch.randn(B, C, H // 2, H // 2, device='cuda'))
+wp0, wp1 = conv.pack_weight(w, 1, 0), conv.pack_weight(w, 1, 1)
+flops = 2.0 * B * (H // 2) ** 2 * C * C * 49
+
+
+def fwd():
+    return conv._conv_fwd_raw(x, wp0, None, B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1, False, False, False)
+
+
+def dgrad():
+    return conv._conv_fwd_raw(gy, wp1, None, B, H // 2, H // 2, C, H, H, C, 7, 7, 2, 3, 1, 1, True, False, False)
+
+
+yr = torch.nn.functional.conv2d(x.float()[:8], w.detach().bfloat16().float(), None, 2, 3)
+y = fwd()
+err = float((y[:8].float() - yr).abs().max() / yr.abs().max())
+tf, tg = timeit(fwd, iters=5), timeit(dgrad, iters=5)
+print(json.dumps({'stem': [B, C, H], 'kernel_fwd': L.danet_conv_forward_kernel(B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1, 0, 0),
+                  'fwd_us': round(tf * 1e6, 1), 'fwd_frac': round(flops / tf / 2.5e15, 4), 'dgrad_us': round(tg * 1e6, 1), 'dgrad_frac': round(flops / tg / 2.5e15, 4),
+                  'err_fwd': round(err, 5)}))
+
+# the 24-group partial-IUV head (3x3, 24 x (48 -> 24 padded) channels) at the step's size: streamed kernel vs gather kernel
+G, Cg, Ng, Bh, Hh = 24, 48, 24, 32, 64
+xg = conv.nhwc_bf16(torch.randn(Bh, G * Cg, Hh, Hh, device='cuda'))
+wg = torch.nn.Parameter(torch.randn(G * Ng, Cg, 3, 3, device='cuda') * 0.05)
+wpg = conv.pack_weight(wg, G, 0)
+sums = torch.zeros(L.danet_bn_ws_floats(G * Ng), device='cuda')
+fl = 2.0 * Bh * Hh * Hh * G * Ng * Cg * 9
+
+
+def grouped(st=None):
+    return conv._conv_fwd_raw(xg, wpg, None, Bh, Hh, Hh, G * Cg, Hh, Hh, G * Ng, 3, 3, 1, 1, 1, G, False, False, False, st)
+
+
+rec = {'grouped_head': [Bh, G * Cg, G * Ng, Hh]}
+for on in (0, 1):
+    prev = L.danet_conv3x3_stream_set(on, -1, -1, -1)
+    kid = L.danet_conv_forward_kernel(Bh, Hh, Hh, G * Cg, Hh, Hh, G * Ng, 3, 3, 1, 1, 1, G, 0, 0)
+    t, ts = timeit(grouped, iters=5), timeit(lambda: grouped(sums), iters=5)
+    L.danet_conv3x3_stream_set(prev, -1, -1, -1)
+    rec['stream' if on else 'gather'] = {'kernel': kid, 'us': round(t * 1e6, 1), 'us_stats': round(ts * 1e6, 1), 'frac': round(fl / t / 2.5e15, 4)}
+print(json.dumps(rec))
