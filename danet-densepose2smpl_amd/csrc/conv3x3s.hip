@@ -462,7 +462,7 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                 const int so = tile_out + (n0 + nt * 16) * osz;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (has_bias) {
-                    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.Cout * 4, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.Cout_tot * 4, 0x00020000);
                     bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(br, cok ? cl * 4 : OOB, 0, 0));
                 }
 #pragma unroll
@@ -872,7 +872,8 @@ bool s3_shape_ok(const ConvP& p) {
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.dil != 1) return false;
     // grouped layers (the 24-group partial-IUV head, /root/reference/models/danet/iuv_estimator.py:193-206): a tile = one group's
     // channels of a pixel tile; forward only (the data gradient's 24 channels per group are no multiple of 16)
-    if (p.groups != 1 && (p.transposed || p.bias || p.addend)) return false;
+    static const bool no_grouped = getenv("DANET_NO_C3S_GROUPED") != nullptr;      // A-B timing knob
+    if (p.groups != 1 && (no_grouped || p.transposed || p.addend)) return false;
     if (p.H != p.OH || p.W != p.OW || p.Cin_g % 16 != 0 || p.Cout_g % 4 != 0) return false;
     if (p.x_bytes >= (1L << 30) || p.y_bytes >= (1L << 31)) return false;       // (rows outside the image add 2^30 to their offsets: see s3_rows)
     if ((long)p.groups * p.Cout_pad * p.Kp * 2 >= (1L << 31)) return false;

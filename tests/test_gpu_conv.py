@@ -555,19 +555,22 @@ def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
     assert L.danet_conv_forward_kernel(B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, 0, 0) % 10 == 4
     yr = F.conv2d(x.float(), w, None, 1, 1, 1, G)
     xn, wp = dconv.nhwc_bf16(x), dconv.pack_weight(torch.nn.Parameter(w), G, 0)
+    bias = torch.randn(G * Ng, generator=g).cuda()
     res = {}
     for on in (1, 0):
         prev = L.danet_conv3x3_stream_set(on, -1, -1, -1)
         try:
             sums = torch.zeros(L.danet_bn_ws_floats(G * Ng), device='cuda')
             y = dconv._conv_fwd_raw(xn, wp, None, B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, False, False, False, sums)
+            yb = dconv._conv_fwd_raw(xn, wp, bias, B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, False, False, False)      # the head's own form: with a bias
             torch.cuda.synchronize()
-            res[on] = (y.float(), sums.view(-1, 2, G * Ng).sum(0))
+            res[on] = (y.float(), sums.view(-1, 2, G * Ng).sum(0), yb.float())
         finally:
             L.danet_conv3x3_stream_set(prev, -1, -1, -1)
     scale = yr.abs().max().item()
     assert (res[1][0] - yr).abs().max().item() <= 1e-2 * scale
     assert (res[1][0] - res[0][0]).abs().max().item() <= 1e-2 * scale
+    assert (res[1][2] - (yr + bias.view(1, -1, 1, 1))).abs().max().item() <= 1e-2 * (scale + bias.abs().max().item())
     st = res[1][1]
     assert (st[0] - yr.sum(dim=(0, 2, 3))).abs().max().item() <= 5e-3 * yr.sum(dim=(0, 2, 3)).abs().max().item() + 1e-3 * scale * B * H
     assert (st[1] - (yr * yr).sum(dim=(0, 2, 3))).abs().max().item() <= 3e-3 * (yr * yr).sum(dim=(0, 2, 3)).abs().max().item()
