@@ -465,6 +465,18 @@ def _conv_fwd_raw(x, wp, bias, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, di
     return y
 
 
+def _conv_stem_raw(x, wp16, B, H, W, Cin, OH, OW, Cout, bn_sums=None):
+    """csrc/conv_stem.hip: 7x7 / stride 2 / pad 3 forward on LDS tiles; wp16 = pack_weight(w, 1, 0, chunk=16)."""
+    L = _lib.lib()
+    y = _empty_nhwc(B, Cout, OH, OW, torch.bfloat16, x.device)
+    tok = PROFILER.begin('conv_stem_kernel', 2.0 * B * OH * OW * Cout * Cin * 49, ('fwd', B, H, W, Cin, Cout, 7, 2, 1)) if PROFILER is not None else None
+    check(L.danet_conv_stem_forward(ptr(x.permute(0, 2, 3, 1)), ptr(wp16), ptr(y.permute(0, 2, 3, 1)), B, H, W, Cin, OH, OW, Cout, ptr(bn_sums), stream()),
+          'danet_conv_stem_forward')
+    if tok is not None:
+        PROFILER.end(tok)
+    return y
+
+
 class ResLink(object):
     """Carries the residual branch's gradient of a block (`out += residual`, res_module.py:39-56) from the closing
     BatchNorm's backward to the data gradient of the block's first convolution, whose epilogue adds it -- instead of
@@ -485,9 +497,13 @@ class Conv2dFunction(torch.autograd.Function):
         if Cin_g * groups != Cin:
             raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
         OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
-        wp = pack_weight(weight, groups, 0)
         b = None if bias is None else bias.detach().float().contiguous()
-        y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
+        if b is None and not out_fp32 and _lib.lib().danet_conv_stem_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
+            # the regressors' 7x7 / stride-2 stems over the part crops: LDS-tile kernel, weights in the chunked (16-channel slab) packing
+            y = _conv_stem_raw(x, pack_weight(weight, groups, 0, 16), B, H, W, Cin, OH, OW, Cout, bn_sums)
+        else:
+            wp = pack_weight(weight, groups, 0)
+            y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
         ctx.bn_ctx = bn_ctx
@@ -529,7 +545,7 @@ class Conv2dFunction(torch.autograd.Function):
             if ctx.link is not None and ctx.link.dres is not None:
                 addend, ctx.link.dres = ctx.link.dres, None
             fused_add = addend is not None and addend.shape == x.shape and bn_bwd is None and \
-                L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2)
+                L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2, 3)      # gather, LDS-tile 3x3, pointwise
             gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
                                None, bn_bwd, addend if fused_add else None)
             if addend is not None:

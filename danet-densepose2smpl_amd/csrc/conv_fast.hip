@@ -425,7 +425,7 @@ int conv_fast_launch(const ConvP& p, int mt, int nt, void* stream) {
     hipStream_t st = (hipStream_t)stream;
 #define FAST_CASE(M_, N_) if (mt == M_ && nt == N_) { launch_fast<M_, N_>(p, st); return 0; }
     FAST_CASE(1, 1) FAST_CASE(2, 1) FAST_CASE(4, 1) FAST_CASE(1, 2) FAST_CASE(2, 2) FAST_CASE(4, 2)
-    FAST_CASE(1, 3) FAST_CASE(2, 3) FAST_CASE(4, 3) FAST_CASE(1, 4) FAST_CASE(2, 4) FAST_CASE(4, 4) FAST_CASE(8, 4)
+    FAST_CASE(1, 3) FAST_CASE(2, 3) FAST_CASE(4, 3) FAST_CASE(1, 4) FAST_CASE(2, 4) FAST_CASE(4, 4)
 #undef FAST_CASE
     return -1;
 }

@@ -489,13 +489,8 @@ extern "C" int danet_conv_kernel_id(int B, int OH, int OW, int Cin, int Cout, in
     const long M = (long)B * OH * OW;
     // pixel tiles per wave: the largest of 4/2/1 that still gives the 256 CUs two workgroups each
     const long nb = (long)(Cout_pad / (16 * nt)) * groups;
-    int mt = (M + 255) / 256 * nb >= 512 ? 4 : ((M + 127) / 128 * nb >= 512 ? 2 : 1);
+    const int mt = (M + 255) / 256 * nb >= 512 ? 4 : ((M + 127) / 128 * nb >= 512 ? 2 : 1);
     const int vec8 = (Cin_g % 8 == 0) && (Cin % 8 == 0);
-    // 128-pixel wave tiles (conv_fast_kernel<8, 4>: the accumulators spill into AGPRs, one wave per SIMD) for the very large 64-channel
-    // layers -- the regressors' 7x7 stems over the 768 part crops: every wave streams the layer's whole weight slab (401 KB) through L2
-    // per pixel tile, so twice the pixels per wave halve the step's largest operand stream
-    static const bool mt8 = getenv("DANET_CONV_MT8") != nullptr;
-    if (mt8 && mt == 4 && nt == 4 && groups == 1 && vec8 && Cin_g >= 64 && M >= 500000) mt = 8;
     return mt * 100 + nt * 10 + vec8;
 }
 

@@ -299,6 +299,16 @@ int danet_conv3x3_stream_tables(void* workspace, size_t bytes);
  * weights in LDS, persistent workgroups, X read once and Y written once) takes such problems ahead of the gather kernel in
  * danet_conv_forward (danet_conv_forward_kernel: last digit 3).  enable 0/1 (-1 keeps); returns the previous setting. */
 int danet_conv_pw_set(int enable);
+/* The regressor ResNets' 7x7 / stride-2 / pad-3 stems (/root/reference/models/module/res_module.py:404, :118) on LDS tiles (csrc/conv_stem.hip):
+ * 64 output channels, input channels a multiple of 16, 2 OH x 64 -> OH x 32 maps with OH % 8 == 0, at least 256 tiles (8 output rows of an
+ * image each).  danet_conv_stem_ok: 1 when the kernel takes the problem.  danet_conv_stem_forward: x [B,H,W,Cin] bf16 NHWC, wp = the weight
+ * packed by danet_conv_pack_weights(mode 0, chunk 16) -- K order (16-channel slab, tap, channel) --, y [B,OH,OW,64] bf16; bn_sums: optional
+ * fused BatchNorm statistics [BN_NCOPY][2][64], pre-zeroed.  The data gradient of these layers stays on danet_conv_forward (transposed).
+ * danet_conv_stem_set: run-time switch (A-B timing, tests): 0 / 1 (-1 keeps); returns the previous setting. */
+int danet_conv_stem_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+int danet_conv_stem_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                            float* bn_sums, void* stream);
+int danet_conv_stem_set(int enable);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);

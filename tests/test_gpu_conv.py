@@ -574,3 +574,48 @@ def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
     st = res[1][1]
     assert (st[0] - yr.sum(dim=(0, 2, 3))).abs().max().item() <= 5e-3 * yr.sum(dim=(0, 2, 3)).abs().max().item() + 1e-3 * scale * B * H
     assert (st[1] - (yr * yr).sum(dim=(0, 2, 3))).abs().max().item() <= 3e-3 * (yr * yr).sum(dim=(0, 2, 3)).abs().max().item()
+
+
+@pytest.mark.parametrize('B,Cin', [(768, 64), (64, 64), (96, 32), (70, 16)])
+def test_stem_7x7_stride2_lds_tile_kernel_vs_torch_fp32(B, Cin):
+    """csrc/conv_stem.hip (7x7 / stride 2 / pad 3 on LDS tiles: 16-channel slabs by LDS-DMA, even / odd column planes, two taps per
+    k-step, K split over two waves) against F.conv2d in fp32 on the bf16-rounded operands: every image border (top / bottom strips,
+    left / right halo columns), the fused BatchNorm statistics, odd tile counts per workgroup; through Conv2d's autograd function, so
+    the data and weight gradients (on their own kernels) are checked in the same call."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    H, Cout = 64, 64
+    assert L.danet_conv_stem_ok(B, H, H, Cin, 32, 32, Cout, 7, 7, 2, 3, 1, 1) == 1
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, Cin, H, H, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 7, 7, generator=g) / np.sqrt(49 * Cin)).bfloat16().float().cuda()
+    nref = min(B, 40)
+    idx = torch.linspace(0, B - 1, nref).long().cuda()
+    xr = x[idx].float().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, 2, 3)
+    xt = x.clone().requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    dconv.FUSION.clear()
+    y = dconv.conv2d(xt, wt, None, 2, 3, want_stats=True)
+    sums = getattr(y, '_bn_sums', None)
+    torch.cuda.synchronize()
+    scale = yr.abs().max().item()
+    assert (y[idx].float() - yr).abs().max().item() <= 1e-2 * scale
+    prev = L.danet_conv_stem_set(0)
+    try:
+        y2 = dconv.conv2d(x, w, None, 2, 3)                       # the gather kernel on the same operands
+    finally:
+        L.danet_conv_stem_set(prev)
+    assert (y.float() - y2.float()).abs().max().item() <= 1e-2 * scale
+    st = sums.view(-1, 2, Cout).sum(0)
+    yb = y.float()
+    assert (st[0] - yb.sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * yb.sum(dim=(0, 2, 3)).abs().max().item() + 1e-4 * scale * B
+    assert (st[1] - (yb * yb).sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * (yb * yb).sum(dim=(0, 2, 3)).abs().max().item()
+    if B <= 96:
+        gy = torch.randn(B, Cout, 32, 32, generator=g).bfloat16().cuda()
+        y.backward(gy)
+        xf = x.float().requires_grad_(True)
+        wf = w.clone().requires_grad_(True)
+        F.conv2d(xf, wf, None, 2, 3).backward(gy.float())
+        assert (xt.grad.float() - xf.grad).abs().max().item() <= 1e-2 * xf.grad.abs().max().item()
+        assert (wt.grad - wf.grad).abs().max().item() <= 3e-3 * wf.grad.abs().max().item()

@@ -19,7 +19,13 @@ wp0, wp1 = conv.pack_weight(w, 1, 0), conv.pack_weight(w, 1, 1)
 flops = 2.0 * B * (H // 2) ** 2 * C * C * 49
 
 
+wp16 = conv.pack_weight(w, 1, 0, 16)
+USE_STEM = bool(L.danet_conv_stem_ok(B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1))
+
+
 def fwd():
+    if USE_STEM:
+        return conv._conv_stem_raw(x, wp16, B, H, H, C, H // 2, H // 2, C)
     return conv._conv_fwd_raw(x, wp0, None, B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1, False, False, False)
 
 
@@ -31,7 +37,7 @@ yr = torch.nn.functional.conv2d(x.float()[:8], w.detach().bfloat16().float(), No
 y = fwd()
 err = float((y[:8].float() - yr).abs().max() / yr.abs().max())
 tf, tg = timeit(fwd, iters=5), timeit(dgrad, iters=5)
-print(json.dumps({'stem': [B, C, H], 'kernel_fwd': L.danet_conv_forward_kernel(B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1, 0, 0),
+print(json.dumps({'stem': [B, C, H], 'lds_tile_kernel': USE_STEM, 'kernel_fwd': L.danet_conv_forward_kernel(B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1, 0, 0),
                   'fwd_us': round(tf * 1e6, 1), 'fwd_frac': round(flops / tf / 2.5e15, 4), 'dgrad_us': round(tg * 1e6, 1), 'dgrad_frac': round(flops / tg / 2.5e15, 4),
                   'err_fwd': round(err, 5)}))
 
