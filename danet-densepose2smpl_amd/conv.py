@@ -720,20 +720,37 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
             x = x[:, :weight.shape[1] * groups]
         return Conv2dF32Function.apply(x, weight, bias, stride, padding, dilation, groups)
     Cout = weight.shape[0]
-    if groups == 1 and x.shape[1] != weight.shape[1] and x.shape[1] == weight.shape[1] + (-weight.shape[1]) % 8:
-        # the producer already zero-padded the channels to a multiple of 8 (part_ops.part_clean): pad the weight only
-        weight = F.pad(weight, (0, 0, 0, 0, 0, x.shape[1] - weight.shape[1]))
-    if groups == 1 and x.shape[1] % 8 != 0:
+    Cin_w, R_, S_ = weight.shape[1], weight.shape[2], weight.shape[3]
+    padc = 0
+    if groups == 1 and x.shape[1] != Cin_w and x.shape[1] == Cin_w + (-Cin_w) % 8:
+        padc = x.shape[1] - Cin_w        # the producer already zero-padded the channels to a multiple of 8 (part_ops.part_clean): pad the weight only
+    elif groups == 1 and x.shape[1] % 8 != 0:
         padc = (-x.shape[1]) % 8
         x = _pad_channels_nhwc(x)
-        weight = F.pad(weight, (0, 0, 0, 0, 0, padc))
     Cout_g = Cout // groups
-    if Cout_g % 8 != 0:
-        padn = (-Cout_g) % 8
-        wv = weight.view(groups, Cout_g, *weight.shape[1:])
-        weight = F.pad(wv, (0, 0, 0, 0, 0, 0, 0, padn)).reshape(groups * (Cout_g + padn), *weight.shape[1:])
-        if bias is not None:
-            bias = F.pad(bias.view(groups, Cout_g), (0, padn)).reshape(-1)
+    padn = (-Cout_g) % 8
+    if padc or padn:
+        # zero-padded copies of the (small) weight / bias: ONE launch for both and one for their gradients (glue.pad_multi) where the
+        # tensor-op form was a fill + a copy per F.pad and dimension
+        if weight.is_cuda and weight.dtype == torch.float32:
+            from .glue import pad_multi
+            items = [(weight, (groups, Cout_g, Cin_w, R_ * S_), (groups, Cout_g + padn, Cin_w + padc, R_ * S_),
+                      (groups * (Cout_g + padn), Cin_w + padc, R_, S_))]
+            if bias is not None and padn:
+                items.append((bias, (groups, Cout_g), (groups, Cout_g + padn), (groups * (Cout_g + padn),)))
+            outs = pad_multi(items)
+            weight = outs[0]
+            if len(outs) > 1:
+                bias = outs[1]
+        else:
+            if padc:
+                weight = F.pad(weight, (0, 0, 0, 0, 0, padc))
+            if padn:
+                wv = weight.view(groups, Cout_g, *weight.shape[1:])
+                weight = F.pad(wv, (0, 0, 0, 0, 0, 0, 0, padn)).reshape(groups * (Cout_g + padn), *weight.shape[1:])
+                if bias is not None:
+                    bias = F.pad(bias.view(groups, Cout_g), (0, padn)).reshape(-1)
+    if padn:
         y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
         if keep_group_padding:       # [B, groups*(Cout_g+padn), OH, OW]: the caller consumes the padded layout (part_ops)
             return y

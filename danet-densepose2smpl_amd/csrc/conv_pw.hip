@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(PwP p)
     const int grp = wave % p.ngroups, sub = wave / p.ngroups;           // this wave's output group and its tile within the iteration
     const int nb0 = grp * NTB;                                          // first sixteen-row block of the group
     const int n0 = nb0 * 16;
-    const int pitch = p.Cin * 2, osz = p.out_fp32 ? 4 : 2;
+    const int pitch = p.Cin * 2;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     // channel chunk of this lane in k-step ks: bytes (ks * 32 + lg * 8) * 2 of a pixel's row; chunks beyond Cin read as zeros

@@ -117,7 +117,6 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
         lanebase[mt] = (2 * oyl * 2 * ST_CELLS + ox) * 32 + (lg & 1) * 16;
     }
     const int nks_tot = nslab * ST_KS;
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, ST_NT * nks_tot * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const int wlane = lane * 16;
 
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
     // cycles) took ~1.7 k cycles.  The K split is 15 | 10 k-steps (= 3 | 2 ring turns, no ragged ends) and the waves with 10 issue the
     // slab copies: a copy is a long-latency entry in THEIR queue, which their next ring wait has to sit out; the 15-step waves never
     // see it, and the 5 k-steps the copying waves do less are the time that wait may take.
-    constexpr int D = 5, NCP = ST_NCP;                      // copy instructions per issuing wave (pixel half pw takes instructions pw, pw + 2, ...)
+    constexpr int D = 5;                      // copy instructions per issuing wave (pixel half pw takes instructions pw, pw + 2, ...)
     const i32x4 wdesc = raw_desc(p.w, ST_NT * nks_tot * 1024);
     int wso[ST_NT];
 #pragma unroll

@@ -1,0 +1,159 @@
+// Small launch-count killers of the train step (no arithmetic of note: each replaces tens of 2-5 us tensor-op launches).
+//
+//   pad_multi     up to 16 "zero-pad at the end of each dimension" (or crop: the same index map read the other way) copies of small
+//                 fp32 tensors in ONE launch.  The parameters of layers whose widths are no multiple of 8 (12 / 21 / 25 / 15 channels:
+//                 the heat-map head's Bottleneck(48, 12), the IUV heads) are padded every step -- F.pad is a fill + a copy per tensor
+//                 forward and a copy backward.
+//   stn_theta     the STN parameters of the 24 part crops from the soft-argmax centres: box / bone scales, learned ratio and offset,
+//                 scale jitter, visibility score of the centre (bilinear sample of the part-membership map of the arg-max index plane)
+//                 and the [[s,0,cx],[0,s,cy]] matrices -- /root/reference/models/danet/iuv_estimator.py:262-301 (affine_para) and
+//                 :176-186 (the single-point grid_sample of the visibility score); one workgroup per batch item.
+//                 No gradient: the reference detaches theta before affine_grid (iuv_estimator.py:197).
+#include "common.h"
+
+namespace {
+
+constexpr int PAD_MAX = 16;
+struct PadJob { const float* src; float* dst; int sd[4]; int dd[4]; };
+struct PadMulti { PadJob j[PAD_MAX]; int start[PAD_MAX + 1]; int n; };
+
+__global__ __launch_bounds__(256) void pad_multi_kernel(const PadMulti P)
+{
+    const int total = P.start[P.n];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int k = 0;
+        while (k + 1 < P.n && i >= P.start[k + 1]) ++k;
+        const PadJob& J = P.j[k];
+        int r = i - P.start[k];
+        const int i3 = r % J.dd[3]; r /= J.dd[3];
+        const int i2 = r % J.dd[2]; r /= J.dd[2];
+        const int i1 = r % J.dd[1];
+        const int i0 = r / J.dd[1];
+        float v = 0.f;
+        if (i0 < J.sd[0] && i1 < J.sd[1] && i2 < J.sd[2] && i3 < J.sd[3])
+            v = J.src[(((long)i0 * J.sd[1] + i1) * J.sd[2] + i2) * J.sd[3] + i3];
+        J.dst[i - P.start[k]] = v;
+    }
+}
+
+constexpr int NJ = 24, NPART = 25;
+
+struct StnThetaP {
+    const float* centers;        // [B,24,2] in [-1,1]
+    const unsigned char* am;     // [B,H,W] arg-max part index or NULL (no visibility test)
+    const float* member;         // [24,25] part membership of the joints
+    const float* ratio;          // [24]
+    const float* offset;         // [24]
+    const float* rnd;            // [2,B,24] uniform [0,1) or NULL
+    const long* child;           // [24]
+    const long* parent;          // [24]
+    float* theta;                // [B,24,2,3]
+    int B, H, W, align;
+    float jit, vis;
+};
+
+__global__ __launch_bounds__(64) void stn_theta_kernel(const StnThetaP P)
+{
+    __shared__ float cx[NJ], cy[NJ];
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j < NJ) {
+        cx[j] = P.centers[(b * NJ + j) * 2];
+        cy[j] = P.centers[(b * NJ + j) * 2 + 1];
+    }
+    __syncthreads();
+    if (j >= NJ) return;
+    float xmin = cx[0], xmax = cx[0], ymin = cy[0], ymax = cy[0];
+    for (int k = 1; k < NJ; ++k) {
+        xmin = fminf(xmin, cx[k]); xmax = fmaxf(xmax, cx[k]);
+        ymin = fminf(ymin, cy[k]); ymax = fmaxf(ymax, cy[k]);
+    }
+    const float scale_box = 0.5f * fmaxf(xmax - xmin, ymax - ymin);
+    const int c = (int)P.child[j], p = (int)P.parent[j];
+    const float dc = sqrtf((cx[c] - cx[j]) * (cx[c] - cx[j]) + (cy[c] - cy[j]) * (cy[c] - cy[j])) * 0.5f;
+    const float dp = sqrtf((cx[p] - cx[j]) * (cx[p] - cx[j]) + (cy[p] - cy[j]) * (cy[p] - cy[j])) * 0.5f;
+    const float raw = j == 0 ? scale_box : 2.f * fmaxf(dc, dp);
+    const float ra = P.ratio[j], of = P.offset[j];
+    float s = raw * fmaxf(ra, 0.f) + fmaxf(of, 0.f);
+    float j1 = 1.f, j2 = 1.f;
+    if (P.rnd && P.jit > 0.f) {
+        j1 = 1.f + P.jit * (P.rnd[b * NJ + j] - 0.5f);
+        j2 = 1.f + P.jit * (P.rnd[(P.B + b) * NJ + j] - 0.5f);
+    }
+    s *= j1;
+    bool hidden = false;
+    if (P.am && P.vis > 0.f && j > 0) {
+        const int H = P.H, W = P.W;
+        float ix, iy;
+        if (P.align) { ix = (cx[j] + 1.f) * 0.5f * (W - 1); iy = (cy[j] + 1.f) * 0.5f * (H - 1); }
+        else { ix = ((cx[j] + 1.f) * W - 1.f) * 0.5f; iy = ((cy[j] + 1.f) * H - 1.f) * 0.5f; }
+        const float x0 = floorf(ix), y0 = floorf(iy);
+        float score = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float xx = x0 + dx, yy = y0 + dy;
+                const float w = (1.f - fabsf(ix - xx)) * (1.f - fabsf(iy - yy));
+                if (xx >= 0.f && xx < (float)W && yy >= 0.f && yy < (float)H) {
+                    const int part = P.am[((long)b * H + (int)yy) * W + (int)xx];
+                    score += w * P.member[j * NPART + part];
+                }
+            }
+        hidden = score < P.vis;
+    }
+    if (hidden) s = 0.8f * scale_box;
+    s *= j2;
+    float* t = P.theta + (long)(b * NJ + j) * 6;
+    t[0] = s; t[1] = 0.f; t[2] = cx[j];
+    t[3] = 0.f; t[4] = s; t[5] = cy[j];
+}
+
+}  // namespace
+
+// n (<= 16) jobs; job k copies the fp32 tensor src[k] of shape sdims[4k..4k+3] into dst[k] of shape ddims[4k..4k+3] (both dense, row
+// major, shapes padded with leading ones): dst[i] = src[i] where i lies inside the source's shape, 0 elsewhere (a source LARGER than the
+// destination is cropped: the backward of a pad).  src / dst: host arrays of device pointers.
+extern "C" int danet_pad_multi(const void* const* src, void* const* dst, const int* sdims, const int* ddims, int n, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(src && dst && sdims && ddims && n > 0 && n <= PAD_MAX, "pad_multi: %d jobs (1..%d)", n, PAD_MAX);
+    PadMulti P;
+    long tot = 0;
+    for (int k = 0; k < n; ++k) {
+        DANET_CHECK_ARG(src[k] && dst[k], "pad_multi: job %d has a NULL tensor", k);
+        P.j[k].src = (const float*)src[k];
+        P.j[k].dst = (float*)dst[k];
+        long nd = 1;
+        for (int q = 0; q < 4; ++q) {
+            P.j[k].sd[q] = sdims[4 * k + q];
+            P.j[k].dd[q] = ddims[4 * k + q];
+            DANET_CHECK_ARG(sdims[4 * k + q] > 0 && ddims[4 * k + q] > 0, "pad_multi: job %d has an empty dimension", k);
+            nd *= ddims[4 * k + q];
+        }
+        P.start[k] = (int)tot;
+        tot += nd;
+        DANET_CHECK_ARG(tot < (1l << 30), "pad_multi: too many elements");
+    }
+    P.start[n] = (int)tot;
+    P.n = n;
+    int grid = danet::cdiv(tot, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(pad_multi_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
+    DANET_CHECK_LAUNCH("pad_multi_kernel");
+    return DANET_OK;
+}
+
+// centers fp32 [B,24,2]; am uint8 [B,H,W] or NULL; member fp32 [24,25]; ratio / offset fp32 [24]; rnd fp32 [2,B,24] or NULL; child /
+// parent int64 [24]; output theta fp32 [B,24,2,3].
+extern "C" int danet_stn_theta_forward(const float* centers, const unsigned char* am, const float* member, const float* ratio,
+                                       const float* offset, const float* rnd, const long* child, const long* parent, int B, int H, int W,
+                                       int align, float jitter, float vis_score, float* theta, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(centers && member && ratio && offset && child && parent && theta && B > 0, "stn_theta_forward: bad arguments");
+    DANET_CHECK_ARG(!am || (H > 0 && W > 0), "stn_theta_forward: index plane %d x %d", H, W);
+    StnThetaP P = {centers, am, member, ratio, offset, rnd, child, parent, theta, B, H, W, align, jitter, vis_score};
+    hipLaunchKernelGGL(stn_theta_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, P);
+    DANET_CHECK_LAUNCH("stn_theta_kernel");
+    return DANET_OK;
+}

@@ -1,0 +1,73 @@
+"""Launch-count glue on csrc/glue.hip: several small zero-pad copies in one launch (pad_multi) -- the parameters of layers whose
+widths are no multiple of 8 are padded every step (F.pad = fill + copy forward, copy backward, per tensor).  GPU only."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, stream
+
+PAD_MAX = 16
+
+
+def _dims4(shape):
+    shape = tuple(int(s) for s in shape)
+    if len(shape) > 4:
+        raise ValueError('pad_multi: at most 4 dimensions')
+    return (1,) * (4 - len(shape)) + shape
+
+
+def _launch(srcs, src_views, dst_views, out_shapes):
+    """srcs[k] (dense fp32, numel == prod(src_views[k])) -> new tensor of out_shapes[k] (numel == prod(dst_views[k]))."""
+    L = _lib.lib()
+    outs = [torch.empty(tuple(s), dtype=torch.float32, device=srcs[0].device) for s in out_shapes]
+    for k0 in range(0, len(srcs), PAD_MAX):
+        n = min(PAD_MAX, len(srcs) - k0)
+        sp = (ctypes.c_void_p * n)(*[srcs[k0 + k].data_ptr() for k in range(n)])
+        dp = (ctypes.c_void_p * n)(*[outs[k0 + k].data_ptr() for k in range(n)])
+        sd = (ctypes.c_int * (4 * n))(*[v for k in range(n) for v in _dims4(src_views[k0 + k])])
+        dd = (ctypes.c_int * (4 * n))(*[v for k in range(n) for v in _dims4(dst_views[k0 + k])])
+        check(L.danet_pad_multi(ctypes.addressof(sp), ctypes.addressof(dp), ctypes.addressof(sd), ctypes.addressof(dd), n, stream()),
+              'danet_pad_multi')
+    return outs
+
+
+class PadMultiFunction(torch.autograd.Function):
+    """spec[k] = (source view shape, padded view shape, output shape); tensors[k] dense fp32.  One launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        for t in tensors:
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError('pad_multi runs on fp32 GPU tensors only')
+        ctx.spec = spec
+        ctx.set_materialize_grads(False)          # an unused output's gradient stays None (no zero tensor, no crop job)
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        outs = _launch([t.detach().contiguous() for t in tensors], [s[0] for s in spec], [s[1] for s in spec], [s[2] for s in spec])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        idx = [k for k, g in enumerate(gs) if g is not None and ctx.needs_input_grad[k + 1]]
+        res = [None] * len(gs)
+        if idx:
+            outs = _launch([gs[k].float().contiguous() for k in idx], [ctx.spec[k][1] for k in idx], [ctx.spec[k][0] for k in idx],
+                           [ctx.shapes[k] for k in idx])
+            for k, o in zip(idx, outs):
+                res[k] = o
+        return (None,) + tuple(res)
+
+
+def pad_multi(items):
+    """items: [(tensor, padded shape)] or [(tensor, source view, padded view, output shape)] -> padded tensors (zeros behind every
+    dimension's end), autograd-tracked; one launch for all of them."""
+    spec, tensors = [], []
+    for it in items:
+        if len(it) == 2:
+            t, shape = it
+            spec.append((tuple(t.shape), tuple(shape), tuple(shape)))
+        else:
+            t, sv, dv, shape = it
+            spec.append((tuple(sv), tuple(dv), tuple(shape)))
+        tensors.append(t)
+    return PadMultiFunction.apply(tuple(spec), *tensors)

@@ -52,6 +52,9 @@ def load_learned_ratio(path=None):
     return np.ones(24, np.float32), 0.1 * np.ones(24, np.float32)
 
 
+FUSED_STN_THETA = True       # visibility score + affine_para as one HIP launch (False: the tensor-op formulation)
+
+
 def _sample_points(maps, pts, align):
     """Bilinear sample of maps [B,J,H,W] at one point per (b,j): pts [B,J,2] in [-1,1] (x,y); zero
     padding -- the single-point grid_sample of iuv_estimator.py:180."""
@@ -139,6 +142,25 @@ class IUV_Estimator(nn.Module):
         theta[:, :, 1, 1] = scale
         theta[:, :, :, 2] = c.detach()
         return theta, scale
+
+    def stn_theta(self, stn_centers, am_raw, align):
+        """affine_para (iuv_estimator.py:262-301) and the visibility test in front of it (:176-186) as ONE launch
+        (csrc/glue.hip stn_theta_kernel): centres [B,24,2], arg-max index plane uint8 [B,H,W] -> thetas [B,24,2,3].
+        No gradient, as in the reference (theta is detached before affine_grid, :197)."""
+        from . import _lib
+        from ._lib import ptr, check, stream
+        c = stn_centers.detach().to(torch.float32).contiguous()
+        B = c.shape[0]
+        jit = float(cfg.DANET.STN_SCALE_JITTER) if self.training else 0.
+        rnd = torch.rand(2, B, 24, device=c.device) if jit > 0 else None
+        vis = float(cfg.DANET.STN_PART_VIS_SCORE)
+        theta = torch.empty(B, 24, 2, 3, device=c.device, dtype=torch.float32)
+        H, W = am_raw.shape[-2], am_raw.shape[-1]
+        check(_lib.lib().danet_stn_theta_forward(
+            ptr(c), ptr(am_raw) if vis > 0 else None, ptr(self._vis_membership), ptr(self.learned_ratio.detach()),
+            ptr(self.learned_offset.detach()), ptr(rnd), ptr(self._child_idx), ptr(self._parent_idx), B, H, W, int(bool(align)),
+            jit, vis, ptr(theta), stream()), 'danet_stn_theta_forward')
+        return theta
 
     def part_iuv_simp(self, U, V, I):
         """Per-joint 7-channel (background + 6 DensePose parts) U,V,I maps (iuv_estimator.py:422-445):
@@ -278,17 +300,20 @@ class IUV_Estimator(nn.Module):
             if cfg.DANET.STN_CENTER_JITTER > 0:
                 centers = centers + cfg.DANET.STN_CENTER_JITTER * (torch.rand_like(centers) - 0.5)
 
-        hidden = None
-        if cfg.DANET.STN_PART_VIS_SCORE > 0:
-            if am_raw is not None:        # membership of the winning part, looked up per pixel
-                score_maps = self._vis_membership.t()[am_raw.long()].permute(0, 3, 1, 2)
-            else:
-                _, _, index_cl, _ = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
-                score_maps = torch.einsum('jc,bchw->bjhw', self._vis_membership, index_cl.detach())
-            score = _sample_points(score_maps, centers.detach(), align)
-            hidden = score < cfg.DANET.STN_PART_VIS_SCORE
-
-        thetas, _ = self.affine_para(centers, hidden)
+        if FUSED_STN_THETA and fused and am_raw is not None and centers.is_cuda:
+            # visibility score + affine_para in one launch (csrc/glue.hip; ~160 tensor-op launches in the form below)
+            thetas = self.stn_theta(centers, am_raw, align)
+        else:
+            hidden = None
+            if cfg.DANET.STN_PART_VIS_SCORE > 0:
+                if am_raw is not None:        # membership of the winning part, looked up per pixel
+                    score_maps = self._vis_membership.t()[am_raw.long()].permute(0, 3, 1, 2)
+                else:
+                    _, _, index_cl, _ = iuvmap_clean(u_pred, v_pred, index_pred, ann_pred)
+                    score_maps = torch.einsum('jc,bchw->bjhw', self._vis_membership, index_cl.detach())
+                score = _sample_points(score_maps, centers.detach(), align)
+                hidden = score < cfg.DANET.STN_PART_VIS_SCORE
+            thetas, _ = self.affine_para(centers, hidden)
         rd['stn_kps_pred'] = centers.detach()
         part_maps = stn_gather(feat, thetas, align_corners=align)                       # [B,24*C,H,W]
         ppi = self.iuv_est.final_pred.predict_partial_iuv

@@ -228,7 +228,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                                           training, momentum, self.eps, relu, fused, link if training else None)
 
 
-def _bn_forward_padded(self, x, d, relu=False, res=None):
+def _bn_forward_padded(self, x, d, relu=False, res=None, padded=None):
     """BatchNorm2d on a tensor that carries d extra, exactly-zero channels behind this module's num_features (resnet.Bottleneck.
     _forward_padded): gamma / beta are padded with zeros, so the extra channels come out as zeros again; the running statistics
     live in padded storage of which `running_mean` / `running_var` are views (state_dict keeps the reference's shapes)."""
@@ -249,7 +249,8 @@ def _bn_forward_padded(self, x, d, relu=False, res=None):
     fused = getattr(x, '_bn_sums', None) if training else None
     if training:
         _conv.FUSION['bn_stats_fused' if fused is not None else 'bn_stats_own'] += 1
-    return BatchNormActFunction.apply(x, res, F.pad(self.weight, (0, d)), F.pad(self.bias, (0, d)), rm, rv, training, momentum, self.eps, relu, fused, None)
+    gamma, beta = padded if padded is not None else (F.pad(self.weight, (0, d)), F.pad(self.bias, (0, d)))     # (padded: the caller's glue.pad_multi copies)
+    return BatchNormActFunction.apply(x, res, gamma, beta, rm, rv, training, momentum, self.eps, relu, fused, None)
 
 
 BatchNorm2d.forward_padded = _bn_forward_padded

@@ -88,13 +88,17 @@ class Bottleneck(nn.Module):
         P = self.conv1.out_channels
         d = (-P) % 8
         tr = self.training
-        w1 = F.pad(self.conv1.weight, (0, 0, 0, 0, 0, 0, 0, d))
+        c1, c2, c3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
+        from .glue import pad_multi
+        # the seven padded parameter copies of the block in ONE launch (and one for their gradients)
+        w1, g1, b1, w2, g2, b2, w3 = pad_multi([
+            (c1, (P + d,) + tuple(c1.shape[1:])), (self.bn1.weight, (P + d,)), (self.bn1.bias, (P + d,)),
+            (c2, (P + d, P + d) + tuple(c2.shape[2:])), (self.bn2.weight, (P + d,)), (self.bn2.bias, (P + d,)),
+            (c3, (c3.shape[0], P + d) + tuple(c3.shape[2:]))])
         out = conv2d(x, w1, None, 1, 0, 1, 1, want_stats=tr)
-        out = self.bn1.forward_padded(out, d, relu=True)
-        w2 = F.pad(self.conv2.weight, (0, 0, 0, 0, 0, d, 0, d))
+        out = self.bn1.forward_padded(out, d, relu=True, padded=(g1, b1))
         out = conv2d(out, w2, None, self.conv2.stride[0], 1, 1, 1, want_stats=tr)
-        out = self.bn2.forward_padded(out, d, relu=True)
-        w3 = F.pad(self.conv3.weight, (0, 0, 0, 0, 0, d))
+        out = self.bn2.forward_padded(out, d, relu=True, padded=(g2, b2))
         out = conv2d(out, w3, None, 1, 0, 1, 1, want_stats=tr)
         return self.bn3(out, res=residual, relu=True)
 

@@ -137,6 +137,21 @@ int danet_softargmax_backward(const float* hm, int ld, int B, int J, int H, int 
                               const float* gout, float* dhm, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Launch-count glue (csrc/glue.hip).
+ * danet_pad_multi: n (<= 16) zero-pad / crop copies of small dense fp32 tensors (<= 4-d, shapes given with leading ones) in one
+ *   launch: dst[i] = src[i] inside the source's shape, 0 elsewhere.  Replaces F.pad on the parameters of layers whose widths are no
+ *   multiple of 8 (the reference runs those widths as they are: models/module/res_module.py:364 Bottleneck(48, 12), the 25 / 15 /
+ *   21-channel heads of models/module/hr_module.py:447-470).
+ * danet_stn_theta_forward: models/danet/iuv_estimator.py:262-301 (affine_para) together with the visibility score of :176-186 (single-point
+ *   bilinear sample of the per-joint part-membership of the arg-max index plane): centres [B,24,2] -> thetas [B,24,2,3].  No
+ *   gradient (theta is detached before affine_grid, iuv_estimator.py:197).
+ */
+int danet_pad_multi(const void* const* src, void* const* dst, const int* sdims, const int* ddims, int n, void* stream);
+int danet_stn_theta_forward(const float* centers, const unsigned char* am, const float* member, const float* ratio,
+                            const float* offset, const float* rnd, const long* child, const long* parent, int B, int H, int W,
+                            int align, float jitter, float vis_score, float* theta, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * SMPL-side losses of the regressor (csrc/loss_ops.hip; models/danet/smpl_regressor.py:141-218,233-298): joint_rotation{0,1},
  * joint_position{0,1}, keypoints_2d (weak-perspective camera -> translation -> pin-hole projection), keypoints_3d (pelvis-
  * centred), smpl_pose, smpl_betas, smpl_verts, cam -- masked means over the rows selected by has_smpl / has_kp3d, times
