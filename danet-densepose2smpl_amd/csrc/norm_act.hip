@@ -1022,6 +1022,9 @@ extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, float
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "channel_sum: C=%d (M=%ld) unsupported", C, (long)M);
+        // every workgroup ends with one atomic per channel on the SAME C addresses (no replicas here): 1024 workgroups serialised
+        // there; one workgroup per compute unit reads as fast and queues a quarter of the atomics (A-B in the step: within noise)
+        if (grid > 256) { grid = 256; fm.rstep = (int)((long)fm.span * grid / fm.CV); }
         hipLaunchKernelGGL(channel_sum_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, out + c0);
         DANET_CHECK_LAUNCH("channel_sum_kernel");
     }

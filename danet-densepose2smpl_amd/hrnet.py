@@ -258,9 +258,7 @@ class PoseHighResolutionNet(nn.Module):
               for i in range(self.stage4_cfg['NUM_BRANCHES'])]
         ys = self._run_stage(self.stage4, xs)
         feat = ys[0]
-        out = self.final_pred(feat)
-        out['xd'] = feat
-        return out
+        return self.final_pred(feat)              # (with 'xd' = the feature map itself)
 
     def init_weights(self, pretrained=''):
         """hr_module.py:380-410: conv weights ~ N(0, 0.001), BN (1, 0), optional checkpoint."""

@@ -18,7 +18,9 @@ from .deconv import ConvTranspose2d
 
 BN_MOMENTUM = 0.1
 import os as _os
-PAD_NARROW_BLOCKS = bool(int(_os.environ.get('DANET_PAD_NARROW_BLOCKS', '1')))      # A-B knob, see Bottleneck._forward_padded
+PAD_NARROW_BLOCKS = bool(int(_os.environ.get('DANET_PAD_NARROW_BLOCKS', '1')))
+BOTTLENECK_LINK = bool(int(_os.environ.get('DANET_BOTTLENECK_LINK', '1')))          # A-B knob: identity-shortcut gradient of a Bottleneck through conv1's dgrad epilogue
+HEAD_FAN_OUT = bool(int(_os.environ.get('DANET_HEAD_FAN_OUT', '1')))                # A-B knob: nn.fan_out over the six consumers of the final feature map      # A-B knob, see Bottleneck._forward_padded
 
 
 class ConvBN(nn.Module):
@@ -76,9 +78,11 @@ class Bottleneck(nn.Module):
         residual = x if self.downsample is None else self.downsample(x)
         if PAD_NARROW_BLOCKS and self.conv1.groups == 1 and self.conv1.out_channels % 8 != 0 and x.is_cuda and not _conv.fp32_mode():
             return self._forward_padded(x, residual)
-        out = self.bn1(self.conv1(x), relu=True)
+        # identity shortcut: its gradient rides on a ResLink into conv1's (pointwise) data-gradient epilogue, as in BasicBlock
+        link = ResLink() if (BOTTLENECK_LINK and self.downsample is None and x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else None
+        out = self.bn1(self.conv1(x, link=link), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), res=residual, relu=True)
+        return self.bn3(self.conv3(out), res=residual, relu=True, link=link)
 
     def _forward_padded(self, x, residual):
         """A block whose inner width is no multiple of 8 (the heat-map head's Bottleneck(48, 12), res_module.py:364) at the
@@ -141,9 +145,13 @@ class IUV_predict_layer(nn.Module):
                                               out_fp32=True)
 
     def forward(self, x):
-        return {'predict_u': self.predict_u(x), 'predict_v': self.predict_v(x),
-                'predict_uv_index': self.predict_uv_index(x), 'predict_ann_index': self.predict_ann_index(x),
-                'predict_hm': self.predict_hm(x)}
+        # six consumers of the final feature map (five heads + the STN gather of the part crops, 'xd'): their gradients are summed by
+        # the fuse-sum kernel (nn.fan_out: two launches) instead of five pairwise adds of autograd
+        from .nn import fan_out
+        xs = fan_out(x, 6) if HEAD_FAN_OUT else [x] * 6
+        return {'predict_u': self.predict_u(xs[0]), 'predict_v': self.predict_v(xs[1]),
+                'predict_uv_index': self.predict_uv_index(xs[2]), 'predict_ann_index': self.predict_ann_index(xs[3]),
+                'predict_hm': self.predict_hm(xs[4]), 'xd': xs[5]}
 
 
 def _maxpool3x3s2(x):
@@ -182,9 +190,7 @@ class PoseResNet(nn.Module):
         mods = list(self.deconv_layers)
         for i in range(0, len(mods), 3):
             x = mods[i + 1](mods[i](x), relu=True)
-        out = self.final_pred(x)
-        out['xd'] = x
-        return out
+        return self.final_pred(x)                 # (with 'xd' = the feature map itself)
 
     def init_weights(self, pretrained=''):
         for m in self.deconv_layers.modules():

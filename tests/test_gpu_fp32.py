@@ -304,6 +304,40 @@ def test_train_step_runs_in_fp32_mode_and_agrees_with_bf16():
     assert g and all(torch.isfinite(t).all() for t in g)
 
 
+def test_bf16_training_curve_tracks_fp32():
+    """bf16 TRAINING-quality parity (round-3 review, weak 4): 30 Adam steps (lr 1e-4, the reference's, train/trainer.py:42-44) on one
+    fixed batch from the same initial weights, once with the bf16 MFMA convolutions and once in the fp32 mode (BASELINE config C4's
+    arithmetic).  Both loss curves fall by a factor > 8 and stay within 12 % of each other at every step after the first two (measured
+    with tools/curve_probe.py: 4412 -> 344 against 4429 -> 329 over 40 steps; two bf16 runs differ by up to 4 % from each other --
+    atomics' summation order)."""
+    _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
+            'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    from danet_densepose2smpl_amd import conv
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    dev = torch.device('cuda')
+    curves = {}
+    for mode in ('bf16', 'fp32'):
+        torch.manual_seed(0)
+        tr = Trainer(default_options(8), device=dev, distributed=False, lr=1e-4)
+        batch = synthetic_in_dict(tr.model, 8, dev, seed=1)
+        tot = []
+        for _ in range(30):
+            if mode == 'fp32':
+                with conv.precision('fp32'):
+                    _, ls = tr.train_step(batch)
+            else:
+                _, ls = tr.train_step(batch)
+            tot.append(sum(float(v.sum()) for v in ls.values()))
+        curves[mode] = tot
+        del tr
+    b, f = curves['bf16'], curves['fp32']
+    assert all(np.isfinite(b)) and all(np.isfinite(f))
+    assert b[-1] < b[0] / 8 and f[-1] < f[0] / 8, (b[0], b[-1], f[0], f[-1])
+    assert abs(b[0] - f[0]) <= 0.02 * f[0], (b[0], f[0])                       # same weights, same batch: the first forward pass
+    for i in range(2, 30):
+        assert abs(b[i] - f[i]) <= 0.12 * f[i], (i, b[i], f[i])
+
+
 def test_full_size_fp32_train_step():
     """BASELINE config C4 at its own size: one full DaNet train step in fp32 at 32 x 256 x 256 -- every loss finite, every
     gradient finite and written, the convolutions on the fp32 MFMA kernels, and well inside the 150 ms/step the round-2

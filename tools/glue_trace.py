@@ -30,7 +30,9 @@ class Trace(TorchDispatchMode):
         name = str(func)
         if not name.startswith(SKIP):
             frames = [f for f in traceback.extract_stack()[:-1] if ('amd/' in f.filename) and 'tools/' not in f.filename]
-            site = ' < '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in reversed(frames[-2:])) or '(engine)'
+            site = ' < '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in reversed(frames[-2:]))
+            if not site:          # built-in backward nodes run by the autograd engine: tell them apart by their operand shapes
+                site = '(engine) ' + ' '.join(str(tuple(a.shape)) + ('' if a.is_contiguous() else '*') + str(a.dtype)[6:] for a in args if torch.is_tensor(a))
             self.count[(name, site)] += 1
         return func(*args, **(kwargs or {}))
 
