@@ -477,6 +477,22 @@ def _conv_stem_raw(x, wp16, B, H, W, Cin, OH, OW, Cout, bn_sums=None):
     return y
 
 
+def _conv_stem_dgrad_raw(gy, wp16t, B, H, W, Cin, OH, OW, Cout, bn_bwd=None):
+    """csrc/conv_stem_dgrad.hip: data gradient of a 7x7 / stride 2 / pad 3 stem (64 -> 64 channels) on LDS tiles; wp16t =
+    pack_weight(w, 1, 1, chunk=16); bn_bwd = (bn_x, gate tensor or None, saved, red, gate mode 0) as for _conv_fwd_raw."""
+    L = _lib.lib()
+    gx = _empty_nhwc(B, Cin, H, W, torch.bfloat16, gy.device)
+    bx = by = sv = rd = None
+    if bn_bwd is not None:
+        bx, by, sv, rd = ptr(bn_bwd[0].permute(0, 2, 3, 1)), None if bn_bwd[1] is None else ptr(bn_bwd[1].permute(0, 2, 3, 1)), ptr(bn_bwd[2]), ptr(bn_bwd[3])
+    tok = PROFILER.begin('conv_stem_dgrad_kernel', 2.0 * B * OH * OW * Cout * Cin * 49, ('dgrad', B, OH, OW, Cout, Cin, 7, 2, 1)) if PROFILER is not None else None
+    check(L.danet_conv_stem_dgrad(ptr(gy.permute(0, 2, 3, 1)), ptr(wp16t), ptr(gx.permute(0, 2, 3, 1)), B, H, W, Cin, OH, OW, Cout, bx, by, sv, rd, stream()),
+          'danet_conv_stem_dgrad')
+    if tok is not None:
+        PROFILER.end(tok)
+    return gx
+
+
 class ResLink(object):
     """Carries the residual branch's gradient of a block (`out += residual`, res_module.py:39-56) from the closing
     BatchNorm's backward to the data gradient of the block's first convolution, whose epilogue adds it -- instead of
@@ -528,7 +544,6 @@ class Conv2dFunction(torch.autograd.Function):
             gw = new_wgrad(weight, (Cout, Cin_g, R, S), x.device)
             _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
         if ctx.needs_input_grad[0]:
-            wp1 = pack_weight(weight, groups, 1)
             bn_bwd = None
             if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
                     L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2):
@@ -546,8 +561,13 @@ class Conv2dFunction(torch.autograd.Function):
                 addend, ctx.link.dres = ctx.link.dres, None
             fused_add = addend is not None and addend.shape == x.shape and bn_bwd is None and \
                 L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2, 3)      # gather, LDS-tile 3x3, pointwise
-            gx = _conv_fwd_raw(gy, wp1, None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
-                               None, bn_bwd, addend if fused_add else None)
+            if addend is None and (bn_bwd is None or (bn_bwd[4] == 0 and bn_bwd[0].dtype == torch.bfloat16)) and \
+                    L.danet_conv_stem_dgrad_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
+                # the part-crop stem (64 -> 64 channels, 7x7 / stride 2): LDS-tile kernel with the same fused BatchNorm-backward sums
+                gx = _conv_stem_dgrad_raw(gy, pack_weight(weight, groups, 1, 16), B, H, W, Cin, OH, OW, Cout, bn_bwd)
+            else:
+                gx = _conv_fwd_raw(gy, pack_weight(weight, groups, 1), None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
+                                   None, bn_bwd, addend if fused_add else None)
             if addend is not None:
                 FUSION['residual_grad_fused' if fused_add else 'residual_grad_added'] += 1
                 if not fused_add:

@@ -74,6 +74,13 @@ __device__ inline float row_sum16(float v) {
     return v;
 }
 
+#ifdef ST_DIAG        // tools/experiments/stem_diag.hip: cycles per wave in the k-steps / at the slab barrier / in the exchange / in the epilogue
+__device__ unsigned long long g_stem_diag[256 * 4 * 8];
+#define ST_CLK(v) v = __builtin_readcyclecounter()
+#else
+#define ST_CLK(v) ((void)0)
+#endif
+
 __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
     constexpr int KW = decltype(kwc)::value;
     constexpr int nk = KW == 0 ? 15 : 10, kb0 = KW == 0 ? 0 : 15;
     int pf_slab = 0, pf_j = 0;                              // prefetch cursor: the k-step the NEXT refill loads (D ahead of the MFMAs)
+    [[maybe_unused]] unsigned long long dk = 0, db = 0, dx = 0, de = 0, c0 = 0, c1 = 0, life0 = 0;
+    ST_CLK(life0);
     auto refill = [&](bf16x8* a) {
         load_a(pf_slab * ST_KS + kb0 + pf_j, a);
         if (++pf_j == nk) { pf_j = 0; if (++pf_slab == nslab) pf_slab = 0; }
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
 #pragma unroll
         for (int d = 0; d < D; ++d) refill(A[d]);           // the ring starts a tile full (drained before the epilogue, see below)
         for (int slab = 0; slab < nslab; ++slab) {
+            ST_CLK(c0);
             const unsigned char* const sX = ring + (g & 1) * ST_SLOT;
             const int jb = kb0;                             // first k-step of this wave in the slab
             bf16x8 Bq[2][ST_MT];
@@ -225,9 +235,17 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
                 for (int q = 5; q < 10; ++q) ST_KSTEP(4 * (D - 1), A[q - 5], Bq[q & 1], Bq[(q + 1) & 1], jb + q, q < 9, false);
             }
 #undef ST_KSTEP
+            ST_CLK(c1);
+#ifdef ST_DIAG
+            dk += c1 - c0;
+#endif
             lds_barrier();                                        // slot g & 1 consumed; the copying waves have waited their copies out (second ring turn)
             ++g;
+#ifdef ST_DIAG
+            ST_CLK(c0); db += c0 - c1;
+#endif
         }
+        ST_CLK(c0);
         // (the MFMAs are inline asm with AGPR accumulators -- left to the compiler 128 accumulator registers + the 80-register ring + 64
         // pixel-fragment registers were juggled between the two files: 900 v_accvgpr moves, 376 bytes of scratch -- so the hazard
         // recogniser does not see them: the last results are read 2 x 16 wait states later, well past a 8-pass MFMA)
@@ -264,6 +282,9 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
                 }
             lds_barrier();
         }
+#ifdef ST_DIAG
+        ST_CLK(c1); dx += c1 - c0;
+#endif
         // ---- epilogue on this wave's four fragments
         const int b = tile / p.strips, strip = tile - b * p.strips;
         const int oy0 = strip * ST_TH;
@@ -312,7 +333,17 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
                     if (li == 0) { atomicAdd(&sAcc[nt * 16 + lg * 4 + r], a); atomicAdd(&sAcc[64 + nt * 16 + lg * 4 + r], bq); }
                 }
         }
+#ifdef ST_DIAG
+        ST_CLK(c0); de += c0 - c1;
+#endif
     }
+#ifdef ST_DIAG
+    ST_CLK(c1);
+    if (lane == 0) {
+        unsigned long long* d = g_stem_diag + (blockIdx.x * 4 + wave) * 8;
+        d[0] = dk; d[1] = db; d[2] = dx; d[3] = de; d[4] = c1 - life0;
+    }
+#endif
     };
     if (kw == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
     if (p.stats) {

@@ -324,6 +324,14 @@ int danet_conv_stem_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, i
 int danet_conv_stem_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
                             float* bn_sums, void* stream);
 int danet_conv_stem_set(int enable);
+/* Data gradient of a stem convolution with 64 input and 64 output channels (csrc/conv_stem_dgrad.hip): (B, H, W, Cin) describe dx (the
+ * convolution's input), (OH, OW, Cout) dy; weights = danet_conv_pack_weights(mode 1, chunk 16).  bn_x / bn_y / bn_saved / bn_red: the fused
+ * BatchNorm-backward sums of danet_conv_forward's arguments of the same names (all NULL: none).  Replaces danet_conv_forward(transposed = 1)
+ * for /root/reference/models/module/res_module.py:404 (SmplResNet.conv1) in the backward pass of models/danet/smpl_regressor.py. */
+int danet_conv_stem_dgrad_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+int danet_conv_stem_dgrad(const void* dy, const void* wp, void* dx, int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                          const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, void* stream);
+int danet_conv_stem_dgrad_set(int enable);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);

@@ -619,3 +619,42 @@ def test_stem_7x7_stride2_lds_tile_kernel_vs_torch_fp32(B, Cin):
         F.conv2d(xf, wf, None, 2, 3).backward(gy.float())
         assert (xt.grad.float() - xf.grad).abs().max().item() <= 1e-2 * xf.grad.abs().max().item()
         assert (wt.grad - wf.grad).abs().max().item() <= 3e-3 * wf.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('B', [768, 64, 70])
+def test_stem_7x7_stride2_data_gradient_lds_tile_kernel(B):
+    """csrc/conv_stem_dgrad.hip (the four parity classes of the 7x7 / stride-2 data gradient on one staged dy tile, table-driven k-steps,
+    fused BatchNorm-backward sums) against (a) conv_transpose2d in fp32 on the bf16-rounded operands (sampled images, every border strip),
+    (b) the gather kernel on the same operands incl. the same fused sums, (c) the sums recomputed from the kernel's own rounded output."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    H, C = 64, 64
+    assert L.danet_conv_stem_dgrad_ok(B, H, H, C, 32, 32, C, 7, 7, 2, 3, 1, 1) == 1
+    g = torch.Generator().manual_seed(100 + B)
+    gy = dconv.nhwc_bf16(torch.randn(B, C, 32, 32, generator=g).cuda())
+    w = (torch.randn(C, C, 7, 7, generator=g) / np.sqrt(49 * C / 4)).bfloat16().float().cuda()
+    bn_x = dconv.nhwc_bf16(torch.randn(B, C, H, H, generator=g).cuda())
+    bn_y = dconv.nhwc_bf16(torch.randn(B, C, H, H, generator=g).cuda())
+    saved = torch.cat([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5]).cuda()
+    nred = L.danet_bn_ws_floats(C)
+    for gate in (bn_y, None):
+        red = torch.zeros(nred, device='cuda')
+        gx = dconv._conv_stem_dgrad_raw(gy, dconv.pack_weight(w, 1, 1, 16), B, H, H, C, 32, 32, C, (bn_x, gate, saved, red, 0))
+        red2 = torch.zeros(nred, device='cuda')
+        gx2 = dconv._conv_fwd_raw(gy, dconv.pack_weight(w, 1, 1), None, B, 32, 32, C, H, H, C, 7, 7, 2, 3, 1, 1, True, False, False, None,
+                                  (bn_x, gate, saved, red2, 0))
+        torch.cuda.synchronize()
+        idx = torch.linspace(0, B - 1, min(B, 24)).long().cuda()
+        ref = F.conv_transpose2d(gy[idx].float(), w, None, 2, 3, 1)
+        scale = ref.abs().max().item()
+        assert (gx[idx].float() - ref).abs().max().item() <= 1e-2 * scale
+        assert (gx.float() - gx2.float()).abs().max().item() <= 1e-2 * scale
+        gf = gx.float() * ((gate.float() > 0).float() if gate is not None else 1.0)
+        xhat = (bn_x.float() - saved[:C].view(1, -1, 1, 1)) * saved[C:].view(1, -1, 1, 1)
+        s1, s2 = gf.sum(dim=(0, 2, 3)), (gf * xhat).sum(dim=(0, 2, 3))
+        st, st2 = red.view(-1, 2, C).sum(0), red2.view(-1, 2, C).sum(0)
+        tol1, tol2 = 2e-3 * gf.abs().sum(dim=(0, 2, 3)).max().item(), 2e-3 * (gf * xhat).abs().sum(dim=(0, 2, 3)).max().item()
+        assert (st[0] - s1).abs().max().item() <= tol1 and (st[1] - s2).abs().max().item() <= tol2
+        assert (st[0] - st2[0]).abs().max().item() <= 4 * tol1 and (st[1] - st2[1]).abs().max().item() <= 4 * tol2
+    gx3 = dconv._conv_stem_dgrad_raw(gy, dconv.pack_weight(w, 1, 1, 16), B, H, H, C, 32, 32, C, None)
+    assert torch.equal(gx3, gx)                                  # no sums requested: the same data gradient, bit for bit

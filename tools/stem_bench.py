@@ -33,10 +33,33 @@ def dgrad():
     return conv._conv_fwd_raw(gy, wp1, None, B, H // 2, H // 2, C, H, H, C, 7, 7, 2, 3, 1, 1, True, False, False)
 
 
+wp16t = conv.pack_weight(w, 1, 1, 16)
+bn_x = conv.nhwc_bf16(torch.randn(B, C, H, H, device='cuda'))
+bn_y = conv.nhwc_bf16(torch.randn(B, C, H, H, device='cuda'))
+saved = torch.cat([torch.randn(C, device='cuda') * 0.1, torch.rand(C, device='cuda') + 0.5])
+red = torch.zeros(L.danet_bn_ws_floats(C), device='cuda')
+USE_DG = bool(L.danet_conv_stem_dgrad_ok(B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1))
+
+
+def dgrad_tile(bn=False):
+    return conv._conv_stem_dgrad_raw(gy, wp16t, B, H, H, C, H // 2, H // 2, C, (bn_x, bn_y, saved, red, 0) if bn else None)
+
+
+def dgrad_gather_bn():
+    return conv._conv_fwd_raw(gy, wp1, None, B, H // 2, H // 2, C, H, H, C, 7, 7, 2, 3, 1, 1, True, False, False, None, (bn_x, bn_y, saved, red, 0))
+
+
 yr = torch.nn.functional.conv2d(x.float()[:8], w.detach().bfloat16().float(), None, 2, 3)
 y = fwd()
 err = float((y[:8].float() - yr).abs().max() / yr.abs().max())
 tf, tg = timeit(fwd, iters=5), timeit(dgrad, iters=5)
+if USE_DG:
+    gr = torch.nn.functional.conv_transpose2d(gy[:8].float(), w.detach().bfloat16().float(), None, 2, 3, 1)
+    gt = dgrad_tile()
+    err_d = float((gt[:8].float() - gr).abs().max() / gr.abs().max())
+    td, tdb, tgb = timeit(dgrad_tile, iters=5), timeit(lambda: dgrad_tile(True), iters=5), timeit(dgrad_gather_bn, iters=5)
+    print(json.dumps({'stem_dgrad': [B, C, H], 'tile_us': round(td * 1e6, 1), 'tile_frac': round(flops / td / 2.5e15, 4), 'tile_bn_us': round(tdb * 1e6, 1),
+                      'gather_us': round(tg * 1e6, 1), 'gather_bn_us': round(tgb * 1e6, 1), 'err_dgrad': round(err_d, 5)}))
 print(json.dumps({'stem': [B, C, H], 'lds_tile_kernel': USE_STEM, 'kernel_fwd': L.danet_conv_forward_kernel(B, H, H, C, H // 2, H // 2, C, 7, 7, 2, 3, 1, 1, 0, 0),
                   'fwd_us': round(tf * 1e6, 1), 'fwd_frac': round(flops / tf / 2.5e15, 4), 'dgrad_us': round(tg * 1e6, 1), 'dgrad_frac': round(flops / tg / 2.5e15, 4),
                   'err_fwd': round(err, 5)}))
