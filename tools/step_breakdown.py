@@ -14,8 +14,8 @@ def family(n):
         return 'weight gradients incl. reduce / unpack'
     if 'conv_pw_kernel' in n:
         return 'pointwise convolutions (1x1 / s1 on csrc/conv_pw.hip, fwd + dgrad)'
-    if 'conv_stem_kernel' in n:
-        return 'stem convolutions (7x7 / s2 forward on LDS row tiles, csrc/conv_stem.hip)'
+    if 'conv_stem' in n:
+        return 'stem convolutions (7x7 / s2 forward + data gradient on LDS row tiles, csrc/conv_stem*.hip)'
     if 'conv_fast' in n or 'conv_igemm' in n:
         return 'gather convolutions (1x1, strided, 7x7, grouped, transposed)'
     if 'bn_' in n or 'sum_relu' in n or 'fuse_' in n or 'channel_sum' in n:
