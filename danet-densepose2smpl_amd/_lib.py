@@ -32,6 +32,8 @@ _SIGNATURES = {
     'danet_conv_wgrad_kernel_id': (c_i, [c_i] * 4),
     'danet_conv_packed_elems': (c_sz, [c_i] * 7),
     'danet_conv_pack_weights': (c_i, [c_f, c_f] + [c_i] * 7 + [c_f]),
+    'danet_conv_pack_weights_padded': (c_i, [c_f, c_f] + [c_i] * 9 + [c_f]),
+    'danet_conv_pack_job_fill_padded': (ctypes.c_long, [c_f, c_f, c_f, ctypes.c_long, ctypes.c_long] + [c_i] * 9),
     'danet_conv_pack_job_bytes': (c_sz, []),
     'danet_conv_pack_job_fill': (ctypes.c_long, [c_f, c_f, c_f, ctypes.c_long, ctypes.c_long] + [c_i] * 7),
     'danet_conv_f32': (c_i, [c_i, c_f, c_f, c_f, c_f] + [c_i] * 13 + [c_f]),

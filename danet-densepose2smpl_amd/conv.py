@@ -303,9 +303,9 @@ class WeightBank(object):
     def start_recording(self):
         self.requests = {}
 
-    def note(self, weight, groups, mode, chunk):
+    def note(self, weight, groups, mode, chunk, pad_to=None):
         if self.requests is not None:
-            self.requests[(id(weight), mode, groups, chunk)] = weight
+            self.requests[(id(weight), mode, groups, chunk, pad_to)] = weight
 
     def build(self):
         global RECORDER
@@ -317,8 +317,8 @@ class WeightBank(object):
         L = _lib.lib()
         dev = next(iter(reqs.values())).device
         sizes = []
-        for (wid, mode, groups, chunk), w in reqs.items():
-            Cout, Cin_g, R, S = w.shape
+        for (wid, mode, groups, chunk, pad_to), w in reqs.items():
+            Cout, Cin_g, R, S = _padded_dims(w, pad_to)
             sizes.append((int(L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode, chunk)) + 63) // 64 * 64)
         self.flat = torch.zeros(sum(sizes), dtype=torch.bfloat16, device=dev)      # zeroed once: the brick launch never writes padding
         jb = int(L.danet_conv_pack_job_bytes())
@@ -326,16 +326,16 @@ class WeightBank(object):
         host = (ctypes.c_uint8 * (jb * len(reqs)))()
         off, start, bstart = 0, 0, 0
         self.entries = []
-        for ((wid, mode, groups, chunk), w), n in zip(reqs.items(), sizes):
+        for ((wid, mode, groups, chunk, pad_to), w), n in zip(reqs.items(), sizes):
             assert w.dtype == torch.float32 and w.is_contiguous()
             view = self.flat[off:off + n]
-            Cout, Cin_g, R, S = w.shape
-            tot = L.danet_conv_pack_job_fill(ctypes.addressof(host) + jb * len(self.entries), w.data_ptr(), view.data_ptr(), start, bstart,
-                                             Cout, Cin_g, R, S, groups, mode, chunk)
+            Cout, Cin_g, R, S = _padded_dims(w, pad_to)
+            tot = L.danet_conv_pack_job_fill_padded(ctypes.addressof(host) + jb * len(self.entries), w.data_ptr(), view.data_ptr(), start, bstart,
+                                                    Cout, Cin_g, R, S, groups, mode, chunk, w.shape[0] // groups, w.shape[1])
             assert 0 < tot <= n
-            self.entries.append(((wid, mode, groups, chunk), weakref.ref(w), view, w.data_ptr()))
+            self.entries.append(((wid, mode, groups, chunk, pad_to), weakref.ref(w), view, w.data_ptr()))
             off += n
-            bricks = L.danet_conv_pack_job_bricks(Cout, Cin_g, R, S, groups, mode, chunk)
+            bricks = L.danet_conv_pack_job_bricks(Cout, Cin_g, R, S, groups, mode, chunk) if pad_to is None else 0
             if bricks > 0:                 # brick launch (csrc/conv_igemm.hip pack_weights_brick_kernel)
                 bstart += bricks
             else:                          # per-element launch
@@ -358,27 +358,35 @@ class WeightBank(object):
 RECORDER = None         # a WeightBank in its recording step
 
 
-def pack_weight(weight, groups, mode, chunk=0):
+def _padded_dims(weight, pad_to):
+    """(Cout, Cin_g, R, S) the kernels run a weight at: its own shape, or pad_to = (Cout, Cin_g) with zero-padded channels."""
+    Cout, Cin_g, R, S = weight.shape
+    return (Cout, Cin_g, R, S) if pad_to is None else (int(pad_to[0]), int(pad_to[1]), R, S)
+
+
+def pack_weight(weight, groups, mode, chunk=0, pad_to=None):
     """Packed bf16 copy of an fp32 conv weight (mode 0: forward operand, 1: data-gradient operand; chunk > 0:
-    the chunked K order of the LDS 3x3 kernel).  Cached per nn.Parameter object and version (so a
-    parameter is re-packed once per optimizer step); temporaries are never cached."""
+    the chunked K order of the LDS 3x3 kernel; pad_to = (Cout, Cin_g): packed at zero-padded widths straight from the
+    unpadded tensor).  Cached per nn.Parameter object and version (so a parameter is re-packed once per optimizer
+    step); temporaries are never cached."""
     cacheable = isinstance(weight, nn.Parameter)
-    key = (id(weight), mode, groups, chunk)
+    key = (id(weight), mode, groups, chunk, pad_to)
     ver = weight._version
     if cacheable:
         if RECORDER is not None and weight.dtype == torch.float32 and weight.is_contiguous():
-            RECORDER.note(weight, groups, mode, chunk)
+            RECORDER.note(weight, groups, mode, chunk, pad_to)
         hit = _PACK_CACHE.get(key)
         if hit is not None and hit[0] == ver and hit[2]() is weight:
             return hit[1]
     L = _lib.lib()
-    Cout, Cin_g, R, S = weight.shape
+    Cout, Cin_g, R, S = _padded_dims(weight, pad_to)
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     n = L.danet_conv_packed_elems(Cout // groups, Cin_g, R, S, groups, mode, chunk)
     wp = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
-    check(L.danet_conv_pack_weights(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, chunk, stream()), 'danet_conv_pack_weights')
+    check(L.danet_conv_pack_weights_padded(ptr(w), ptr(wp), Cout, Cin_g, R, S, groups, mode, chunk, weight.shape[0] // groups, weight.shape[1], stream()),
+          'danet_conv_pack_weights')
     if cacheable:
         _PACK_CACHE[key] = (ver, wp, weakref.ref(weight))
     return wp
@@ -506,22 +514,25 @@ class ResLink(object):
 
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None, bn_ctx=None, link=None):
+    def forward(ctx, x, weight, bias, stride, pad, dil, groups, out_fp32, bn_sums=None, bn_ctx=None, link=None, wpad=None):
+        """wpad = (Cout, Cin_g): the weight runs zero-padded to these widths (packed straight from the unpadded parameter: its packed
+        copies live in the WeightBank like any other layer's, and the weight gradient is cropped back to the parameter's shape)."""
         x = nhwc_bf16(x)
         B, Cin, H, W = x.shape
-        Cout, Cin_g, R, S = weight.shape
+        Cout, Cin_g, R, S = _padded_dims(weight, wpad)
         if Cin_g * groups != Cin:
             raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
         OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         b = None if bias is None else bias.detach().float().contiguous()
         if b is None and not out_fp32 and _lib.lib().danet_conv_stem_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
             # the regressors' 7x7 / stride-2 stems over the part crops: LDS-tile kernel, weights in the chunked (16-channel slab) packing
-            y = _conv_stem_raw(x, pack_weight(weight, groups, 0, 16), B, H, W, Cin, OH, OW, Cout, bn_sums)
+            y = _conv_stem_raw(x, pack_weight(weight, groups, 0, 16, wpad), B, H, W, Cin, OH, OW, Cout, bn_sums)
         else:
-            wp = pack_weight(weight, groups, 0)
+            wp = pack_weight(weight, groups, 0, 0, wpad)
             y = _conv_fwd_raw(x, wp, b, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, False, False, out_fp32, bn_sums)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, groups, bias is not None)
+        ctx.wpad = wpad
         ctx.bn_ctx = bn_ctx
         ctx.link = link
         if link is not None and ctx.needs_input_grad[0]:
@@ -533,16 +544,25 @@ class Conv2dFunction(torch.autograd.Function):
         L = _lib.lib()
         x, weight = ctx.saved_tensors
         stride, pad, dil, groups, has_bias = ctx.cfg
+        wpad = ctx.wpad
         B, Cin, H, W = x.shape
-        Cout, Cin_g, R, S = weight.shape
+        Cout, Cin_g, R, S = _padded_dims(weight, wpad)
         gy = nhwc_bf16(gy)
         OH, OW = gy.shape[2], gy.shape[3]
         gx = gw = gb = None
         if ctx.needs_input_grad[1]:
             # the weight gradient is off the critical path (only the optimizer consumes it): with DEFER_WGRAD it is
             # only queued here and computed by flush_wgrads() in multi-problem launches after the backward pass
-            gw = new_wgrad(weight, (Cout, Cin_g, R, S), x.device)
-            _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
+            if wpad is None:
+                gw = new_wgrad(weight, (Cout, Cin_g, R, S), x.device)
+                _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
+            else:
+                # at the padded widths, then cropped to the parameter's own shape (one launch of csrc/glue.hip)
+                gwp = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
+                _wgrad_into(gwp, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, None)
+                from .glue import crop
+                so, si = weight.shape[0] // groups, weight.shape[1]
+                gw = crop(gwp, (groups, Cout // groups, Cin_g, R * S), (groups, so, si, R * S), tuple(weight.shape))
         if ctx.needs_input_grad[0]:
             bn_bwd = None
             if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
@@ -564,9 +584,9 @@ class Conv2dFunction(torch.autograd.Function):
             if addend is None and (bn_bwd is None or (bn_bwd[4] == 0 and bn_bwd[0].dtype == torch.bfloat16)) and \
                     L.danet_conv_stem_dgrad_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
                 # the part-crop stem (64 -> 64 channels, 7x7 / stride 2): LDS-tile kernel with the same fused BatchNorm-backward sums
-                gx = _conv_stem_dgrad_raw(gy, pack_weight(weight, groups, 1, 16), B, H, W, Cin, OH, OW, Cout, bn_bwd)
+                gx = _conv_stem_dgrad_raw(gy, pack_weight(weight, groups, 1, 16, wpad), B, H, W, Cin, OH, OW, Cout, bn_bwd)
             else:
-                gx = _conv_fwd_raw(gy, pack_weight(weight, groups, 1), None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
+                gx = _conv_fwd_raw(gy, pack_weight(weight, groups, 1, 0, wpad), None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False,
                                    None, bn_bwd, addend if fused_add else None)
             if addend is not None:
                 FUSION['residual_grad_fused' if fused_add else 'residual_grad_added'] += 1
@@ -576,7 +596,7 @@ class Conv2dFunction(torch.autograd.Function):
                 gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
             gb = channel_sum(gy)
-        return gx, gw, gb, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 def channel_sum(gy):
@@ -731,7 +751,7 @@ def _pad_channels_nhwc(x, mult=8):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_fp32=False, want_stats=False,
-           keep_group_padding=False, link=None):
+           keep_group_padding=False, link=None, weight_pad=None):
     """Convolution on the MFMA kernels.  Channel counts that are not a multiple of 8 (3-channel image,
     21/75-channel IUV maps, 25/15/21-channel heads) are zero-padded to the next multiple of 8 so that
     forward, dgrad and wgrad all take the 16-byte vector path; the padding is sliced off again."""
@@ -739,8 +759,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         if x.shape[1] != weight.shape[1] * groups:           # a producer's zero-padded channels: drop them
             x = x[:, :weight.shape[1] * groups]
         return Conv2dF32Function.apply(x, weight, bias, stride, padding, dilation, groups)
-    Cout = weight.shape[0]
-    Cin_w, R_, S_ = weight.shape[1], weight.shape[2], weight.shape[3]
+    if weight_pad is not None:                              # the caller runs this layer at padded widths (resnet.Bottleneck._forward_padded)
+        Cout, Cin_w = int(weight_pad[0]), int(weight_pad[1])
+    else:
+        Cout, Cin_w = weight.shape[0], weight.shape[1]
     padc = 0
     if groups == 1 and x.shape[1] != Cin_w and x.shape[1] == Cin_w + (-Cin_w) % 8:
         padc = x.shape[1] - Cin_w        # the producer already zero-padded the channels to a multiple of 8 (part_ops.part_clean): pad the weight only
@@ -749,19 +771,15 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         x = _pad_channels_nhwc(x)
     Cout_g = Cout // groups
     padn = (-Cout_g) % 8
+    wpad = weight_pad
     if padc or padn:
-        # zero-padded copies of the (small) weight / bias: ONE launch for both and one for their gradients (glue.pad_multi) where the
-        # tensor-op form was a fill + a copy per F.pad and dimension
-        if weight.is_cuda and weight.dtype == torch.float32:
-            from .glue import pad_multi
-            items = [(weight, (groups, Cout_g, Cin_w, R_ * S_), (groups, Cout_g + padn, Cin_w + padc, R_ * S_),
-                      (groups * (Cout_g + padn), Cin_w + padc, R_, S_))]
+        if weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous() and weight_pad is None:
+            # the weight is packed at the padded widths straight from the parameter (pack_weight pad_to: its packed copies live in the
+            # WeightBank like any other layer's) and its gradient is cropped back; only a bias still needs a padded copy
+            wpad = (groups * (Cout_g + padn), Cin_w + padc)
             if bias is not None and padn:
-                items.append((bias, (groups, Cout_g), (groups, Cout_g + padn), (groups * (Cout_g + padn),)))
-            outs = pad_multi(items)
-            weight = outs[0]
-            if len(outs) > 1:
-                bias = outs[1]
+                from .glue import pad_multi
+                bias = pad_multi([(bias, (groups, Cout_g), (groups, Cout_g + padn), (groups * (Cout_g + padn),))])[0]
         else:
             if padc:
                 weight = F.pad(weight, (0, 0, 0, 0, 0, padc))
@@ -771,7 +789,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
                 if bias is not None:
                     bias = F.pad(bias.view(groups, Cout_g), (0, padn)).reshape(-1)
     if padn:
-        y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32)
+        y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, None, None, None, wpad)
         if keep_group_padding:       # [B, groups*(Cout_g+padn), OH, OW]: the caller consumes the padded layout (part_ops)
             return y
         if groups == 1:              # a view: channels stay at the epilogue's padded pixel stride (iuv_ops reads it as it is)
@@ -788,7 +806,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     # the BatchNorm that produced x (if any) leaves its tensors on x: the data gradient then also reduces that
     # BatchNorm's backward sums (saves one pass over dy, x, y per BatchNorm with a single consumer)
     bn_ctx = getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and torch.is_grad_enabled()) else None
-    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums, bn_ctx, link)
+    y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums, bn_ctx, link, wpad)
     if sums is not None:
         y._bn_sums = sums              # picked up by the BatchNorm2d that consumes y (nn.BatchNorm2d.forward)
     return y

@@ -292,7 +292,7 @@ __device__ inline bool pack_decode(int k, int inner, int RS, int chunk, int& tap
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp,
-                                    int Cout_g, int Cin_g, int R, int S, int G, int rows_pad, int Kp, int mode, int chunk)
+                                    int Cout_g, int Cin_g, int R, int S, int G, int rows_pad, int Kp, int mode, int chunk, int sCout_g, int sCin_g)
 {
     const long total = (long)G * rows_pad * Kp;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,7 +307,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
     if (pack_decode(k, inner, R * S, chunk, tap, ch) && row < rows) {
         const int r = tap / S, s = tap - r * S;
         const int cout = mode == 0 ? row : ch, cin = mode == 0 ? ch : row;
-        v = w[(((size_t)(g * Cout_g + cout) * Cin_g + cin) * R + r) * S + s];
+        // (sCout_g x sCin_g: the source tensor's own per-group extent -- a weight whose widths are zero-padded to multiples of 8 is packed
+        //  straight from the unpadded parameter)
+        if (cout < sCout_g && cin < sCin_g) v = w[(((size_t)(g * sCout_g + cout) * sCin_g + cin) * R + r) * S + s];
     }
     // fragment-major destination: [g][row/16][k/32][(k%32)/8][row%16][k%8]
     const size_t dst = (((((size_t)g * (rows_pad / 16) + row / 16) * (Kp / 32) + k / 32) * 4 + (k % 32) / 8) * 16 + row % 16) * 8 + k % 8;
@@ -319,6 +321,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
 struct PackJob {
     const float* w; bf16_t* wp; long start; long bstart;
     int Cout_g, Cin_g, R, S, G, rows_pad, Kp, mode, chunk, brick_ch;
+    int sCout_g, sCin_g;          // per-group extent of the fp32 source (<= Cout_g, Cin_g: the rest packs as zeros)
 };
 
 // Brick path of the batched packing (jobs with brick_ch > 0: unchunked K order, channel counts that are multiples of
@@ -445,7 +448,7 @@ __global__ void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, in
         int tap, ch;
         if (pack_decode(k0 + e, inner, RS, j.chunk, tap, ch) && row < rows) {
             const int cout = j.mode == 0 ? row : ch, cin = j.mode == 0 ? ch : row;
-            v = j.w[((size_t)(g * j.Cout_g + cout) * j.Cin_g + cin) * RS + tap];
+            if (cout < j.sCout_g && cin < j.sCin_g) v = j.w[((size_t)(g * j.sCout_g + cout) * j.sCin_g + cin) * RS + tap];
         }
         o.h[e] = f2bf(v);
     }
@@ -507,13 +510,17 @@ extern "C" size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, i
     return (size_t)groups * rows_pad * packed_kp(R, S, inner, chunk);
 }
 
-extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
-                                       int mode, int chunk, void* stream)
+// src_Cout_g / src_Cin_g: the per-group extent of the fp32 source tensor W[groups * src_Cout_g][src_Cin_g][R][S]; channels beyond it (up to
+// Cout / groups, Cin_g) pack as zeros -- layers whose widths are no multiple of 8 run zero-padded, and their parameters keep their shapes.
+extern "C" int danet_conv_pack_weights_padded(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
+                                              int mode, int chunk, int src_Cout_g, int src_Cin_g, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(w && wp && Cout > 0 && Cin_g > 0 && R > 0 && S > 0 && groups > 0 && Cout % groups == 0 && (mode == 0 || mode == 1),
                     "conv_pack_weights: bad arguments");
     const int Cout_g = Cout / groups;
+    DANET_CHECK_ARG(src_Cout_g > 0 && src_Cout_g <= Cout_g && src_Cin_g > 0 && src_Cin_g <= Cin_g, "conv_pack_weights: source extent %d x %d exceeds %d x %d",
+                    src_Cout_g, src_Cin_g, Cout_g, Cin_g);
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
     DANET_CHECK_ARG(chunk >= 0 && (chunk == 0 || inner % chunk == 0), "conv_pack_weights: chunk %d does not divide %d channels", chunk, inner);
     const int nt = danet_conv_nt(rows);
@@ -521,9 +528,15 @@ extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int C
     const int Kp = packed_kp(R, S, inner, chunk);
     const long total = (long)groups * rows_pad * Kp;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       (bf16_t*)wp, Cout_g, Cin_g, R, S, groups, rows_pad, Kp, mode, chunk);
+                       (bf16_t*)wp, Cout_g, Cin_g, R, S, groups, rows_pad, Kp, mode, chunk, src_Cout_g, src_Cin_g);
     DANET_CHECK_LAUNCH("pack_weights_kernel");
     return DANET_OK;
+}
+
+extern "C" int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
+                                       int mode, int chunk, void* stream)
+{
+    return danet_conv_pack_weights_padded(w, wp, Cout, Cin_g, R, S, groups, mode, chunk, groups > 0 ? Cout / groups : 0, Cin_g, stream);
 }
 
 // Batched packing: the caller fills a host table of jobs with danet_conv_pack_job_fill (entry i at byte offset
@@ -553,22 +566,30 @@ extern "C" long danet_conv_pack_job_bricks(int Cout, int Cin_g, int R, int S, in
     return ch ? (long)groups * ((rows + 15) / 16) * (inner / ch) : 0;
 }
 
-extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start, long bstart,
-                                         int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk)
+extern "C" long danet_conv_pack_job_fill_padded(void* job_host, const float* w, void* wp, long start, long bstart,
+                                                int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk, int src_Cout_g, int src_Cin_g)
 {
     if (!job_host || groups <= 0 || Cout % groups != 0 || chunk < 0) return -1;
     PackJob* j = (PackJob*)job_host;
     const int Cout_g = Cout / groups;
+    if (src_Cout_g <= 0 || src_Cout_g > Cout_g || src_Cin_g <= 0 || src_Cin_g > Cin_g) return -1;
     const int rows = mode == 0 ? Cout_g : Cin_g, inner = mode == 0 ? Cin_g : Cout_g;
     const int nt = danet_conv_nt(rows);
     j->w = w; j->wp = (bf16_t*)wp; j->start = start; j->bstart = bstart;
-    j->brick_ch = pack_brick_ch(inner, R * S, chunk);
+    j->brick_ch = (src_Cout_g == Cout_g && src_Cin_g == Cin_g) ? pack_brick_ch(inner, R * S, chunk) : 0;      // (the brick path reads whole runs: unpadded sources only)
     j->Cout_g = Cout_g; j->Cin_g = Cin_g; j->R = R; j->S = S; j->G = groups; j->mode = mode;
+    j->sCout_g = src_Cout_g; j->sCin_g = src_Cin_g;
     j->rows_pad = (rows + 16 * nt - 1) / (16 * nt) * (16 * nt);
     if (chunk > 0 && inner % chunk != 0) return -1;
     j->chunk = chunk;
     j->Kp = packed_kp(R, S, inner, chunk);
     return (long)groups * j->rows_pad * j->Kp;
+}
+
+extern "C" long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start, long bstart,
+                                         int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk)
+{
+    return danet_conv_pack_job_fill_padded(job_host, w, wp, start, bstart, Cout, Cin_g, R, S, groups, mode, chunk, groups > 0 ? Cout / groups : 0, Cin_g);
 }
 
 extern "C" int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, long total_bricks, void* stream)

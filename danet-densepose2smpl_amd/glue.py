@@ -71,3 +71,9 @@ def pad_multi(items):
             spec.append((tuple(sv), tuple(dv), tuple(shape)))
         tensors.append(t)
     return PadMultiFunction.apply(tuple(spec), *tensors)
+
+
+def crop(t, src_view, dst_view, out_shape):
+    """The leading block of a dense fp32 tensor: t viewed as src_view -> new tensor of out_shape (viewed as dst_view <= src_view in every
+    dimension); one launch, no autograd (the backward of a pad, used on weight gradients computed at padded widths)."""
+    return _launch([t.contiguous()], [src_view], [dst_view], [out_shape])[0]

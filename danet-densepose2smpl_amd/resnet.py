@@ -94,16 +94,14 @@ class Bottleneck(nn.Module):
         tr = self.training
         c1, c2, c3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
         from .glue import pad_multi
-        # the seven padded parameter copies of the block in ONE launch (and one for their gradients)
-        w1, g1, b1, w2, g2, b2, w3 = pad_multi([
-            (c1, (P + d,) + tuple(c1.shape[1:])), (self.bn1.weight, (P + d,)), (self.bn1.bias, (P + d,)),
-            (c2, (P + d, P + d) + tuple(c2.shape[2:])), (self.bn2.weight, (P + d,)), (self.bn2.bias, (P + d,)),
-            (c3, (c3.shape[0], P + d) + tuple(c3.shape[2:]))])
-        out = conv2d(x, w1, None, 1, 0, 1, 1, want_stats=tr)
+        # the convolutions' weights are packed at the padded widths straight from the parameters (conv.pack_weight pad_to); the four
+        # padded BatchNorm vectors of the block are ONE launch (and one for their gradients)
+        g1, b1, g2, b2 = pad_multi([(self.bn1.weight, (P + d,)), (self.bn1.bias, (P + d,)), (self.bn2.weight, (P + d,)), (self.bn2.bias, (P + d,))])
+        out = conv2d(x, c1, None, 1, 0, 1, 1, want_stats=tr, weight_pad=(P + d, c1.shape[1]))
         out = self.bn1.forward_padded(out, d, relu=True, padded=(g1, b1))
-        out = conv2d(out, w2, None, self.conv2.stride[0], 1, 1, 1, want_stats=tr)
+        out = conv2d(out, c2, None, self.conv2.stride[0], 1, 1, 1, want_stats=tr, weight_pad=(P + d, P + d))
         out = self.bn2.forward_padded(out, d, relu=True, padded=(g2, b2))
-        out = conv2d(out, w3, None, 1, 0, 1, 1, want_stats=tr)
+        out = conv2d(out, c3, None, 1, 0, 1, 1, want_stats=tr, weight_pad=(c3.shape[0], P + d))
         return self.bn3(out, res=residual, relu=True)
 
 

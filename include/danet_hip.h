@@ -249,6 +249,13 @@ int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups, int taps);        
 size_t danet_conv_packed_elems(int Cout_g, int Cin_g, int R, int S, int groups, int mode, int chunk);
 int danet_conv_pack_weights(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
                             int mode, int chunk, void* stream);
+/* ... packed straight from a parameter whose per-group extent (src_Cout_g x src_Cin_g) is smaller than the padded widths the kernels run at
+ * (Cout / groups x Cin_g, multiples of 8): the missing channels pack as zeros (the reference runs 3 / 12 / 21 / 25 / 15-channel layers as they
+ * are, models/module/hr_module.py:447-470, res_module.py:364; here they are zero-padded and the parameters keep the reference's shapes) */
+int danet_conv_pack_weights_padded(const float* w, void* wp, int Cout, int Cin_g, int R, int S, int groups,
+                                   int mode, int chunk, int src_Cout_g, int src_Cin_g, void* stream);
+long danet_conv_pack_job_fill_padded(void* job_host, const float* w, void* wp, long start, long bstart,
+                                     int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk, int src_Cout_g, int src_Cin_g);
 size_t danet_conv_pack_job_bytes(void);
 long danet_conv_pack_job_bricks(int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
 long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start, long bstart,

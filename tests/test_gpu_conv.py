@@ -141,8 +141,9 @@ def test_weight_bank_matches_individual_packing():
         bank.note(w, 1, 0, 0)
         bank.note(w, 1, 1, 0)
     bank.build()
-    assert dconv.RECORDER is None and len(bank.entries) >= 8          # forward + dgrad operand of each weight (padded copies of
-    #                                                                   channel-padded layers are not Parameters and are not recorded)
+    assert dconv.RECORDER is None and len(bank.entries) >= 8          # forward + dgrad operand of each weight
+    assert any(k[0][4] is not None for k in bank.entries)             # channel-padded layers (96 -> 40, 64 -> 25, 25 -> 512): packed at the padded
+    #                                                                   widths straight from the parameter (pad_to), recorded like the others
     assert 0 < bank.total_bricks and 0 < bank.total                   # both the brick and the per-element launch are exercised
     with torch.no_grad():
         for w in [c.weight for c in convs] + odd:
@@ -154,7 +155,7 @@ def test_weight_bank_matches_individual_packing():
         hit = dconv._PACK_CACHE[key]
         assert hit[1].data_ptr() == view.data_ptr() and hit[0] == w._version
         dconv._PACK_CACHE.pop(key)
-        ref = dconv.pack_weight(w, key[2], key[1])
+        ref = dconv.pack_weight(w, key[2], key[1], key[3], key[4])
         assert torch.equal(view[:ref.numel()].view(torch.int16), ref.view(torch.int16)), key
     dconv._PACK_CACHE.clear()
 
