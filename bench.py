@@ -184,7 +184,7 @@ def geometry_rooflines(tr, B, size, dev):
     peak = 8000.0
     mk = lambda name, by, t: {'kernel': name, 'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': peak, 'unit': 'GB/s',   # noqa: E731
                               'frac': round(by / t / 1e9 / peak, 4), 'us': round(t * 1e6, 1), 'alg_bytes': int(by)}
-    return [mk('smpl_lbs forward (prep+main+finalize)', by_f, t_f), mk('smpl_lbs backward', by_b, max(t_fb - t_f, 1e-9)),
+    return [mk('smpl layer forward (LBS as one launch + rotation concat + two joint selections)', by_f, t_f), mk('smpl layer backward (three LBS launches + the selections\' scatters)', by_b, max(t_fb - t_f, 1e-9)),
             mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 
