@@ -54,6 +54,9 @@ _SIGNATURES = {
     'danet_conv_stem_dgrad_ok': (c_i, [c_i] * 13),
     'danet_conv_stem_dgrad': (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f] * 5),
     'danet_conv_stem_dgrad_set': (c_i, [c_i]),
+    'danet_conv3x3a_ok': (c_i, [c_i] * 11),
+    'danet_conv3x3a': (c_i, [c_f, c_f, c_f] + [c_i] * 4 + [c_f] * 5 + [c_i, c_f, c_f]),
+    'danet_conv3x3a_set': (c_i, [c_i]),
     'danet_conv3x3_stream_table_bytes': (c_sz, []),
     'danet_conv3x3_stream_tables': (c_i, [c_f, c_sz]),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, ctypes.c_long, c_f]),

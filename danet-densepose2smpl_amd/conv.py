@@ -485,6 +485,31 @@ def _conv_stem_raw(x, wp16, B, H, W, Cin, OH, OW, Cout, bn_sums=None):
     return y
 
 
+C3A_WIDTHS = (16,)        # map widths csrc/conv3x3a.hip is used for (measured, tools/c3a_bench.py: 768 x 16 x 16: 29.1 / 26.5 us forward / data gradient
+#                           against 32.2 / 30.4 on the LDS-tile kernel; 32 x 64 x 64: 22.5 / 21.1 against 20.6 / 18.8 -- two tiles per workgroup: slower)
+
+
+def _conv3x3a_raw(x, wp16, B, H, W, transposed, bn_sums=None, bn_bwd=None, addend=None):
+    """csrc/conv3x3a.hip: 3x3 / stride 1 / pad 1, 64 -> 64 channels, forward (wp16 = pack_weight(w, 1, 0, chunk=16)) or data gradient
+    (transposed: x is dy, wp16 = pack_weight(w, 1, 1, chunk=16)); bn_bwd = (bn_x, gate tensor or None, saved, red, gate mode 0 / 2)."""
+    L = _lib.lib()
+    y = _empty_nhwc(B, 64, H, W, torch.bfloat16, x.device)
+    bx = by = sv = rd = None
+    gate = 0
+    if bn_bwd is not None:
+        gate = int(bn_bwd[4])
+        by = None if bn_bwd[1] is None else (ptr(bn_bwd[1].permute(0, 2, 3, 1)) if gate == 0 else bn_bwd[1].data_ptr())
+        bx, sv, rd = ptr(bn_bwd[0].permute(0, 2, 3, 1)), ptr(bn_bwd[2]), ptr(bn_bwd[3])
+        if by is None:
+            gate = 0
+    tok = PROFILER.begin('conv3x3a_kernel', 2.0 * B * H * W * 64 * 64 * 9, ('dgrad' if transposed else 'fwd', B, H, W, 64, 64, 3, 1, 1)) if PROFILER is not None else None
+    check(L.danet_conv3x3a(ptr(x.permute(0, 2, 3, 1)), ptr(wp16), ptr(y.permute(0, 2, 3, 1)), B, H, W, int(transposed), ptr(bn_sums), bx, by, sv, rd, gate,
+                           None if addend is None else ptr(addend.permute(0, 2, 3, 1)), stream()), 'danet_conv3x3a')
+    if tok is not None:
+        PROFILER.end(tok)
+    return y
+
+
 def _conv_stem_dgrad_raw(gy, wp16t, B, H, W, Cin, OH, OW, Cout, bn_bwd=None):
     """csrc/conv_stem_dgrad.hip: data gradient of a 7x7 / stride 2 / pad 3 stem (64 -> 64 channels) on LDS tiles; wp16t =
     pack_weight(w, 1, 1, chunk=16); bn_bwd = (bn_x, gate tensor or None, saved, red, gate mode 0) as for _conv_fwd_raw."""
@@ -524,7 +549,10 @@ class Conv2dFunction(torch.autograd.Function):
             raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_g * groups))
         OH, OW = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
         b = None if bias is None else bias.detach().float().contiguous()
-        if b is None and not out_fp32 and _lib.lib().danet_conv_stem_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
+        if b is None and not out_fp32 and W in C3A_WIDTHS and _lib.lib().danet_conv3x3a_ok(B, H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+            # the regressor ResNets' layer1 (64 -> 64 channels, 3x3): the AGPR row-tile kernel, weights in the chunked packing
+            y = _conv3x3a_raw(x, pack_weight(weight, groups, 0, 16, wpad), B, H, W, False, bn_sums)
+        elif b is None and not out_fp32 and _lib.lib().danet_conv_stem_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
             # the regressors' 7x7 / stride-2 stems over the part crops: LDS-tile kernel, weights in the chunked (16-channel slab) packing
             y = _conv_stem_raw(x, pack_weight(weight, groups, 0, 16, wpad), B, H, W, Cin, OH, OW, Cout, bn_sums)
         else:
@@ -581,7 +609,13 @@ class Conv2dFunction(torch.autograd.Function):
                 addend, ctx.link.dres = ctx.link.dres, None
             fused_add = addend is not None and addend.shape == x.shape and bn_bwd is None and \
                 L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2, 3)      # gather, LDS-tile 3x3, pointwise
-            if addend is None and (bn_bwd is None or (bn_bwd[4] == 0 and bn_bwd[0].dtype == torch.bfloat16)) and \
+            if (addend is None or (bn_bwd is None and addend.shape == x.shape and addend.dtype == torch.bfloat16)) and \
+                    (bn_bwd is None or bn_bwd[0].dtype == torch.bfloat16) and W in C3A_WIDTHS and L.danet_conv3x3a_ok(B, H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+                gx = _conv3x3a_raw(gy, pack_weight(weight, groups, 1, 16, wpad), B, H, W, True, None, bn_bwd, addend)
+                if addend is not None:
+                    FUSION['residual_grad_fused'] += 1
+                    addend = None
+            elif addend is None and (bn_bwd is None or (bn_bwd[4] == 0 and bn_bwd[0].dtype == torch.bfloat16)) and \
                     L.danet_conv_stem_dgrad_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
                 # the part-crop stem (64 -> 64 channels, 7x7 / stride 2): LDS-tile kernel with the same fused BatchNorm-backward sums
                 gx = _conv_stem_dgrad_raw(gy, pack_weight(weight, groups, 1, 16, wpad), B, H, W, Cin, OH, OW, Cout, bn_bwd)

@@ -31,6 +31,7 @@ UNITS = {
     'conv_fast.hip': MFMA_VGPR,
     'conv_pw.hip': MFMA_VGPR,
     'conv_pw_wgrad.hip': MFMA_VGPR,
+    'conv3x3a.hip': [],
     'conv_stem_dgrad.hip': [],
     'conv_stem.hip': [],            # (accumulators in AGPRs: 8 x 4 tiles per wave, one workgroup per compute unit)
     'conv_f32.hip': ['-ffp-contract=off'],

@@ -339,6 +339,14 @@ int danet_conv_stem_dgrad_ok(int B, int H, int W, int Cin, int OH, int OW, int C
 int danet_conv_stem_dgrad(const void* dy, const void* wp, void* dx, int B, int H, int W, int Cin, int OH, int OW, int Cout,
                           const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, void* stream);
 int danet_conv_stem_dgrad_set(int enable);
+/* 3x3 / stride 1 / pad 1, 64 -> 64 channels on 16- or 64-wide maps (csrc/conv3x3a.hip: the BasicBlocks of the regressor ResNets' layer1,
+ * /root/reference/models/module/res_module.py:27-56 under SmplResNet :404): forward (transposed = 0, weights mode 0 / chunk 16, optional output
+ * statistics bn_sums) and data gradient (transposed = 1, weights mode 1 / chunk 16, optional fused BatchNorm-backward sums -- bn_gate 0: bn_y is
+ * the BatchNorm's bf16 output, 2: its byte mask -- and residual addend), the contracts of danet_conv_forward's arguments of the same names. */
+int danet_conv3x3a_ok(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+int danet_conv3x3a(const void* x, const void* wp, void* y, int B, int H, int W, int transposed, float* bn_sums,
+                   const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, int bn_gate, const void* addend, void* stream);
+int danet_conv3x3a_set(int enable);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);

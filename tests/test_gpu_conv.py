@@ -680,3 +680,61 @@ def test_stem_kernels_repeat_bit_identically():
             out = fn()
             if i % 8 == 7:
                 assert torch.equal(out, ref), i
+
+
+@pytest.mark.parametrize('B,H,W', [(768, 16, 16), (32, 64, 64), (300, 16, 16), (20, 64, 64), (140, 32, 16)])
+def test_conv3x3a_row_tile_kernel_forward_and_data_gradient(B, H, W):
+    """csrc/conv3x3a.hip (3x3 / stride 1, 64 -> 64 channels on the stem kernels' machinery: whole-tile LDS-DMA staging, table-driven
+    k-steps of one tap x 32 channels, K cut 12 | 6 over two waves, AGPR accumulators): forward with fused output statistics and data
+    gradient with (a) the residual addend, (b) the fused BatchNorm-backward sums gated by the BatchNorm's output, (c) by its byte mask
+    -- against F.conv2d / conv_transpose2d in fp32 on the bf16-rounded operands and against the kernels that ran these layers before."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    C = 64
+    assert L.danet_conv3x3a_ok(B, H, W, C, C, 3, 3, 1, 1, 1, 1) == 1
+    g = torch.Generator().manual_seed(B + H)
+    x = dconv.nhwc_bf16(torch.randn(B, C, H, W, generator=g).cuda())
+    w = (torch.randn(C, C, 3, 3, generator=g) / np.sqrt(9 * C / 4)).bfloat16().float().cuda()
+    idx = torch.linspace(0, B - 1, min(B, 24)).long().cuda()
+    nred = L.danet_bn_ws_floats(C)
+    # ---- forward + statistics
+    sums = torch.zeros(nred, device='cuda')
+    y = dconv._conv3x3a_raw(x, dconv.pack_weight(w, 1, 0, 16), B, H, W, False, sums)
+    y0 = dconv._conv_fwd_raw(x, dconv.pack_weight(w, 1, 0), None, B, H, W, C, H, W, C, 3, 3, 1, 1, 1, 1, False, False, False)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x[idx].float(), w, None, 1, 1)
+    scale = ref.abs().max().item()
+    assert (y[idx].float() - ref).abs().max().item() <= 1e-2 * scale
+    assert (y.float() - y0.float()).abs().max().item() <= 1e-2 * scale
+    yb, st = y.float(), sums.view(-1, 2, C).sum(0)
+    assert (st[0] - yb.sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * yb.abs().sum(dim=(0, 2, 3)).max().item()
+    assert (st[1] - (yb * yb).sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * (yb * yb).sum(dim=(0, 2, 3)).max().item()
+    # ---- data gradient
+    gy = dconv.nhwc_bf16(torch.randn(B, C, H, W, generator=g).cuda())
+    wpt = dconv.pack_weight(w, 1, 1, 16)
+    refg = F.conv_transpose2d(gy[idx].float(), w, None, 1, 1)
+    gscale = refg.abs().max().item()
+    gx = dconv._conv3x3a_raw(gy, wpt, B, H, W, True)
+    assert (gx[idx].float() - refg).abs().max().item() <= 1e-2 * gscale
+    add = dconv.nhwc_bf16(torch.randn(B, C, H, W, generator=g).cuda())
+    gxa = dconv._conv3x3a_raw(gy, wpt, B, H, W, True, None, None, add)
+    assert (gxa[idx].float() - (refg + add[idx].float())).abs().max().item() <= 1e-2 * (gscale + add.float().abs().max().item())
+    bn_x = dconv.nhwc_bf16(torch.randn(B, C, H, W, generator=g).cuda())
+    bn_y = dconv.nhwc_bf16(torch.randn(B, C, H, W, generator=g).cuda())
+    saved = torch.cat([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5]).cuda()
+    mask = (bn_y.permute(0, 2, 3, 1) > 0).to(torch.uint8).contiguous()
+    xhat = (bn_x.float() - saved[:C].view(1, -1, 1, 1)) * saved[C:].view(1, -1, 1, 1)
+    for gate_t, mode in ((bn_y, 0), (mask, 2), (None, 0)):
+        red = torch.zeros(nred, device='cuda')
+        gxb = dconv._conv3x3a_raw(gy, wpt, B, H, W, True, None, (bn_x, gate_t, saved, red, mode))
+        torch.cuda.synchronize()
+        assert torch.equal(gxb, gx)
+        gf = gx.float() * ((bn_y.float() > 0).float() if gate_t is not None else 1.0)
+        s1, s2 = gf.sum(dim=(0, 2, 3)), (gf * xhat).sum(dim=(0, 2, 3))
+        st = red.view(-1, 2, C).sum(0)
+        assert (st[0] - s1).abs().max().item() <= 2e-3 * gf.abs().sum(dim=(0, 2, 3)).max().item(), mode
+        assert (st[1] - s2).abs().max().item() <= 2e-3 * (gf * xhat).abs().sum(dim=(0, 2, 3)).max().item(), mode
+    # ---- repeatability of the hand-counted waits
+    for _ in range(100):
+        out = dconv._conv3x3a_raw(gy, wpt, B, H, W, True)
+    assert torch.equal(out, gx)
