@@ -8,8 +8,8 @@ import sys
 def family(n):
     if 'conv3x3_stream' in n:
         return 'conv3x3 stream (3x3 / s1 branch layers, fwd + dgrad)'
-    if 'conv3x3_' in n:
-        return 'conv3x3 tile / one (fused BN-backward dgrads, fall-backs)'
+    if 'conv3x3_' in n or 'conv3x3a' in n:
+        return 'conv3x3 tile / one / row-tile (fused BN-backward dgrads, 64-channel crop layers, fall-backs)'
     if 'wgrad' in n or 'unpack' in n:
         return 'weight gradients incl. reduce / unpack'
     if 'conv_pw_kernel' in n:
