@@ -53,4 +53,37 @@ betas = torch.randn(32, 10, device='cuda')
 rot = torch.linalg.qr(torch.randn(32, 24, 3, 3, device='cuda'))[0]
 with torch.no_grad():
     soak('smpl_fused_fwd_kernel', lambda: model(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False).vertices, n=2 * N)
+# the four-branch lockstep launch of conv3x3_stream_kernel (the step's workhorse) -- alone, and with a memory-hungry copy running on a second
+# stream: its stage copies are published on the strength of a vmcnt count that assumes they complete before younger register loads
+# ("a device fact found on the way"); a late copy would show here as a mismatch
+import ctypes    # noqa: E402
+chans, sizes = (48, 96, 192, 384), (64, 32, 16, 8)
+xs = [conv.nhwc_bf16(torch.randn(32, c, s_, s_, device='cuda')) for c, s_ in zip(chans, sizes)]
+wps = [conv.pack_weight(torch.nn.Parameter(torch.randn(c, c, 3, 3, device='cuda') * 0.05), 1, 0) for c in chans]
+ys = [torch.empty_like(x_) for x_ in xs]
+jobs = (_lib.ConvJob * 4)()
+for j, x_, wp_, y_, c, s_ in zip(jobs, xs, wps, ys, chans, sizes):
+    conv._conv_job(j, x_, wp_, y_, (32, s_, s_, c, s_, s_, c, 3, 3, 1, 1, 1, 1), False, None)
+assert 'conv3x3_stream' in conv._multi_kernel_name(jobs, 4, 48)
+
+
+def four_branch():
+    conv.check(L.danet_conv_forward_multi(ctypes.addressof(jobs), 4, _lib.stream()), 'multi')
+    return torch.cat([y_.reshape(-1) for y_ in ys])
+
+
+soak('four-branch conv3x3_stream_kernel', four_branch, n=N)
+big_a, big_b = torch.empty(256 << 20, dtype=torch.uint8, device='cuda'), torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
+side = torch.cuda.Stream()
+stop = {'n': 0}
+
+
+def four_branch_contended():
+    with torch.cuda.stream(side):
+        big_b.copy_(big_a, non_blocking=True)          # 0.5 GB of HBM traffic per call on the other stream
+    return four_branch()
+
+
+soak('four-branch conv3x3_stream_kernel under a concurrent 256 MB copy', four_branch_contended, n=N)
+torch.cuda.synchronize()
 print(json.dumps(rec))
