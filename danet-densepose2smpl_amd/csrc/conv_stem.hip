@@ -74,6 +74,10 @@ __device__ inline float row_sum16(float v) {
     return v;
 }
 
+#ifndef ST_STRICT_COPIES
+#define ST_STRICT_COPIES 1
+#endif
+
 #ifdef ST_DIAG        // tools/experiments/stem_diag.hip: cycles per wave in the k-steps / at the slab barrier / in the exchange / in the epilogue
 __device__ unsigned long long g_stem_diag[256 * 4 * 8];
 #define ST_CLK(v) v = __builtin_readcyclecounter()
@@ -235,6 +239,14 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
                 for (int q = 5; q < 10; ++q) ST_KSTEP(4 * (D - 1), A[q - 5], Bq[q & 1], Bq[(q + 1) & 1], jb + q, q < 9, false);
             }
 #undef ST_KSTEP
+#if ST_STRICT_COPIES
+            if constexpr (KW == 1) {
+                // before the barrier that publishes the other slot: every load of this copying wave has landed -- a count never says WHICH
+                // loads are outstanding, and LDS-DMA / register loads do not return in order with respect to each other
+#pragma unroll
+                for (int d = 0; d < D; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]), "+v"(A[d][3]));
+            }
+#endif
             ST_CLK(c1);
 #ifdef ST_DIAG
             dk += c1 - c0;
