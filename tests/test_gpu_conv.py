@@ -738,3 +738,36 @@ def test_conv3x3a_row_tile_kernel_forward_and_data_gradient(B, H, W):
     for _ in range(100):
         out = dconv._conv3x3a_raw(gy, wpt, B, H, W, True)
     assert torch.equal(out, gx)
+
+
+@pytest.mark.parametrize('shape,groups,pad_to', [((25, 48, 3, 3), 1, (32, 48)), ((64, 75, 7, 7), 1, (64, 80)), ((12, 48, 1, 1), 1, (16, 48)),
+                                                 ((12, 12, 3, 3), 1, (16, 16)), ((24 * 21, 48, 3, 3), 24, (24 * 24, 48)), ((15, 3, 3, 3), 1, (16, 8))])
+def test_packing_at_padded_widths_equals_packing_a_zero_padded_copy(shape, groups, pad_to):
+    """danet_conv_pack_weights_padded (pack_weight pad_to): a weight packed at zero-padded widths straight from the unpadded tensor is
+    bit-identical, in every mode and K order, to packing an explicitly zero-padded copy -- and a convolution run through it (wpad) has the
+    same output, data gradient and (cropped) weight gradient as one run on the padded copy."""
+    from danet_densepose2smpl_amd import conv as dconv
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(*shape, generator=g).cuda()
+    Cout, Cin_g = shape[0], shape[1]
+    Cp, Cip = pad_to
+    wv = w.view(groups, Cout // groups, Cin_g, shape[2], shape[3])
+    wpad = F.pad(wv, (0, 0, 0, 0, 0, Cip - Cin_g, 0, Cp // groups - Cout // groups)).reshape(Cp, Cip, shape[2], shape[3]).contiguous()
+    for mode in (0, 1):
+        for chunk in ((0, 16) if (Cip if mode == 0 else Cp // groups) % 16 == 0 else (0,)):
+            a = dconv.pack_weight(w, groups, mode, chunk, pad_to)
+            b = dconv.pack_weight(wpad, groups, mode, chunk)
+            assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16)), (mode, chunk)
+    if groups == 1 and shape[2] == 3:
+        B, H = 4, 16
+        x = dconv.nhwc_bf16(torch.randn(B, Cip, H, H, generator=g).cuda()).requires_grad_(True)
+        gy = dconv.nhwc_bf16(torch.randn(B, Cp, H, H, generator=g).cuda())
+        wa = w.clone().requires_grad_(True)
+        ya = dconv.Conv2dFunction.apply(x, wa, None, 1, 1, 1, 1, False, None, None, None, pad_to)
+        ya.backward(gy)
+        gxa, x.grad = x.grad.clone(), None
+        wb = wpad.clone().requires_grad_(True)
+        yb = dconv.Conv2dFunction.apply(x, wb, None, 1, 1, 1, 1, False)
+        yb.backward(gy)
+        assert torch.equal(ya, yb) and torch.equal(gxa, x.grad)
+        assert wa.grad.shape == w.shape and torch.equal(wa.grad, wb.grad[:Cout, :Cin_g])
