@@ -108,6 +108,37 @@ __global__ __launch_bounds__(64) void stn_theta_kernel(const StnThetaP P)
     t[3] = 0.f; t[4] = s; t[5] = cy[j];
 }
 
+// SMPL joint bookkeeping (/root/reference/models/smpl.py:31-37): joints = joints54[:, JOINT_MAP], smpl_joints = joints54[:, :24], joints_J19 =
+// joints[:, -24:][:, J24_TO_J19] -- three index ops forward, their scatters and the accumulation of three gradients backward; here one launch each.
+__global__ __launch_bounds__(256) void smpl_joints_fwd_kernel(const float* __restrict__ j54, const long* __restrict__ map49, const long* __restrict__ map19,
+                                                              int B, int NJ54, int N49, int N19, float* __restrict__ j49, float* __restrict__ j19, float* __restrict__ j24)
+{
+    const int per = (N49 + N19 + 24) * 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * per) return;
+    const int b = i / per, r = i - b * per, row = r / 3, c = r - 3 * row;
+    const float* src = j54 + (long)b * NJ54 * 3;
+    if (row < N49) j49[((long)b * N49 + row) * 3 + c] = src[map49[row] * 3 + c];
+    else if (row < N49 + N19) { const int k = row - N49; j19[((long)b * N19 + k) * 3 + c] = src[map49[N49 - 24 + map19[k]] * 3 + c]; }
+    else { const int k = row - N49 - N19; j24[((long)b * 24 + k) * 3 + c] = src[k * 3 + c]; }
+}
+
+// g54[b, row] = (row < 24 ? g24[b, row] : 0) + sum over k with map49[k] == row of g49[b, k] + sum over k with map49[N49 - 24 + map19[k]] == row of g19[b, k]
+__global__ __launch_bounds__(256) void smpl_joints_bwd_kernel(const float* __restrict__ g49, const float* __restrict__ g19, const float* __restrict__ g24,
+                                                              const long* __restrict__ map49, const long* __restrict__ map19,
+                                                              int B, int NJ54, int N49, int N19, float* __restrict__ g54)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * NJ54 * 3) return;
+    const int b = i / (NJ54 * 3), r = i - b * NJ54 * 3, row = r / 3, c = r - 3 * row;
+    float s = (g24 && row < 24) ? g24[((long)b * 24 + row) * 3 + c] : 0.f;
+    if (g49)
+        for (int k = 0; k < N49; ++k) if ((int)map49[k] == row) s += g49[((long)b * N49 + k) * 3 + c];
+    if (g19)
+        for (int k = 0; k < N19; ++k) if ((int)map49[N49 - 24 + map19[k]] == row) s += g19[((long)b * N19 + k) * 3 + c];
+    g54[i] = s;
+}
+
 }  // namespace
 
 // n (<= 16) jobs; job k copies the fp32 tensor src[k] of shape sdims[4k..4k+3] into dst[k] of shape ddims[4k..4k+3] (both dense, row
@@ -155,5 +186,30 @@ extern "C" int danet_stn_theta_forward(const float* centers, const unsigned char
     StnThetaP P = {centers, am, member, ratio, offset, rnd, child, parent, theta, B, H, W, align, jitter, vis_score};
     hipLaunchKernelGGL(stn_theta_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, P);
     DANET_CHECK_LAUNCH("stn_theta_kernel");
+    return DANET_OK;
+}
+
+// j54 fp32 [B,NJ54,3]; map49 int64 [N49] (rows of j54), map19 int64 [N19] (indices into the LAST 24 of the N49); outputs j49 [B,N49,3],
+// j19 [B,N19,3], j24 [B,24,3] (= j54[:, :24]).
+extern "C" int danet_smpl_joints_forward(const float* j54, const long* map49, const long* map19, int B, int NJ54, int N49, int N19,
+                                         float* j49, float* j19, float* j24, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(j54 && map49 && map19 && j49 && j19 && j24 && B > 0 && NJ54 >= 24 && N49 >= 24 && N19 > 0, "smpl_joints_forward: bad arguments");
+    const long n = (long)B * (N49 + N19 + 24) * 3;
+    hipLaunchKernelGGL(smpl_joints_fwd_kernel, dim3(danet::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, j54, map49, map19, B, NJ54, N49, N19, j49, j19, j24);
+    DANET_CHECK_LAUNCH("smpl_joints_fwd_kernel");
+    return DANET_OK;
+}
+
+// g49 / g19 / g24: gradients of the three outputs (any of them NULL = zero); g54 fp32 [B,NJ54,3] is fully written.
+extern "C" int danet_smpl_joints_backward(const float* g49, const float* g19, const float* g24, const long* map49, const long* map19,
+                                          int B, int NJ54, int N49, int N19, float* g54, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(map49 && map19 && g54 && B > 0 && NJ54 >= 24 && N49 >= 24 && N19 > 0, "smpl_joints_backward: bad arguments");
+    const long n = (long)B * NJ54 * 3;
+    hipLaunchKernelGGL(smpl_joints_bwd_kernel, dim3(danet::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g49, g19, g24, map49, map19, B, NJ54, N49, N19, g54);
+    DANET_CHECK_LAUNCH("smpl_joints_bwd_kernel");
     return DANET_OK;
 }

@@ -79,6 +79,41 @@ class SmplLbsFunction(torch.autograd.Function):
         return g_betas, g_rot, None
 
 
+class SmplJointsFunction(torch.autograd.Function):
+    """joints54 [B,54,3] -> (joints49 = j54[:, map49], joints_J19 = joints49[:, -24:][:, map19], smpl_joints = j54[:, :24]) in one launch,
+    and their three gradients back into one (/root/reference/models/smpl.py:31-37: three index ops, their scatters and two accumulations)."""
+
+    @staticmethod
+    def forward(ctx, j54, map49, map19):
+        L = _lib.lib()
+        j = _f32c(j54)
+        B, NJ = j.shape[0], j.shape[1]
+        N49, N19 = map49.numel(), map19.numel()
+        j49 = torch.empty(B, N49, 3, device=j.device, dtype=torch.float32)
+        j19 = torch.empty(B, N19, 3, device=j.device, dtype=torch.float32)
+        j24 = torch.empty(B, 24, 3, device=j.device, dtype=torch.float32)
+        check(L.danet_smpl_joints_forward(ptr(j), ptr(map49), ptr(map19), B, NJ, N49, N19, ptr(j49), ptr(j19), ptr(j24), stream()), 'danet_smpl_joints_forward')
+        ctx.maps = (map49, map19, B, NJ, N49, N19)
+        ctx.set_materialize_grads(False)
+        return j49, j19, j24
+
+    @staticmethod
+    def backward(ctx, g49, g19, g24):
+        L = _lib.lib()
+        map49, map19, B, NJ, N49, N19 = ctx.maps
+        if g49 is None and g19 is None and g24 is None:
+            return None, None, None
+        f = lambda g: None if g is None else _f32c(g)      # noqa: E731
+        g49, g19, g24 = f(g49), f(g19), f(g24)
+        g54 = torch.empty(B, NJ, 3, device=map49.device, dtype=torch.float32)
+        check(L.danet_smpl_joints_backward(ptr(g49), ptr(g19), ptr(g24), ptr(map49), ptr(map19), B, NJ, N49, N19, ptr(g54), stream()), 'danet_smpl_joints_backward')
+        return g54, None, None
+
+
+def smpl_joints(j54, map49, map19):
+    return SmplJointsFunction.apply(j54, map49, map19)
+
+
 def smpl_lbs(betas, rotmats, model):
     return SmplLbsFunction.apply(betas, rotmats, model)
 

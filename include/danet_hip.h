@@ -147,6 +147,12 @@ int danet_softargmax_backward(const float* hm, int ld, int B, int J, int H, int 
  *   gradient (theta is detached before affine_grid, iuv_estimator.py:197).
  */
 int danet_pad_multi(const void* const* src, void* const* dst, const int* sdims, const int* ddims, int n, void* stream);
+/* /root/reference/models/smpl.py:31-37 (joints = joints54[:, JOINT_MAP]; smpl_joints = joints54[:, :24]; joints_J19 = joints[:, -24:][:, J24_TO_J19]):
+ * one launch forward, one backward (the three gradients scattered and summed into g54; NULL = zero). */
+int danet_smpl_joints_forward(const float* j54, const long* map49, const long* map19, int B, int NJ54, int N49, int N19,
+                              float* j49, float* j19, float* j24, void* stream);
+int danet_smpl_joints_backward(const float* g49, const float* g19, const float* g24, const long* map49, const long* map19,
+                               int B, int NJ54, int N49, int N19, float* g54, void* stream);
 int danet_stn_theta_forward(const float* centers, const unsigned char* am, const float* member, const float* ratio,
                             const float* offset, const float* rnd, const long* child, const long* parent, int B, int H, int W,
                             int align, float jitter, float vis_score, float* theta, void* stream);

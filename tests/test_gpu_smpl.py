@@ -168,3 +168,42 @@ def test_one_launch_forward_replays_from_a_graph(smpl, smpl_model):
             torch.cuda.synchronize()
             assert torch.equal(verts, eager.vertices)
             assert (j54[:, :24] - eager.smpl_joints).abs().max().item() == 0
+
+
+@pytest.mark.gpu
+def test_fused_joint_selection_and_sliced_rotations_equal_the_index_ops():
+    """models/smpl.py:31-37 through ops.smpl_joints (one launch forward, one backward) and with global_orient / body_pose recognised as the two
+    slices of one [B,24,3,3] tensor (no concatenation) against the index-op formulation: outputs identical, gradients w.r.t. betas and the
+    rotations equal to 1e-6 when every output (vertices, 49 joints, J19, the 24 SMPL joints) carries a gradient, and when only some do."""
+    from danet_densepose2smpl_amd import smpl as dsmpl, assets
+    dev = torch.device('cuda')
+    model = dsmpl.SMPL(assets.make_synthetic_smpl(0)).to(dev)
+    torch.manual_seed(3)
+    B = 9
+    betas0 = torch.randn(B, 10, device=dev)
+    rot0 = torch.linalg.qr(torch.randn(B, 24, 3, 3, device=dev))[0].contiguous()
+    ws = [torch.randn(B, model.v_template.shape[0], 3, device=dev), torch.randn(B, 49, 3, device=dev), torch.randn(B, 19, 3, device=dev),
+          torch.randn(B, 24, 3, device=dev)]
+    res = {}
+    for fused in (True, False):
+        dsmpl.FUSED_JOINTS = fused
+        try:
+            for which in ((0, 1, 2, 3), (1,), (0, 3)):
+                betas, rot = betas0.clone().requires_grad_(True), rot0.clone().requires_grad_(True)
+                assert not fused or dsmpl._same_base(rot[:, :1], rot[:, 1:], B) is not None
+                if fused:
+                    out = model(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)       # slices of one tensor
+                else:
+                    out = model(betas=betas, body_pose=rot[:, 1:].clone(), global_orient=rot[:, :1].clone(), pose2rot=False)
+                outs = [out.vertices, out.joints, out.joints_J19, out.smpl_joints]
+                sum((outs[k] * ws[k]).sum() for k in which).backward()
+                res[(fused, which)] = ([o.detach().clone() for o in outs], betas.grad.clone(), rot.grad.clone())
+        finally:
+            dsmpl.FUSED_JOINTS = True
+    for which in ((0, 1, 2, 3), (1,), (0, 3)):
+        a, b = res[(True, which)], res[(False, which)]
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert (a[1] - b[1]).abs().max().item() <= 1e-6 * max(1.0, b[1].abs().max().item())
+        assert (a[2] - b[2]).abs().max().item() <= 1e-6 * max(1.0, b[2].abs().max().item())
+    assert dsmpl._same_base(rot0[:, :1], rot0[:, 1:], B) is not None and dsmpl._same_base(rot0[:, :1].clone(), rot0[:, 1:], B) is None
