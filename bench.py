@@ -146,7 +146,7 @@ def geometry_rooflines(tr, B, size, dev):
     cam = torch.tensor([[0.9, 0.0, 0.0]]).repeat(B, 1).to(dev)
 
     def fwd():
-        return smpl(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+        return smpl(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False, rotmats=rot)      # (as smpl_regressor.py calls it)
 
     def timed(fn, n=20):
         # replayed from a hipGraph: an event pair then brackets device time, not the host's launch latency
@@ -184,7 +184,7 @@ def geometry_rooflines(tr, B, size, dev):
     peak = 8000.0
     mk = lambda name, by, t: {'kernel': name, 'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': peak, 'unit': 'GB/s',   # noqa: E731
                               'frac': round(by / t / 1e9 / peak, 4), 'us': round(t * 1e6, 1), 'alg_bytes': int(by)}
-    return [mk('smpl layer forward (LBS as one launch + rotation concat + two joint selections)', by_f, t_f), mk('smpl layer backward (three LBS launches + the selections\' scatters)', by_b, max(t_fb - t_f, 1e-9)),
+    return [mk('smpl layer forward (LBS as one launch + the joint selections as one)', by_f, t_f), mk('smpl layer backward (three LBS launches + the selections\' gradients as one)', by_b, max(t_fb - t_f, 1e-9)),
             mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 

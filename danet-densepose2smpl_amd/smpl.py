@@ -21,24 +21,6 @@ ModelOutput_.__new__.__defaults__ = (None,) * len(ModelOutput_._fields)
 FUSED_JOINTS = True        # joint selections of models/smpl.py:34-37 as one HIP launch (False: the index ops)
 
 
-def _same_base(global_orient, body_pose, B):
-    """The [B,24,3,3] tensor `global_orient` = t[:, :1] and `body_pose` = t[:, 1:] are views of (smpl_regressor.py:138-139 slices the predicted
-    rotations that way), or None: the concatenation and its backward (two copies and an add) are then not needed."""
-    base = getattr(global_orient, '_base', None)
-    if base is None or getattr(body_pose, '_base', None) is not base or not base.is_contiguous():
-        return None
-    if base.numel() != B * 24 * 9 or tuple(global_orient.shape[-2:]) != (3, 3) or tuple(body_pose.shape[-2:]) != (3, 3):
-        return None
-    b4 = base.view(B, 24, 3, 3)
-    if global_orient.shape[:2] != (B, 1) or body_pose.shape[:2] != (B, 23):
-        return None
-    if global_orient.data_ptr() != b4.data_ptr() or body_pose.data_ptr() != b4.data_ptr() + 9 * b4.element_size():
-        return None
-    if tuple(global_orient.stride()) != tuple(b4[:, :1].stride()) or tuple(body_pose.stride()) != tuple(b4[:, 1:].stride()):
-        return None
-    return b4
-
-
 class SMPL(nn.Module):
     def __init__(self, model=None, batch_size=1, gender='neutral', create_transl=False, **kwargs):
         """model: dict of numpy arrays (see assets.make_synthetic_smpl), a path -- the official SMPL_*.pkl or a directory holding
@@ -85,8 +67,13 @@ class SMPL(nn.Module):
             full_pose = torch.cat([global_orient.reshape(B, -1, 3), body_pose.reshape(B, -1, 3)], dim=1)   # [B,24,3]
             rotmats = ops.rodrigues_smplx(full_pose.reshape(-1, 3)).view(B, 24, 3, 3)
         else:
-            rotmats = _same_base(global_orient, body_pose, B)       # callers slice ONE [B,24,3,3] tensor into the two arguments: use it as it is
-            if rotmats is None:
+            # callers that slice ONE [B,24,3,3] tensor into the two arguments (smpl_regressor.py:138-139) may hand that tensor over as
+            # `rotmats=` as well: the concatenation and its backward (two copies and an add) are then not needed
+            rotmats = kwargs.get('rotmats')
+            if rotmats is not None:
+                if tuple(rotmats.shape) != (B, 24, 3, 3) or rotmats.data_ptr() != global_orient.data_ptr():
+                    raise ValueError('SMPL.forward: rotmats must be the [B,24,3,3] tensor global_orient / body_pose are slices of')
+            else:
                 rotmats = torch.cat([global_orient.reshape(B, -1, 3, 3), body_pose.reshape(B, -1, 3, 3)], dim=1)
             full_pose = rotmats
         vertices, joints54 = ops.smpl_lbs(betas, rotmats, self)

@@ -129,7 +129,8 @@ class SMPL_Regressor(nn.Module):
             with torch.no_grad():
                 gt_pts = self.smpl(betas=target[:, 3:13].contiguous(), body_pose=gt_rotmat[:, 1:].contiguous(),
                                    global_orient=gt_rotmat[:, :1].contiguous(), pose2rot=False).smpl_joints
-            pred = self.smpl(betas=pred_betas, body_pose=pred_rotmat[:, 1:], global_orient=pred_rotmat[:, :1], pose2rot=False)
+            pred = self.smpl(betas=pred_betas, body_pose=pred_rotmat[:, 1:], global_orient=pred_rotmat[:, :1], pose2rot=False,
+                             rotmats=pred_rotmat if pred_rotmat.is_contiguous() else None)
             pred_vertices, pred_joints = pred.vertices, pred.joints
             w = {'SMPL_POSE': D.SMPL_POSE_WEIGHTS, 'JOINT_POSITION': D.JOINT_POSITION_WEIGHTS, 'PROJ_KPS': D.PROJ_KPS_WEIGHTS,
                  'KPS3D': D.KPS3D_WEIGHTS, 'SMPL_BETAS': D.SMPL_BETAS_WEIGHTS, 'VERTS': D.VERTS_WEIGHTS}
@@ -159,7 +160,8 @@ class SMPL_Regressor(nn.Module):
             for i, pos in enumerate(out['joint_position']):
                 rd['losses']['joint_position%d' % i] = self.l1_losses(pos, gt_pts, has_smpl) * D.JOINT_POSITION_WEIGHTS
 
-        pred = self.smpl(betas=pred_betas, body_pose=pred_rotmat[:, 1:], global_orient=pred_rotmat[:, :1], pose2rot=False)
+        pred = self.smpl(betas=pred_betas, body_pose=pred_rotmat[:, 1:], global_orient=pred_rotmat[:, :1], pose2rot=False,
+                             rotmats=pred_rotmat if pred_rotmat.is_contiguous() else None)
         pred_vertices, pred_joints = pred.vertices, pred.joints
         # weak perspective (s,tx,ty) -> translation (:182-193)
         pred_cam_t = torch.stack([pred_camera[:, 1], pred_camera[:, 2],

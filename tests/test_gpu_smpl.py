@@ -172,8 +172,8 @@ def test_one_launch_forward_replays_from_a_graph(smpl, smpl_model):
 
 @pytest.mark.gpu
 def test_fused_joint_selection_and_sliced_rotations_equal_the_index_ops():
-    """models/smpl.py:31-37 through ops.smpl_joints (one launch forward, one backward) and with global_orient / body_pose recognised as the two
-    slices of one [B,24,3,3] tensor (no concatenation) against the index-op formulation: outputs identical, gradients w.r.t. betas and the
+    """models/smpl.py:31-37 through ops.smpl_joints (one launch forward, one backward) and with the [B,24,3,3] tensor that global_orient / body_pose
+    are slices of handed over as `rotmats=` (no concatenation) against the index-op formulation: outputs identical, gradients w.r.t. betas and the
     rotations equal to 1e-6 when every output (vertices, 49 joints, J19, the 24 SMPL joints) carries a gradient, and when only some do."""
     from danet_densepose2smpl_amd import smpl as dsmpl, assets
     dev = torch.device('cuda')
@@ -190,9 +190,8 @@ def test_fused_joint_selection_and_sliced_rotations_equal_the_index_ops():
         try:
             for which in ((0, 1, 2, 3), (1,), (0, 3)):
                 betas, rot = betas0.clone().requires_grad_(True), rot0.clone().requires_grad_(True)
-                assert not fused or dsmpl._same_base(rot[:, :1], rot[:, 1:], B) is not None
                 if fused:
-                    out = model(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)       # slices of one tensor
+                    out = model(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False, rotmats=rot)   # slices of one tensor, handed over
                 else:
                     out = model(betas=betas, body_pose=rot[:, 1:].clone(), global_orient=rot[:, :1].clone(), pose2rot=False)
                 outs = [out.vertices, out.joints, out.joints_J19, out.smpl_joints]
@@ -206,4 +205,5 @@ def test_fused_joint_selection_and_sliced_rotations_equal_the_index_ops():
             assert torch.equal(x, y)
         assert (a[1] - b[1]).abs().max().item() <= 1e-6 * max(1.0, b[1].abs().max().item())
         assert (a[2] - b[2]).abs().max().item() <= 1e-6 * max(1.0, b[2].abs().max().item())
-    assert dsmpl._same_base(rot0[:, :1], rot0[:, 1:], B) is not None and dsmpl._same_base(rot0[:, :1].clone(), rot0[:, 1:], B) is None
+    with pytest.raises(ValueError):
+        model(betas=betas0, body_pose=rot0[:, 1:], global_orient=rot0[:, :1].clone(), pose2rot=False, rotmats=rot0)
