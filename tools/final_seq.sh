@@ -14,5 +14,7 @@ bash tools/prof_bench.sh r04_bf16only --no-fp32 --no-cpu-baseline | tail -1 | cu
 python tools/step_breakdown.py gpurun_out/r04_bf16only_kernel_stats.csv > gpurun_out/r04_step_breakdown.txt; cat gpurun_out/r04_step_breakdown.txt
 echo "== full GPU suite"
 timeout 1300 python -m pytest tests -q -x -m gpu 2>&1 | grep -E "^E  |passed|failed" | cut -c1-300 | head -8
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-200
 echo "== soak"
 timeout 300 python tools/soak.py 4000 2>&1 | tail -1 | cut -c1-900
