@@ -9,8 +9,7 @@
 //     while this one is multiplied;
 //   * a k-step = ONE tap x 32 channels (lanes 0-31 / 32-63: two neighbouring channel planes); 18 per tile, cut 12 | 6 between the two
 //     K halves of a pixel half (multiples of the three-deep weight ring); the waves with the 6 issue the next tile's copies first and sit
-//     them out (an LDS-DMA load may complete before an older register load, so only "at most 8 outstanding" says the oldest fragment
-//     is there); per (K half, k-step) a table entry holds the tap's LDS offset and the weight offsets of the two half fragments
+//     them out (the ring wait, "at most 8 outstanding", counts them); per (K half, k-step) a table entry holds the tap's LDS offset and the weight offsets of the two half fragments
 //     (chunk-16 packing of danet_conv_pack_weights: a tap's 16 channels are 512 contiguous bytes);
 //   * the data gradient is the same loop with the taps mirrored (cell (2 - r, 2 - s)) over the mode-1 packing;
 //   * the K halves meet in LDS, then the epilogue: optional residual addend (the identity shortcut's gradient, conv.ResLink), 16-byte
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3a_kernel(C3aP p)
                 }
         }
         if constexpr (KW == 1) {
-            // before the barrier that publishes the other slot: every load of this wave has landed (a count never says WHICH are outstanding)
+            // before the barrier that publishes the other slot: every load of this wave has landed (belt and braces, see conv_stem.hip)
 #pragma unroll
             for (int d = 0; d < CA_D; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]), "+v"(A[d][3]));
         }

@@ -10,10 +10,10 @@
 //     outside the image carry an out-of-range offset and the hardware writes zeros, so halo columns, rows outside the image
 //     and padding chunks are zero-filled by the same instructions; tools/experiments/lds_dma*.hip: 16 cycles per 1 KB
 //     copy to issue, the chip's full fabric rate with one tile in flight per workgroup).
-//   * (round 3 assumed: vmcnt returns in order, so a weight-fragment load issued after those copies completes after them.  Round 4
-//     found that LDS-DMA and register loads are NOT ordered with respect to each other: a stage's slot is now published after a
-//     full vmcnt(0) wait, S3_STRICT_COPIES, measured free.)  The fragment
-//     ring is deep (D k-steps = ~2 k cycles of MFMA work ahead) and refilled BEFORE the copies at a tile's start:
+//   * vmcnt returns in order, so a weight-fragment load issued after those copies completes after them (observed: tools/experiments/
+//     dma_order.hip, 0 violations in 196 k wave-rounds; since round 4 a stage's slot is published after a full vmcnt(0) wait all the
+//     same, S3_STRICT_COPIES, measured free).  The fragment
+//     ring is therefore deep (D k-steps = ~2 k cycles of MFMA work ahead) and refilled BEFORE the copies at a tile's start:
 //     by the time a k-step needs a fragment requested after the copies, they have landed anyway.  (A first version used a
 //     fifth, loader wave with its own vmcnt queue: 5-wave workgroups at 168 VGPRs do not co-reside two per CU -- measured
 //     one -- and half the chip's MFMA issue slots sat empty.)
@@ -730,9 +730,9 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             if (dbg) { const int tq2 = (int)clock64(); dsum[0] += tq1 - tq0; dsum[1] += tq2 - tq1; }
             if (nsteps < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if S3_STRICT_COPIES
-            // prove the copies have landed before the slot is published: LDS-DMA and register loads share vmcnt but need not return in
-            // order with respect to each other (found on the stem kernel), so no partial count says so -- wait for
-            // everything; the ring's slots stay valid, their latest refills are simply waited for here instead of D - 1 k-steps later
+            // belt and braces before the slot is published: the ring waits since the copies imply they have landed IF loads return in
+            // order (observed, tools/experiments/dma_order.hip; not documented) -- wait for everything; the ring's slots stay valid,
+            // their latest refills are simply waited for here instead of D - 1 k-steps later (measured free)
             if (s + 1 < nst) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {

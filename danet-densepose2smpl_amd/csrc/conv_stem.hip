@@ -78,6 +78,7 @@ __device__ inline float row_sum16(float v) {
 #define ST_STRICT_COPIES 1
 #endif
 
+
 #ifdef ST_DIAG        // tools/experiments/stem_diag.hip: cycles per wave in the k-steps / at the slab barrier / in the exchange / in the epilogue
 __device__ unsigned long long g_stem_diag[256 * 4 * 8];
 #define ST_CLK(v) v = __builtin_readcyclecounter()
@@ -224,15 +225,17 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
                 for (int q = 0; q < 5; ++q) ST_KSTEP(4 * (D - 1), A[q], Bq[q & 1], Bq[(q + 1) & 1], jb + 10 + q, q < 4, false);
             } else {
                 // the next stage (next slab, or the next tile's first one) starts travelling into the other slot: requested here, behind the
-                // ring's loads in flight, so that the first ring turn steps over the copies
+                // ring's loads in flight
                 const bool copying = slab + 1 < nslab ? issue_mine(tile, slab + 1, (g + 1) & 1) : issue_mine(tile + gridDim.x, 0, (g + 1) & 1);
                 (void)copying;
                 load_b(jb, Bq[0]);                          // (after the copies were requested: nothing is carried across their issue)
-                // The copies just requested sit in this wave's queue behind the ring's 20 loads.  Stepping over them (vmcnt(16 + copies))
-                // was WRONG on the device: an LDS-DMA load may complete before an OLDER register load, so "at most 16 + 23 outstanding"
-                // does not mean the oldest fragment has arrived (NaNs).  "At most 16 outstanding" is safe whatever the order between
-                // the two kinds (register loads return in order among themselves): this wave's first k-step therefore waits most of its
-                // copies out -- the 5 k-steps (~2.5 k cycles) it does less than the other K half are there to absorb exactly that.
+                // The copies just requested sit in this wave's queue behind the ring's 20 loads; the ring wait below (at most 16 outstanding)
+                // therefore also waits most of them out -- the 5 k-steps (~2.5 k cycles) this wave does less than the other K half absorb that.
+                // Stepping over them (vmcnt(16 + copies) when copies were requested, vmcnt(16) in the last stage) was tried and gave NaNs:
+                // NOT because loads return out of order (tools/experiments/dma_order.hip: 0 violations in 196 k wave-rounds, this very
+                // sequence included) but because the two copies of the unrolled ring turn under the run-time branch took the kernel to
+                // 256 + 256 registers and 168 bytes of scratch: the compiler then moves and spills registers that inline-asm loads are
+                // still in flight to, which it cannot know.  One code path, no spills (200 VGPRs + 128 AGPRs, no scratch).
 #pragma unroll
                 for (int q = 0; q < 5; ++q) ST_KSTEP(4 * (D - 1), A[q], Bq[q & 1], Bq[(q + 1) & 1], jb + q, true, q == 0 && first);
 #pragma unroll
@@ -241,8 +244,9 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
 #undef ST_KSTEP
 #if ST_STRICT_COPIES
             if constexpr (KW == 1) {
-                // before the barrier that publishes the other slot: every load of this copying wave has landed -- a count never says WHICH
-                // loads are outstanding, and LDS-DMA / register loads do not return in order with respect to each other
+                // before the barrier that publishes the other slot: every load of this copying wave has landed (belt and braces: the ring waits
+                // since the copies already imply it if loads return in order, which tools/experiments/dma_order.hip observes but no document
+                // at hand states; +1 %)
 #pragma unroll
                 for (int d = 0; d < D; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]), "+v"(A[d][3]));
             }

@@ -14,8 +14,7 @@
 //     -- the weights are the chunk-16 mode-1 packing of danet_conv_pack_weights (K order: channel slab, tap, channel), of which a tap's
 //     16 channels are one contiguous 512-byte half fragment, so lanes 0-31 / 32-63 fetch the halves of two arbitrary taps;
 //   * the K halves are cut 12|8, 12|12, 12|12, 16|16 k-steps (multiples of the four-deep weight ring): the waves with the 8 issue the
-//     next tile's copies first and wait them out in their first ring turn (an LDS-DMA load may complete before an older register load:
-//     see conv_stem.hip), the K halves meet in LDS once per class;
+//     next tile's copies first and wait them out in their first ring turn (the ring wait counts them: see conv_stem.hip), the K halves meet in LDS once per class;
 //   * epilogue per class: 16-byte stores through v_permlane16_swap to the class's pixels, and -- when the consumer is the BatchNorm
 //     that produced the stem's input -- that BatchNorm's two backward sums (sum g, sum g * xhat, gated by its ReLU) from the rounded
 //     outputs, kept in registers over all tiles and flushed once per workgroup (the gather kernel's bn_red contract).
@@ -307,9 +306,9 @@ __global__ __launch_bounds__(256, 1) void conv_stem_dgrad_kernel(StemDP p)
         do_class(std::integral_constant<int, 2>{});
         do_class(std::integral_constant<int, 3>{});
         if constexpr (KW == 1) {
-            // the next tile's copies were requested ~48 k-steps ago and every ring wait since has counted them, but a count never says
-            // WHICH loads are outstanding (the two kinds do not return in order with respect to each other): before the barrier that
-            // publishes the slot, wait for everything (the ring's refills included: one refill latency per tile)
+            // the next tile's copies were requested ~48 k-steps ago and every ring wait since has counted them; before the barrier that
+            // publishes the slot, wait for everything all the same (belt and braces: in-order return is observed -- tools/experiments/
+            // dma_order.hip -- not documented; one refill latency per tile)
 #pragma unroll
             for (int d = 0; d < SD_D; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[d][0]), "+v"(A[d][1]), "+v"(A[d][2]), "+v"(A[d][3]));
         }
