@@ -11,8 +11,7 @@
 //     and padding chunks are zero-filled by the same instructions; tools/experiments/lds_dma*.hip: 16 cycles per 1 KB
 //     copy to issue, the chip's full fabric rate with one tile in flight per workgroup).
 //   * vmcnt returns in order, so a weight-fragment load issued after those copies completes after them (observed: tools/experiments/
-//     dma_order.hip, 0 violations in 196 k wave-rounds; since round 4 a stage's slot is published after a full vmcnt(0) wait all the
-//     same, S3_STRICT_COPIES, measured free).  The fragment
+//     dma_order.hip, 0 violations in 260 k wave-rounds, out-of-range copies included; S3_STRICT_COPIES builds the vmcnt(0) variant).  The fragment
 //     ring is therefore deep (D k-steps = ~2 k cycles of MFMA work ahead) and refilled BEFORE the copies at a tile's start:
 //     by the time a k-step needs a fragment requested after the copies, they have landed anyway.  (A first version used a
 //     fifth, loader wave with its own vmcnt queue: 5-wave workgroups at 168 VGPRs do not co-reside two per CU -- measured
@@ -30,6 +29,7 @@
 // branch's tile is computed, the first stage of the next branch's tile is already arriving.
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -60,6 +60,12 @@ constexpr bool S3_PLAIN_EPI = DANET_S3_PLAIN_EPI != 0;      // specialised epilo
 #define DANET_S3_WRAP 0
 #endif
 constexpr bool S3_WRAP = DANET_S3_WRAP != 0;     // the ring carries over from a tile to the next (build knob; measured neutral: 40.1 vs 40.3 us on the four-branch launch, so off)
+#ifndef S3_STEP_OVER
+#define S3_STEP_OVER 0         // build knob: ring waits step over the stage copies queued in front of them (ring_wait).  Correct, but the four-
+#endif                         // branch launch takes 40.9 us with it against 39.4: the CU's other workgroup already covers that stall.  Off.
+#ifndef S3_STRICT_COPIES
+#define S3_STRICT_COPIES 0     // build knob: a stage's slot is published after vmcnt(0) instead of on the ring waits' in-order argument
+#endif                         // (38.2-40.4 us against 38.6-39.4: no need -- tools/experiments/dma_order.hip finds loads in issue order).  Off.
 #ifndef DANET_S3_WIDE_STORES
 #define DANET_S3_WIDE_STORES 0
 #endif
@@ -280,7 +286,7 @@ __device__ inline i32x4 raw_desc(const void* base, int bytes) {           // raw
 }
 
 template <int NIR>
-__device__ __forceinline__ void s3_rows(const S3Prob& p, int s, int img0, int y0, int gofs, unsigned char* buf, int wave, int lane)
+__device__ __forceinline__ int s3_rows(const S3Prob& p, int s, int img0, int y0, int gofs, unsigned char* buf, int wave, int lane)
 {
     const int Sp = p.Sp, Wp = p.Wp, W = p.W, H = p.H, TH2 = p.TH + 2, NI = p.NI;
     const int S_s = 2 * st_nc(p, s), ch0 = st_c0(p, s) * 32 + gofs;        // gofs: byte offset of the tile's group within a pixel
@@ -314,28 +320,31 @@ __device__ __forceinline__ void s3_rows(const S3Prob& p, int s, int img0, int y0
         for (int i = 0; i < NIR - 1; ++i) dma16(dst + i * 1024, voff[i], desc, soff);
         if (in_tail) dma16(dst + (NIR - 1) * 1024, voff[NIR - 1], desc, soff);
     }
+    return nrows > wave ? ((nrows - wave + 3) >> 2) * NIR : 0;        // copy instructions this wave has just queued (wave-uniform)
 }
 
 // with_tab: the problem's tap table travels with this stage (wave 0 copies it to LDS address tab_dst: S3_TAB entries = 1 KB + 768 B)
-__device__ inline void s3_issue(const S3Prob& p, int tau, int s, unsigned char* buf, bool with_tab, unsigned tab_dst, int wave, int lane)
+__device__ inline int s3_issue(const S3Prob& p, int tau, int s, unsigned char* buf, bool with_tab, unsigned tab_dst, int wave, int lane)
 {
+    int extra = 0;
     if (with_tab && wave == 0) {
         const i32x4 tdesc = raw_desc(p.tab, S3_TABB);
         dma16(tab_dst, lane * 16, tdesc, 0);
         if (lane < (S3_TABB - 1024) / 16) dma16(tab_dst + 1024, lane * 16, tdesc, 1024);
+        extra = 2;
     }
     int img0, y0, nb;
     tile_coords(p, tau, img0, y0, nb);
     const int gofs = p.groups > 1 ? __builtin_amdgcn_readfirstlane((int)udiv24((unsigned)nb, (unsigned)p.nnbg, p.rc_nnbg) * p.Cin * 2) : 0;
     switch ((p.Wp * p.Sp + 63) >> 6) {
-        case 1: s3_rows<1>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        case 2: s3_rows<2>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        case 3: s3_rows<3>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        case 4: s3_rows<4>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        case 5: s3_rows<5>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        case 6: s3_rows<6>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        case 7: s3_rows<7>(p, s, img0, y0, gofs, buf, wave, lane); break;
-        default: s3_rows<8>(p, s, img0, y0, gofs, buf, wave, lane); break;
+        case 1: return extra + s3_rows<1>(p, s, img0, y0, gofs, buf, wave, lane);
+        case 2: return extra + s3_rows<2>(p, s, img0, y0, gofs, buf, wave, lane);
+        case 3: return extra + s3_rows<3>(p, s, img0, y0, gofs, buf, wave, lane);
+        case 4: return extra + s3_rows<4>(p, s, img0, y0, gofs, buf, wave, lane);
+        case 5: return extra + s3_rows<5>(p, s, img0, y0, gofs, buf, wave, lane);
+        case 6: return extra + s3_rows<6>(p, s, img0, y0, gofs, buf, wave, lane);
+        case 7: return extra + s3_rows<7>(p, s, img0, y0, gofs, buf, wave, lane);
+        default: return extra + s3_rows<8>(p, s, img0, y0, gofs, buf, wave, lane);
     }
 }
 
@@ -363,12 +372,14 @@ __device__ inline Pos pos_next(int nprob, int bid, int nblk, int rot, const Pos&
     return pos_first(nprob, bid, nblk, rot, c.ii + 1);
 }
 // np: problem visits started so far (the table slot of the problem being computed is (np - 1) & 1, a new one's np & 1)
-__device__ inline void issue_pos(int nprob, int rot, const Pos& q, unsigned char* smem, unsigned char* slot, int np, int wave, int lane) {
+// returns the number of copy instructions this wave queued (0: no further stage)
+__device__ inline int issue_pos(int nprob, int rot, const Pos& q, unsigned char* smem, unsigned char* slot, int np, int wave, int lane) {
     if (q.valid) {
         const S3Prob p = desc_prob(wrap_idx(q.ii + rot, nprob));
         const unsigned tab_dst = (unsigned)(unsigned long long)(lds_ptr_t)(smem + (np & 1) * S3_TABB);
-        s3_issue(p, q.tau, q.s, slot, q.newprob, tab_dst, wave, lane);
+        return s3_issue(p, q.tau, q.s, slot, q.newprob, tab_dst, wave, lane);
     }
+    return 0;
 }
 
 // ---- a tile's end: K-split exchange, epilogue, statistics ---------------------------------------------------------------
@@ -597,6 +608,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
         int img0, y0, nb;
         tile_coords(p, tau, img0, y0, nb);
         const int n0 = nb * (16 * NT);                               // row of the packed weights ([group][rows_pad / 16][k-step] fragments)
+        [[maybe_unused]] int since = D, cq = 0;                       // ring waits since this wave last queued stage copies, and how many (ring_wait)
         const bf16_t* wblk = p.w + (size_t)(n0 / 16) * (size_t)nks * 512;
         int cb = n0, clim = p.Cout;                                  // the block's first output channel / the end of its group's channels
         if (p.groups > 1) {
@@ -618,10 +630,32 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             for (int nt = 0; nt < NT; ++nt)
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a[nt]) : "v"(voff), "s"(wdesc), "s"(wso[nt]) : "memory");
         };
+        // `since` ring waits ago this wave queued `cq` stage copies.  The slot a k-step uses was requested D k-steps earlier: for the first D
+        // k-steps after the copies that is BEFORE them, and everything younger -- NT (D - 1) fragment loads and the copies -- may still be
+        // in flight (loads return in issue order: tools/experiments/dma_order.hip): stepping over the copies instead of sitting them out
+        // (S3_STEP_OVER; the count is rounded down to a multiple of 7: a smaller allowance only waits longer).  Every alternative is ONE
+        // s_waitcnt behind a scalar branch -- the k-step itself exists once (a duplicated ring turn is what broke the stem kernel's
+        // first version: DESIGN.md 3.1).
+        // (The alternatives are operand-free waits followed by ONE statement that hands the slot's registers to the compiler: alternatives
+        // that each carried the registers as "+v" operands made them phi-joined values, and the copies the compiler may then insert read
+        // registers whose loads are still in flight -- wrong results, measured.)
         auto ring_wait = [&](bf16x8* a) {
-            if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(1 * (D - 1)));
-            if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(2 * (D - 1)));
-            if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(3 * (D - 1)));
+            constexpr int N0 = NT * (D - 1);
+            static_assert(N0 + 28 <= 63, "vmcnt");
+#if S3_STEP_OVER
+            if (since < D) {
+                ++since;
+                if (cq >= 28) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0 + 28) : "memory");
+                else if (cq >= 21) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0 + 21) : "memory");
+                else if (cq >= 14) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0 + 14) : "memory");
+                else if (cq >= 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0 + 7) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0) : "memory");
+            } else
+#endif
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0) : "memory");
+            if constexpr (NT == 1) asm volatile("" : "+v"(a[0]));
+            if constexpr (NT == 2) asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+            if constexpr (NT == 3) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
         };
         // The ring runs over this wave's k-steps of the whole tile (stage after stage): k-step i sits in slot i % D and, once
         // used, the slot is refilled with k-step i + D.  The prefetch walks the table's successor links D k-steps ahead of
@@ -659,7 +693,8 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             // of this point: see the header)
             const int tq0 = dbg ? (int)clock64() : 0;      // (debug launches only: per-workgroup sums over ALL stages -- copy issue, k-steps, tile end)
             const Pos nxt = pos_next(nprob, bid, nblk, rot, cur);
-            issue_pos(nprob, rot, nxt, smem, ring + ((g + 1) & 1) * S3_BUF, np, wave, lane);
+            cq = issue_pos(nprob, rot, nxt, smem, ring + ((g + 1) & 1) * S3_BUF, np, wave, lane);
+            since = 0;
             if (dbg && t == 0 && g == 0) dbg[2] = (int)clock64();
             const int tq1 = dbg ? (int)clock64() : 0;
             const unsigned char* const sX = ring + (g & 1) * S3_BUF;
@@ -730,9 +765,8 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
             if (dbg) { const int tq2 = (int)clock64(); dsum[0] += tq1 - tq0; dsum[1] += tq2 - tq1; }
             if (nsteps < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if S3_STRICT_COPIES
-            // belt and braces before the slot is published: the ring waits since the copies imply they have landed IF loads return in
-            // order (observed, tools/experiments/dma_order.hip; not documented) -- wait for everything; the ring's slots stay valid,
-            // their latest refills are simply waited for here instead of D - 1 k-steps later (measured free)
+            // (build knob, off) publish the slot after a full wait instead of on the ring waits' in-order argument; the ring's slots stay
+            // valid, their latest refills are simply waited for here instead of D - 1 k-steps later
             if (s + 1 < nst) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {

@@ -20,7 +20,8 @@ __device__ inline i32x4 mkdesc(const void* p, unsigned bytes) {
 }
 
 // cold: [nblk * rounds][8 KB] of distinct lines per (block, round); hot: 8 KB re-read by everybody.  Every buffer word holds its own word index.
-__global__ __launch_bounds__(64) void order_a(const int* __restrict__ cold, const int* __restrict__ hot, int rounds, int* __restrict__ stale)
+// oob = 1: the copies are requested OUT OF RANGE (the way halo cells and rows outside the image are zero-filled): no memory access behind them
+__global__ __launch_bounds__(64) void order_a(const int* __restrict__ cold, const int* __restrict__ hot, int rounds, int* __restrict__ stale, int oob)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int t = threadIdx.x;
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(64) void order_a(const int* __restrict__ cold, cons
     for (int r = 0; r < rounds; ++r) {
         const int so = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * rounds + r) * 8192));
         const int vo = t * 16;
+        const int hoff = oob ? 0x40000000 : 0;
         int v0 = SENT, v1 = SENT, v2 = SENT, v3 = SENT;
         int snap;
         asm volatile(
@@ -38,21 +40,21 @@ __global__ __launch_bounds__(64) void order_a(const int* __restrict__ cold, cons
             "buffer_load_dword %2, %5, %6, %7 offen offset:2048\n\t"
             "buffer_load_dword %3, %5, %6, %7 offen offset:3072\n\t"
             "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
-            "buffer_load_dwordx4 %5, %9, 0 offen lds\n\t"
-            "buffer_load_dwordx4 %5, %9, 0 offen offset:1024 lds\n\t"
-            "buffer_load_dwordx4 %5, %9, 0 offen offset:2048 lds\n\t"
-            "buffer_load_dwordx4 %5, %9, 0 offen offset:3072 lds\n\t"
+            "buffer_load_dwordx4 %5, %9, %10 offen lds\n\t"
+            "buffer_load_dwordx4 %5, %9, %10 offen offset:1024 lds\n\t"
+            "buffer_load_dwordx4 %5, %9, %10 offen offset:2048 lds\n\t"
+            "buffer_load_dwordx4 %5, %9, %10 offen offset:3072 lds\n\t"
             "s_waitcnt vmcnt(4)\n\t"                       // in order: the four register loads (older) have landed
             "v_mov_b32 %4, %0\n\t"                          // snapshot the OLDEST load's destination (a read of a pending load's register sees the old value)
             "s_waitcnt vmcnt(0)"
             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&v"(snap)
-            : "v"(vo), "s"(dc), "s"(so), "s"(lds0), "s"(dh)
+            : "v"(vo), "s"(dc), "s"(so), "s"(lds0), "s"(dh), "s"(hoff)
             : "memory");
         if (snap == SENT) ++bad;
         if (v0 != (so + vo) / 4 || v3 != (so + 3072 + vo) / 4) bad += 1000;            // (sanity: after vmcnt(0) the data is the word index)
         __syncthreads();
     }
-    if (bad) atomicAdd(&stale[t == 0 ? 0 : 1], bad >= 1000 ? 1000000 : bad);
+    if (bad) atomicAdd(&stale[(oob ? 6 : 0) + (t == 0 ? 0 : 1)], bad >= 1000 ? 1000000 : bad);
 }
 
 __global__ __launch_bounds__(64) void order_b(const int* __restrict__ cold, const int* __restrict__ hot, int rounds, int* __restrict__ stale)
@@ -146,16 +148,17 @@ int main()
     int* h = (int*)malloc(coldb);
     for (size_t i = 0; i < coldb / 4; ++i) h[i] = (int)i;
     CK(hipMemcpy(cold, h, coldb, hipMemcpyHostToDevice)); CK(hipMemcpy(hot, h, 32768, hipMemcpyHostToDevice));
-    int res[6];
+    int res[8];
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(stale, 0, 64));
-        hipLaunchKernelGGL(order_a, dim3(nblk), dim3(64), 8192, 0, cold, hot, rounds, stale);
+        hipLaunchKernelGGL(order_a, dim3(nblk), dim3(64), 8192, 0, cold, hot, rounds, stale, 0);
+        hipLaunchKernelGGL(order_a, dim3(nblk), dim3(64), 8192, 0, cold, hot, rounds, stale, 1);
         hipLaunchKernelGGL(order_b, dim3(nblk), dim3(64), 8192, 0, cold, hot, rounds, stale);
         hipLaunchKernelGGL(order_c, dim3(nblk), dim3(64), 8192, 0, cold, hot, rounds, stale);
         CK(hipDeviceSynchronize());
-        CK(hipMemcpy(res, stale, 24, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(res, stale, 32, hipMemcpyDeviceToHost));
         printf("{\"waves\": %d, \"rounds_per_wave\": %d, \"A_register_load_not_landed_after_vmcnt\": {\"lane0\": %d, \"other_lanes\": %d}, "
-               "\"B_copy_not_landed_after_vmcnt\": {\"lane0\": %d, \"other_lanes\": %d}, \"C_oldest_of_20_register_loads_not_landed_after_vmcnt39_behind_23_copies\": {\"lane0\": %d, \"other_lanes\": %d}}\n", nblk, rounds, res[0], res[1], res[2], res[3], res[4], res[5]);
+               "\"B_copy_not_landed_after_vmcnt\": {\"lane0\": %d, \"other_lanes\": %d}, \"C_oldest_of_20_register_loads_not_landed_after_vmcnt39_behind_23_copies\": {\"lane0\": %d, \"other_lanes\": %d}, \"A_with_out_of_range_copies\": {\"lane0\": %d, \"other_lanes\": %d}}\n", nblk, rounds, res[0], res[1], res[2], res[3], res[4], res[5], res[6], res[7]);
     }
     return 0;
 }
