@@ -56,6 +56,14 @@ class ZeroArena(object):
 
 
 ARENA = ZeroArena()
+
+
+def bn_sums_total(ws, C):
+    """[2, C] fp32 totals of a statistics workspace (danet_bn_ws_floats(C) floats holding [replicas][2][C] accumulators of
+    danet_bn_acc_bytes() bytes -- doubles unless the library was built with DANET_BN_ACC32): the replicas added in index
+    order.  For tests and tools; the kernels read the workspace themselves."""
+    acc = ws.view(torch.float64) if _lib.lib().danet_bn_acc_bytes() == 8 else ws
+    return acc.view(-1, 2, C).sum(0).float()
 # dgrad epilogue reduces the producing BN's backward sums.  Off by default since the one-pass BatchNorm backward (nn.ONEPASS:
 # dy and x read once, sums and apply in one launch) -- measured 34.7 vs 35.1 ms/step with both, 35.4 with the fused
 # reduction alone (the reduction costs the 3x3 data gradients +18 us per launch, as much as it saves elsewhere)
@@ -638,11 +646,11 @@ def channel_sum(gy):
     B, C, H, W = gy.shape
     if not gy.is_cuda or C % 4 != 0 or gy.dtype not in (torch.bfloat16, torch.float32) or not gy.permute(0, 2, 3, 1).is_contiguous():
         return gy.sum(dim=(0, 2, 3), dtype=torch.float32)
-    out = torch.empty(C, dtype=torch.float32, device=gy.device)
+    out = torch.empty(C, dtype=torch.float64, device=gy.device)      # double accumulators: order-independent (csrc/conv_common.h)
     L = _lib.lib()
     fn = L.danet_channel_sum_f32 if gy.dtype == torch.float32 else L.danet_channel_sum
     check(fn(ptr(gy.permute(0, 2, 3, 1)), B * H * W, C, ptr(out), stream()), 'danet_channel_sum')
-    return out
+    return out.float()
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches

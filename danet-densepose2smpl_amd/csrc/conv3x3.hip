@@ -103,7 +103,7 @@ __device__ inline void flush_channel_sums(float (*s1)[4], float (*s2)[4], float*
         const int which = t / (NT * 16), c = t - which * (NT * 16);
         const float v = (sc[(0 * 2 + which) * (NT * 16) + c] + sc[(1 * 2 + which) * (NT * 16) + c]) +
                         (sc[(2 * 2 + which) * (NT * 16) + c] + sc[(3 * 2 + which) * (NT * 16) + c]);
-        if (n0 + c < Ctot) atomicAdd(dst + ((size_t)(rep % bn_ncopy(Ctot)) * 2 + which) * Ctot + n0 + c, v);
+        if (n0 + c < Ctot) bn_acc_add(dst, rep, which, Ctot, n0 + c, v);
     }
     lds_barrier();                          // (the scratch overlays tile cells: the next staging pass rewrites them, pad columns included)
 }

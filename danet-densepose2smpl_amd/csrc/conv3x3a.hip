@@ -37,7 +37,7 @@ template <int TW> struct Geo {
     static constexpr int ROWB = CELLS * 32, PLANE = ROWS * ROWB, SLOT = 4 * PLANE;
     static constexpr int PIECES = SLOT / 16, NDMA = (PIECES + 63) / 64, NCP = (NDMA + 1) / 2;
     static constexpr int TAB = 2 * CA_NEMAX * 2 * 4, OFFT = 2 * NCP * 64 * 4;
-    static constexpr int LDS = 2 * SLOT + CA_EXCH + 2 * TAB + OFFT + 512 + 512;
+    static constexpr int LDS = 2 * SLOT + CA_EXCH + 2 * TAB + OFFT + 512 + 4 * 512;   // + mean / invstd [2][64] + per-wave statistics accumulators [4][2][64]
 };
 
 struct C3aP {
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3a_kernel(C3aP p)
     int* const sTabA = reinterpret_cast<int*>(smem + 2 * G_::SLOT + CA_EXCH);           // [role][entry][half]
     int* const sTabB = sTabA + 2 * CA_NEMAX * 2;
     int* const sOff = sTabB + 2 * CA_NEMAX * 2;                                            // [issuing wave][instruction][lane]
-    float* const sAcc = reinterpret_cast<float*>(sOff + 2 * G_::NCP * 64);                 // [2][64]
-    float* const sMean = sAcc + 128;                                                       // [2][64] mean, invstd
+    float* const sMean = reinterpret_cast<float*>(sOff + 2 * G_::NCP * 64);                // [2][64] mean, invstd
+    float* const sAcc = sMean + 128;                                                       // [wave][2][64]: every wave adds to its own copy (no LDS atomics: their order is not fixed)
     // ---- k-step tables: k-step kidx of the tile = (tap = kidx >> 1, channel pair = kidx & 1); lane half h takes channel plane 2 pair + h
     for (int e = t; e < 2 * CA_NEMAX * 2; e += 256) {
         const int half = e & 1, ent = (e >> 1) % CA_NEMAX, role = (e >> 1) / CA_NEMAX;
@@ -114,10 +114,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3a_kernel(C3aP p)
         if (i < G_::NDMA && q < G_::PIECES) v = ((unsigned)ox < (unsigned)p.W ? row * rowb + ox * pixb + plane * 32 + half * 16 : 0x00ffffff) | (row << 24);
         sOff[e] = v;
     }
-    if (t < 128) {
-        sAcc[t] = 0.f;
-        sMean[t] = p.bn_red ? p.bn_saved[t] : 0.f;
-    }
+    sAcc[t] = 0.f; sAcc[256 + t] = 0.f;
+    if (t < 128) sMean[t] = p.bn_red ? p.bn_saved[t] : 0.f;
     const i32x4 xdesc = raw_desc(p.x, p.bytes);
     int lanebase[CA_MT];
 #pragma unroll
@@ -323,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3a_kernel(C3aP p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a = row_sum16(t1[nt][r]), bq = row_sum16(t2[nt][r]);
-                    if (li == 0) { atomicAdd(&sAcc[nt * 16 + lg * 4 + r], a); atomicAdd(&sAcc[64 + nt * 16 + lg * 4 + r], bq); }
+                    if (li == 0) { sAcc[wave * 128 + nt * 16 + lg * 4 + r] += a; sAcc[wave * 128 + 64 + nt * 16 + lg * 4 + r] += bq; }
                 }
         }
         if constexpr (KW == 1) {
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3a_kernel(C3aP p)
             for (int k = 0; k < 8; ++k) {
                 const float u = row_sum16(s1[a][k]), v = row_sum16(s2[a][k]);
                 const int c = (2 * a + (lg & 1)) * 16 + (lg >> 1) * 8 + k;
-                if (li == 0) { atomicAdd(&sAcc[c], u); atomicAdd(&sAcc[64 + c], v); }
+                if (li == 0) { sAcc[wave * 128 + c] += u; sAcc[wave * 128 + 64 + c] += v; }
             }
     }
     float* const dst = p.bn_red ? p.bn_red : p.stats;
@@ -353,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3a_kernel(C3aP p)
         __syncthreads();
         if (t < 128) {
             const int which = t >> 6, c = t & 63;
-            atomicAdd(dst + ((size_t)(blockIdx.x % bn_ncopy(64)) * 2 + which) * 64 + c, sAcc[t]);
+            bn_acc_add(dst, blockIdx.x, which, 64, c, (sAcc[t] + sAcc[128 + t]) + (sAcc[256 + t] + sAcc[384 + t]));
         }
     }
 }

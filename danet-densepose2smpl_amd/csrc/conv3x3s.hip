@@ -523,8 +523,7 @@ __device__ __forceinline__ void s3_finish(const S3Prob& p, f32x4 (*acc)[NT], flo
                             (sScr[(2 * 2 + which) * (NT * 16) + c] + sScr[(3 * 2 + which) * (NT * 16) + c]);
             // (a GLOBAL atomic: see dbg_ptr -- a FLAT one would serialise every later LDS wait of the kernel)
             if (n0 + c < climit)
-                __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(p.stats + ((size_t)(bid % bn_ncopy(p.Cout_tot)) * 2 + which) * p.Cout_tot + n0 + c), v,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bn_acc_add(p.stats, bid, which, p.Cout_tot, n0 + c, v);
         }
     }
 }

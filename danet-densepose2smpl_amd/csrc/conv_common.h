@@ -24,6 +24,28 @@ __device__ inline float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 1
 constexpr int BN_NCOPY = 32;                        // copies a workspace has room for
 __host__ __device__ inline int bn_ncopy(int C) { return C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); }   // (8/4 and 16/8/4 measured the same step time)
 
+// The accumulators are DOUBLES (DANET_BN_ACC32: floats, the round-1..4 form, kept for A-B timing).  A workgroup's partial sum is an
+// fp32 value; up to 2^4 of them (workgroups / replicas) are added into one replica with global_atomic_add_f64.  Every such
+// addition is EXACT while the non-zero partials of a channel lie within 2^25 of each other in magnitude (24-bit significands,
+// 4 bits of carries, 53-bit accumulator), and exact additions commute: the replica's value -- and with it every BatchNorm
+// statistic of the step -- does not depend on the order in which the workgroups arrive.  (fp32 atomics did: last-bit
+// differences between two executions of the same step, which a deep random-weight net amplifies to per cents)
+// Consumers add the replicas in index order in double precision and round once.  Partials further apart than 2^25 lose
+// bits below 2^-29 of the sum, i.e. could change the fp32 result by one ulp with probability ~2^-29 per sum.
+#ifdef DANET_BN_ACC32
+typedef float bn_acc_t;
+#else
+typedef double bn_acc_t;
+#endif
+constexpr int BN_ACC_FLOATS = (int)(sizeof(bn_acc_t) / sizeof(float));       // workspace floats per accumulator
+// ws: a [BN_NCOPY][2][Ctot] accumulator workspace (danet_bn_ws_floats(Ctot) floats, 8-byte aligned, zeroed); adds v to
+// channel c of row `which` (0: first sum, 1: second) of replica rep % bn_ncopy(Ctot).  A GLOBAL (address space 1) atomic:
+// a flat one would count against the LDS waits of the calling kernel.
+__device__ inline void bn_acc_add(float* ws, int rep, int which, int Ctot, int c, float v) {
+    bn_acc_t* const p = reinterpret_cast<bn_acc_t*>(ws) + ((size_t)(rep % bn_ncopy(Ctot)) * 2 + which) * Ctot + c;
+    __hip_atomic_fetch_add((__attribute__((address_space(1))) bn_acc_t*)p, (bn_acc_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct ConvP {
     const bf16_t* x; const bf16_t* w; const float* bias; void* y;
     int B, H, W, Cin, OH, OW, Cout;

@@ -67,7 +67,7 @@ __device__ inline void channel_sums_to_replicas(float (*s1)[4], float (*s2)[4], 
         const int which = t / (NT * 16), c = t - which * (NT * 16);
         const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
         const int cl = n0 + c;
-        if (cl < Cg) atomicAdd(dst + ((size_t)(rep % bn_ncopy(Ctot)) * 2 + which) * Ctot + cbase + cl, v);
+        if (cl < Cg) bn_acc_add(dst, rep, which, Ctot, cbase + cl, v);
     }
 }
 

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
             const float v = (sStat[0][which][c] + sStat[1][which][c]) + (sStat[2][which][c] + sStat[3][which][c]);
             const int cl = n0 + c;
             if (cl < p.Cout_g)
-                atomicAdd(p.stats + ((size_t)(blockIdx.x % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + g * p.Cout_g + cl, v);
+                bn_acc_add(p.stats, blockIdx.x, which, p.Cout, g * p.Cout_g + cl, v);
         }
     }
 

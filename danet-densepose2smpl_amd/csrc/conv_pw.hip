@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(PwP p)
             for (int s = 0; s < nsub; ++s) v += sStat[((s * p.ngroups + g2) * 2 + which) * (NTB * 16) + c];
             const int ch = g2 * NTB * 16 + c;
             if (ch < p.Cout && g2 * NTB + c / 16 < NB)
-                atomicAdd(p.stats + ((size_t)(blockIdx.x % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + ch, v);
+                bn_acc_add(p.stats, blockIdx.x, which, p.Cout, ch, v);
         }
     }
 }

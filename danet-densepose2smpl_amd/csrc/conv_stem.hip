@@ -42,7 +42,7 @@ constexpr int ST_KS = 25;                                   // k-steps per slab:
 constexpr int ST_TAB = 64 * 4;                              // tap table (bytes)
 constexpr int ST_NCP = (ST_NDMA + 1) / 2;                   // copy instructions per issuing wave
 constexpr int ST_OFFT = 2 * ST_NCP * 64 * 4;                // per-lane source offsets of the copy instructions (two issuing waves)
-constexpr int ST_LDS = 2 * ST_SLOT + ST_TAB + ST_OFFT + 512;      // + per-channel statistics accumulators [2][64]
+constexpr int ST_LDS = 2 * ST_SLOT + ST_TAB + ST_OFFT + 4 * 512;  // + per-wave, per-channel statistics accumulators [4][2][64]
 
 struct StemP {
     const bf16_t* x; const bf16_t* w; void* y; float* stats;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
     // row (row), channels 8 half .. + 7 of the slab.  What a lane copies does not depend on the tile: offsets relative to the tile's first
     // input row, and the row index for the bounds test of the image's top and bottom strips.
     int* const sOff = reinterpret_cast<int*>(smem + 2 * ST_SLOT + ST_TAB);          // [pixel half][instruction][lane]: offset | row << 24, -1 = nothing to copy
-    float* const sAcc = reinterpret_cast<float*>(smem + 2 * ST_SLOT + ST_TAB + ST_OFFT);   // [2][64] statistics of the workgroup's tiles
+    float* const sAcc = reinterpret_cast<float*>(smem + 2 * ST_SLOT + ST_TAB + ST_OFFT);   // [wave][2][64] statistics of the workgroup's tiles (a copy per wave: the order of LDS atomics is not fixed)
     for (int e = t; e < 2 * ST_NCP * 64; e += 256) {
         const int ln = e & 63, u = (e >> 6) % ST_NCP, half_w = (e >> 6) / ST_NCP;
         const int i = half_w + 2 * u;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
         if (i < ST_NDMA && q < ST_PIECES) v = ((unsigned)ix < (unsigned)p.W ? row * rowb + ix * pixb + half * 16 : 0x00ffffff) | (row << 24);
         sOff[e] = v;
     }
-    if (t < 128) sAcc[t] = 0.f;
+    sAcc[t] = 0.f; sAcc[256 + t] = 0.f;
     // ---- per-lane pixel geometry: fragment mt = output row pw * 4 + (mt >> 1), columns (mt & 1) * 16 + li
     int lanebase[ST_MT];
 #pragma unroll
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a = row_sum16(s1[nt][r]), bq = row_sum16(s2[nt][r]);
-                    if (li == 0) { atomicAdd(&sAcc[nt * 16 + lg * 4 + r], a); atomicAdd(&sAcc[64 + nt * 16 + lg * 4 + r], bq); }
+                    if (li == 0) { sAcc[wave * 128 + nt * 16 + lg * 4 + r] += a; sAcc[wave * 128 + 64 + nt * 16 + lg * 4 + r] += bq; }
                 }
         }
 #ifdef ST_DIAG
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_kernel(StemP p)
         __syncthreads();
         if (t < 128) {
             const int which = t >> 6, c = t & 63;
-            atomicAdd(p.stats + ((size_t)(blockIdx.x % bn_ncopy(p.Cout)) * 2 + which) * p.Cout + c, sAcc[t]);
+            bn_acc_add(p.stats, blockIdx.x, which, p.Cout, c, (sAcc[t] + sAcc[128 + t]) + (sAcc[256 + t] + sAcc[384 + t]));
         }
     }
 }

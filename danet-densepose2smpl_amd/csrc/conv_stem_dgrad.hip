@@ -44,7 +44,7 @@ constexpr int SD_NE0 = 52, SD_NE1 = 48, SD_NEMAX = 56;       // k-steps per tile
 constexpr int SD_EXCH = 32768;
 constexpr int SD_TABB = 2 * SD_NEMAX * 2 * 4;                // [role][entry][half] ints
 constexpr int SD_OFFT = 2 * SD_NCP * 64 * 4;
-constexpr int SD_LDS = 2 * SD_SLOT + SD_EXCH + 2 * SD_TABB + SD_OFFT + 512 + 512;   // + statistics accumulators [2][64] + mean / invstd [2][64]
+constexpr int SD_LDS = 2 * SD_SLOT + SD_EXCH + 2 * SD_TABB + SD_OFFT + 512 + 4 * 512;   // + mean / invstd [2][64] + per-wave statistics accumulators [4][2][64]
 
 struct StemDP {
     const bf16_t* dy; const bf16_t* w; void* dx;
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 1) void conv_stem_dgrad_kernel(StemDP p)
     int* const sTabA = reinterpret_cast<int*>(smem + 2 * SD_SLOT + SD_EXCH);          // [role][entry][half]: weight byte offset of the half fragment
     int* const sTabB = sTabA + 2 * SD_NEMAX * 2;                                        // ... LDS byte offset of the tap's cell relative to the pixel's
     int* const sOff = sTabB + 2 * SD_NEMAX * 2;                                         // [issuing wave][instruction][lane]
-    float* const sAcc = reinterpret_cast<float*>(sOff + 2 * SD_NCP * 64);               // [2][64]
-    float* const sMean = sAcc + 128;                                                    // [2][64] mean, invstd
+    float* const sMean = reinterpret_cast<float*>(sOff + 2 * SD_NCP * 64);              // [2][64] mean, invstd
+    float* const sAcc = sMean + 128;                                                    // [wave][2][64]: a copy per wave (the order of LDS atomics is not fixed)
     // ---- k-step tables
     for (int e = t; e < 2 * SD_NEMAX * 2; e += 256) {
         const int half = e & 1, ent = (e >> 1) % SD_NEMAX, role = (e >> 1) / SD_NEMAX;
@@ -129,10 +129,8 @@ __global__ __launch_bounds__(256, 1) void conv_stem_dgrad_kernel(StemDP p)
         if (i < SD_NDMA && q < SD_PIECES) v = ((unsigned)ox < (unsigned)SD_JW ? row * rowb + ox * pixb + plane * 32 + half * 16 : 0x00ffffff) | (row << 24);
         sOff[e] = v;
     }
-    if (t < 128) {
-        sAcc[t] = 0.f;
-        sMean[t] = p.bn_red ? p.bn_saved[t] : 0.f;                                      // [2][64]: mean, invstd
-    }
+    sAcc[t] = 0.f; sAcc[256 + t] = 0.f;
+    if (t < 128) sMean[t] = p.bn_red ? p.bn_saved[t] : 0.f;                             // [2][64]: mean, invstd
     const i32x4 ydesc = raw_desc(p.dy, p.dy_bytes);
     int lanebase[SD_MT];
 #pragma unroll
@@ -327,12 +325,12 @@ __global__ __launch_bounds__(256, 1) void conv_stem_dgrad_kernel(StemDP p)
             for (int k = 0; k < 8; ++k) {
                 const float u = row_sum16(s1[a][k]), v = row_sum16(s2[a][k]);
                 const int c = (2 * a + (lg & 1)) * 16 + (lg >> 1) * 8 + k;
-                if (li == 0) { atomicAdd(&sAcc[c], u); atomicAdd(&sAcc[64 + c], v); }
+                if (li == 0) { sAcc[wave * 128 + c] += u; sAcc[wave * 128 + 64 + c] += v; }
             }
         __syncthreads();
         if (t < 128) {
             const int which = t >> 6, c = t & 63;
-            atomicAdd(p.bn_red + ((size_t)(blockIdx.x % bn_ncopy(64)) * 2 + which) * 64 + c, sAcc[t]);
+            bn_acc_add(p.bn_red, blockIdx.x, which, 64, c, (sAcc[t] + sAcc[128 + t]) + (sAcc[256 + t] + sAcc[384 + t]));
         }
     }
 }

@@ -47,7 +47,7 @@ __device__ inline float wave_sum(float v) {
 __global__ __launch_bounds__(256) void iuv_global_fwd_kernel(
     const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ ix, const float* __restrict__ an, int ld, int lda,
     const float* __restrict__ gt, const float* __restrict__ w, const float* __restrict__ keep, int B, int HW, int want_loss,
-    bf16_t* __restrict__ map, unsigned char* __restrict__ am_raw, unsigned char* __restrict__ am_drop, float* __restrict__ sums)
+    bf16_t* __restrict__ map, unsigned char* __restrict__ am_raw, unsigned char* __restrict__ am_drop, double* __restrict__ sums)
 {
     __shared__ float sred[4][4];
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void iuv_global_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float s = wave_sum(l[i]); if (lane == 0) sred[wv][i] = s; }
         __syncthreads();
-        if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]));
+        // double accumulators: adding the workgroups' fp32 partial sums is exact, so the totals do not depend on the arrival order (conv_common.h)
+        if (threadIdx.x < 4)
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) double*)(sums + threadIdx.x),
+                                   (double)((sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void softargmax_bwd_kernel(const float* __rest
 // mask), sums[4] += (sum smooth-L1 U, sum smooth-L1 V, sum CE index, sum CE ann), each term weighted by w.
 extern "C" int danet_iuv_global_forward(const float* u, const float* v, const float* ix, const float* an, int ld, int lda,
                                         const float* gt, const float* w, const float* keep, int B, int H, int W, int want_loss,
-                                        void* map, unsigned char* am_raw, unsigned char* am_drop, float* sums, void* stream)
+                                        void* map, unsigned char* am_raw, unsigned char* am_drop, double* sums, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(u && v && ix && map && am_raw && am_drop && B > 0 && H > 0 && W > 0, "iuv_global_forward: bad arguments");

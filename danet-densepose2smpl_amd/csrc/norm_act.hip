@@ -123,8 +123,11 @@ struct RowIter {
     __device__ inline void next() { row += rstep * UNR; off += ostride * UNR; }
 };
 
-__device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int CV, int span, float* dst /* [C] */) {
-    // sm: [256][VW]; lanes with equal (t % CV) are summed in a fixed order, then one atomic per channel
+using danet_conv::bn_acc_t;
+template <typename T>
+__device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int CV, int span, T* dst /* [C] */) {
+    // sm: [256][VW]; lanes with equal (t % CV) are summed in a fixed order, then one atomic per channel (T = bn_acc_t: a
+    // double accumulator, whose value does not depend on the order of these atomics -- conv_common.h)
     if (t < span) {
 #pragma unroll
         for (int j = 0; j < VW; ++j) sm[t][j] = a.v[j];
@@ -138,7 +141,8 @@ __device__ inline void block_channel_reduce(float (*sm)[VW], Vec a, int t, int C
 #pragma unroll
             for (int j = 0; j < VW; ++j) s.v[j] += sm[u][j];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) atomicAdd(dst + t * VW + j, s.v[j]);
+        for (int j = 0; j < VW; ++j)
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) T*)(dst + t * VW + j), (T)s.v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 }
@@ -147,24 +151,24 @@ constexpr int SLAB = 1024;   // channels per launch (wider tensors are processed
 
 // Sum the NCOPY replicas of a [2][Cst] accumulator for the Cs channels of this slab into LDS: the
 // 2*Cs sums are spread over the block's lanes, each issuing NCOPY independent loads (fixed order).
-__device__ inline void reduce_replicas(const float* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
+__device__ inline void reduce_replicas(const bn_acc_t* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
     const int ncopy = danet_conv::bn_ncopy(Cst);             // 4 .. 32 (a multiple of 4): the replicas this width uses
     for (int i = t; i < 2 * Cs; i += 256) {
         const int which = i >= Cs ? 1 : 0, c = i - which * Cs;
-        float s = 0.f;
+        bn_acc_t s = 0;
         for (int r0 = 0; r0 < ncopy; r0 += 4) {
-            float v[4];
+            bn_acc_t v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = rep[(size_t)(r0 + r) * 2 * Cst + (size_t)which * Cst + c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) s += v[r];
         }
-        sStat[which][c] = s;
+        sStat[which][c] = (float)s;
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict__ x, FlatMap fm, float* __restrict__ sums /* [2][Cst] */, int Cst)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict__ x, FlatMap fm, bn_acc_t* __restrict__ sums /* [2][Cst] */, int Cst)
 {
     __shared__ float sm[256][VW];
     const int t = threadIdx.x;
@@ -196,13 +200,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict_
                 }
         }
     }
-    float* dst = sums + (size_t)(blockIdx.x % danet_conv::bn_ncopy(Cst)) * 2 * Cst;
+    bn_acc_t* dst = sums + (size_t)(blockIdx.x % danet_conv::bn_ncopy(Cst)) * 2 * Cst;
     block_channel_reduce(sm, s, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, q, t, fm.CV, fm.span, dst + Cst);
 }
 
-// per-channel sums of a [M, C] tensor (bias gradients): one atomic per channel and block into out[C] (fp32, zeroed by the host)
-__global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restrict__ x, FlatMap fm, float* __restrict__ out)
+// per-channel sums of a [M, C] tensor (bias gradients): one atomic per channel and block into out[C] (DOUBLES, zeroed by the host: the
+// additions of the workgroups' fp32 partial sums are exact, so the totals do not depend on their order -- conv_common.h)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restrict__ x, FlatMap fm, double* __restrict__ out)
 {
     __shared__ float sm[256][VW];
     const int t = threadIdx.x;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restri
 // mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
 __device__ __forceinline__ void bn_apply_body(
     const int bid, const elem_t* __restrict__ x, const elem_t* __restrict__ res, elem_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const bn_acc_t* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved /* [2][Cst] mean, invstd */,
     int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu, unsigned char* __restrict__ mask)
 {
@@ -317,7 +322,7 @@ __device__ __forceinline__ void bn_apply_body(
 template <int GATE>
 __device__ __forceinline__ void bn_bwd_reduce_body_g(
     const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ saved, int Cst, float* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */,
+    const float* __restrict__ saved, int Cst, bn_acc_t* __restrict__ red /* [2][Cst]: sum dy', sum dy'*xhat */,
     const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta, float (*sm)[VW])
 {
     constexpr int relu = GATE != 3, mask_mode = GATE == 3 ? 0 : GATE;
@@ -361,13 +366,13 @@ __device__ __forceinline__ void bn_bwd_reduce_body_g(
                 }
         }
     }
-    float* dst = red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
+    bn_acc_t* dst = red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
 }
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red,
+    const float* __restrict__ saved, int Cst, int relu, bn_acc_t* __restrict__ red,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
 {
     __shared__ float sm[256][VW];
@@ -382,7 +387,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
 template <int GATE>
 __device__ __forceinline__ void bn_bwd_apply_body_g(
     const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const bn_acc_t* __restrict__ red,
     int Cst, float inv_count, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
     const unsigned char* __restrict__ mask, const float* __restrict__ beta, float (*sStat)[SLAB])
 {
@@ -447,7 +452,7 @@ __device__ __forceinline__ void bn_bwd_apply_body_g(
 }
 __device__ __forceinline__ void bn_bwd_apply_body(
     const int bid, const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, const FlatMap& fm,
-    const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const bn_acc_t* __restrict__ red,
     int Cst, float inv_count, int relu, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
 {
@@ -462,7 +467,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const elem_t* __restrict__ x, const elem_t* __restrict__ res, elem_t* __restrict__ y, FlatMap fm,
-    const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const bn_acc_t* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ saved,
     int Cst, float inv_count, float unbias, float momentum, float eps, int mode, int relu, unsigned char* __restrict__ mask)
 {
@@ -470,14 +475,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 }
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, FlatMap fm,
-    const float* __restrict__ saved, int Cst, int relu, float* __restrict__ red,
+    const float* __restrict__ saved, int Cst, int relu, bn_acc_t* __restrict__ red,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ beta)
 {
     bn_bwd_reduce_body(blockIdx.x, dy, x, y, fm, saved, Cst, relu, red, mask_mode, mask, gamma, beta);
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ y, FlatMap fm,
-    const float* __restrict__ saved, const float* __restrict__ gamma, const float* __restrict__ red,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const bn_acc_t* __restrict__ red,
     int Cst, float inv_count, int relu, elem_t* __restrict__ dx, elem_t* __restrict__ dres, float* __restrict__ dparam,
     int mask_mode, const unsigned char* __restrict__ mask, const float* __restrict__ beta)
 {
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // small branches' launches are dominated by the per-launch floor, one launch over all of them is not.
 constexpr int NBM = 8;
 struct BnFwdOne {
-    const elem_t* x; const elem_t* res; elem_t* y; const float* sums; const float* gamma; const float* beta;
+    const elem_t* x; const elem_t* res; elem_t* y; const bn_acc_t* sums; const float* gamma; const float* beta;
     float* running_mean; float* running_var; float* saved; unsigned char* mask; FlatMap fm; int C; float inv_count, unbias; int relu;
 };
 struct BnFwdMulti { BnFwdOne a[NBM]; int start[NBM + 1]; int n; float momentum, eps; int mode; };
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdMulti m)
                   a.C, a.inv_count, a.unbias, m.momentum, m.eps, m.mode, a.relu, a.mask);
 }
 struct BnBwdOne {
-    const elem_t* dy; const elem_t* x; const elem_t* y; const float* saved; const float* gamma; float* red;
+    const elem_t* dy; const elem_t* x; const elem_t* y; const float* saved; const float* gamma; bn_acc_t* red;
     elem_t* dx; elem_t* dres; float* dparam; const float* beta; const unsigned char* mask;
     FlatMap fm; int C; float inv_count; int relu; int have_red; int mask_mode;
 };
@@ -593,21 +598,26 @@ __device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
 // reduce_replicas with agent-scope loads (sc1: served by L2, never by this CU's L1): the sums other workgroups added
 // before a grid barrier.  The loads of a lane are independent buffer loads (a loop of __hip_atomic_load was serialised
 // one round trip each: 30 us per launch).
-__device__ inline void reduce_replicas_sc1(const float* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
+__device__ inline void ld_acc_sc1(__amdgpu_buffer_rsrc_t rr, int off, double& v) { v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 16 /* sc1 */)); }
+__device__ inline void ld_acc_sc1(__amdgpu_buffer_rsrc_t rr, int off, float& v) { v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off, 0, 16 /* sc1 */)); }
+__device__ inline void reduce_replicas_sc1(const bn_acc_t* __restrict__ rep, int Cst, int Cs, int t, float (*sStat)[SLAB]) {
     const int ncopy = danet_conv::bn_ncopy(Cst);
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc(rep, (int)((size_t)NCOPY * 2 * Cst * 4));
+    constexpr int AB = (int)sizeof(bn_acc_t);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(rep, (int)((size_t)NCOPY * 2 * Cst * AB));
     for (int i = t; i < 2 * Cs; i += 256) {
         const int which = i >= Cs ? 1 : 0, c = i - which * Cs;
-        float s = 0.f;
+        bn_acc_t s = 0;
         for (int r0 = 0; r0 < ncopy; r0 += 4) {
-            float v[4];
+            bn_acc_t v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (((r0 + r) * 2 + which) * Cst + c) * 4, 0, 16 /* sc1 */));
+            for (int r = 0; r < 4; ++r) {
+                const int off = (((r0 + r) * 2 + which) * Cst + c) * AB;
+                ld_acc_sc1(rr, off, v[r]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) s += v[r];
         }
-        sStat[which][c] = s;
+        sStat[which][c] = (float)s;
     }
     __syncthreads();
 }
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
         gq[k].x = q0; gq[k].y = q1; xq[k].x = q2; xq[k].y = q3;
     }
-    float* dst = a.red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
+    bn_acc_t* dst = a.red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
     if (!(m.dbg & 1)) grid_barrier(m.bar, gridDim.x);
@@ -949,7 +959,7 @@ extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y
 #endif
     hipStream_t st = (hipStream_t)stream;
     if (training && !ws_is_zero) {
-        hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
+        hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_forward: memset: %s", hipGetErrorString(e));
     }
     const float inv = 1.0f / (float)M, unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
@@ -959,11 +969,11 @@ extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_forward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         // per-slab views of the per-channel buffers: [2][C] buffers are addressed as base+c0 with stride C
         if (training && ws_is_zero != 2) {          // ws_is_zero == 2: the statistics were accumulated by the conv epilogue
-            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, sums_ws + c0, C);
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, (bn_acc_t*)sums_ws + c0, C);
             DANET_CHECK_LAUNCH("bn_stats_kernel");
         }
         hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, (const elem_t*)res, (elem_t*)y, fm,
-                           sums_ws ? sums_ws + c0 : nullptr, gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr,
+                           sums_ws ? (const bn_acc_t*)sums_ws + c0 : nullptr, gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr,
                            running_mean ? running_mean + c0 : nullptr, running_var ? running_var + c0 : nullptr,
                            saved ? saved + c0 : nullptr, C, inv, unbias, momentum, eps, training ? 0 : 1, relu, (unsigned char*)relu_mask);
         DANET_CHECK_LAUNCH("bn_apply_kernel");
@@ -973,7 +983,8 @@ extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y
 
 // red_ws: danet_bn_ws_floats(C) floats of scratch; dparam [2][C] (may be NULL) receives (d beta, d gamma).
 #ifndef NA_F32
-extern "C" size_t danet_bn_ws_floats(int C) { return (size_t)NCOPY * 2 * C; }
+extern "C" size_t danet_bn_ws_floats(int C) { return (size_t)NCOPY * 2 * C * danet_conv::BN_ACC_FLOATS; }
+extern "C" int danet_bn_acc_bytes(void) { return (int)sizeof(bn_acc_t); }
 #endif
 
 extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const void* y, int64_t M, int C,
@@ -988,7 +999,7 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
     DANET_CHECK_ARG(C % VW == 0, "bn_backward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
     if (!ws_is_zero) {
-        hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * C * NCOPY, st);
+        hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
     }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
@@ -997,26 +1008,26 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "bn_backward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
         if (ws_is_zero != 2) {                     // ws_is_zero == 2: the sums were accumulated by the consumer conv's dgrad epilogue
             hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)y,
-                               fm, saved + c0, C, relu, red_ws + c0, mask_mode, (const unsigned char*)relu_mask,
+                               fm, saved + c0, C, relu, (bn_acc_t*)red_ws + c0, mask_mode, (const unsigned char*)relu_mask,
                                gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr);
             DANET_CHECK_LAUNCH("bn_bwd_reduce_kernel");
         }
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)y,
-                           fm, saved + c0, gamma ? gamma + c0 : nullptr, red_ws + c0, C, 1.0f / (float)M, relu, (elem_t*)dx, (elem_t*)dres,
+                           fm, saved + c0, gamma ? gamma + c0 : nullptr, (const bn_acc_t*)red_ws + c0, C, 1.0f / (float)M, relu, (elem_t*)dx, (elem_t*)dres,
                            dparam ? dparam + c0 : nullptr, mask_mode, (const unsigned char*)relu_mask, beta ? beta + c0 : nullptr);
         DANET_CHECK_LAUNCH("bn_bwd_apply_kernel");
     }
     return DANET_OK;
 }
 
-// out[C] (fp32) = sum over the M rows of x [M, C] (the bias gradient of a convolution: gy.sum(dim = (0, 2, 3))); out is zeroed
+// out[C] (doubles) = sum over the M rows of x [M, C] (the bias gradient of a convolution: gy.sum(dim = (0, 2, 3))); out is zeroed
 // here (memset node) and accumulated with one atomic per channel and workgroup.  C % 4 == 0, C <= 1024 per launch slab.
-extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, float* out, void* stream)
+extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, double* out, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && out && M > 0 && C > 0 && C % VW == 0, "channel_sum: bad arguments (C=%d must be a multiple of %d)", C, VW);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t err = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+    hipError_t err = hipMemsetAsync(out, 0, sizeof(double) * (size_t)C, st);
     if (err != hipSuccess) return danet::fail(DANET_ERR_HIP, "channel_sum: memset: %s", hipGetErrorString(err));
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
@@ -1113,10 +1124,10 @@ extern "C" int NA_NAME(danet_bn_forward_multi)(const void* jobs_, int n, float m
         int grid;
         DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_forward_multi: job %d: C=%d unsupported", i, j.C);
         if (j.sums_state == 1) {
-            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)j.x, a.fm, j.sums, j.C);
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)j.x, a.fm, (bn_acc_t*)j.sums, j.C);
             DANET_CHECK_LAUNCH("bn_stats_kernel");
         }
-        a.x = (const elem_t*)j.x; a.res = (const elem_t*)j.res; a.y = (elem_t*)j.y; a.sums = j.sums; a.gamma = j.gamma; a.beta = j.beta;
+        a.x = (const elem_t*)j.x; a.res = (const elem_t*)j.res; a.y = (elem_t*)j.y; a.sums = (const bn_acc_t*)j.sums; a.gamma = j.gamma; a.beta = j.beta;
         a.running_mean = j.running_mean; a.running_var = j.running_var; a.saved = j.saved; a.C = j.C; a.mask = (unsigned char*)j.mask;
         a.inv_count = 1.0f / (float)j.M; a.unbias = j.M > 1 ? (float)j.M / (float)(j.M - 1) : 1.f; a.relu = j.relu;
         m.start[i + 1] = m.start[i] + grid;
@@ -1143,7 +1154,7 @@ extern "C" int NA_NAME(danet_bn_backward_multi)(const void* jobs_, int n, void* 
         BnBwdOne& a = m.a[i];
         int grid;
         DANET_CHECK_ARG(make_map(j.M, j.C, 0, j.C, &a.fm, &grid) == 0, "bn_backward_multi: job %d: C=%d unsupported", i, j.C);
-        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
+        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = (bn_acc_t*)j.red;
         a.dx = (elem_t*)j.dx; a.dres = (elem_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
         a.have_red = j.red_state == 2; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
         need_reduce = need_reduce || !a.have_red;
@@ -1205,7 +1216,7 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */, 
         if (blocks < 1) blocks = 1;
         if (blocks > max_blocks) return 0;
         a.fm.rstep = (int)(rows_per_block * blocks);
-        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = j.red;
+        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = (bn_acc_t*)j.red;
         a.dx = (elem_t*)j.dx; a.dres = (elem_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
         a.have_red = 0; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
         if (!m || m->start[m->n] + blocks > max_blocks) { m = &ms[nl++]; m->n = 0; m->start[0] = 0; }

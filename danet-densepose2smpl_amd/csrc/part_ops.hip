@@ -155,7 +155,7 @@ __device__ inline float smooth_l1(float d) { const float a = fabsf(d); return a 
 __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
                                                         const float* __restrict__ theta, const float* __restrict__ wsample,
                                                         const int* __restrict__ sel, int B, int H, int W, int align, int cpj,
-                                                        float* __restrict__ sums /* [NREP][3] */)
+                                                        double* __restrict__ sums /* [NREP][3] */)
 {
     const int HW = H * W;
     const long total = (long)B * HW * NJ;
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict
     __syncthreads();
     if (threadIdx.x < 3) {
         const float s = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
-        atomicAdd(sums + (blockIdx.x % NREP) * 3 + threadIdx.x, s);
+        // (double accumulators: exact, order-independent adds -- conv_common.h)
+        __hip_atomic_fetch_add((__attribute__((address_space(1))) double*)(sums + (blockIdx.x % NREP) * 3 + threadIdx.x), (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -257,7 +258,7 @@ extern "C" int danet_part_clean_backward(const void* g24, const void* pred, cons
 
 // sums: [32][3] floats, zeroed by the caller; the loss terms are the column sums.
 extern "C" int danet_part_loss_forward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
-                                       const int* sel, int B, int H, int W, int align, int cpj, float* sums, void* stream)
+                                       const int* sel, int B, int H, int W, int align, int cpj, double* sums, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(pred && iuv_img && theta && sel && sums && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_loss_forward: bad arguments");

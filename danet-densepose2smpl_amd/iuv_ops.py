@@ -41,13 +41,13 @@ class IuvGlobalFunction(torch.autograd.Function):
         mp = torch.empty(B, H, W, MAPC, dtype=torch.bfloat16, device=dev)
         am_raw = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
         am_drop = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
-        sums = torch.zeros(4, dtype=torch.float32, device=dev)
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)         # double accumulators: exact, order-independent adds of the workgroups' partial sums
         check(L.danet_iuv_global_forward(u.data_ptr(), v.data_ptr(), ix.data_ptr(), an.data_ptr(), 32, 16, ptr(gtc), ptr(wc), ptr(kc),
                                          B, H, W, int(want), ptr(mp), ptr(am_raw), ptr(am_drop), ptr(sums), stream()), 'danet_iuv_global_forward')
         ctx.save_for_backward(u, v, ix, an, gtc, wc, kc, am_drop)
         ctx.want = want
         ctx.mark_non_differentiable(am_raw)
-        return sums, mp.permute(0, 3, 1, 2), am_raw
+        return sums.float(), mp.permute(0, 3, 1, 2), am_raw
 
     @staticmethod
     def backward(ctx, gsums, gmap, _g_am):

@@ -83,14 +83,14 @@ class PartLossFunction(torch.autograd.Function):
         ctx.cpj = _cpj(C)
         if img.shape != (B, 3, H, W) or th.shape != (B, NJ, 2, 3) or sel.shape != (NJ, 6):
             raise ValueError('part_losses: bad shapes %s %s %s' % (tuple(img.shape), tuple(th.shape), tuple(sel.shape)))
-        sums = ARENA.alloc(32 * 3)
+        sums = ARENA.alloc(32 * 3 * 2)              # [32][3] doubles: exact, order-independent adds of the workgroups' partial sums
         if sums is None:
-            sums = torch.zeros(32 * 3, dtype=torch.float32, device=pred.device)
+            sums = torch.zeros(32 * 3 * 2, dtype=torch.float32, device=pred.device)
         check(_lib.lib().danet_part_loss_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), B, H, W, int(align), ctx.cpj,
                                                  ptr(sums), stream()), 'danet_part_loss_forward')
         ctx.save_for_backward(pred, img, th, w, sel)
         ctx.align = int(align)
-        return sums.view(32, 3).sum(dim=0)
+        return sums.view(torch.float64).view(32, 3).sum(dim=0, dtype=torch.float64).float()
 
     @staticmethod
     def backward(ctx, g):

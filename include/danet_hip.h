@@ -120,14 +120,14 @@ int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float
  *  u, v, ix: fp32 [B*H*W][ld] (25 valid channels, 28 <= ld <= 32, ld % 4 == 0); an: [B*H*W][lda = 16] (15 valid);
  *  gt: rendered IUV image [B,3,H,W] fp32 NCHW (want_loss only); w: [B] per-sample weights or NULL; keep: [B,25] part-drop
  *  mask or NULL.  forward: map = bf16 [B*H*W][80] (U*onehot | V*onehot | onehot | 5 zeros; one-hot of argmax(ix*keep)),
- *  am_raw / am_drop = uint8 argmax of ix / ix*keep, sums[4] += (sum smooth-L1 U, V at the ground-truth part's channel,
+ *  am_raw / am_drop = uint8 argmax of ix / ix*keep, sums[4] (DOUBLES: order-independent accumulation) += (sum smooth-L1 U, V at the ground-truth part's channel,
  *  sum CE of the 25-way index, sum CE of the 15-way Ann logits), weighted by w.  backward: coef[4] = dL/dsums (device),
  *  dmap = gradient of map or NULL; du, dv, di ([..][ld]) and da ([..][lda]) are fully written.
  *  softargmax: hm fp32 [B*H*W][ld] (J valid) -> out [B,J,2] = E[(x, y)] under softmax(scale*hm); saved [B,J,4] feeds the
  *  backward, which writes dhm as dense [B*H*W][J]. */
 int danet_iuv_global_forward(const float* u, const float* v, const float* ix, const float* an, int ld, int lda,
                              const float* gt, const float* w, const float* keep, int B, int H, int W, int want_loss,
-                             void* map, unsigned char* am_raw, unsigned char* am_drop, float* sums, void* stream);
+                             void* map, unsigned char* am_raw, unsigned char* am_drop, double* sums, void* stream);
 int danet_iuv_global_backward(const float* u, const float* v, const float* ix, const float* an, int ld, int lda,
                               const float* gt, const float* w, const float* keep, const unsigned char* am_drop,
                               const void* dmap, const float* coef, int B, int H, int W, int want_loss,
@@ -194,7 +194,7 @@ int danet_adam_step(const void* table, int nchunks, float* m, float* v, const fl
  * when the conv's group-padded output is consumed as it is (the 3 padding channels per joint get zero gradients).
  *  danet_part_clean_*   x24 [B*24,H,W,24] bf16 = iuvmap_clean(keep[B,24,7] * pred) (+3 zero channels);
  *                       backward: d pred from d x24 (U,V channels only).
- *  danet_part_loss_*    sums [32][3] (zeroed by the caller; column sums = smooth-L1 U, smooth-L1 V,
+ *  danet_part_loss_*    sums [32][3] DOUBLES (order-independent accumulation; zeroed by the caller; column sums = smooth-L1 U, smooth-L1 V,
  *                       index cross-entropy) against the [B,3,H,W] IUV image resampled per joint by
  *                       theta [B,24,2,3]; sel [24][6] int; sample_w [B] (NULL = 1).  backward: d pred for
  *                       scale[0..2] * the three sums (scale on the device).
@@ -202,7 +202,7 @@ int danet_adam_step(const void* table, int nchunks, float* m, float* v, const fl
 int danet_part_clean_forward(const void* pred, const float* keep, int B, int H, int W, int cpj, void* x24, void* stream);
 int danet_part_clean_backward(const void* g24, const void* pred, const float* keep, int B, int H, int W, int cpj, void* gpred, void* stream);
 int danet_part_loss_forward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
-                            const int* sel, int B, int H, int W, int align, int cpj, float* sums, void* stream);
+                            const int* sel, int B, int H, int W, int align, int cpj, double* sums, void* stream);
 int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
                              const int* sel, const float* scale, int B, int H, int W, int align, int cpj, void* gpred, void* stream);
 
@@ -236,13 +236,13 @@ int danet_part_loss_backward(const void* pred, const float* iuv_img, const float
  *      start = running sum of the element counts danet_conv_pack_job_fill returned for the per-element jobs
  *      before it.  total_elems / total_bricks are the two final sums.  The destination buffers must be zeroed
  *      once (the brick launch does not write padding).
- *      bn_sums (optional, [32][2][Cout] fp32, zeroed by the caller): per-channel sum and sum of squares of the
+ *      bn_sums (optional, danet_bn_ws_floats(Cout) floats = [32][2][Cout] accumulators, see danet_bn_acc_bytes; zeroed by the caller): per-channel sum and sum of squares of the
  *      bf16 output, accumulated by the epilogue; pass it to danet_bn_forward with ws_is_zero = 2 to skip
  *      the separate statistics pass.
  *      bn_x / bn_y / bn_saved / bn_red (optional, data-gradient launches on the fast kernel only): the
  *      BatchNorm that produced this conv's input -- its input bn_x, its output bn_y (NULL = no ReLU), its
  *      saved [mean | invstd] -- for which the epilogue accumulates sum(dy') and sum(dy'*xhat) into bn_red
- *      ([32][2][C], zeroed); danet_bn_backward with ws_is_zero = 2 then skips its reduction pass.
+ *      ([32][2][C] accumulators, zeroed); danet_bn_backward with ws_is_zero = 2 then skips its reduction pass.
  *      bn_gate (LDS-tile 3x3 kernel only; 0 elsewhere) says where that reduction takes the ReLU gate from: 0 = bn_y
  *      as above, 2 = bn_y points at the byte mask danet_bn_forward wrote (relu_mask): one byte per lane instead of eight.
  *  danet_conv_wgrad         dW (fp32, torch layout) = beta*dW + sum_pixels dY (x) X.
@@ -426,6 +426,13 @@ int danet_bn_forward(const void* x, const void* res, void* y, int64_t M, int C,
                      float* saved, float* sums_ws, int ws_is_zero, float momentum, float eps, int training, int relu,
                      void* relu_mask, void* stream);
 size_t danet_bn_ws_floats(int C);
+/* The statistics workspaces (sums_ws, red_ws, bn_sums, bn_red: danet_bn_ws_floats(C) floats each, 8-byte aligned) hold
+ * [32][2][C] accumulators of danet_bn_acc_bytes() bytes: 8 = double (the default), 4 = float (library built with
+ * -DDANET_BN_ACC32, the round-1..4 form, for A-B timing).  A workgroup adds its fp32 partial sums into replica
+ * (workgroup id % replicas) with one device-scope atomic per channel; in double precision every such addition is exact
+ * (partials of a channel within 2^25 of each other), so the statistics -- and the whole training step -- do not depend on
+ * the order in which workgroups arrive: two executions of the same step agree bit for bit (tests/test_gpu_zz_paths.py). */
+int danet_bn_acc_bytes(void);
 int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, int C,
                       const float* gamma, const float* saved, int relu,
                       void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero,
@@ -458,10 +465,10 @@ int danet_bn_backward_multi(const void* jobs, int n, void* stream);
 int danet_bn_backward_onepass_bar_words(void);
 int danet_bn_backward_onepass_ok(const void* jobs, int n, int max_blocks);
 int danet_bn_backward_onepass(const void* jobs, int n, void* bar, int max_blocks, void* stream);
-/* out[C] (fp32) = sum over the M rows of x [M, C] (bf16; _f32: fp32): the bias gradient of a convolution,
+/* out[C] (DOUBLES: order-independent accumulation) = sum over the M rows of x [M, C] (bf16; _f32: fp32): the bias gradient of a convolution,
  * gy.sum(dim = (0, 2, 3)) in /root/reference's autograd.  out is zeroed here; C % 4 == 0. */
-int danet_channel_sum(const void* x, int64_t M, int C, float* out, void* stream);
-int danet_channel_sum_f32(const void* x, int64_t M, int C, float* out, void* stream);
+int danet_channel_sum(const void* x, int64_t M, int C, double* out, void* stream);
+int danet_channel_sum_f32(const void* x, int64_t M, int C, double* out, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,
                            int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,

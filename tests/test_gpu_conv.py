@@ -236,7 +236,7 @@ def test_lds_tile_3x3_kernel_vs_torch_fp32(shape, tiling):
         assert sums is not None
         # the epilogue accumulates the statistics from its fp32 accumulators (conv3x3.hip) or from the bf16-rounded values
         # (conv_fast.hip): both sit within the rounding noise of the fp32 result's sums
-        s = sums.view(-1, 2, Cout).sum(0)
+        s = dconv.bn_sums_total(sums, Cout)
         yf = yr.detach()
         close(s[0], yf.sum(dim=(0, 2, 3)), 5e-3, 'statistics: sum')
         close(s[1], (yf * yf).sum(dim=(0, 2, 3)), 2e-3, 'statistics: sum of squares')
@@ -410,7 +410,7 @@ def test_production_launches_run_on_the_streamed_kernel_and_match_torch_fp32():
         gx = dconv._conv_fwd_raw(gn[i], wp1[i], None, B, s, s, c, s, s, c, 3, 3, 1, 1, 1, 1, True, False, False)
         close(y, refs[i][0], 1e-2, 'forward %d' % c)
         close(gx, refs[i][1], 1e-2, 'dgrad %d' % c)
-        st = sums.view(-1, 2, c).sum(0)
+        st = dconv.bn_sums_total(sums, c)
         close(st[0], refs[i][0].sum(dim=(0, 2, 3)), 5e-3, 'statistics: sum %d' % c)
         close(st[1], (refs[i][0] ** 2).sum(dim=(0, 2, 3)), 2e-3, 'statistics: squares %d' % c)
     # the four-branch lockstep launch (forward + statistics, then the data gradients)
@@ -427,7 +427,7 @@ def test_production_launches_run_on_the_streamed_kernel_and_match_torch_fp32():
         for i, c in enumerate(chans):
             close(ys[i], refs[i][1 if transposed else 0], 1e-2, 'four-branch %s %d' % ('dgrad' if transposed else 'forward', c))
             if not transposed:
-                st = sums[i].view(-1, 2, c).sum(0)
+                st = dconv.bn_sums_total(sums[i], c)
                 close(st[0], refs[i][0].sum(dim=(0, 2, 3)), 5e-3, 'four-branch statistics: sum %d' % c)
                 close(st[1], (refs[i][0] ** 2).sum(dim=(0, 2, 3)), 2e-3, 'four-branch statistics: squares %d' % c)
 
@@ -475,7 +475,7 @@ def test_pointwise_kernel_vs_torch_fp32(shape):
             y32 = dconv._conv_fwd_raw(xn, wp, b, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, False, True, True)
             yadd = dconv._conv_fwd_raw(xn, wp, None, B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, 1, False, False, False, None, None, add)
             torch.cuda.synchronize()
-            res[on] = (y.detach(), xt.grad, None if sums is None else sums.view(-1, 2, Cout).sum(0), y32, yadd, add, wt.grad.clone())
+            res[on] = (y.detach(), xt.grad, None if sums is None else dconv.bn_sums_total(sums, Cout), y32, yadd, add, wt.grad.clone())
         finally:
             L.danet_conv_pw_set(prev)
     y, gx, st, y32, yadd, add, gw = res[1]
@@ -565,7 +565,7 @@ def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
             y = dconv._conv_fwd_raw(xn, wp, None, B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, False, False, False, sums)
             yb = dconv._conv_fwd_raw(xn, wp, bias, B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, False, False, False)      # the head's own form: with a bias
             torch.cuda.synchronize()
-            res[on] = (y.float(), sums.view(-1, 2, G * Ng).sum(0), yb.float())
+            res[on] = (y.float(), dconv.bn_sums_total(sums, G * Ng), yb.float())
         finally:
             L.danet_conv3x3_stream_set(prev, -1, -1, -1)
     scale = yr.abs().max().item()
@@ -608,7 +608,7 @@ def test_stem_7x7_stride2_lds_tile_kernel_vs_torch_fp32(B, Cin):
     finally:
         L.danet_conv_stem_set(prev)
     assert (y.float() - y2.float()).abs().max().item() <= 1e-2 * scale
-    st = sums.view(-1, 2, Cout).sum(0)
+    st = dconv.bn_sums_total(sums, Cout)
     yb = y.float()
     assert (st[0] - yb.sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * yb.sum(dim=(0, 2, 3)).abs().max().item() + 1e-4 * scale * B
     assert (st[1] - (yb * yb).sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * (yb * yb).sum(dim=(0, 2, 3)).abs().max().item()
@@ -653,7 +653,7 @@ def test_stem_7x7_stride2_data_gradient_lds_tile_kernel(B):
         gf = gx.float() * ((gate.float() > 0).float() if gate is not None else 1.0)
         xhat = (bn_x.float() - saved[:C].view(1, -1, 1, 1)) * saved[C:].view(1, -1, 1, 1)
         s1, s2 = gf.sum(dim=(0, 2, 3)), (gf * xhat).sum(dim=(0, 2, 3))
-        st, st2 = red.view(-1, 2, C).sum(0), red2.view(-1, 2, C).sum(0)
+        st, st2 = dconv.bn_sums_total(red, C), dconv.bn_sums_total(red2, C)
         tol1, tol2 = 2e-3 * gf.abs().sum(dim=(0, 2, 3)).max().item(), 2e-3 * (gf * xhat).abs().sum(dim=(0, 2, 3)).max().item()
         assert (st[0] - s1).abs().max().item() <= tol1 and (st[1] - s2).abs().max().item() <= tol2
         assert (st[0] - st2[0]).abs().max().item() <= 4 * tol1 and (st[1] - st2[1]).abs().max().item() <= 4 * tol2
@@ -706,7 +706,7 @@ def test_conv3x3a_row_tile_kernel_forward_and_data_gradient(B, H, W):
     scale = ref.abs().max().item()
     assert (y[idx].float() - ref).abs().max().item() <= 1e-2 * scale
     assert (y.float() - y0.float()).abs().max().item() <= 1e-2 * scale
-    yb, st = y.float(), sums.view(-1, 2, C).sum(0)
+    yb, st = y.float(), dconv.bn_sums_total(sums, C)
     assert (st[0] - yb.sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * yb.abs().sum(dim=(0, 2, 3)).max().item()
     assert (st[1] - (yb * yb).sum(dim=(0, 2, 3))).abs().max().item() <= 2e-3 * (yb * yb).sum(dim=(0, 2, 3)).max().item()
     # ---- data gradient
@@ -731,7 +731,7 @@ def test_conv3x3a_row_tile_kernel_forward_and_data_gradient(B, H, W):
         assert torch.equal(gxb, gx)
         gf = gx.float() * ((bn_y.float() > 0).float() if gate_t is not None else 1.0)
         s1, s2 = gf.sum(dim=(0, 2, 3)), (gf * xhat).sum(dim=(0, 2, 3))
-        st = red.view(-1, 2, C).sum(0)
+        st = dconv.bn_sums_total(red, C)
         assert (st[0] - s1).abs().max().item() <= 2e-3 * gf.abs().sum(dim=(0, 2, 3)).max().item(), mode
         assert (st[1] - s2).abs().max().item() <= 2e-3 * (gf * xhat).abs().sum(dim=(0, 2, 3)).max().item(), mode
     # ---- repeatability of the hand-counted waits
