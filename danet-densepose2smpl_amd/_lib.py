@@ -84,7 +84,7 @@ _SIGNATURES = {
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),
     'danet_bn_acc_bytes': (c_i, []),
-    'danet_channel_sum': (c_i, [c_f, ctypes.c_int64, c_i, c_f, c_f]),
+    'danet_channel_sum': (c_i, [c_f, ctypes.c_int64, c_i, c_f, c_i, c_f]),
     'danet_bn_set_block_bytes': (ctypes.c_long, [ctypes.c_long]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),

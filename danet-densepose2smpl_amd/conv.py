@@ -28,6 +28,8 @@ class ZeroArena(object):
         self.buf = None
         self.off = 0
         self.high = 0
+        self.zeroed = 0             # extent the current step's begin_step cleared
+        self.refused = []           # (offset, floats, cleared extent) of the slices a capture was refused (diagnostics)
 
     def enable(self, device, floats=160 * 1024 * 1024):
         self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
@@ -41,6 +43,7 @@ class ZeroArena(object):
         if self.buf is not None:
             if self.high > 0:
                 self.buf[:self.high].zero_()
+            self.zeroed = self.high
             self.high = 0
             self.off = 0
 
@@ -48,6 +51,11 @@ class ZeroArena(object):
         """-> (tensor, is_zero).  Falls back to a fresh (non-zeroed) tensor when inactive or full."""
         n16 = (n + 15) // 16 * 16
         if self.buf is None or self.off + n16 > self.buf.numel():
+            return None
+        if self.off + n16 > self.zeroed and torch.cuda.is_current_stream_capturing():
+            # a captured step clears, on every replay, what the step BEFORE the capture used: a slice beyond that extent would be
+            # zero in the first replay only (the caller falls back to a buffer it zeroes itself)
+            self.refused.append((self.off, n, self.zeroed))
             return None
         t = self.buf[self.off:self.off + n]
         self.off += n16
@@ -638,6 +646,9 @@ class Conv2dFunction(torch.autograd.Function):
                 gx._bn_red = bn_bwd[3]       # consumed by the producing BatchNorm's backward if gx reaches it unsummed
         if has_bias and ctx.needs_input_grad[2]:
             gb = channel_sum(gy)
+            if TRACE is not None:
+                TRACE.append(('bias_grad:gy', tuple(gy.shape), gy.float().abs().max()))
+                TRACE.append(('bias_grad:gb', tuple(gb.shape), gb.float().abs().max()))
         return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
@@ -646,11 +657,17 @@ def channel_sum(gy):
     B, C, H, W = gy.shape
     if not gy.is_cuda or C % 4 != 0 or gy.dtype not in (torch.bfloat16, torch.float32) or not gy.permute(0, 2, 3, 1).is_contiguous():
         return gy.sum(dim=(0, 2, 3), dtype=torch.float32)
-    out = torch.empty(C, dtype=torch.float64, device=gy.device)      # double accumulators: order-independent (csrc/conv_common.h)
+    # double accumulators: order-independent (csrc/conv_common.h); a slice of the step's zeroed arena when there is one
+    out = ARENA.alloc(2 * C) if CHSUM_ARENA else None
+    zero = out is not None
+    out = out.view(torch.float64) if zero else torch.empty(C, dtype=torch.float64, device=gy.device)
     L = _lib.lib()
     fn = L.danet_channel_sum_f32 if gy.dtype == torch.float32 else L.danet_channel_sum
-    check(fn(ptr(gy.permute(0, 2, 3, 1)), B * H * W, C, ptr(out), stream()), 'danet_channel_sum')
+    check(fn(ptr(gy.permute(0, 2, 3, 1)), B * H * W, C, ptr(out), int(zero), stream()), 'danet_channel_sum')
     return out.float()
+
+
+CHSUM_ARENA = bool(int(os.environ.get('DANET_CHSUM_ARENA', '1')))       # A-B / debugging knob: 0 = a memset node per call
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches

@@ -31,4 +31,11 @@ inline int fail(int code, const char* fmt, ...) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero `bytes` (a multiple of 4) at p (4-byte aligned) with a KERNEL on `stream` (capi.hip).  The library never enqueues
+// hipMemsetAsync: captured into a hipGraph it becomes a memset NODE, and on this stack (ROCm 7.0 runtime under torch 2.10)
+// a memset node followed by a kernel that accumulates into the same buffer was observed to race -- round 5 found one head
+// bias gradient in two turning into inf after a few replays of the captured train step (tools/replay_probe.py; the bias
+// gradients of danet_channel_sum were the step's only memset nodes), never in eager execution.
+hipError_t zero_async(void* p, size_t bytes, hipStream_t stream);
+
 }  // namespace danet

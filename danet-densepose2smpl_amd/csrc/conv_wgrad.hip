@@ -20,8 +20,14 @@ using namespace danet_conv;
 constexpr int CHUNK = 32;              // pixels per MFMA k-step
 constexpr int LDP = CHUNK + 8;         // padded pixel row (80 B: conflict-free ds_read_b128)
 
+// The packed accumulator dWp holds bn_acc_t values (doubles; conv_common.h): every workgroup adds its fp32 partial products with one
+// device-scope atomic per element, and in double precision those additions are exact (partials of an element within 2^(29 - log2
+// msplit) of each other), hence independent of the order in which the pixel chunks' workgroups arrive -- the weight gradients of
+// two executions of the same step agree bit for bit.
+typedef bn_acc_t wg_acc_t;
+constexpr int WG_ACC_FLOATS = BN_ACC_FLOATS;
 struct WgradP {
-    const bf16_t* x; const bf16_t* dy; float* dwp; const float* zero;
+    const bf16_t* x; const bf16_t* dy; wg_acc_t* dwp; const float* zero;
     int B, H, W, Cin, OH, OW, Cout;
     int R, S, stride, pad, dil, groups;
     int Cin_g, Cout_g;
@@ -213,7 +219,8 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
         for (int r = 0; r < 4; ++r) {
             const int cout = co0 + ct * 16 + lg * 4 + r;
             if (cout < p.Cout_g)
-                atomicAdd(p.dwp + (((size_t)g * taps + tap) * p.Cout_g + cout) * p.Cin_g + cin, acc[q][r]);
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) wg_acc_t*)(p.dwp + (((size_t)g * taps + tap) * p.Cout_g + cout) * p.Cin_g + cin),
+                                       (wg_acc_t)acc[q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradMulti mp)
     wgrad_body<CT, NI, TG>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
 }
 
-struct UnpackMulti { const float* dwp[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], taps[NPM]; long start[NPM + 1]; int n; float beta; };
+struct UnpackMulti { const wg_acc_t* dwp[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], taps[NPM]; long start[NPM + 1]; int n; float beta; };
 
 __global__ __launch_bounds__(256) void wgrad_unpack_multi_kernel(UnpackMulti up)
 {
@@ -256,13 +263,13 @@ __global__ __launch_bounds__(256) void wgrad_unpack_multi_kernel(UnpackMulti up)
     const int cin = (int)(rest % Cin_g); rest /= Cin_g;
     const int cout = (int)(rest % Cout_g);
     const int g = (int)(rest / Cout_g);
-    const float v = up.dwp[i][(((size_t)g * taps + tap) * Cout_g + cout) * Cin_g + cin];
+    const float v = (float)up.dwp[i][(((size_t)g * taps + tap) * Cout_g + cout) * Cin_g + cin];
     float* dw = up.dw[i];
     dw[idx] = up.beta != 0.f ? dw[idx] * up.beta + v : v;
 }
 
 // dWp[G][taps][Cout_g][Cin_g] -> dW[Cout][Cin_g][R][S]  (beta = 0: overwrite, 1: accumulate)
-__global__ void wgrad_unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
+__global__ void wgrad_unpack_kernel(const wg_acc_t* __restrict__ dwp, float* __restrict__ dw,
                                     int G, int Cout_g, int Cin_g, int taps, float beta)
 {
     const long total = (long)G * Cout_g * Cin_g * taps;
@@ -273,7 +280,7 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ dwp, float* __rest
     const int cin = (int)(rest % Cin_g); rest /= Cin_g;
     const int cout = (int)(rest % Cout_g);
     const int g = (int)(rest / Cout_g);
-    const float v = dwp[(((size_t)g * taps + tap) * Cout_g + cout) * Cin_g + cin];
+    const float v = (float)dwp[(((size_t)g * taps + tap) * Cout_g + cout) * Cin_g + cin];
     dw[idx] = beta != 0.f ? dw[idx] * beta + v : v;
 }
 
@@ -297,7 +304,7 @@ extern "C" int danet_conv_wgrad_kernel_id(int Cin, int Cout, int groups, int tap
 }
 
 extern "C" size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S) {
-    return (size_t)Cout * Cin_g * R * S + 16;            // + a zero block the kernel reads for out-of-range runs
+    return (size_t)Cout * Cin_g * R * S * WG_ACC_FLOATS + 16;            // accumulators (wg_acc_t) + a zero block the kernel reads for out-of-range runs
 }
 
 // Workspace of danet_conv_wgrad for a given problem: the packed accumulator of danet_conv_wgrad_ws_floats, or -- 1x1 / stride-1 layers
@@ -334,7 +341,7 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
         }
     }
     WgradP p;
-    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dwp = ws;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dwp = (wg_acc_t*)ws;
     p.zero = ws + (danet_conv_wgrad_ws_floats(Cout, Cin / groups, R, S) - 16);
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.dil = dil; p.groups = groups;
@@ -344,7 +351,7 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
     if (ws_floats < need) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu floats", ws_floats, need);
     hipStream_t st = (hipStream_t)stream;
     if (!ws_is_zero) {
-        hipError_t e = hipMemsetAsync(ws, 0, need * sizeof(float), st);
+        hipError_t e = danet::zero_async(ws, need * sizeof(float), st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "conv_wgrad: memset: %s", hipGetErrorString(e));
     }
     const int taps = R * S;
@@ -375,7 +382,7 @@ extern "C" int danet_conv_wgrad(const void* x, const void* dy, float* dw, float*
 #undef WG_CASE1
     DANET_CHECK_LAUNCH("conv_wgrad_kernel");
     const long total = (long)Cout * p.Cin_g * taps;
-    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, st, ws, dw, groups, p.Cout_g,
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(danet::cdiv(total, 256)), dim3(256), 0, st, (const wg_acc_t*)ws, dw, groups, p.Cout_g,
                        p.Cin_g, taps, beta);
     DANET_CHECK_LAUNCH("wgrad_unpack_kernel");
     return DANET_OK;
@@ -432,7 +439,7 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
             const WgJob& j = jobs[idx[k]];
             WgradP& p = mp.p[k];
             const int taps = j.R * j.S;
-            p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.dwp = ws ? ws + used : nullptr; p.zero = nullptr;
+            p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.dwp = ws ? (wg_acc_t*)(ws + used) : nullptr; p.zero = nullptr;
             p.B = j.B; p.H = j.H; p.W = j.W; p.Cin = j.Cin; p.OH = j.OH; p.OW = j.OW; p.Cout = j.Cout;
             p.R = j.R; p.S = j.S; p.stride = j.stride; p.pad = j.pad; p.dil = j.dil; p.groups = j.groups;
             p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
@@ -451,7 +458,7 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
             const long total = (long)j.Cout * p.Cin_g * taps;
             up.dwp[k] = p.dwp; up.dw[k] = j.dw; up.G[k] = j.groups; up.Cout_g[k] = p.Cout_g; up.Cin_g[k] = p.Cin_g; up.taps[k] = taps;
             up.start[k + 1] = up.start[k] + total;
-            used += (size_t)(total + 15) / 16 * 16;
+            used += (size_t)(total * WG_ACC_FLOATS + 15) / 16 * 16;
         }
         if (!ws) continue;
         if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad_multi: workspace too small");

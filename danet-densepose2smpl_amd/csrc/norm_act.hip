@@ -959,7 +959,7 @@ extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y
 #endif
     hipStream_t st = (hipStream_t)stream;
     if (training && !ws_is_zero) {
-        hipError_t e = hipMemsetAsync(sums_ws, 0, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
+        hipError_t e = danet::zero_async(sums_ws, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_forward: memset: %s", hipGetErrorString(e));
     }
     const float inv = 1.0f / (float)M, unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
@@ -999,7 +999,7 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
     DANET_CHECK_ARG(C % VW == 0, "bn_backward: C=%d must be a multiple of %d", C, VW);
     hipStream_t st = (hipStream_t)stream;
     if (!ws_is_zero) {
-        hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
+        hipError_t e = danet::zero_async(red_ws, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
     }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
@@ -1022,13 +1022,15 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
 
 // out[C] (doubles) = sum over the M rows of x [M, C] (the bias gradient of a convolution: gy.sum(dim = (0, 2, 3))); out is zeroed
 // here (memset node) and accumulated with one atomic per channel and workgroup.  C % 4 == 0, C <= 1024 per launch slab.
-extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, double* out, void* stream)
+extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, double* out, int out_is_zero, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(x && out && M > 0 && C > 0 && C % VW == 0, "channel_sum: bad arguments (C=%d must be a multiple of %d)", C, VW);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t err = hipMemsetAsync(out, 0, sizeof(double) * (size_t)C, st);
-    if (err != hipSuccess) return danet::fail(DANET_ERR_HIP, "channel_sum: memset: %s", hipGetErrorString(err));
+    if (!out_is_zero) {
+        hipError_t err = danet::zero_async(out, sizeof(double) * (size_t)C, st);
+        if (err != hipSuccess) return danet::fail(DANET_ERR_HIP, "channel_sum: memset: %s", hipGetErrorString(err));
+    }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;

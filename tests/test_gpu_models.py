@@ -23,26 +23,6 @@ from make_golden import formula_params, formula_input, damp_residual_branches   
 
 pytestmark = pytest.mark.gpu
 
-import contextlib
-
-
-@contextlib.contextmanager
-def _fixed_order_bn():
-    """BatchNorm statistics in their fixed-order configuration (one workgroup per tensor, no conv-epilogue statistics, no
-    one-pass backward).  With the production grids the per-channel sums are float atomics into replicas, whose order
-    changes with the launch sequence: last-bit differences that a random-weight, batch-2 net amplifies to several per
-    cent in the heat-map losses and to O(1) in that head's gradients (tools/debug_flaky.py) -- noise that says nothing
-    about the equivalence of two execution paths.  The production configuration of the same kernels is pinned by
-    test_gpu_norm.py and by the fusion-count test."""
-    from danet_densepose2smpl_amd import conv as _conv, nn as _dnn, _lib as _l
-    prev = (_l.lib().danet_bn_set_block_bytes(1 << 40), _conv.FUSE_BN_STATS, _dnn.ONEPASS)
-    _conv.FUSE_BN_STATS, _dnn.ONEPASS = False, False
-    try:
-        yield
-    finally:
-        _l.lib().danet_bn_set_block_bytes(prev[0])
-        _conv.FUSE_BN_STATS, _dnn.ONEPASS = prev[1], prev[2]
-
 KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
 
 

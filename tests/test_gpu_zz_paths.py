@@ -18,26 +18,6 @@ from make_golden import formula_params, formula_input, damp_residual_branches   
 
 pytestmark = pytest.mark.gpu
 
-import contextlib
-
-
-@contextlib.contextmanager
-def _fixed_order_bn():
-    """BatchNorm statistics in their fixed-order configuration (one workgroup per tensor, no conv-epilogue statistics, no
-    one-pass backward).  With the production grids the per-channel sums are float atomics into replicas, whose order
-    changes with the launch sequence: last-bit differences that a random-weight, batch-2 net amplifies to several per
-    cent in the heat-map losses and to O(1) in that head's gradients (tools/debug_flaky.py) -- noise that says nothing
-    about the equivalence of two execution paths.  The production configuration of the same kernels is pinned by
-    test_gpu_norm.py and by the fusion-count test."""
-    from danet_densepose2smpl_amd import conv as _conv, nn as _dnn, _lib as _l
-    prev = (_l.lib().danet_bn_set_block_bytes(1 << 40), _conv.FUSE_BN_STATS, _dnn.ONEPASS)
-    _conv.FUSE_BN_STATS, _dnn.ONEPASS = False, False
-    try:
-        yield
-    finally:
-        _l.lib().danet_bn_set_block_bytes(prev[0])
-        _conv.FUSE_BN_STATS, _dnn.ONEPASS = prev[1], prev[2]
-
 KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
 
 
@@ -120,63 +100,48 @@ def test_full_size_graphed_step_properties():
 
 
 def test_graphed_step_matches_eager_step():
-    """hipGraph replay (side-stream branches, accumulator arena, weight bank) computes what plain eager
-    launches compute.  The learning rate is ~0 so that every step sees the same weights and the loss
-    terms can be compared directly.
-
-    BatchNorm sums in fixed order: see _fixed_order_bn."""
-    with _fixed_order_bn():
-        _graphed_step_matches_eager_step()
-
-
-def _graphed_step_matches_eager_step():
+    """hipGraph replay (accumulator arena, weight bank, weight packing inside the graph) computes what plain eager launches
+    compute, in the production BatchNorm configuration: the learning rate is ~0, so every step sees the same weights, and
+    since the step's sums are order-independent (csrc/conv_common.h) the replayed losses and weight gradients must EQUAL the
+    eager step's bit for bit.  The first eager step computes every weight gradient inside its backward node (single-problem
+    launches), the later ones through the deferred multi-problem launches: a different decomposition into partial sums,
+    so those two agree to fp32 rounding (1e-4 relative L2 per tensor), not bit for bit."""
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
     from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
     dev = torch.device('cuda')
     torch.manual_seed(0)
     from danet_densepose2smpl_amd import trainer as trainer_mod
-    # 'pretrain_mode' (danet.py: IUV estimator only, no SMPL regressor): the limb regressor ends in BatchNorms over
-    # B x 1 x 1 values, whose backward at a test-sized batch is a difference of nearly equal numbers -- it turns
-    # last-bit changes (atomics order, the GEMM variant hipBLASLt picks for the GCN) into 20 %..O(1) gradient changes
-    # from one run to the next (tools/debug_flaky.py), which says nothing about graph-vs-eager equivalence.
     NB = 2
     tr = Trainer(default_options(NB), device=dev, distributed=False, lr=1e-30)
     batch = synthetic_in_dict(tr.model, NB, dev, seed=1)
-    batch['pretrain_mode'] = True
+    batch['pretrain_mode'] = True            # (danet.py: IUV estimator only, no SMPL regressor)
     trainer_mod.DEFER_WGRAD = False          # first step: every weight gradient computed inside its backward node ...
     try:
         _, losses = tr.train_step(batch)
     finally:
         trainer_mod.DEFER_WGRAD = True       # ... afterwards: queued and computed by the multi-problem launches
-    eager = {k: float(v.sum()) for k, v in losses.items()}
+    eager = {k: v.detach().float().sum().clone() for k, v in losses.items()}
     named = [(n, p) for n, p in tr.model.named_parameters() if p.grad is not None and p.dim() == 4]
-    picks = named[::max(1, len(named) // 40)]                      # ~40 conv weights spread over the model
-    g_eager = {n: p.grad.detach().clone() for n, p in picks}
+    g_eager = {n: p.grad.detach().clone() for n, p in named}
     _, losses = tr.train_step(batch)
-    eager2 = {k: float(v.sum()) for k, v in losses.items()}
-    g_eager2 = {n: p.grad.detach().clone() for n, p in picks}
+    eager2 = {k: v.detach().float().sum().clone() for k, v in losses.items()}
+    g_eager2 = {n: p.grad.detach().clone() for n, p in named}
     tr.capture(batch, warmup=2)
     tr.train_step_graphed()
     _, losses = tr.train_step_graphed()
     torch.cuda.synchronize()
-    graphed = {k: float(v.sum()) for k, v in losses.items()}
+    graphed = {k: v.detach().float().sum().clone() for k, v in losses.items()}
     for k in eager:
-        noise = abs(eager[k] - eager2[k])
-        # (serial eager launches can be bit-reproducible while the graph's concurrent branches reorder the float
-        # atomics: allow the few-per-mille drift a batch-2 bf16 net turns that into)
-        assert abs(eager[k] - graphed[k]) <= 6 * noise + 3e-2 * abs(eager[k]) + 1e-4, (k, eager[k], eager2[k], graphed[k])
+        assert torch.equal(eager[k], eager2[k]) and torch.equal(eager2[k], graphed[k]), (k, float(eager[k]), float(eager2[k]), float(graphed[k]))
     assert tr.bank is not None and tr.bank.jobs is not None and len(tr.bank.entries) > 200
-    # Weight gradients: step 1 computed them inside the backward nodes, step 2 and the graph through the deferred
-    # multi-problem launches (and, in the graph, with side-stream branches).  Run-to-run differences come from float
-    # atomics amplified by a deep bf16 net at batch 2 -- a few per cent on the earliest layers -- while an
-    # unwritten / stale gradient would be off by O(1): relative L2 error per tensor, loose bound on each, tight on the median.
+
     def rel(a, ref):
         return ((a - ref).norm() / (ref.norm() + 1e-12)).item()
-    r_defer = [rel(g_eager2[n], g_eager[n]) for n, _ in picks]
-    r_graph = [rel(p.grad, g_eager[n]) for n, p in picks]
-    assert max(r_defer) < 0.3 and sorted(r_defer)[len(r_defer) // 2] < 0.05, ('deferred vs immediate', sorted(r_defer)[-3:])
-    assert max(r_graph) < 0.3 and sorted(r_graph)[len(r_graph) // 2] < 0.05, ('graph vs eager', sorted(r_graph)[-3:])
+    r_defer = {n: rel(g_eager2[n], g_eager[n]) for n, _ in named}
+    assert max(r_defer.values()) < 1e-4, ('deferred vs immediate', sorted(r_defer.items(), key=lambda kv: -kv[1])[:3])
+    for n, p in named:
+        assert torch.equal(p.grad, g_eager2[n]), ('graph vs eager', n, rel(p.grad, g_eager2[n]))
 
 
 @pytest.mark.parametrize('lds_tile', [False, True], ids=['gather_kernel', 'lds_tile_kernel'])
@@ -219,14 +184,8 @@ def test_lockstep_branches_match_per_branch_execution(lds_tile):
 
 
 def test_graphed_full_step_losses_match_eager():
-    """The full model (regressor included) through hipGraph replay: every loss term equals the eager step's
-    (learning rate ~0; gradients of this path are not compared at test batch sizes, see the test above).
-    BatchNorm sums in fixed order: see _fixed_order_bn."""
-    with _fixed_order_bn():
-        _graphed_full_step_losses_match_eager()
-
-
-def _graphed_full_step_losses_match_eager():
+    """The full model (regressor included) at batch 2 through hipGraph replay, production BatchNorm configuration: every loss
+    term equals the eager step's bit for bit (learning rate ~0; the gradients of the full model are compared in the next test)."""
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
     from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
@@ -235,77 +194,76 @@ def _graphed_full_step_losses_match_eager():
     tr = Trainer(default_options(2), device=dev, distributed=False, lr=1e-30)
     batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
     _, l1 = tr.train_step(batch)
-    e1 = {k: float(v.sum()) for k, v in l1.items()}
+    e1 = {k: v.detach().float().sum().clone() for k, v in l1.items()}
     _, l2 = tr.train_step(batch)
-    e2 = {k: float(v.sum()) for k, v in l2.items()}
+    e2 = {k: v.detach().float().sum().clone() for k, v in l2.items()}
     tr.capture(batch, warmup=1)
     tr.train_step_graphed()
     _, lg = tr.train_step_graphed()
     torch.cuda.synchronize()
-    g = {k: float(v.sum()) for k, v in lg.items()}
+    g = {k: v.detach().float().sum().clone() for k, v in lg.items()}
     assert set(g) == set(e1) and len(g) == 17
     for k in e1:
-        assert abs(e1[k] - g[k]) <= 6 * abs(e1[k] - e2[k]) + 3e-2 * abs(e1[k]) + 1e-4, (k, e1[k], e2[k], g[k])
+        assert torch.isfinite(e1[k]) and torch.equal(e1[k], e2[k]) and torch.equal(e1[k], g[k]), (k, float(e1[k]), float(e2[k]), float(g[k]))
 
 
 def test_graph_equals_eager_in_the_production_batchnorm_configuration():
-    """Path equivalence WITHOUT _fixed_order_bn: replica atomics + conv-epilogue statistics + the one-pass
-    BatchNorm backward with its grid barrier -- the configuration bench.py runs -- eager against hipGraph replay of the same
-    step.  The residual branches are damped (the closing BatchNorm's gamma of every block x 0.2, the zero-init-residual idea, as
-    make_golden.damp_residual_branches does for the ResNet fixture) so that the last-bit noise of atomic ordering is not
-    amplified layer by layer: two EAGER runs then agree to well under 1e-2, and the replayed graph must agree with them to
-    1e-2 on every loss and on the gradients -- a wrong-but-finite interaction of the three fusions would not."""
+    """Path equivalence in the configuration bench.py runs (replica accumulators + conv-epilogue statistics + the one-pass
+    BatchNorm backward with its grid barrier), with NO noise precondition: every per-channel statistic,
+    loss sum, bias gradient and atomically accumulated weight gradient of the step is an order-independent sum (doubles:
+    csrc/conv_common.h), so three eager executions and four hipGraph replays of one step (same batch, same weights, learning
+    rate ~0) must produce BIT-IDENTICAL losses and -- parameter by parameter -- bit-identical gradients.  A wrong-but-finite
+    interaction of the three fusions, a race, or a replay that reads stale memory (round 5 found one: a memset NODE racing
+    with the bias-gradient kernel turned one head bias gradient into inf after a few replays) cannot pass this.
+    The only tolerated differences: gradient elements below 1e-6 of their tensor's largest (doubles are exact only while the
+    partial sums of an element lie within 2^25 of each other: elements that are zero up to rounding may differ in that
+    rounding), and the handful of GCN parameters whose gradient is a sum of huge cancelling terms computed by torch's own
+    library kernels (BatchNorm1d / BLAS), which choose their algorithm differently under capture."""
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
     from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
-    from danet_densepose2smpl_amd import nn as dnn, conv as dconv
+    from danet_densepose2smpl_amd import nn as dnn, conv as dconv, _lib
+    if _lib.lib().danet_bn_acc_bytes() != 8:
+        pytest.skip('library built with DANET_BN_ACC32 (fp32 accumulators, the A-B timing form): sums depend on the arrival order')
     dev = torch.device('cuda')
     torch.manual_seed(0)
     assert dnn.ONEPASS and dconv.FUSE_BN_STATS
     tr = Trainer(default_options(8), device=dev, distributed=False, lr=1e-30)
-    with torch.no_grad():
-        for k, p in tr.model.named_parameters():
-            if k.endswith('bn2.weight') or k.endswith('bn3.weight'):
-                p.mul_(0.2)
     batch = synthetic_in_dict(tr.model, 8, dev, seed=1)
     tr.train_step(batch)
 
     def snap(losses):
         torch.cuda.synchronize()
-        return ({k: float(v.sum()) for k, v in losses.items()},
-                {n: p.grad.detach().float().clone() for n, p in tr.model.named_parameters() if p.grad is not None and p.dim() == 4})
+        return ({k: v.detach().float().sum().clone() for k, v in losses.items()},
+                {n: p.grad.detach().float().clone() for n, p in tr.model.named_parameters() if p.grad is not None})
     dconv.FUSION.clear()
-    e1 = snap(tr.train_step(batch)[1])
+    runs = [snap(tr.train_step(batch)[1])]
     assert dconv.FUSION.get('bn_bwd_onepass', 0) > 100 and dconv.FUSION.get('bn_stats_fused', 0) > 100, dict(dconv.FUSION)
-    eager = [e1] + [snap(tr.train_step(batch)[1]) for _ in range(3)]
+    runs += [snap(tr.train_step(batch)[1]) for _ in range(2)]
     tr.capture(batch, warmup=1)
     assert tr.fusion_counts.get('bn_bwd_onepass', 0) > 100 and tr.fusion_counts.get('bn_stats_fused', 0) > 100
-    tr.train_step_graphed()
-    g = snap(tr.train_step_graphed()[1])
+    runs += [snap(tr.train_step_graphed()[1]) for _ in range(4)]
     assert not dnn.onepass_error()
-    rel = lambda a, b: abs(a - b) / (abs(b) + 1e-6)               # noqa: E731
-    pairs = [(i, j) for i in range(len(eager)) for j in range(i)]
-    # noise = the largest disagreement among FOUR eager runs (one pair is a single draw of a heavy-tailed quantity and made this
-    # test flaky inside the full suite); the replay is compared with the eager run nearest to it
-    noise = {k: max(rel(eager[i][0][k], eager[j][0][k]) for i, j in pairs) for k in e1[0]}
-    diff = {k: min(rel(g[0][k], e[0][k]) for e in eager) for k in e1[0]}
-    quiet = [k for k in noise if noise[k] < 3e-3]
-    # the dense IUV losses and most others are quiet in this net (eager runs agree to < 3e-3): the replayed graph must match those
-    # to 1e-2; the regressor's joint losses sit behind the soft-argmax / STN crop chain and stay noisy (~1e-2) even damped: those are
-    # held to three times their own eager-vs-eager noise
-    assert len(quiet) >= 8 and all(k in quiet for k in ('loss_U', 'loss_V', 'loss_IndexUV', 'loss_segAnn')), ('the damped net is not quiet enough for this test', noise)
-    for k in diff:
-        assert diff[k] < (1e-2 if k in quiet else 3 * noise[k] + 2e-2), (k, diff[k], noise[k], e1[0][k], g[0][k])
-    gn = lambda a, b: ((a - b).norm() / (b.norm() + 1e-20)).item()   # noqa: E731
-    names = sorted(e1[1])
-    assert set(g[1]) == set(e1[1])
-    # (gradients: two EAGER runs of this random-weight net differ by tens of per cent in the median layer -- N(0, 0.001) convolutions
-    # under BatchNorm amplify the atomics' last-bit noise -- so the graph is held to the eager-vs-eager noise, not to an absolute bound)
-    noise = sorted(max(gn(eager[i][1][n], eager[j][1][n]) for i, j in pairs) for n in names)
-    diff = sorted(min(gn(g[1][n], e[1][n]) for e in eager) for n in names)
-    med = len(names) // 2
-    assert diff[med] <= 3 * noise[med] + 1e-3, (diff[med], noise[med])
-    assert diff[-1] <= 3 * noise[-1] + 2e-2, (diff[-3:], noise[-3:])
+    ref = runs[0]
+    assert len(ref[0]) == 17 and len(ref[1]) > 1000
+    for i, r in enumerate(runs[1:], 1):
+        kind = 'eager' if i < 3 else 'replay'
+        for k in ref[0]:
+            assert torch.equal(r[0][k], ref[0][k]), ('loss differs', kind, i, k, float(r[0][k]), float(ref[0][k]))
+        assert set(r[1]) == set(ref[1])
+        for n in ref[1]:
+            assert torch.isfinite(r[1][n]).all(), ('non-finite gradient', kind, i, n)
+            if torch.equal(r[1][n], ref[1][n]):
+                continue
+            worst = float((r[1][n] - ref[1][n]).abs().max() / (ref[1][n].abs().max() + 1e-30))
+            library_side = 'gcn' in n and (n.endswith('.bias') or '.act.' in n)
+            assert worst <= (4.0 if library_side else 1e-6), ('gradient differs', kind, i, n, worst)
+    # every replay equals every other replay, the library-side parameters included (same tolerance for elements that are zero up
+    # to rounding: measured 2e-27 against a largest element of 0.14 in one grouped 1x1 weight gradient)
+    for r in runs[4:]:
+        for n in ref[1]:
+            d = float((r[1][n] - runs[3][1][n]).abs().max() / (runs[3][1][n].abs().max() + 1e-30))
+            assert d <= 1e-6, ('replays differ', n, d)
 
 
 def test_data_parallel_graph_path_single_rank():
@@ -320,8 +278,6 @@ def test_data_parallel_graph_path_single_rank():
     dev = torch.device('cuda', 0)
     port = 29500 + (os.getpid() % 2000)
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
-    fixed = _fixed_order_bn()
-    fixed.__enter__()
     try:
         res = {}
         for mode in ('single', 'ddp'):
@@ -350,57 +306,63 @@ def test_data_parallel_graph_path_single_rank():
                 assert p.grad.data_ptr() == tr.store.grad_ptr(p), n      # zero-copy: .grad IS the bucket slot
             res[mode] = ({k: float(v.sum()) for k, v in l_eager.items()}, {k: float(v.sum()) for k, v in l_graph.items()},
                          {n: p.grad.detach().clone() for n, p in named})
+        # production BatchNorm configuration (order-independent sums, csrc/conv_common.h): the forward pass of the two trainers is
+        # the same arithmetic, so every loss -- eager and replayed -- is identical; the data-parallel trainer packs its one-pass
+        # BatchNorm launches under a smaller co-residency budget and flushes its weight gradients bucket by bucket, i.e. other
+        # partial sums of the same totals: gradients agree to fp32 rounding
         for k in res['single'][0]:
-            for a, b in ((res['ddp'][0][k], res['single'][0][k]), (res['ddp'][1][k], res['single'][1][k])):
-                assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
-        names = sorted(res['single'][2])[::max(1, len(res['single'][2]) // 20)]
-        rel = [((res['ddp'][2][n] - res['single'][2][n]).norm() / (res['single'][2][n].norm() + 1e-12)).item() for n in names]
-        assert max(rel) < 0.3 and sorted(rel)[len(rel) // 2] < 0.05, sorted(rel)[-3:]
+            for a, b in ((res['ddp'][0][k], res['single'][0][k]), (res['ddp'][1][k], res['single'][1][k]), (res['single'][1][k], res['single'][0][k])):
+                assert a == b, (k, a, b)
+        rel = {n: ((res['ddp'][2][n] - res['single'][2][n]).norm() / (res['single'][2][n].norm() + 1e-12)).item() for n in res['single'][2]}
+        assert max(rel.values()) < 1e-3, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
     finally:
-        fixed.__exit__(None, None, None)
         dist.destroy_process_group()
 
 
 def test_segmented_backward_equals_one_autograd_call():
     """segments.py: cutting the autograd graph at the HRNet module boundaries and at the estimator -> regressor interface
     changes no arithmetic -- the same trainer, same batch, same weights, backward as ONE call and in segments: every loss is
-    identical and the gradients agree to the noise floor of two identical runs (weight-gradient atomics)."""
+    identical and so is every gradient (production BatchNorm configuration; the step's sums are order-independent)."""
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
     from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
     from danet_densepose2smpl_amd import segments
     dev = torch.device('cuda')
-    with _fixed_order_bn():
-        torch.manual_seed(0)
-        tr = Trainer(default_options(2), device=dev, distributed=False, lr=1e-30)
-        batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
-        tr.train_step(batch)                                   # (BatchNorm running statistics, weight bank)
-        runs = []
-        for seg in (False, False, True):
-            tr.segmented = seg
-            levels = []
-            orig = segments.backward
+    torch.manual_seed(0)
+    tr = Trainer(default_options(2), device=dev, distributed=False, lr=1e-30)
+    batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
+    tr.train_step(batch)                                   # (BatchNorm running statistics, weight bank)
+    runs = []
+    for seg in (False, False, True):
+        tr.segmented = seg
+        levels = []
+        orig = segments.backward
 
-            def spy(losses, between=None, _o=orig, _l=levels):
-                _l.append(segments.level())
-                return _o(losses, between)
-            segments.backward = spy
-            try:
-                _, l = tr.train_step(batch)
-            finally:
-                segments.backward = orig
-            torch.cuda.synchronize()
-            assert (levels == [9]) if seg else (levels == []), levels        # 8 HRNet modules + the regressor
-            runs.append(({k: float(v.sum()) for k, v in l.items()},
-                         {n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None}))
-        (la, ga), (lb, gb), (ls, gs) = runs
-        assert set(gs) == set(ga)
-        for k in la:
-            assert abs(ls[k] - la[k]) <= 2 * abs(lb[k] - la[k]) + 1e-5 * abs(la[k]) + 1e-7, (k, la[k], lb[k], ls[k])
-        rel = lambda x, y: ((x - y).norm() / (y.norm() + 1e-20)).item()       # noqa: E731
-        noise = sorted(rel(gb[n], ga[n]) for n in ga)
-        diff = sorted(rel(gs[n], ga[n]) for n in ga)
-        assert diff[len(diff) // 2] <= 2 * noise[len(noise) // 2] + 1e-6 and diff[-1] <= 4 * noise[-1] + 1e-3, (diff[-3:], noise[-3:])
+        def spy(losses, between=None, _o=orig, _l=levels):
+            _l.append(segments.level())
+            return _o(losses, between)
+        segments.backward = spy
+        try:
+            _, l = tr.train_step(batch)
+        finally:
+            segments.backward = orig
+        torch.cuda.synchronize()
+        assert (levels == [9]) if seg else (levels == []), levels        # 8 HRNet modules + the regressor
+        runs.append(({k: float(v.sum()) for k, v in l.items()},
+                     {n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb), (ls, gs) = runs
+    assert set(gs) == set(ga)
+    for k in la:
+        assert la[k] == lb[k] == ls[k], (k, la[k], lb[k], ls[k])
+    # two one-call runs are bit-identical (order-independent sums); the segmented run launches the same kernels on the same
+    # operands, gradient by gradient
+    # (elements that are zero up to rounding -- 1e-27 beside 0.2 in one grouped 1x1 weight gradient of the regressor -- may differ in
+    # that rounding: doubles add exactly only partial sums within 2^25 of each other)
+    dmax = lambda x, y: float((x - y).abs().max() / (y.abs().max() + 1e-30))       # noqa: E731
+    for n in ga:
+        assert dmax(gb[n], ga[n]) <= 1e-6, ('two identical runs differ', n, dmax(gb[n], ga[n]))
+        assert dmax(gs[n], ga[n]) <= 1e-6, ('segmented vs one call', n, dmax(gs[n], ga[n]))
+    assert sum(1 for n in ga if not torch.equal(gs[n], ga[n])) <= 8
 
 
 def test_bench_dry_launch_line_on_a_one_rank_group():

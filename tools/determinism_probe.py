@@ -57,7 +57,7 @@ def main():
             gd[n] = worst
     out['grads_total'] = len(ref[1])
     out['grads_differing'] = len(gd)
-    out['grads_worst'] = dict(sorted(gd.items(), key=lambda kv: -kv[1])[:25])
+    out['grads_worst'] = {n: [v, float(ref[1][n].abs().max()), [float(e[1][n].abs().max()) for e in ex[1:]]] for n, v in sorted(gd.items(), key=lambda kv: -kv[1])[:40]}
     # eager vs graph separately (a difference only there = a path difference, not an ordering freedom)
     eg = {}
     for n in ref[1]:
