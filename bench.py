@@ -253,9 +253,9 @@ def fp32_line(args, tr, batch, world, rank, dev):
                           'finite_losses': rec['finite_losses'], 'roofline': rec.get('roofline')}), flush=True)
 
 
-def _dnn_blocks():
+def _dnn_error():
     from danet_densepose2smpl_amd import nn as _dnn
-    return _dnn.ONEPASS_MAX_BLOCKS
+    return _dnn.onepass_error()
 
 
 def profile_step(tr, batch, dev):
@@ -405,7 +405,9 @@ def main():
                           'ms_per_step_per_rank': per_rank,
                           # compute units left to the communication library while the backward pass runs (NCCL_MAX_NCHANNELS) and the
                           # workgroup budget of the one-pass BatchNorm backward's grid barrier that follows from it
-                          'comm_channels_reserved': int(os.environ.get('NCCL_MAX_NCHANNELS', 0)), 'onepass_max_blocks': int(_dnn_blocks())}
+                          'comm_channels_reserved': int(os.environ.get('NCCL_MAX_NCHANNELS', 0)), 'onepass_max_blocks': int(getattr(tr, 'onepass_blocks', 0)),
+                          # the one-pass BatchNorm backward's barrier error word on this rank and its all-reduced sum (0 / 0.0: no launch timed out)
+                          'onepass_error': bool(_dnn_error()), 'poison_sum': float(st.poison)}
     if rank == 0:
         ips = world * B * args.steps / elapsed
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',

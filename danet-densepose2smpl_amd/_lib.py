@@ -72,6 +72,7 @@ _SIGNATURES = {
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 7),
     'danet_conv_wgrad_multi_ws_floats': (c_sz, [c_f, c_i]),
+    'danet_conv_wgrad_multi_ws_zero_from': (c_sz, [c_f, c_i]),
     'danet_conv_wgrad_multi': (c_i, [c_f, c_i, c_f, c_sz, c_fl, c_f]),
     'danet_conv_wgrad3x3_multi_ws_floats': (c_sz, [c_f, c_i]),
     'danet_conv_wgrad3x3_multi': (c_i, [c_f, c_i, c_f, c_sz, c_fl, c_f]),
@@ -116,7 +117,7 @@ _SIGNATURES = {
     'danet_smpl_loss_forward': (c_i, [c_f] * 5),
     'danet_smpl_loss_backward': (c_i, [c_f] * 5),
     'danet_adam_chunk_bytes': (c_sz, []),
-    'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f]),
+    'danet_adam_step': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, c_fl, c_fl, c_fl, c_f, c_f, c_f]),
     'danet_batch_rodrigues': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),

@@ -733,15 +733,24 @@ def flush_wgrads(bucket=None):
             (j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups) = dims
         n = len(wqg)
         need = L.danet_conv_wgrad_multi_ws_floats(ctypes.addressof(jobs), n)
-        ws = ARENA.alloc(need)
-        if ws is None:
-            ws = torch.zeros(need, dtype=torch.float32, device=wqg[0][2].device)
+        zfrom = L.danet_conv_wgrad_multi_ws_zero_from(ctypes.addressof(jobs), n)
+        # the leading part (partial sums of the pointwise kernel: ~290 MB of the bench step's 377 MB) needs no zeroing: only the packed
+        # accumulators behind it come out of the zeroed arena when the two can be adjacent -- else a buffer of its own, tail zeroed
+        ws = _wgrad_scratch(need, zfrom, wqg[0][2].device)
         tok = PROFILER.begin('conv_wgrad_multi', sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in (q[4] for q in wqg)),
                              ('wgrad-multi', n)) if PROFILER is not None else None
         check(L.danet_conv_wgrad_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad_multi')
         if tok is not None:
             PROFILER.end(tok)
         _WQG[:] = [q for q in _WQG if not mine(q)]
+
+
+def _wgrad_scratch(need, zero_from, device):
+    """need floats of scratch whose floats [zero_from, need) are zero (one fill launch over that tail only)."""
+    ws = torch.empty(need, dtype=torch.float32, device=device)
+    if need > zero_from:
+        ws[zero_from:].zero_()
+    return ws
 
 
 def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight=None):

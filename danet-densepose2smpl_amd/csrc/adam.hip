@@ -14,10 +14,13 @@
 // in.  (The reference pre-trains the IUV estimator alone for 5000 steps, /root/reference/train/base_trainer.py:74: the
 // regressor's first update must see step 1, not 5001.)
 //
-// Poison guard: `poison` points at the error word of the one-pass BatchNorm backward's grid barrier (norm_act.hip, bar[2]).
-// A barrier that timed out in this step left garbage gradients; with the word set EVERY parameter is skipped (and counted
-// in idle, so the bias corrections stay those of the updates that were applied): a poisoned step can never reach the
-// weights or the moments, whatever the host does or does not check (Trainer.check_onepass reports it).
+// Poison guard: `poison` points at the error word of THIS device's one-pass BatchNorm backward grid barrier (norm_act.hip,
+// bar[2]); `poison_sum` at a float that holds the SUM of that word over all ranks (distributed.GradStore stamps the local word
+// into the tail of its last gradient bucket, whose all-reduce sums it -- like the `used` mask, a global fact).  A barrier
+// that timed out in this step left garbage gradients on its rank, and after the all-reduce in every rank's sums; with either
+// value set EVERY parameter is skipped on EVERY rank (and counted in idle, so the bias corrections stay those of the updates
+// that were applied): a poisoned step can never reach the weights or the moments of any replica, whatever the host does or
+// does not check (Trainer.check_onepass reports it, on all ranks alike).  One process: poison alone (poison_sum NULL).
 #include "common.h"
 
 namespace {
@@ -27,11 +30,12 @@ struct AdamChunk { float* p; const float* g; long off; int n; int param; };     
 __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ lr_p, const float* __restrict__ step_p,
                                                    const float* __restrict__ used, float* __restrict__ idle,
-                                                   float beta1, float beta2, float eps, float gscale, const int* __restrict__ poison)
+                                                   float beta1, float beta2, float eps, float gscale, const int* __restrict__ poison,
+                                                   const float* __restrict__ poison_sum)
 {
     const AdamChunk c = table[blockIdx.x];
     const int pi = c.param >> 1;
-    if (!c.g || (used && !(used[pi] > 0.f)) || (poison && poison[0] != 0)) {                             // parameter without a gradient this step: skipped, and counted
+    if (!c.g || (used && !(used[pi] > 0.f)) || (poison && poison[0] != 0) || (poison_sum && poison_sum[0] > 0.f)) {                             // parameter without a gradient this step: skipped, and counted
         if (idle && (c.param & 1) && threadIdx.x == 0) idle[pi] += 1.f;
         return;
     }
@@ -73,14 +77,14 @@ extern "C" size_t danet_adam_chunk_bytes(void) { return sizeof(AdamChunk); }
 // gradient pointer): float per parameter, > 0 = some rank produced a gradient this step; idle (NULL = none): float per
 // parameter, the steps it was skipped in, maintained here.  grad_scale multiplies every gradient (1 / world size turns
 // all-reduced sums into the average without a pass of its own).  poison (NULL = none): device int; non-zero = skip the
-// whole step (see the header).
+// whole step; poison_sum (NULL = none): device float, the all-reduced sum of the ranks' words; > 0 = skip (see the header).
 extern "C" int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
                                const float* used, float* idle, float beta1, float beta2, float eps, float grad_scale,
-                               const int* poison, void* stream)
+                               const int* poison, const float* poison_sum, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(table && nchunks > 0 && m && v && lr && step, "adam_step: bad arguments");
-    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, used, idle, beta1, beta2, eps, grad_scale, poison);
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table, m, v, lr, step, used, idle, beta1, beta2, eps, grad_scale, poison, poison_sum);
     DANET_CHECK_LAUNCH("adam_kernel");
     return DANET_OK;
 }

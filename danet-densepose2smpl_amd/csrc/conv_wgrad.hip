@@ -401,7 +401,7 @@ static bool wg_job_ok(const WgJob& j) {
            (long)j.B * j.OH * j.OW < (1L << 24);
 }
 
-static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float beta, hipStream_t st, size_t* need_out)
+static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float beta, hipStream_t st, size_t* need_out, size_t* zero_from_out = nullptr)
 {
     if (n > 4096) return danet::fail(DANET_ERR_ARG, "conv_wgrad_multi: too many jobs (%d)", n);
     bool done[4096];
@@ -421,6 +421,7 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
             used += need;
         }
     }
+    if (zero_from_out) *zero_from_out = used;         // the pointwise kernel's partial sums come first and need no zeroing; the packed accumulators follow
     long target = 1024;     // swept on MI355X (512 / 768 / 1024 / 1536 / 2048: 33.04 / 32.82 / 32.67 / 32.81 / 32.89 ms per step once
                             // the 7x7 stem has its own kernel and one process flushes all problems at once)
     if (const char* e = getenv("DANET_WGRAD_MULTI_BLOCKS")) target = atol(e);
@@ -485,6 +486,16 @@ extern "C" size_t danet_conv_wgrad_multi_ws_floats(const void* jobs, int n)
     if (!jobs || n <= 0) return 0;
     wg_multi((const WgJob*)jobs, n, nullptr, 0, 0.f, nullptr, &need);
     return need;
+}
+
+// First float of the workspace that must be zero when danet_conv_wgrad_multi is called (everything from there to
+// danet_conv_wgrad_multi_ws_floats): the leading part holds partial sums that are written before they are read.
+extern "C" size_t danet_conv_wgrad_multi_ws_zero_from(const void* jobs, int n)
+{
+    size_t need = 0, from = 0;
+    if (!jobs || n <= 0) return 0;
+    wg_multi((const WgJob*)jobs, n, nullptr, 0, 0.f, nullptr, &need, &from);
+    return from;
 }
 
 extern "C" int danet_conv_wgrad_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream)

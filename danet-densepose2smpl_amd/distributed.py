@@ -66,12 +66,19 @@ class GradStore(object):
             self.offsets[id(p)] = off
             self.bucket_of[id(p)] = len(self.buckets)
             off += n
-        # the last bucket ends in one float per parameter: "received a gradient on this rank in this step" (see `used`)
+        # the last bucket ends in one float per parameter: "received a gradient on this rank in this step" (see `used`), and one
+        # more for "this rank's step is poisoned" (see `poison`)
         npad = (len(self.params) + 3) // 4 * 4
-        self.buckets.append((start, off + npad, first, len(self.params)))
-        self.flat = torch.zeros(off + npad, dtype=torch.float32, device=self.device)
+        self.buckets.append((start, off + npad + 4, first, len(self.params)))
+        self.flat = torch.zeros(off + npad + 4, dtype=torch.float32, device=self.device)
         self.wire_dtype = wire_dtype
-        self.wire = None if wire_dtype == torch.float32 else torch.zeros(off + npad, dtype=wire_dtype, device=self.device)
+        self.wire = None if wire_dtype == torch.float32 else torch.zeros(off + npad + 4, dtype=wire_dtype, device=self.device)
+        # Whether the step's gradients are garbage is a GLOBAL fact as well: a rank whose one-pass BatchNorm barrier timed out
+        # (poison_src: its error word, a one-element integer tensor the trainer names) has already added that garbage to every
+        # rank's sums when the optimizer runs.  stamp_poison() writes the word behind the mask, the last bucket's all-reduce sums it,
+        # and optim.FusedAdam skips the step wherever the sum is > 0 -- every rank or none.
+        self.poison = self.flat[off + npad:off + npad + 1]
+        self.poison_src = None
         self.index = {id(p): i for i, p in enumerate(self.params)}
         # In how many ranks each parameter (self.params order) received a gradient in the last backward pass: written from
         # the post-accumulate-grad hooks when the trainer leaves backward_scope, summed over the ranks by the last bucket's
@@ -89,6 +96,8 @@ class GradStore(object):
         self._mask_set = [None, None]
         self._mask_event = [None, None]
         self._mask_turn = 0
+        self._mask_captured = []            # pinned masks owned by captured graphs (one per capture)
+        self._mask_for_capture = None       # the next capture's (prepare_capture)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._works = []
         self.issued = []                    # bucket indices in the order their collectives were issued this step ...
@@ -159,8 +168,36 @@ class GradStore(object):
                 raise RuntimeError('GradStore: %d parameter(s) received a gradient after their bucket had been all-reduced '
                                    '(the set of parameters in use changed between steps); the step is incomplete -- rerun it' % len(late))
 
+    def prepare_capture(self):
+        """Before a hipGraph capture of a step: the pinned host buffer its usage-mask upload will read on every replay (pinned
+        memory cannot be allocated while a stream is capturing)."""
+        if self._mask_for_capture is None:
+            m = torch.ones(len(self.params), dtype=torch.float32)
+            self._mask_for_capture = m.pin_memory() if self.device.type == 'cuda' else m
+
+    def stamp_poison(self):
+        """Copy this rank's poison word into the tail of the last bucket (after the backward pass, before that bucket's
+        all-reduce); without a source the slot stays 0."""
+        if self.poison_src is not None:
+            self.poison.copy_(self.poison_src)
+
     def _upload_mask(self):
         fired = frozenset(self.index[i] for i in self._fired)
+        if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            # a hipGraph capture: the memcpy node re-reads its host buffer on EVERY replay, so the graph gets a pinned buffer of its
+            # own that no eager step ever rewrites (kept alive here), and no event is recorded (an event recorded in a capture cannot
+            # be synchronized on later: hipErrorCapturedEvent) -- ADVICE r4.  The set of parameters in use is frozen into the graph
+            # like the batch's host-side switches (Trainer.load_batch): capture() again when it changes (pretrain -> full model).
+            if self._mask_for_capture is None:
+                raise RuntimeError('GradStore: call prepare_capture() before capturing a step (pinned memory cannot be allocated inside a capture)')
+            m, self._mask_for_capture = self._mask_for_capture, None
+            m.zero_()
+            if fired:
+                m[sorted(fired)] = 1.0
+            self._mask_captured.append(m)
+            self.used.copy_(m, non_blocking=True)
+            self._mask_fresh = True
+            return
         k = self._mask_turn
         if self._mask_set[k] != fired:
             k ^= 1

@@ -26,8 +26,8 @@ RELU_MASK = bool(int(os.environ.get('DANET_BN_RELU_MASK', '1')))     # A/B knob:
 # trainer names in ONEPASS_STREAM (its capture stream); BatchNorms running on other (side) streams take the two-kernel path.
 ONEPASS = bool(int(os.environ.get('DANET_BN_ONEPASS', '1')))
 ONEPASS_STREAM = None
-# Co-residency budget of a one-pass launch (workgroups; 0 = the whole device, two per compute unit).  A data-parallel trainer
-# lowers it to 2 * (compute units - communication channels): the all-reduce kernels of the step's earlier gradient buckets run
+# Co-residency budget of a one-pass launch (workgroups; 0 = the whole device, two per compute unit; < 0 = no one-pass launches).  A
+# data-parallel trainer lowers it, for the duration of its steps, to 2 * (compute units - communication channels): the all-reduce kernels of the step's earlier gradient buckets run
 # on the communication stream WHILE the backward pass continues, and a grid barrier over more workgroups than fit beside them
 # could wait for ever (include/danet_hip.h, danet_bn_backward_onepass).
 ONEPASS_MAX_BLOCKS = 0
@@ -37,7 +37,7 @@ _ONEPASS_BAR = {}
 def _onepass_bar(device):
     """The barrier state of the one-pass launches on `device` (zeroed once), or None when the current stream is
     not the one these launches are confined to."""
-    if not ONEPASS:
+    if not ONEPASS or ONEPASS_MAX_BLOCKS < 0:
         return None
     cur = torch.cuda.current_stream(device)
     if cur != (ONEPASS_STREAM if ONEPASS_STREAM is not None else torch.cuda.default_stream(device)):
@@ -74,13 +74,15 @@ def onepass_error(device=None):
     return any(int(b[2]) != 0 for d, b in _ONEPASS_BAR.items() if _on_device(d, device))
 
 
-def onepass_recover(device=None):
+def onepass_recover(device=None, force=False):
     """After a barrier time-out (onepass_error): the arrival counts of the expired barrier are stale, so every later one-pass
     launch would time out as well.  Zeroes the barrier state and switches the one-pass backward off (the two-kernel path
     takes over); returns True when there was an error to recover from.  Steps computed since the time-out are garbage:
-    the caller decides what to redo (trainer.Trainer re-captures its graph and raises)."""
+    the caller decides what to redo (trainer.Trainer re-captures its graph and raises).  force: another data-parallel rank
+    reported the time-out (the all-reduced poison word): switch this rank over as well, so that all replicas keep running
+    the same kernels."""
     global ONEPASS
-    if not onepass_error(device):
+    if not (onepass_error(device) or force):
         return False
     torch.cuda.synchronize()
     for d, b in _ONEPASS_BAR.items():

@@ -89,8 +89,10 @@ class FusedAdam(object):
             self._used_perm = torch.tensor([grad_store.index_of(p) for p in self.params], dtype=torch.long, device=dev)
             self._used = torch.ones(len(self.params), dtype=torch.float32, device=dev)
         # device int the kernel tests before it touches anything: non-zero = this step's gradients are invalid (set by the trainer
-        # to the one-pass BatchNorm backward's barrier error word, nn.onepass_poison)
+        # to the one-pass BatchNorm backward's barrier error word, nn.onepass_poison) ...
         self.poison = None
+        # ... and, data-parallel, the float that holds the sum of that word over all ranks (GradStore.poison): > 0 = skip, everywhere
+        self.poison_sum = None
 
     def state_dict(self):
         """torch.optim.Adam's layout (per-parameter step / exp_avg / exp_avg_sq + one param group), so the checkpoints of
@@ -163,7 +165,7 @@ class FusedAdam(object):
         check(_lib.lib().danet_adam_step(ptr(self._table), self.nchunks, ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                          ptr(self.param_groups[0]['lr']), ptr(self.step_t), ptr(used), ptr(self.idle),
                                          float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale),
-                                         ptr(self.poison), stream()), 'danet_adam_step')
+                                         ptr(self.poison), ptr(self.poison_sum), stream()), 'danet_adam_step')
         # the kernel wrote the parameters through raw pointers: bump their version counters like an in-place op would
         # (the conv weight-pack cache and autograd's saved-tensor checks key on them)
         upd = self.params if self.grad_store is not None else [p for p in self.params if p.grad is not None]

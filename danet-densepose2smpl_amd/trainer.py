@@ -29,19 +29,29 @@ USE_FUSED_ADAM = bool(int(os.environ.get('DANET_FUSED_ADAM', '1')))
 # on in a single-process trainer (tests, A/B timing).
 SEGMENTS = os.environ.get('DANET_SEGMENTS', '')
 # Compute units the communication library may occupy while the backward pass runs (one workgroup per channel): the one-pass
-# BatchNorm backward's grid barrier is sized to fit beside them (nn.ONEPASS_MAX_BLOCKS).  The trainer exports it as
-# NCCL_MAX_NCHANNELS unless the environment already names a limit (must happen before the first collective creates the
-# communicator; bench.py sets it before init_process_group).
+# BatchNorm backward's grid barrier is sized to fit beside them (nn.ONEPASS_MAX_BLOCKS).  The limit is the LAUNCHER's to set --
+# NCCL_MAX_NCHANNELS must be in the environment before the first collective creates the communicator: bench.py calls
+# reserve_comm_channels() before init_process_group.  A Trainer never touches the environment: it reads the limit,
+# and without one it does not know how many compute units the all-reduce kernels may take, so its data-parallel steps run the
+# two-kernel BatchNorm backward (a warning says so).  Trade-off: 24 channels leave the all-reduce 24 of 256 compute units;
+# DANET_COMM_CHANNELS chooses another number (tools/scale_sweep.sh sweeps it), NCCL_MAX_NCHANNELS set by hand wins.
 COMM_CHANNELS = int(os.environ.get('DANET_COMM_CHANNELS', '24'))
 
 
 def reserve_comm_channels():
-    """Export the channel limit (if none is set) and return the number of compute units to keep free for collectives."""
+    """For LAUNCH scripts, before torch.distributed.init_process_group: export the channel limit (if none is set) and return the
+    number of compute units kept free for collectives."""
     cur = os.environ.get('NCCL_MAX_NCHANNELS')
     if cur is None:
         os.environ['NCCL_MAX_NCHANNELS'] = str(COMM_CHANNELS)
         return COMM_CHANNELS
     return max(1, int(cur))
+
+
+def comm_channel_limit():
+    """The channel limit the environment names (what the communicator was, or will be, created with), or None."""
+    cur = os.environ.get('NCCL_MAX_NCHANNELS')
+    return None if cur is None else max(1, int(cur))
 
 
 def default_options(batch_size=32):
@@ -134,10 +144,26 @@ class Trainer(object):
             if isinstance(self.optimizer, torch.optim.Optimizer) is False:
                 # a step whose one-pass BatchNorm backward timed out at its grid barrier is skipped by the Adam kernel itself
                 self.optimizer.poison = _nn.onepass_poison(self.device)
+                if self.distributed:
+                    # ... and, since its gradients are in every rank's sums by then, by every other rank's as well: the word travels
+                    # with the last gradient bucket (GradStore.stamp_poison) and the kernel tests the all-reduced sum
+                    self.store.poison_src = self.optimizer.poison
+                    self.optimizer.poison_sum = self.store.poison
+            # workgroup budget of the one-pass BatchNorm backward in THIS trainer's steps (installed by _core for the duration of a
+            # step): 0 = the whole device; data-parallel: all-reduce kernels of earlier buckets run beside the backward pass, so the grid
+            # barrier must fit next to them -- 2 * (compute units - channel limit); -1 = no limit known: two-kernel path
+            self.onepass_blocks = 0
             if self.distributed:
-                # all-reduce kernels of earlier buckets run beside the backward pass: size the grid barrier to fit next to them
-                cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-                _nn.ONEPASS_MAX_BLOCKS = max(2, 2 * (cus - reserve_comm_channels()))
+                ch = comm_channel_limit()
+                if ch is None:
+                    import warnings
+                    warnings.warn('data-parallel Trainer without NCCL_MAX_NCHANNELS in the environment: the number of compute units the '
+                                  'all-reduce kernels may occupy is unknown, so the one-pass BatchNorm backward (a grid barrier over 2 workgroups '
+                                  'per compute unit) is off for this trainer; call trainer.reserve_comm_channels() before init_process_group')
+                    self.onepass_blocks = -1
+                else:
+                    cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+                    self.onepass_blocks = max(2, 2 * (cus - ch))
         self._graph = None
         self._static = None
         self._reduce_in_graph = True
@@ -193,13 +219,20 @@ class Trainer(object):
         reads the barrier's error word and skips such a step on the device (csrc/adam.hip `poison`), so nothing is ever
         applied; this host-side check (every ONEPASS_CHECK_EVERY steps and before a checkpoint is written) is for reporting and
         recovery: the barrier is reset, the one-pass path switched off (two-kernel BatchNorm backward from here on), a
-        captured graph dropped, and the caller told."""
+        captured graph dropped, and the caller told.  Data-parallel: the decision is taken from the all-reduced poison word
+        (GradStore.poison: the error word is sticky, so the last step's sum tells whether ANY rank has timed out since the last
+        check) -- every rank recovers and raises in the same call, none is left waiting in a collective."""
         from . import nn as dnn
-        if self.device.type == 'cuda' and dnn.onepass_recover(self.device):
+        if self.device.type != 'cuda':
+            return
+        elsewhere = bool(self.distributed and self.store is not None and self.store.poison_src is not None and float(self.store.poison) > 0)
+        if dnn.onepass_recover(self.device, force=elsewhere):
             self._graph = None
             guarded = getattr(self.optimizer, 'poison', None) is not None
-            raise RuntimeError('a one-pass BatchNorm launch timed out at its grid barrier: gradients since then are invalid'
-                               + (' -- the optimizer skipped those steps (device-side guard), parameters and moments are intact. '
+            raise RuntimeError('a one-pass BatchNorm launch timed out at its grid barrier' + (' on some rank' if elsewhere else '') +
+                               ': gradients since then are invalid'
+                               + (' -- the optimizer skipped those steps on every rank (device-side guard on the all-reduced error word), '
+                                  'parameters and moments are intact. '
                                   if guarded else ' and were applied: resume from the last checkpoint. ') +
                                'The barrier was reset and the one-pass path switched off (nn.ONEPASS = False); capture() again if you '
                                'replay a graph')
@@ -275,7 +308,15 @@ class Trainer(object):
         communication stream: the next segment's backward kernels overlap it); then the remaining buckets the same way; Adam
         waits for the last all-reduce."""
         from . import segments
+        from . import nn as _nn
         st = self.store
+        prev_blocks, _nn.ONEPASS_MAX_BLOCKS = _nn.ONEPASS_MAX_BLOCKS, getattr(self, 'onepass_blocks', 0)
+        try:
+            return self._core_body(batch, reduce, with_optimizer, segments, st)
+        finally:
+            _nn.ONEPASS_MAX_BLOCKS = prev_blocks
+
+    def _core_body(self, batch, reduce, with_optimizer, segments, st):
         self._begin_step()
         if st is not None:
             st.begin_step()
@@ -308,6 +349,7 @@ class Trainer(object):
                 if st is not None:
                     try:
                         st.backward_scope(False)
+                        st.stamp_poison()
                     except RuntimeError:
                         _conv._WQ.clear()
                         _conv._WQG.clear()
@@ -391,6 +433,8 @@ class Trainer(object):
             conv._PACK_CACHE.clear()              # weight packing must be part of the captured work
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
+            if self.store is not None:
+                self.store.prepare_capture()
             hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
             conv.FUSION.clear()
             try:
@@ -404,7 +448,7 @@ class Trainer(object):
                 self.captured_collectives = (list(self.store.issued), self.store.issued_early) if (self.store is not None and in_graph) else ([], 0)
                 break
             except RuntimeError:
-                if not in_graph:
+                if not (in_graph and self.distributed):      # (only a capture that holds collectives has a fallback: reduce after the replay)
                     raise
                 torch.cuda.synchronize(self.device)
                 # the aborted capture left host-side state behind: queued weight-gradient jobs that point at tensors of its

@@ -180,12 +180,14 @@ int danet_smpl_loss_backward(const void* params, const float* gout, const float*
  * parameter, the number of ranks in which it received a gradient this step (summed with the gradients), 0 -> the parameter is
  * skipped (moments untouched) and idle[param] (float per parameter, NULL = none, maintained by the kernel) counts it; bias
  * corrections use step - idle[param].  grad_scale multiplies every gradient (1 / world size: all-reduced sums become the
- * average without a pass of its own).  poison (NULL = none): device int, non-zero = the step's gradients are invalid (the
- * one-pass BatchNorm backward's barrier error word, danet_bn_backward_onepass): every parameter is skipped and counted idle. */
+ * average without a pass of its own).  poison (NULL = none): device int, non-zero = the step's gradients are invalid (this
+ * device's one-pass BatchNorm backward barrier error word, danet_bn_backward_onepass): every parameter is skipped and counted
+ * idle.  poison_sum (NULL = none): device float, the SUM of that word over the data-parallel ranks (all-reduced with the last
+ * gradient bucket): > 0 skips the step the same way -- on every rank, so the replicas cannot diverge. */
 size_t danet_adam_chunk_bytes(void);
 int danet_adam_step(const void* table, int nchunks, float* m, float* v, const float* lr, const float* step,
                     const float* used, float* idle, float beta1, float beta2, float eps, float grad_scale,
-                    const int* poison, void* stream);
+                    const int* poison, const float* poison_sum, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Partial-IUV ("limb") path glue (replaces /root/reference/models/danet/danet.py:264-283 and
@@ -376,8 +378,11 @@ size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int
  * jobs: array of n { const void* x; const void* dy; float* dw; int B, H, W, Cin, Cout, groups, stride; } (host memory). */
 size_t danet_conv_wgrad3x3_multi_ws_floats(const void* jobs, int n);
 /* the same for the general weight-gradient kernel; jobs: { const void* x; const void* dy; float* dw;
- * int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; }; ws must be ZEROED by the caller. */
+ * int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups; }; ws must be ZEROED by the caller from float
+ * danet_conv_wgrad_multi_ws_zero_from(jobs, n) on (packed accumulators -- doubles, see danet_bn_acc_bytes; the leading part holds
+ * the pointwise kernel's partial sums, which need no zeroing). */
 size_t danet_conv_wgrad_multi_ws_floats(const void* jobs, int n);
+size_t danet_conv_wgrad_multi_ws_zero_from(const void* jobs, int n);
 int danet_conv_wgrad_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
 int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, size_t ws_floats, float beta, void* stream);
 int danet_conv_wgrad3x3_kernel_id(int B, int H, int W, int Cin, int Cout, int groups, int stride);   /* CT*10 + NI */

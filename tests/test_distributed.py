@@ -121,6 +121,30 @@ def _worker(rank, world, port, tmp):
     st3.reduce_all()
     torch.save({'used': st3.used.clone(), 'order': [k for p in st3.params for k, q in net3.named_parameters() if q is p]},
                os.path.join(tmp, 'u%d.pt' % rank))
+    # the poison word: rank 1's one-pass BatchNorm barrier "timed out" in step 1 and stays set (the word is sticky);
+    # the word rides in the tail of the last bucket, so after that bucket's all-reduce BOTH ranks read a sum > 0 -- which is what
+    # the Adam kernel tests (csrc/adam.hip poison_sum) -- for both wire formats; step 0 reads 0 on both
+    sums = {}
+    for wire in (torch.float32, torch.bfloat16):
+        net4 = _Net()
+        st4 = GradStore(net4.parameters(), bucket_mb=0.0002, device=torch.device('cpu'), wire_dtype=wire)
+        st4.broadcast_parameters(net4)
+        word = torch.zeros(1, dtype=torch.int32)
+        st4.poison_src = word
+        seen = []
+        for step in range(3):
+            net4.zero_grad(set_to_none=True)
+            st4.begin_step()
+            st4.backward_scope(True, early=False)
+            net4(data[rank]).pow(2).mean().backward()
+            if rank == 1 and step == 1:
+                word.fill_(1)
+            st4.backward_scope(False)
+            st4.stamp_poison()
+            st4.reduce_all()
+            seen.append(float(st4.poison))
+        sums['bf16' if wire == torch.bfloat16 else 'fp32'] = seen
+    torch.save(sums, os.path.join(tmp, 'p%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -150,6 +174,8 @@ def test_two_rank_gradient_average_matches_single_process(tmp_path):
         u = torch.load(tmp_path / ('u%d.pt' % r))
         for name, c in zip(u['order'], u['used'].tolist()):
             assert c == (1.0 if name.startswith('unused') else 2.0), (r, name, c)
+    for r in (0, 1):                                                   # the poison word is a global fact as well: set on rank 1 from step 1 on
+        assert torch.load(tmp_path / ('p%d.pt' % r)) == {'fp32': [0.0, 1.0, 1.0], 'bf16': [0.0, 1.0, 1.0]}, r
     n0 = torch.load(tmp_path / 'n0.pt')
     for k in n0:
         assert torch.allclose(n0[k], (grads[0][k] + grads[1][k]) / 2, atol=1e-6), k

@@ -275,8 +275,11 @@ def test_data_parallel_graph_path_single_rank():
     _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.PARTDROP_RATE': 0.,
             'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
     from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    from danet_densepose2smpl_amd.trainer import reserve_comm_channels
     dev = torch.device('cuda', 0)
     port = 29500 + (os.getpid() % 2000)
+    had = os.environ.get('NCCL_MAX_NCHANNELS')
+    reserve_comm_channels()              # what a launch script does before the communicator exists (bench.py): the trainer only READS the limit
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
     try:
         res = {}
@@ -284,6 +287,7 @@ def test_data_parallel_graph_path_single_rank():
             torch.manual_seed(0)
             tr = Trainer(default_options(2), device=dev, distributed=(mode == 'ddp'), lr=1e-30, bucket_mb=8.0)
             assert (tr.reducer is not None) == (mode == 'ddp') and len(tr.store.buckets) > 8
+            assert tr.onepass_blocks == (2 * (256 - int(os.environ['NCCL_MAX_NCHANNELS'])) if mode == 'ddp' else 0)
             batch = synthetic_in_dict(tr.model, 2, dev, seed=1)
             batch['pretrain_mode'] = True
             tr.train_step(batch)
@@ -317,6 +321,8 @@ def test_data_parallel_graph_path_single_rank():
         assert max(rel.values()) < 1e-3, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
     finally:
         dist.destroy_process_group()
+        if had is None:
+            os.environ.pop('NCCL_MAX_NCHANNELS', None)
 
 
 def test_segmented_backward_equals_one_autograd_call():
@@ -412,7 +418,28 @@ def _two_proc_worker(rank, world, port, tmp):
     tr.train_step(batch)
     torch.cuda.synchronize()
     p1 = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
-    torch.save({'p0': p0, 'local': local.cpu(), 'summed': summed.cpu(), 'flat': tr.store.flat.cpu(), 'p1': p1}, os.path.join(tmp, 'r%d.pt' % rank))
+    flat1 = tr.store.flat.cpu()
+    # a one-pass BatchNorm barrier "times out" on rank 1 only (its sticky error word is set): rank 1's gradients are garbage
+    # and, after the all-reduce, so are rank 0's sums -- the word travels with the last bucket and BOTH ranks' Adam kernels skip the step
+    from danet_densepose2smpl_amd import nn as dnn
+    if rank == 1:
+        dnn.onepass_poison(dev).fill_(1)
+    m0 = tr.optimizer.exp_avg.clone()
+    tr.train_step(batch)
+    torch.cuda.synchronize()
+    p2 = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+    psum, moved = float(tr.store.poison), not torch.equal(tr.optimizer.exp_avg, m0)
+    raised = False
+    try:
+        tr.check_onepass()           # decided from the all-reduced word: both ranks recover and raise together
+    except RuntimeError as e:
+        raised = 'on some rank' in str(e) or rank == 1
+    onepass_after = dnn.ONEPASS
+    tr.train_step(batch)            # the two-kernel BatchNorm backward from here on, on both ranks: a normal step again
+    torch.cuda.synchronize()
+    p3 = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+    torch.save({'p0': p0, 'local': local.cpu(), 'summed': summed.cpu(), 'flat': flat1, 'p1': p1, 'p2': p2, 'p3': p3, 'psum': psum,
+                'moved': moved, 'raised': raised, 'onepass_after': onepass_after, 'psum_after': float(tr.store.poison)}, os.path.join(tmp, 'r%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -437,4 +464,10 @@ def test_two_process_trainer_gradient_allreduce(tmp_path):
     assert (r0['local'] - r1['local']).abs().max().item() > 1e-3 * scale          # the shards really differ
     assert torch.equal(r0['flat'], r1['flat']) and r0['flat'].abs().max().item() > 0
     assert torch.equal(r0['p1'], r1['p1']) and not torch.equal(r0['p1'], r0['p0'])
+    # the poisoned step (error word set on rank 1 only): skipped on BOTH ranks -- parameters and moments untouched, replicas identical --,
+    # both ranks raise from check_onepass and switch the one-pass path off, and the next step is a normal one on both
+    for r in (r0, r1):
+        assert r['psum'] == 1.0 and not r['moved'] and torch.equal(r['p2'], r['p1']), (r['psum'], r['moved'])
+        assert r['raised'] and r['onepass_after'] is False and r['psum_after'] == 0.0
+    assert torch.equal(r0['p3'], r1['p3']) and not torch.equal(r0['p3'], r0['p2'])
 
