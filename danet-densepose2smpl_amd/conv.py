@@ -699,10 +699,12 @@ def _check_adopted(queue):
                                'set DANET_DEFER_WGRAD=0 for this model' % (tuple(weight.shape),))
 
 
-def flush_wgrads(bucket=None):
+def flush_wgrads(bucket=None, hold=None):
     """Compute every queued weight gradient (call after backward, before anything reads parameter .grad).  With
     `bucket` = a bucket index of GRAD_STORE only that bucket's parameters are processed (the trainer walks the buckets
-    in order and all-reduces each one while the next one's launches run)."""
+    in order and all-reduces each one while the next one's launches run).  hold: a list that receives the processed queue
+    entries -- a caller that flushes on a SIDE stream keeps the operands (x, dy: allocated on the step's stream) alive until the
+    streams have joined again."""
     import ctypes
     L = _lib.lib()
 
@@ -723,6 +725,8 @@ def flush_wgrads(bucket=None):
         check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
         if tok is not None:
             PROFILER.end(tok)
+        if hold is not None:
+            hold.extend(wq)
         _WQ[:] = [q for q in _WQ if not mine(q)]
     wqg = [q for q in _WQG if mine(q)]
     if wqg:
@@ -742,6 +746,8 @@ def flush_wgrads(bucket=None):
         check(L.danet_conv_wgrad_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad_multi')
         if tok is not None:
             PROFILER.end(tok)
+        if hold is not None:
+            hold.extend(wqg)
         _WQG[:] = [q for q in _WQG if not mine(q)]
 
 

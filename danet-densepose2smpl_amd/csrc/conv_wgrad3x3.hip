@@ -31,6 +31,8 @@ constexpr int halo_w(int st) { return st * (TW - 1) + 3; }
 
 struct Wg3P {
     const bf16_t* x; const bf16_t* dy; float* part;
+    float* direct;                                      // msplit == 1 and beta == 0: the block IS the gradient -- written straight into dW
+                                                        // (torch layout [Cout][Cin_g][3][3]), no partial block, no reduction pass
     int B, H, W, Cin, Cout, groups, Cin_g, Cout_g;      // H, W: OUTPUT size (= input size / stride)
     int IH, IW;                                         // input size
     int tiles_h, tiles_w, msplit;
@@ -182,6 +184,26 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
     }
     // partial dW of this block: part[blockIdx.x][g][tap][cout][cin] (32-bit index arithmetic, one add per store)
     const int gsz = 9 * p.Cout_g * p.Cin_g;
+    if (p.direct) {
+        // the deep layers of a multi-problem launch (384 / 192 channels: 64 / 16 channel blocks per layer already fill their share of
+        // the launch) take no pixel split: their only block used to travel through a partial copy and the reduction kernel for nothing
+        float* const dw = p.direct + (size_t)g * gsz;
+#pragma unroll
+        for (int pi = 0; pi < MAXP; ++pi) {
+            const int pair = wave + 4 * pi;
+            const int tap = pair / NI, ni = pair - tap * NI;
+            const int cin = ci0 + ni * 16 + li;
+            if (pair >= NPAIR || cin >= p.Cin_g) continue;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cout = co0 + ct * 16 + lg * 4 + r;
+                    if (cout < p.Cout_g) dw[((size_t)cout * p.Cin_g + cin) * 9 + tap] = acc[pi][ct][r];
+                }
+        }
+        return;
+    }
     float* dst = p.part + ((size_t)bx * p.groups + g) * gsz;
 #pragma unroll
     for (int pi = 0; pi < MAXP; ++pi) {
@@ -333,7 +355,7 @@ extern "C" int danet_conv_wgrad3x3(const void* x, const void* dy, float* dw, flo
     DANET_CHECK_ARG(x && dy && dw && ws && B > 0 && phase >= 0 && phase <= 2, "conv_wgrad3x3: bad arguments");
     DANET_CHECK_ARG(danet_conv_wgrad3x3_ok(H, W, Cin, Cout, 3, 3, stride, 1, 1, groups), "conv_wgrad3x3: unsupported shape");
     Wg3P p;
-    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.part = ws;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.part = ws; p.direct = nullptr;
     p.IH = H; p.IW = W; H /= stride; W /= stride;                      // from here on (H, W) = output size
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.groups = groups;
     p.Cin_g = Cin / groups; p.Cout_g = Cout / groups;
@@ -390,6 +412,7 @@ static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int 
         long ms = (long)(target * (w / tot) / other + 0.5);
         if (ms > nchunks / 4) ms = nchunks / 4;
         if (ms < 1) ms = 1;
+        if (ms == 2 && other >= 16 && getenv("DANET_WGRAD3_FORCE1")) ms = 1;      // a layer with >= 16 channel blocks: one undivided block each, written straight into dW (Wg3P.direct)
         msplit[k] = (int)ms;
     }
 }
@@ -420,7 +443,10 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         for (int k = 0; k < cnt; ++k) {
             const Wg3Job& j = jobs[idx[k]];
             Wg3P& p = mp.p[k];
-            p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.part = ws ? ws + used : nullptr;
+            static const bool no_direct = getenv("DANET_WGRAD3_NO_DIRECT") != nullptr;          // A-B timing knob
+            const bool direct = msplit[k] == 1 && beta == 0.f && !no_direct;
+            p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.part = (ws && !direct) ? ws + used : nullptr;
+            p.direct = direct ? j.dw : nullptr;
             p.IH = j.H; p.IW = j.W;
             p.B = j.B; p.H = j.H / stride; p.W = j.W / stride; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
             p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
@@ -433,8 +459,8 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
             mp.start[k + 1] = mp.start[k] + msplit[k] * nyb * j.groups;
             const long total = (long)j.Cout * p.Cin_g * 9;
             rp.part[k] = p.part; rp.dw[k] = j.dw; rp.G[k] = j.groups; rp.Cout_g[k] = p.Cout_g; rp.Cin_g[k] = p.Cin_g; rp.msplit[k] = msplit[k];
-            rp.start[k + 1] = rp.start[k] + total;
-            used += (size_t)msplit[k] * total;
+            rp.start[k + 1] = rp.start[k] + (direct ? 0 : total);          // (nothing to reduce for a direct job)
+            if (!direct || !ws) used += (size_t)msplit[k] * total;          // (the sizing pass does not know beta: room for the partial form)
             if (ws && !(p.x_bytes < (1L << 31) && p.dy_bytes < (1L << 31)))
                 return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: tensors of 2 GB or more are not supported");
         }
@@ -449,8 +475,10 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: no kernel for tiles %dx%d", ct, ni);
 #undef W3M
         DANET_CHECK_LAUNCH("conv_wgrad3x3_multi_kernel");
-        hipLaunchKernelGGL(wgrad3x3_reduce_multi_kernel, dim3((unsigned)danet::cdiv(rp.start[cnt], 256)), dim3(256), 0, st, rp);
-        DANET_CHECK_LAUNCH("wgrad3x3_reduce_multi_kernel");
+        if (rp.start[cnt] > 0) {
+            hipLaunchKernelGGL(wgrad3x3_reduce_multi_kernel, dim3((unsigned)danet::cdiv(rp.start[cnt], 256)), dim3(256), 0, st, rp);
+            DANET_CHECK_LAUNCH("wgrad3x3_reduce_multi_kernel");
+        }
     }
     if (need_out) *need_out = used;
     return DANET_OK;

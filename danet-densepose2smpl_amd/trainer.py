@@ -28,6 +28,14 @@ USE_FUSED_ADAM = bool(int(os.environ.get('DANET_FUSED_ADAM', '1')))
 # DANET_SEGMENTS=0 switches the cuts off (every bucket after the backward pass: round 2's order); DANET_SEGMENTS=1 forces them
 # on in a single-process trainer (tests, A/B timing).
 SEGMENTS = os.environ.get('DANET_SEGMENTS', '')
+# Experiment knob (round 5, OFF): one process launches the queued weight gradients of a finished backward segment on a SIDE stream while
+# the next segment's data-gradient / BatchNorm chain continues on the step's stream -- the chain's kernels are latency-bound and leave
+# most of the chip idle, the weight gradients need nothing from it.  Measured on MI355X inside the captured step (bench.py, one gpurun
+# call): 27.9 ms without; with it 1 842 ms -- the one-pass BatchNorm backward's grid barrier needs all its workgroups resident at once
+# and a chip-filling weight-gradient kernel beside it makes the barrier run into its spin bound --; with the two-kernel
+# BatchNorm backward instead 28.86 ms against 28.47 without overlap, and 57 ms with the step's stream at high priority.  Graph
+# branches do not buy concurrency on this stack: the step stays one stream.
+WGRAD_OVERLAP = bool(int(os.environ.get('DANET_WGRAD_OVERLAP', '0')))
 # Compute units the communication library may occupy while the backward pass runs (one workgroup per channel): the one-pass
 # BatchNorm backward's grid barrier is sized to fit beside them (nn.ONEPASS_MAX_BLOCKS).  The limit is the LAUNCHER's to set --
 # NCCL_MAX_NCHANNELS must be in the environment before the first collective creates the communicator: bench.py calls
@@ -135,7 +143,9 @@ class Trainer(object):
         # Every step (eager or captured) runs on ONE dedicated stream: autograd pins each parameter's
         # gradient-accumulation node to the stream it was created on, and a node created on the default
         # stream would pull that (non-capturing) stream into a later hipGraph capture.
-        self.stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+        self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('DANET_MAIN_PRIORITY', '0'))) if on_gpu else None
+        self.wgrad_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('DANET_WGRAD_PRIORITY', '0'))) if on_gpu else None
+        self._held = []
         self.segmented = (self.distributed and SEGMENTS != '0') or SEGMENTS == '1'
         if on_gpu:
             _conv.ARENA.enable(self.device)
@@ -322,7 +332,8 @@ class Trainer(object):
             st.begin_step()
         BatchNorm2d.count_batches = False
         reduce_now = bool(self.distributed and reduce)
-        segments.begin(self.segmented and st is not None)
+        overlap = bool(WGRAD_OVERLAP and DEFER_WGRAD and st is not None and not self.distributed and self.wgrad_stream is not None)
+        segments.begin((self.segmented or overlap) and st is not None)
         try:
             try:
                 out = self.model(batch)
@@ -337,7 +348,8 @@ class Trainer(object):
                 st.backward_scope(True, early=reduce_now)
             try:
                 if segments.level() > 0:
-                    segments.backward(losses, (lambda k: st.release_ready(self._release_bucket)) if reduce_now else None)
+                    segments.backward(losses, (lambda k: st.release_ready(self._release_bucket)) if reduce_now else
+                                      ((lambda k: self._flush_on_side_stream()) if overlap else None))
                 else:
                     # (every loss is a 1-element tensor, models/danet/danet.py:359-364: views + one cat + one sum)
                     torch.cat([v.reshape(-1) for v in losses.values()]).sum().backward()
@@ -367,7 +379,12 @@ class Trainer(object):
                         self._release_bucket(bi)
                 else:
                     # one process: no all-reduce to overlap with, so all queued weight gradients go out in the fewest, largest
-                    # multi-problem launches (-0.15 ms against 13 bucket-sized flushes)
+                    # multi-problem launches (-0.15 ms against 13 bucket-sized flushes) -- or, with WGRAD_OVERLAP, segment by segment on
+                    # the side stream, which joins the step's stream here
+                    if overlap:
+                        self._flush_on_side_stream()
+                        torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+                        del self._held[:]
                     _conv.flush_wgrads()
                     st.collect()
                 _conv.flush_wgrads()                     # (nothing left: every parameter belongs to a bucket)
@@ -378,6 +395,14 @@ class Trainer(object):
         if with_optimizer:
             self.optimizer.step()
         return out, losses
+
+    def _flush_on_side_stream(self):
+        """Launch everything queued so far (conv.flush_wgrads) on the weight-gradient stream, ordered after the work already on
+        the step's stream; the operands stay referenced (self._held) until the streams join at the end of the backward pass."""
+        cur = torch.cuda.current_stream(self.device)
+        self.wgrad_stream.wait_stream(cur)
+        with torch.cuda.stream(self.wgrad_stream):
+            _conv.flush_wgrads(hold=self._held)
 
     def _release_bucket(self, bi):
         """A complete gradient bucket: its queued weight gradients are launched, its other gradients copied into the store, and

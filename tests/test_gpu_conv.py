@@ -190,6 +190,41 @@ def test_deferred_multi_problem_wgrad_matches_immediate():
         assert (g - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-6, cfg
 
 
+def test_multi_problem_wgrad3x3_direct_and_reduced_jobs():
+    """danet_conv_wgrad3x3_multi on the four HRNet branch shapes at B = 32 (the production launch): the deep layers' jobs take no
+    pixel split and write their one block straight into dW (Wg3P.direct: no partial copy, no reduction pass), the shallow ones go
+    through partial blocks + the fixed-order reduction -- both equal torch's fp32 weight gradient; with beta = 1 (accumulation)
+    every job takes the reduced form and adds to what dW held; two runs are bit-identical."""
+    import ctypes
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    from danet_densepose2smpl_amd._lib import ptr, stream, check
+    L = _lib.lib()
+    torch.manual_seed(5)
+    B = 32
+    shapes = [(48, 64), (96, 32), (192, 16), (384, 8)] * 3           # 12 jobs of one kernel instance in one launch
+    xs = [dconv.nhwc_bf16(torch.randn(B, c, s, s, device='cuda')) for c, s in shapes]
+    gs = [dconv.nhwc_bf16(torch.randn(B, c, s, s, device='cuda') * 0.1) for c, s in shapes]
+    refs = [torch.nn.grad.conv2d_weight(x.float(), (c, c, 3, 3), g.float(), stride=1, padding=1) for x, g, (c, s) in zip(xs, gs, shapes)]
+
+    def run(beta, init):
+        outs = [torch.full((c, c, 3, 3), init, device='cuda') for c, s in shapes]
+        jobs = (_lib.Wg3Job * len(shapes))()
+        for j, x, g, o, (c, s) in zip(jobs, xs, gs, outs, shapes):
+            j.x, j.dy, j.dw = x.data_ptr(), g.data_ptr(), o.data_ptr()
+            j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = B, s, s, c, c, 1, 1
+        need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), len(shapes))
+        ws = torch.full((need,), float('nan'), device='cuda')
+        check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), len(shapes), ptr(ws), need, beta, stream()), 'wgrad3x3_multi')
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(0.0, float('nan')), run(0.0, 7.0)
+    for o, o2, r, sh in zip(a, b, refs, shapes):
+        assert torch.isfinite(o).all() and torch.equal(o, o2), sh
+        assert (o - r).abs().max().item() <= 2e-4 * r.abs().max().item(), sh
+    for o, r, sh in zip(run(1.0, 0.5), refs, shapes):
+        assert (o - (r + 0.5)).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-5, sh
+
+
 # (Cin, Cout, H, W, B): HRNet branch shapes at 256^2 and 224^2 inputs (row widths 64..8 and 56..7), the regressor
 # trunks (small images: several per tile), a non-square image, channel counts with 1..4 output tiles per block
 C3_SHAPES = [(48, 48, 64, 64, 4), (96, 96, 32, 32, 4), (192, 192, 16, 16, 8), (384, 384, 8, 8, 8),
