@@ -412,7 +412,7 @@ static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int 
         long ms = (long)(target * (w / tot) / other + 0.5);
         if (ms > nchunks / 4) ms = nchunks / 4;
         if (ms < 1) ms = 1;
-        if (ms == 2 && other >= 16 && getenv("DANET_WGRAD3_FORCE1")) ms = 1;      // a layer with >= 16 channel blocks: one undivided block each, written straight into dW (Wg3P.direct)
+        // (forcing ms 2 -> 1 for the 192-channel layers so that they go direct as well measured +0.4 ms/step: half as many workgroups for them)
         msplit[k] = (int)ms;
     }
 }
