@@ -356,6 +356,12 @@ def main():
     sync()
     elapsed = time.time() - t0
     elapsed_local = elapsed
+    # what the timed steps computed must be numbers: the last step's losses and a sample of the parameters the optimizer has
+    # updated W + K times by now (round 5 found replays of the round-4 graph turning NaN after a few steps: a memset node racing the
+    # bias-gradient kernel -- the timing was unaffected, the training was not)
+    last = tr._static_out[1] if use_graph else tr.train_step(batch)[1]
+    finite = bool(all(torch.isfinite(v.float()).all() for v in last.values())) and \
+        bool(all(torch.isfinite(p).all() for p in list(tr.model.parameters())[::7]))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -413,7 +419,7 @@ def main():
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-                'exec': 'hipgraph' if use_graph else 'eager',
+                'exec': 'hipgraph' if use_graph else 'eager', 'finite_losses_and_parameters': finite, 'onepass_error': bool(_dnn_error()),
                 'dry': bool(args.dry),
                 'allreduce': allreduce_info,
                 'config': {'workload': 'full DaNet train step (HRNet-W48 + global and part-wise IUV heads + regressor nets + SMPL LBS '

@@ -97,7 +97,7 @@ class GradStore(object):
         self._mask_event = [None, None]
         self._mask_turn = 0
         self._mask_captured = []            # pinned masks owned by captured graphs (one per capture)
-        self._mask_for_capture = None       # the next capture's (prepare_capture)
+        self._mask_for_capture = []         # buffers for the next captures (prepare_capture)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._works = []
         self.issued = []                    # bucket indices in the order their collectives were issued this step ...
@@ -168,12 +168,13 @@ class GradStore(object):
                 raise RuntimeError('GradStore: %d parameter(s) received a gradient after their bucket had been all-reduced '
                                    '(the set of parameters in use changed between steps); the step is incomplete -- rerun it' % len(late))
 
-    def prepare_capture(self):
-        """Before a hipGraph capture of a step: the pinned host buffer its usage-mask upload will read on every replay (pinned
-        memory cannot be allocated while a stream is capturing)."""
-        if self._mask_for_capture is None:
+    def prepare_capture(self, attempts=1):
+        """Before the hipGraph capture(s) of a step: the pinned host buffer each capture's usage-mask upload will read on every
+        replay (pinned memory cannot be allocated while a stream is capturing -- nor, it turned out, right after a capture that
+        failed: one buffer per attempt, all of them up front)."""
+        while len(self._mask_for_capture) < attempts:
             m = torch.ones(len(self.params), dtype=torch.float32)
-            self._mask_for_capture = m.pin_memory() if self.device.type == 'cuda' else m
+            self._mask_for_capture.append(m.pin_memory() if self.device.type == 'cuda' else m)
 
     def stamp_poison(self):
         """Copy this rank's poison word into the tail of the last bucket (after the backward pass, before that bucket's
@@ -188,9 +189,9 @@ class GradStore(object):
             # own that no eager step ever rewrites (kept alive here), and no event is recorded (an event recorded in a capture cannot
             # be synchronized on later: hipErrorCapturedEvent) -- ADVICE r4.  The set of parameters in use is frozen into the graph
             # like the batch's host-side switches (Trainer.load_batch): capture() again when it changes (pretrain -> full model).
-            if self._mask_for_capture is None:
+            if not self._mask_for_capture:
                 raise RuntimeError('GradStore: call prepare_capture() before capturing a step (pinned memory cannot be allocated inside a capture)')
-            m, self._mask_for_capture = self._mask_for_capture, None
+            m = self._mask_for_capture.pop()
             m.zero_()
             if fired:
                 m[sorted(fired)] = 1.0

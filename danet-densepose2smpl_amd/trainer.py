@@ -454,12 +454,20 @@ class Trainer(object):
         if self.store is not None:
             self.store.quiesce()                  # no collective of the eager steps may still be on the watchdog's list (see there)
         from . import hrnet
-        for in_graph in ((True, False) if self.distributed else (True,)):
+        if self.store is not None:
+            self.store.prepare_capture(attempts=2 if self.distributed else 1)
+        modes = (True,)
+        if self.distributed:
+            # collectives inside the graph need a backend whose calls are stream work (RCCL); any other backend (gloo: host-side
+            # reductions on its own threads) cannot be captured -- and a capture that FAILS half-way is not something to rely on
+            # recovering from: round 5 tried it with gloo, the step's stream stayed in capture mode after the failed capture and the
+            # second capture_begin raised.  So the choice is made up front; the retry below remains for an RCCL capture that raises.
+            backend = torch.distributed.get_backend(self.store.group) if torch.distributed.is_initialized() else ''
+            modes = (True, False) if 'nccl' in str(backend) else (False,)
+        for in_graph in modes:
             conv._PACK_CACHE.clear()              # weight packing must be part of the captured work
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            if self.store is not None:
-                self.store.prepare_capture()
             hrnet.BRANCH_STREAMS = bool(int(os.environ.get('DANET_BRANCH_STREAMS', '1')))
             conv.FUSION.clear()
             try:
@@ -475,6 +483,7 @@ class Trainer(object):
             except RuntimeError:
                 if not (in_graph and self.distributed):      # (only a capture that holds collectives has a fallback: reduce after the replay)
                     raise
+                self._end_stray_capture()
                 torch.cuda.synchronize(self.device)
                 # the aborted capture left host-side state behind: queued weight-gradient jobs that point at tensors of its
                 # pool, BatchNorm call counters, the arena cursor, pending collectives
@@ -486,6 +495,21 @@ class Trainer(object):
                 hrnet.BRANCH_STREAMS = False
         self._graph = graph
         return self
+
+    def _end_stray_capture(self):
+        """A capture that raised may leave the step's stream in capture mode (observed: hipStreamCaptureStatusActive after
+        torch.cuda.graph's own clean-up): end it through the runtime so that the next capture can begin.  Best effort."""
+        try:
+            if not self.stream.is_capturing():
+                return
+            import ctypes
+            hip = ctypes.CDLL('libamdhip64.so')
+            g = ctypes.c_void_p()
+            hip.hipStreamEndCapture(ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(g))
+            if g.value:
+                hip.hipGraphDestroy(g)
+        except Exception:          # noqa: BLE001 -- nothing more to try; the second capture will report the state it finds
+            pass
 
     def load_batch(self, in_dict):
         """Copy a new batch into the captured graph's static input tensors (nested dictionaries included)."""

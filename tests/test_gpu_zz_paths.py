@@ -471,3 +471,55 @@ def test_two_process_trainer_gradient_allreduce(tmp_path):
         assert r['raised'] and r['onepass_after'] is False and r['psum_after'] == 0.0
     assert torch.equal(r0['p3'], r1['p3']) and not torch.equal(r0['p3'], r0['p2'])
 
+
+
+def _two_proc_capture_worker(rank, world, port, tmp):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)          # (both processes share GPU 0: RCCL needs one GPU per rank)
+    from danet_densepose2smpl_amd.config import reset_cfg, cfg_from_dict
+    from danet_densepose2smpl_amd.trainer import Trainer, synthetic_in_dict, default_options
+    reset_cfg()
+    cfg_from_dict({'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16, 'DANET.PARTDROP_RATE': 0.,
+                   'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.})
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(20 + rank)
+    tr = Trainer(default_options(2), device=dev, distributed=True, lr=1e-4, bucket_mb=4.0)
+    batch = synthetic_in_dict(tr.model, 2, dev, seed=200 + rank)
+    tr.train_step(batch)
+    tr.train_step(batch)                       # (the second step releases buckets between the backward segments)
+    early_eager = tr.store.issued_early
+    torch.cuda.synchronize()
+    tr.capture(batch, warmup=1)                # gloo collectives are no stream work: the trainer must capture forward + backward only ...
+    in_graph = tr._reduce_in_graph             # ... and reduce + update after every replay
+    p_before = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+    for _ in range(3):
+        _, losses = tr.train_step_graphed()    # replay, then reduce_all() + optimizer.step() on the step's stream
+    torch.cuda.synchronize()
+    p_after = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+    finite = bool(all(torch.isfinite(v.float()).all() for v in losses.values()))
+    torch.save({'in_graph': in_graph, 'early_eager': early_eager, 'p_before': p_before, 'p_after': p_after, 'finite': finite,
+                'flat': tr.store.flat.cpu()}, os.path.join(tmp, 'c%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_process_capture_falls_back_to_reduce_after_replay(tmp_path):
+    """Trainer.capture() in a two-process group whose collectives cannot be captured (gloo; both ranks on
+    GPU 0).  The trainer must not try to put them into the graph (a capture that fails half-way left the step's stream in
+    capture mode when round 5 tried: the decision is made from the backend, up front), capture forward + backward only, and run
+    `reduce_all()` + the optimizer after every replay ("after the graph replay" in bench.py's line) -- the execution path a
+    failed RCCL capture falls back to as well.  Three such steps leave both ranks with identical, finite, CHANGED parameters and
+    identical gradient sums.  (With RCCL the in-graph capture succeeds: test_data_parallel_graph_path_single_rank.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_proc_capture_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = torch.load(tmp_path / 'c0.pt'), torch.load(tmp_path / 'c1.pt')
+    for c in (c0, c1):
+        assert c['in_graph'] is False and c['finite'] and c['early_eager'] >= 1
+        assert torch.isfinite(c['p_after']).all() and not torch.equal(c['p_after'], c['p_before'])
+    assert torch.equal(c0['p_before'], c1['p_before']) and torch.equal(c0['p_after'], c1['p_after'])
+    assert torch.equal(c0['flat'], c1['flat'])
