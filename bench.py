@@ -111,7 +111,7 @@ def cpu_baseline(size, cpu_batch):
     from danet_densepose2smpl_amd import assets
     nthr = torch.get_num_threads()
     counts = sorted({max(1, nthr), max(1, nthr // 2), max(1, nthr // 4)}, reverse=True)
-    sweep, nparam = torch_ref.train_step_cpu_sweep(cpu_batch, size, counts)
+    sweep, nparam, spread = torch_ref.train_step_cpu_sweep(cpu_batch, size, counts)
     best_thr, t_net = min(sweep, key=lambda r: r[1])
     model = assets.make_synthetic_smpl(0)
     vm, faces, tex = assets.densepose_render_tables(assets.make_synthetic_densepose(model, 0))
@@ -129,7 +129,9 @@ def cpu_baseline(size, cpu_batch):
     return {'value': round(cpu_batch / (t_net + t_geo), 4), 'unit': 'images/sec', 'cores': best_thr,
             'kind': 'port', 'cpu': _cpu_model(), 'host_threads': nthr,
             'thread_sweep': [{'threads': n, 'images_per_sec': round(cpu_batch / (t + t_geo), 4)} for n, t in sweep],
-            'sample': 'B=%d of the B=32 step, one timed step per thread count after one warm-up step, best of %s threads reported: '
+            # three draws at the reported setting: `value` is the best of them, this is their range (images/sec)
+            'spread': [round(cpu_batch / (spread[1] + t_geo), 4), round(cpu_batch / (spread[0] + t_geo), 4)],
+            'sample': 'B=%d of the B=32 step, one timed step per thread count after one warm-up step, then two more at the fastest of %s threads (best of the three reported, range in `spread`): '
                       'oracle/torch_ref.StepNets fwd+bwd+Adam fp32 (%.2fs; %.1f M parameters; 30.06 of the step\'s 30.07 GMAC/img = 99.9 %% of its '
                       '5.77 TFLOP: only the GCN / 1x1 regressors and the loss glue are left out) + 2x C SMPL fwd, 1x C SMPL bwd, 1x C IUV '
                       'raster on one thread (%.2fs)' % (cpu_batch, counts, t_net, nparam / 1e6, t_geo)}

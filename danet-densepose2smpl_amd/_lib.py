@@ -43,20 +43,14 @@ _SIGNATURES = {
     'danet_conv_f32m_forward': (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 15 + [c_f]),
     'danet_conv_f32m_wgrad_ws_floats': (c_sz, [c_i] * 15),
     'danet_conv_f32m_wgrad': (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 15 + [c_f]),
-    'danet_conv3x3_set': (c_i, [c_i] * 5),
     'danet_conv3x3_debug': (None, [c_f]),
-    'danet_conv3x3_stream_set': (c_i, [c_i, c_i, c_i, c_i]),
     'danet_conv3x3_stream_plan': (c_i, [c_i] * 6),
-    'danet_conv_pw_set': (c_i, [c_i]),
     'danet_conv_stem_ok': (c_i, [c_i] * 13),
     'danet_conv_stem_forward': (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f, c_f]),
-    'danet_conv_stem_set': (c_i, [c_i]),
     'danet_conv_stem_dgrad_ok': (c_i, [c_i] * 13),
     'danet_conv_stem_dgrad': (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f] * 5),
-    'danet_conv_stem_dgrad_set': (c_i, [c_i]),
     'danet_conv3x3a_ok': (c_i, [c_i] * 11),
     'danet_conv3x3a': (c_i, [c_f, c_f, c_f] + [c_i] * 4 + [c_f] * 5 + [c_i, c_f, c_f]),
-    'danet_conv3x3a_set': (c_i, [c_i]),
     'danet_conv3x3_stream_table_bytes': (c_sz, []),
     'danet_conv3x3_stream_tables': (c_i, [c_f, c_sz]),
     'danet_conv_pack_weights_batched': (c_i, [c_f, c_i, ctypes.c_long, ctypes.c_long, c_f]),
@@ -80,13 +74,12 @@ _SIGNATURES = {
     'danet_conv_wgrad3x3': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 7 + [c_fl, c_i, c_f]),
     'danet_conv_wgrad_ws_floats': (c_sz, [c_i] * 4),
     'danet_conv_wgrad_ws_floats_for': (c_sz, [c_i] * 13),
-    'danet_conv_pw_wgrad_set': (c_i, [c_i]),
     'danet_conv_wgrad': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 13 + [c_fl, c_i, c_f]),
     'danet_bn_forward': (c_i, [c_f, c_f, c_f, ctypes.c_int64, c_i] + [c_f] * 6 + [c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'danet_bn_ws_floats': (c_sz, [c_i]),
+    'danet_knob': (ctypes.c_long, [c_i, ctypes.c_long]),
     'danet_bn_acc_bytes': (c_i, []),
     'danet_channel_sum': (c_i, [c_f, ctypes.c_int64, c_i, c_f, c_i, c_f]),
-    'danet_bn_set_block_bytes': (ctypes.c_long, [ctypes.c_long]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_bn_backward_onepass_ok': (c_i, [c_f, c_i, c_i]),
@@ -165,6 +158,80 @@ def exported_symbols():
     return list(_SIGNATURES)
 
 
+# include/danet_hip.h DANET_KNOB_*: the library's only run-time switches (A-B timing, tests)
+KNOBS = {'c3_enable': 1, 'c3_mt': 2, 'c3_kw': 3, 'c3_blocks': 4, 'c3_want': 5, 'c3s_enable': 6, 'c3s_blocks': 7, 'c3s_kw': 8, 'c3s_want': 9,
+         'pw': 10, 'pw_wgrad': 11, 'stem': 12, 'stem_dgrad': 13, 'c3a': 14, 'bn_block_bytes': 15}
+
+
+class _Library(object):
+    """The loaded libdanet_hip.so (attribute access = its C entry points, include/danet_hip.h) plus the host-side spellings of
+    the switch board: `knob(name, value)` and the multi-argument setters tests and tools have always called, all of them thin
+    wrappers of danet_knob.  Prefer `knobs(...)` below: a context manager cannot leak a flipped switch."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        return getattr(self._cdll, name)
+
+    def knob(self, name, value=-1):
+        """Set (value >= 0; bn_block_bytes: > 0) or query (value < 0) a switch; returns the previous value."""
+        return int(self._cdll.danet_knob(KNOBS[name], int(value)))
+
+    # (enable, ...) with -1 / <= 0 = keep, returning the previous `enable`: the round-1..4 signatures
+    def danet_conv3x3_set(self, enable, force_mt, force_kw, blocks, want_tiles):
+        prev = self.knob('c3_enable', enable)
+        if force_mt >= 0 and force_kw >= 0:
+            self.knob('c3_mt', force_mt)
+            self.knob('c3_kw', force_kw)
+        self.knob('c3_blocks', blocks if blocks > 0 else -1)
+        self.knob('c3_want', want_tiles)
+        return prev
+
+    def danet_conv3x3_stream_set(self, enable, blocks, kw, want_tiles):
+        prev = self.knob('c3s_enable', enable)
+        self.knob('c3s_blocks', blocks if blocks > 0 else -1)
+        self.knob('c3s_kw', kw)
+        self.knob('c3s_want', want_tiles)
+        return prev
+
+    def danet_conv_pw_set(self, enable):
+        return self.knob('pw', enable)
+
+    def danet_conv_pw_wgrad_set(self, enable):
+        return self.knob('pw_wgrad', enable)
+
+    def danet_conv_stem_set(self, enable):
+        return self.knob('stem', enable)
+
+    def danet_conv_stem_dgrad_set(self, enable):
+        return self.knob('stem_dgrad', enable)
+
+    def danet_conv3x3a_set(self, enable):
+        return self.knob('c3a', enable)
+
+    def danet_bn_set_block_bytes(self, nbytes):
+        return self.knob('bn_block_bytes', nbytes if nbytes > 0 else -1)
+
+
+import contextlib   # noqa: E402
+
+
+@contextlib.contextmanager
+def knobs(**settings):
+    """`with _lib.knobs(c3s_enable=0, pw=0): ...` -- the named switches (KNOBS) hold the given values inside the block and their
+    previous values after it, whatever happens inside."""
+    L = lib()
+    prev = {}
+    try:
+        for k, v in settings.items():
+            prev[k] = L.knob(k, v)
+        yield L
+    finally:
+        for k, v in prev.items():
+            L.knob(k, v)
+
+
 def lib():
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
@@ -181,7 +248,7 @@ def lib():
             fn = getattr(l, name)       # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        _lib = l
+        _lib = _Library(l)
     return _lib
 
 

@@ -1,5 +1,6 @@
 // Library-level entry points: version + thread-local error string.
 #include "common.h"
+#include "conv_common.h"
 
 namespace danet {
 char* last_error_buf() {
@@ -30,4 +31,22 @@ hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
 }  // namespace danet
 
 extern "C" int danet_version(void) { return 100; }
+
+// The library's only run-time switch board (A-B timing and tests; production code never calls it): include/danet_hip.h DANET_KNOB_*.
+extern "C" long danet_knob(int id, long value) {
+    using namespace danet_conv;
+    switch (id) {
+        case DANET_KNOB_C3_ENABLE: case DANET_KNOB_C3_MT: case DANET_KNOB_C3_KW: case DANET_KNOB_C3_BLOCKS: case DANET_KNOB_C3_WANT:
+            return conv3x3_knob(id, value);
+        case DANET_KNOB_C3S_ENABLE: case DANET_KNOB_C3S_BLOCKS: case DANET_KNOB_C3S_KW: case DANET_KNOB_C3S_WANT:
+            return conv3x3s_knob(id, value);
+        case DANET_KNOB_PW: return conv_pw_knob(value);
+        case DANET_KNOB_PW_WGRAD: return conv_pw_wgrad_knob(value);
+        case DANET_KNOB_STEM: return conv_stem_knob(value);
+        case DANET_KNOB_STEM_DGRAD: return conv_stem_dgrad_knob(value);
+        case DANET_KNOB_C3A: return conv3x3a_knob(value);
+        case DANET_KNOB_BN_BLOCK_BYTES: return bn_block_bytes_knob(value);
+        default: return -1;
+    }
+}
 extern "C" const char* danet_last_error(void) { return danet::last_error_buf(); }

@@ -510,7 +510,7 @@ void launch_one(const C3Launch& L, int grid, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_one_kernel<MT, NT, KW>), dim3((unsigned)grid), dim3(256), lds, st, L);
 }
 
-// run-time knobs (A-B timing, tests): defaults from the environment, settable through danet_conv3x3_set
+// run-time knobs (A-B timing, tests): defaults from the environment, settable through danet_knob (DANET_KNOB_C3_*)
 struct Forced { int mt, kw; };
 Forced g_force = [] {
     Forced f{0, 0};
@@ -686,15 +686,18 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry) {
 
 }  // namespace danet_conv
 
-// enable: 0/1 (-1 keeps); force_mt, force_kw: register tiling for every problem (0, 0 = planner's choice; -1 keeps);
-// blocks: workgroup cap of a launch (<= 0 keeps); want_tiles: tiles per problem the planner aims for (0 = 512 / problems
-// of the launch; < 0 keeps).  Returns the previous `enable`.
-extern "C" int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks, int want_tiles) {
-    const int prev = g_c3_on ? 1 : 0;
-    if (enable >= 0) g_c3_on = enable != 0;
-    if (force_mt >= 0 && force_kw >= 0) g_force = Forced{force_mt, force_kw};
-    if (blocks > 0) g_c3_blocks = blocks;
-    if (want_tiles >= 0) g_c3_want = want_tiles;
+// danet_knob ids of this file: enable 0/1; forced register tiling (mt, kw) of every problem (0 = planner's choice); workgroup cap
+// of a launch (0 is not a cap: ignored); tiles per problem the planner aims for (0 = 512 / problems of the launch).
+long danet_conv::conv3x3_knob(int id, long v) {
+    long prev = 0;
+    switch (id) {
+        case DANET_KNOB_C3_ENABLE: prev = g_c3_on ? 1 : 0; if (v >= 0) g_c3_on = v != 0; break;
+        case DANET_KNOB_C3_MT: prev = g_force.mt; if (v >= 0) g_force.mt = (int)v; break;
+        case DANET_KNOB_C3_KW: prev = g_force.kw; if (v >= 0) g_force.kw = (int)v; break;
+        case DANET_KNOB_C3_BLOCKS: prev = g_c3_blocks; if (v > 0) g_c3_blocks = (int)v; break;
+        case DANET_KNOB_C3_WANT: prev = g_c3_want; if (v >= 0) g_c3_want = (int)v; break;
+        default: break;
+    }
     return prev;
 }
 // Profiling hook: device buffer of blocks*8 ints that receives every workgroup's phase timestamps (NULL: off).

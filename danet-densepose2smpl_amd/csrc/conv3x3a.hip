@@ -411,4 +411,4 @@ extern "C" int danet_conv3x3a(const void* x, const void* wp, void* y, int B, int
     return DANET_OK;
 }
 
-extern "C" int danet_conv3x3a_set(int enable) { const int old = g_c3a_on; g_c3a_on = enable != 0; return old; }
+long danet_conv::conv3x3a_knob(long enable) { const long old = g_c3a_on ? 1 : 0; if (enable >= 0) g_c3a_on = enable != 0; return old; }

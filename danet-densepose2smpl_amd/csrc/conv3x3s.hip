@@ -1033,12 +1033,15 @@ extern "C" int danet_conv3x3_stream_tables(void* ws, size_t bytes) {
     pool.index.clear();
     return pool.cap;
 }
-extern "C" int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want_tiles) {
-    const int prev = g_s3_on ? 1 : 0;
-    if (enable >= 0) g_s3_on = enable != 0;
-    if (blocks > 0) g_s3_blocks = blocks;
-    if (kw >= 0) g_s3_kw = kw;
-    if (want_tiles >= 0) g_s3_want = want_tiles;
+long danet_conv::conv3x3s_knob(int id, long v) {
+    long prev = 0;
+    switch (id) {
+        case DANET_KNOB_C3S_ENABLE: prev = g_s3_on ? 1 : 0; if (v >= 0) g_s3_on = v != 0; break;
+        case DANET_KNOB_C3S_BLOCKS: prev = g_s3_blocks; if (v > 0) g_s3_blocks = (int)v; break;
+        case DANET_KNOB_C3S_KW: prev = g_s3_kw; if (v >= 0) g_s3_kw = (int)v; break;
+        case DANET_KNOB_C3S_WANT: prev = g_s3_want; if (v >= 0) g_s3_want = (int)v; break;
+        default: break;
+    }
     return prev;
 }
 // What the streamed kernel would do with a problem: KW * 100 + stages * 10 + NT (0: not taken).

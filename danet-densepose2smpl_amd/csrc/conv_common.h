@@ -90,6 +90,17 @@ int conv3x3_launch(const ConvP* ps, int n, void* stream, bool dry = false);     
 // conv3x3s.hip: the streamed successor (LDS-DMA stage copies into a two-slot LDS ring); conv3x3_launch tries it first.  0 = launched (or, dry, would be)
 int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry);
 bool conv3x3_stream_first();
-int* conv3x3_debug_buffer();        // danet_conv3x3_debug's buffer (NULL: off); the streamed kernel writes 16 ints per workgroup
+int* conv3x3_debug_buffer();
+
+// Run-time knobs (A-B timing, tests) behind the ONE entry point danet_knob (include/danet_hip.h, DANET_KNOB_*): every translation
+// unit keeps its own switches and answers for its ids; value < 0 only queries; the previous value is returned.
+long conv3x3_knob(int id, long value);          // conv3x3.hip:  C3_ENABLE, C3_MT, C3_KW, C3_BLOCKS, C3_WANT
+long conv3x3s_knob(int id, long value);         // conv3x3s.hip: C3S_ENABLE, C3S_BLOCKS, C3S_KW, C3S_WANT
+long conv_pw_knob(long value);
+long conv_pw_wgrad_knob(long value);
+long conv_stem_knob(long value);
+long conv_stem_dgrad_knob(long value);
+long conv3x3a_knob(long value);
+long bn_block_bytes_knob(long value);        // danet_conv3x3_debug's buffer (NULL: off); the streamed kernel writes 16 ints per workgroup
 
 }  // namespace danet_conv

@@ -324,8 +324,8 @@ int conv_pw_launch(const ConvP& p, void* stream) {
 }  // namespace danet_conv
 
 // Run-time switch of the pointwise kernel (A-B timing, tests): enable 0 / 1 (-1 keeps); returns the previous setting.
-extern "C" int danet_conv_pw_set(int enable) {
-    const int prev = g_pw_on ? 1 : 0;
+long danet_conv::conv_pw_knob(long enable) {
+    const long prev = g_pw_on ? 1 : 0;
     if (enable >= 0) g_pw_on = enable != 0;
     return prev;
 }

@@ -324,8 +324,8 @@ int conv_pw_wgrad_launch(const WgJob* jobs, const int* idx, int cnt, float* ws, 
 }  // namespace danet_conv
 
 // Run-time switch of the pointwise weight-gradient kernel (A-B timing, tests): enable 0 / 1 (-1 keeps); returns the previous setting.
-extern "C" int danet_conv_pw_wgrad_set(int enable) {
-    const int prev = g_pwg_on ? 1 : 0;
+long danet_conv::conv_pw_wgrad_knob(long enable) {
+    const long prev = g_pwg_on ? 1 : 0;
     if (enable >= 0) g_pwg_on = enable != 0;
     return prev;
 }

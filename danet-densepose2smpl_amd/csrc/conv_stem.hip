@@ -415,8 +415,8 @@ extern "C" int danet_conv_stem_forward(const void* x, const void* wp, void* y, i
     return DANET_OK;
 }
 
-extern "C" int danet_conv_stem_set(int enable) {
-    const int prev = g_stem_on ? 1 : 0;
+long danet_conv::conv_stem_knob(long enable) {
+    const long prev = g_stem_on ? 1 : 0;
     if (enable >= 0) g_stem_on = enable != 0;
     return prev;
 }

@@ -384,4 +384,4 @@ extern "C" int danet_conv_stem_dgrad(const void* dy, const void* wp, void* dx, i
     return DANET_OK;
 }
 
-extern "C" int danet_conv_stem_dgrad_set(int enable) { const int old = g_stem_dgrad_on; g_stem_dgrad_on = enable != 0; return old; }
+long danet_conv::conv_stem_dgrad_knob(long enable) { const long old = g_stem_dgrad_on ? 1 : 0; if (enable >= 0) g_stem_dgrad_on = enable != 0; return old; }

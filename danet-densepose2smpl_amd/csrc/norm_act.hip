@@ -915,7 +915,7 @@ long danet_bn_block_bytes() { return g_bn_block_bytes; }
 // Run-time knob (A-B timing, tests): bytes <= 0 keeps; returns the previous value.  With a value above every tensor's size each
 // BatchNorm launch is ONE workgroup per tensor: its float sums then have a fixed order (the replicated atomics of larger grids
 // do not), which tests that compare two executions of a chaotic deep net need.
-extern "C" long danet_bn_set_block_bytes(long bytes) { const long prev = g_bn_block_bytes; if (bytes > 0) g_bn_block_bytes = bytes; return prev; }
+long danet_conv::bn_block_bytes_knob(long bytes) { const long prev = g_bn_block_bytes; if (bytes > 0) g_bn_block_bytes = bytes; return prev; }
 #endif
 namespace {
 // slab [c_begin, c_begin + Cs) of a [M, C] tensor; Cs <= 1024

@@ -304,18 +304,26 @@ int danet_conv_f32m_wgrad(const float* x, const float* dy, float* dw, float* ws,
 int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
 int danet_conv_forward_multi_kernel(const void* jobs, int n);      /* the kernel the set runs on: 0 none, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel,
                                                                        3 conv3x3_stream_kernel (csrc/conv3x3s.hip) */
-/* Run-time knobs of the LDS-tile 3x3 kernel (A-B timing, tests): enable 0/1 (-1 keeps); force_mt/force_kw = register
- * tiling for every problem (0,0 = planner's choice; -1 keeps); blocks = workgroup cap (<= 0 keeps); want_tiles = tiles per
- * problem the planner aims for (0 = 512 / problems of the launch; < 0 keeps). Returns the previous enable. */
-int danet_conv3x3_set(int enable, int force_mt, int force_kw, int blocks, int want_tiles);
-/* The streamed 3x3 kernel (csrc/conv3x3s.hip: a loader wave copies the next stage's halo tile into a two-deep LDS ring with
- * LDS-DMA while four waves run the MFMA loop on the current one) takes the 3x3 / stride-1 problems with at most 48 output
- * channels per block ahead of conv3x3_tile_kernel.  enable 0/1 (-1 keeps), blocks = workgroup cap (<= 0 keeps), kw = forced K
- * split over the four waves 1/2/4 (0 = planner's choice, < 0 keeps), want_tiles = tiles per problem the planner aims for (0 = 512 /
- * problems of the launch, < 0 keeps); returns the previous enable.  A forced register tiling (danet_conv3x3_set) keeps a problem on
- * conv3x3.hip.  danet_conv3x3_stream_plan: KW*100 + stages*10 + NT the kernel would use for a problem in a launch of nprob
- * problems (0: not taken). */
-int danet_conv3x3_stream_set(int enable, int blocks, int kw, int want_tiles);
+/* ---------------------------------------------------------------------------------------
+ * The library's ONE run-time switch board, for A-B timing and tests (production code never calls it; the defaults come from
+ * the environment variables the kernels' files name).  danet_knob(id, value): value < 0 only queries; returns the previous value
+ * (-1: unknown id).  The switches are process-wide -- callers that flip one restore it (the Python host side offers a context
+ * manager that cannot leak a flipped knob: _lib.knobs(...)).
+ *   C3_*   the LDS-tile 3x3 kernel (csrc/conv3x3.hip): ENABLE 0/1; MT, KW = register tiling forced on every problem (0, 0 = the
+ *          planner's choice); BLOCKS = workgroup cap (> 0); WANT = tiles per problem the planner aims for (0 = 512 / problems)
+ *   C3S_*  the streamed 3x3 kernel (csrc/conv3x3s.hip), which takes the 3x3 / stride-1 problems with at most 48 output channels
+ *          per block ahead of the tile kernel: ENABLE; BLOCKS; KW = forced K split over the four waves 1/2/4 (0 = planner);
+ *          WANT as above.  A forced register tiling (C3_MT / C3_KW) keeps a problem on conv3x3.hip.
+ *   PW, PW_WGRAD, STEM, STEM_DGRAD, C3A   0/1: the pointwise forward / data-gradient kernel, the pointwise weight gradient, the
+ *          7x7 stem forward and data gradient on LDS row tiles, the 64-channel row-tile 3x3 kernel (their sections below)
+ *   BN_BLOCK_BYTES   bytes of the tensor one workgroup of the BatchNorm kernels handles at least (default 24576; > 0 sets) */
+enum { DANET_KNOB_C3_ENABLE = 1, DANET_KNOB_C3_MT = 2, DANET_KNOB_C3_KW = 3, DANET_KNOB_C3_BLOCKS = 4, DANET_KNOB_C3_WANT = 5,
+       DANET_KNOB_C3S_ENABLE = 6, DANET_KNOB_C3S_BLOCKS = 7, DANET_KNOB_C3S_KW = 8, DANET_KNOB_C3S_WANT = 9,
+       DANET_KNOB_PW = 10, DANET_KNOB_PW_WGRAD = 11, DANET_KNOB_STEM = 12, DANET_KNOB_STEM_DGRAD = 13, DANET_KNOB_C3A = 14,
+       DANET_KNOB_BN_BLOCK_BYTES = 15 };
+long danet_knob(int id, long value);
+/* danet_conv3x3_stream_plan: KW*100 + stages*10 + NT the streamed 3x3 kernel (csrc/conv3x3s.hip) would use for a problem in a launch of
+ * nprob problems (0: not taken). */
 int danet_conv3x3_stream_plan(int B, int H, int W, int Cin, int Cout, int nprob);
 /* The streamed kernel reads a per-shape tap table (<= 112 k-step entries, danet_conv3x3_stream_table_bytes() bytes each) from
  * device memory.  The library allocates none: the caller registers a workspace for the CURRENT device once (it must outlive
@@ -327,18 +335,16 @@ size_t danet_conv3x3_stream_table_bytes(void);
 int danet_conv3x3_stream_tables(void* workspace, size_t bytes);
 /* The pointwise kernel (csrc/conv_pw.hip: 1x1 / stride-1 layers with <= 64 KB of packed weights and >= 8192 pixels; the layer's
  * weights in LDS, persistent workgroups, X read once and Y written once) takes such problems ahead of the gather kernel in
- * danet_conv_forward (danet_conv_forward_kernel: last digit 3).  enable 0/1 (-1 keeps); returns the previous setting. */
-int danet_conv_pw_set(int enable);
+ * danet_conv_forward (danet_conv_forward_kernel: last digit 3).  Switch: DANET_KNOB_PW. */
 /* The regressor ResNets' 7x7 / stride-2 / pad-3 stems (/root/reference/models/module/res_module.py:404, :118) on LDS tiles (csrc/conv_stem.hip):
  * 64 output channels, input channels a multiple of 16, 2 OH x 64 -> OH x 32 maps with OH % 8 == 0, at least 256 tiles (8 output rows of an
  * image each).  danet_conv_stem_ok: 1 when the kernel takes the problem.  danet_conv_stem_forward: x [B,H,W,Cin] bf16 NHWC, wp = the weight
  * packed by danet_conv_pack_weights(mode 0, chunk 16) -- K order (16-channel slab, tap, channel) --, y [B,OH,OW,64] bf16; bn_sums: optional
  * fused BatchNorm statistics [BN_NCOPY][2][64], pre-zeroed.  The data gradient of these layers stays on danet_conv_forward (transposed).
- * danet_conv_stem_set: run-time switch (A-B timing, tests): 0 / 1 (-1 keeps); returns the previous setting. */
+ * Switch: DANET_KNOB_STEM. */
 int danet_conv_stem_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
 int danet_conv_stem_forward(const void* x, const void* wp, void* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
                             float* bn_sums, void* stream);
-int danet_conv_stem_set(int enable);
 /* Data gradient of a stem convolution with 64 input and 64 output channels (csrc/conv_stem_dgrad.hip): (B, H, W, Cin) describe dx (the
  * convolution's input), (OH, OW, Cout) dy; weights = danet_conv_pack_weights(mode 1, chunk 16).  bn_x / bn_y / bn_saved / bn_red: the fused
  * BatchNorm-backward sums of danet_conv_forward's arguments of the same names (all NULL: none).  Replaces danet_conv_forward(transposed = 1)
@@ -346,7 +352,6 @@ int danet_conv_stem_set(int enable);
 int danet_conv_stem_dgrad_ok(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
 int danet_conv_stem_dgrad(const void* dy, const void* wp, void* dx, int B, int H, int W, int Cin, int OH, int OW, int Cout,
                           const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, void* stream);
-int danet_conv_stem_dgrad_set(int enable);
 /* 3x3 / stride 1 / pad 1, 64 -> 64 channels on 16- or 64-wide maps (csrc/conv3x3a.hip: the BasicBlocks of the regressor ResNets' layer1,
  * /root/reference/models/module/res_module.py:27-56 under SmplResNet :404): forward (transposed = 0, weights mode 0 / chunk 16, optional output
  * statistics bn_sums) and data gradient (transposed = 1, weights mode 1 / chunk 16, optional fused BatchNorm-backward sums -- bn_gate 0: bn_y is
@@ -354,7 +359,6 @@ int danet_conv_stem_dgrad_set(int enable);
 int danet_conv3x3a_ok(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
 int danet_conv3x3a(const void* x, const void* wp, void* y, int B, int H, int W, int transposed, float* bn_sums,
                    const void* bn_x, const void* bn_y, const float* bn_saved, float* bn_red, int bn_gate, const void* addend, void* stream);
-int danet_conv3x3a_set(int enable);
 /* Profiling hook: device buffer of blocks*8 ints receiving each workgroup's phase timestamps (s_memtime; NULL = off). */
 void danet_conv3x3_debug(int* dev_buf);
 int danet_conv_forward_multi(const void* jobs, int n, void* stream);
@@ -400,9 +404,8 @@ size_t danet_conv_wgrad_ws_floats(int Cout, int Cin_g, int R, int S);
  * weight-gradient kernel (csrc/conv_pw_wgrad.hip: 32-pixel chunks of dY and X staged as they lie in memory, LDS transpose reads,
  * per-workgroup partial sums reduced in a fixed order -- deterministic, no atomics) when the workspace has room for its partial
  * sums; with the smaller workspace the generic kernel runs.  danet_conv_wgrad_multi sizes its own (danet_conv_wgrad_multi_ws_floats).
- * danet_conv_pw_wgrad_set: run-time switch (A-B timing, tests): 0 / 1 (-1 keeps); returns the previous setting. */
+ * Switch: DANET_KNOB_PW_WGRAD. */
 size_t danet_conv_wgrad_ws_floats_for(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups);
-int danet_conv_pw_wgrad_set(int enable);
 int danet_conv_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout,
                      int R, int S, int stride, int pad, int dil, int groups, float beta, int ws_is_zero, void* stream);
@@ -448,10 +451,8 @@ int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, i
  *  backward job { const void* dy, *x, *y; const float* gamma, *saved; void* dx, *dres; float* dparam, *red; const float* beta;
  *                 const void* mask; int64_t M; int C, red_state, relu, mask_mode; }
  *                 red_state 1: zeroed scratch, 2: accumulated by the dgrad epilogue; mask / mask_mode as above */
-/* Run-time knob (A-B timing, tests): bytes of the tensor one workgroup of the BatchNorm kernels handles at least (default
- * 24576, or DANET_BN_BLOCK_BYTES); <= 0 keeps; returns the previous value.  Above every tensor's size each launch is a single
- * workgroup per tensor, whose float sums have a fixed order. */
-long danet_bn_set_block_bytes(long bytes);
+/* (DANET_KNOB_BN_BLOCK_BYTES: bytes of the tensor one workgroup of these kernels handles at least -- default 24576, or
+ * DANET_BN_BLOCK_BYTES; above every tensor's size each launch is a single workgroup per tensor.) */
 int danet_bn_forward_multi(const void* jobs, int n, float momentum, float eps, void* stream);
 int danet_bn_backward_multi(const void* jobs, int n, void* stream);
 /* One-pass form of danet_bn_backward_multi: every lane keeps its share of dy / x in registers across a grid-wide barrier,

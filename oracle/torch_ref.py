@@ -340,9 +340,11 @@ def train_step_cpu(B, size, reps=1):
     return (time.time() - t0) / reps, sum(p.numel() for p in net.parameters())
 
 
-def train_step_cpu_sweep(B, size, thread_counts):
+def train_step_cpu_sweep(B, size, thread_counts, repeats_best=2):
     """[(threads, seconds per fwd + bwd + Adam step of StepNets)] for every thread count: ONE network and one warm-up step, then
-    one timed step per setting (bench.py's cpu_baseline reports the best); restores the thread count."""
+    one timed step per setting, then `repeats_best` more steps at the fastest setting -- its entry becomes the BEST of those
+    draws and `spread` their (min, max) (bench.py's cpu_baseline reports both); restores the thread count.
+    Returns (results, parameter count, spread)."""
     import time
     torch.manual_seed(0)
     net = StepNets().train()
@@ -364,6 +366,14 @@ def train_step_cpu_sweep(B, size, thread_counts):
             t0 = time.time()
             step()
             res.append((int(n), time.time() - t0))
+        best = min(range(len(res)), key=lambda i: res[i][1])
+        draws = [res[best][1]]
+        torch.set_num_threads(res[best][0])
+        for _ in range(int(repeats_best)):
+            t0 = time.time()
+            step()
+            draws.append(time.time() - t0)
+        res[best] = (res[best][0], min(draws))
     finally:
         torch.set_num_threads(prev)
-    return res, sum(p.numel() for p in net.parameters())
+    return res, sum(p.numel() for p in net.parameters()), (min(draws), max(draws))

@@ -4,6 +4,13 @@ batch_rigid_transform with homogeneous 4x4 matrices and `transforms - pad(transf
 the flattened 4x4s -> homogeneous vertices) plus what /root/reference/models/smpl.py:27-46 adds (nine regressed extra
 joints on the POSED vertices, landmark vertices).  Gradients come from torch.autograd, not from hand-derived formulas.
 
+Provenance: `rodrigues_smplx`, `transform_mat` and `batch_rigid_transform` below are written AFTER the published source of the
+third-party package smplx (smplx/lbs.py, Max-Planck-Gesellschaft; not vendored under /root/reference, not installed in this
+image), whose function structure they follow statement by statement -- that is the point of this file: to restate what the
+reference's dependency computes, independently of oracle/'s own formulation.  smplx's source is distributed under the
+Max-Planck non-commercial scientific research licence; this file is test infrastructure only (imported by nothing outside
+tests/) and "independent" above means independent of the C oracle, not of smplx.
+
 The C oracle (oracle/lbs_ref_impl.inc) is a different formulation by construction: 3x4 affine chains without homogeneous
 rows, rest-pose subtraction folded into the translation, a hand-written backward pass.  smplx itself and the licensed
 model file are absent from this image, so neither restatement can be run against the original; two independently
