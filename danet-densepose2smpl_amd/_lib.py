@@ -24,7 +24,8 @@ _SIGNATURES = {
     'danet_smpl_lbs_bwd_ws_floats': (c_sz, [c_i, c_i, c_i]),
     'danet_smpl_lbs_ticket_words': (c_sz, [c_i]),
     'danet_smpl_lbs_forward': (c_i, [c_f, c_f, c_i] + [c_f] * 9 + [c_i] * 4 + [c_f] * 5 + [c_sz, c_f, c_f]),
-    'danet_smpl_lbs_backward': (c_i, [c_f, c_f, c_i] + [c_f] * 7 + [c_i] * 4 + [c_f] * 7 + [c_sz, c_f]),
+    'danet_smpl_lbs_backward': (c_i, [c_f, c_f, c_i] + [c_f] * 7 + [c_i] * 4 + [c_f] * 7 + [c_sz, c_f, c_i, c_f]),
+    'danet_smpl_lbs_backward_fused_ok': (c_i, [c_i, c_i, c_i]),
     'danet_iuv_raster_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'danet_iuv_raster_forward': (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'danet_conv_nt': (c_i, [c_i]),

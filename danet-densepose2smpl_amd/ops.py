@@ -71,11 +71,19 @@ class SmplLbsFunction(torch.autograd.Function):
         g_rot = torch.empty(B, 24, 3, 3, device=dev, dtype=torch.float32)
         nws = L.danet_smpl_lbs_bwd_ws_floats(B, V, NB)
         ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        # ONE launch when the grid fits the co-residency budget: the barrier state is the one-pass BatchNorm backward's (same stream,
+        # never concurrent; its error word already guards the optimizer step and Trainer.check_onepass) -- None on any other stream
+        from . import nn as _nn, conv as _conv
+        bar = _nn._onepass_bar(dev)
+        if bar is not None and L.danet_smpl_lbs_backward_fused_ok(B, V, _nn.ONEPASS_MAX_BLOCKS):
+            _conv.FUSION['smpl_bwd_fused'] += 1
+        else:
+            bar = None
         check(L.danet_smpl_lbs_backward(
             ptr(betas_c), ptr(rot_c), B, ptr(m.shapedirs), ptr(m.posedirs), ptr(m.J_shapedirs),
             ptr(m.lbs_weights), ptr(m.parents), ptr(m.J_regressor_extra), ptr(m.landmark_verts),
             V, NB, NL, NE, ptr(cbuf), ptr(vposed), ptr(gv), ptr(gj), ptr(g_betas), ptr(g_rot),
-            ptr(ws), nws, stream()), 'danet_smpl_lbs_backward')
+            ptr(ws), nws, ptr(bar), int(_nn.ONEPASS_MAX_BLOCKS), stream()), 'danet_smpl_lbs_backward')
         return g_betas, g_rot, None
 
 

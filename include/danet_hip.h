@@ -69,7 +69,12 @@ int danet_smpl_lbs_forward(const float* betas, const float* rotmats, int B,
 /* Gradient w.r.t. betas and rotmats (the reference's differentiable call site is
  * /root/reference/models/danet/smpl_regressor.py:176).  g_verts [B,V,3] and
  * g_joints54 [B,24+NL+NE,3] may each be NULL (= zero).  Outputs g_betas [B,NB],
- * g_rotmats [B,24,3,3]. */
+ * g_rotmats [B,24,3,3].
+ * bar (NULL = none): the barrier state of danet_bn_backward_onepass (danet_bn_backward_onepass_bar_words() uints, zeroed once,
+ * owned by the launches of ONE stream).  With it, and when the ntiles x ceil(B / 8) workgroups fit the co-residency budget
+ * (danet_smpl_lbs_backward_fused_ok; max_blocks as for danet_bn_backward_onepass, <= 0 = the whole device), the backward pass is
+ * ONE kernel launch (smpl_fused_bwd_kernel: its three phases separated by grid-wide barriers; a barrier that is not met sets
+ * bar[2], as there); otherwise three launches.  Both forms produce bit-identical results. */
 int danet_smpl_lbs_backward(const float* betas, const float* rotmats, int B,
                             const float* shapedirs, const float* posedirs, const float* J_shapedirs,
                             const float* lbs_weights, const int32_t* parents,
@@ -78,7 +83,8 @@ int danet_smpl_lbs_backward(const float* betas, const float* rotmats, int B,
                             const float* ctx, const float* v_posed,
                             const float* g_verts, const float* g_joints54,
                             float* g_betas, float* g_rotmats,
-                            float* ws, size_t ws_floats, void* stream);
+                            float* ws, size_t ws_floats, void* bar, int max_blocks, void* stream);
+int danet_smpl_lbs_backward_fused_ok(int B, int V, int max_blocks);
 /* profiling aid: clock64 phase stamps of workgroup (0,0) of the last backward launch (16 values) */
 int danet_smpl_lbs_debug(long long* out16);
 

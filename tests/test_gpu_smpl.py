@@ -145,6 +145,47 @@ def test_one_launch_forward_equals_three_launch_forward(smpl, smpl_model, B):
     np.testing.assert_allclose(a[1].cpu().numpy(), j_ref, atol=TOL)
 
 
+@pytest.mark.parametrize('B', [1, 8, 32, 33])
+def test_one_launch_backward_equals_three_launch_backward(smpl, smpl_model, B):
+    """csrc/smpl_lbs.hip smpl_fused_bwd_kernel (VERDICT r4 missing 4): the backward pass as ONE launch -- per-tile partials,
+    pose-feature contraction and the fixed-order reduction + chain back-propagation separated by grid-wide barriers -- against the
+    three launches it replaces (DANET-side switch: no barrier state handed in).  Same arithmetic, same summation orders: the
+    gradients are bit-identical; both match the oracle; the barrier's error word stays clear; three calls in a row (the barrier
+    state is reused).  (Inside a hipGraph: tests/test_gpu_zz_paths.py -- the captured train step holds this launch, and its replays
+    must reproduce the eager gradients bit for bit.)  B = 33 is 540 workgroups, more than fit the device two per compute unit: the host must take the
+    three-launch path by itself."""
+    from danet_densepose2smpl_amd import ops, nn as dnn, conv as dconv, _lib
+    betas, pose = rand_pose_shape(B, 500 + B, pose_sigma=0.4)
+    rot = R.batch_rodrigues(pose.reshape(-1, 3)).reshape(B, 24, 3, 3)
+    rng = np.random.default_rng(B)
+    gv, gj = _t(rng.normal(0, 1, (B, 6890, 3)) * 1e-2), _t(rng.normal(0, 1, (B, 54, 3)))
+    fits = bool(_lib.lib().danet_smpl_lbs_backward_fused_ok(B, 6890, 0))
+    assert fits == (B <= 32)
+    assert dnn.ONEPASS and dnn._onepass_bar(torch.device('cuda')) is not None           # (default stream = the one-pass stream outside a trainer)
+
+    def run(fused):
+        prev = dnn.ONEPASS
+        dnn.ONEPASS = fused                        # no barrier state -> three launches
+        try:
+            dconv.FUSION.clear()
+            tb, tr = _t(betas).requires_grad_(True), _t(rot).requires_grad_(True)
+            verts, j54 = ops.smpl_lbs(tb, tr, smpl)
+            ((verts * gv).sum() + (j54 * gj).sum()).backward()
+            torch.cuda.synchronize()
+            return tb.grad.clone(), tr.grad.clone(), dconv.FUSION.get('smpl_bwd_fused', 0)
+        finally:
+            dnn.ONEPASS = prev
+    one = [run(True) for _ in range(3)]
+    three = run(False)
+    assert three[2] == 0 and all(o[2] == (1 if fits else 0) for o in one)
+    assert not dnn.onepass_error()
+    for o in one:
+        assert torch.equal(o[0], three[0]) and torch.equal(o[1], three[1])
+    gb_ref, gr_ref = oracle.lbs_backward(smpl_model, betas, rot, gv.cpu().numpy(), gj.cpu().numpy())
+    np.testing.assert_allclose(one[0][0].cpu().numpy(), gb_ref, atol=2e-4 * np.abs(gb_ref).max())
+    np.testing.assert_allclose(one[0][1].cpu().numpy(), gr_ref, atol=2e-4 * np.abs(gr_ref).max())
+
+
 def test_one_launch_forward_replays_from_a_graph(smpl, smpl_model):
     """The SMPL forward inside a hipGraph (as in the captured train step): replays give the eager result, again and again
     (the tickets end every launch at zero).  (That it is ONE kernel is visible in the kernel statistics, profiles/r04_*.)"""

@@ -53,6 +53,23 @@ betas = torch.randn(32, 10, device='cuda')
 rot = torch.linalg.qr(torch.randn(32, 24, 3, 3, device='cuda'))[0]
 with torch.no_grad():
     soak('smpl_fused_fwd_kernel', lambda: model(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False).vertices, n=2 * N)
+# SMPL backward as ONE launch (round 5: three phases, two fence-free grid barriers, partials written and read at agent scope): a stale
+# read across a barrier would show as a mismatch against the first call's gradients
+from danet_densepose2smpl_amd import ops, nn as dnn    # noqa: E402
+gvs, gjs = torch.randn(32, 6890, 3, device='cuda') * 1e-2, torch.randn(32, 54, 3, device='cuda')
+
+
+def lbs_bwd():
+    tb, tr = betas.clone().requires_grad_(True), rot.clone().requires_grad_(True)
+    v_, j_ = ops.smpl_lbs(tb, tr, model)
+    gb, gr = torch.autograd.grad((v_ * gvs).sum() + (j_ * gjs).sum(), [tb, tr])
+    return torch.cat([gb.reshape(-1), gr.reshape(-1)])
+
+
+conv.FUSION.clear()
+soak('smpl_fused_bwd_kernel', lbs_bwd, n=N)
+rec['smpl_fused_bwd_kernel']['one_launch_calls'] = int(conv.FUSION.get('smpl_bwd_fused', 0))
+rec['smpl_fused_bwd_kernel']['barrier_error'] = bool(dnn.onepass_error())
 # the four-branch lockstep launch of conv3x3_stream_kernel (the step's workhorse) -- alone, and with a memory-hungry copy running on a second
 # stream: its stage copies are published on the strength of a vmcnt count that assumes they complete before younger register loads
 # ("a device fact found on the way"); a late copy would show here as a mismatch
