@@ -32,7 +32,7 @@ def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, source description) from this round's committed PMC summary
     (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a 512 MiB copy
     in the same run), or (None, reason).  The file records the commit it was measured at."""
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             f = json.load(open(path))
@@ -47,9 +47,9 @@ def pmc_traffic(kernel):
 
 def rocprof_avg_us(kernel):
     """(average duration of `kernel` in us, source) from this round's committed `rocprofv3 --kernel-trace --stats` summary of the same
-    command (profiles/r04_bench_kernel_stats.csv), to sit beside the live HIP-event figure; (None, reason) without one."""
+    command (profiles/r05_bench_kernel_stats.csv), to sit beside the live HIP-event figure; (None, reason) without one."""
     import csv
-    for name in ('r04_bench_kernel_stats.csv', 'r03_bench_bf16_only_kernel_stats.csv'):
+    for name in ('r05_bench_kernel_stats.csv', 'r04_bench_kernel_stats.csv', 'r03_bench_bf16_only_kernel_stats.csv'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             for row in csv.DictReader(open(path)):
@@ -157,19 +157,26 @@ def geometry_rooflines(tr, B, size, dev):
         torch.cuda.synchronize(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            fn()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=side):
+        # (the one-launch SMPL backward borrows the one-pass BatchNorm backward's barrier state, which belongs to the launches of ONE
+        # stream: here the measuring stream, as the step's own stream inside the trainer)
+        from danet_densepose2smpl_amd import nn as _dnn
+        prev_stream, _dnn.ONEPASS_STREAM = _dnn.ONEPASS_STREAM, side
+        try:
+            with torch.cuda.stream(side):
                 fn()
-            for _ in range(2):
-                gr.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(n):
-                gr.replay()
-            e1.record()
-        torch.cuda.synchronize(dev)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    fn()
+                for _ in range(2):
+                    gr.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    gr.replay()
+                e1.record()
+            torch.cuda.synchronize(dev)
+        finally:
+            _dnn.ONEPASS_STREAM = prev_stream
         return e0.elapsed_time(e1) * 1e-3 / n
     t_f = timed(fwd)
 
@@ -186,7 +193,7 @@ def geometry_rooflines(tr, B, size, dev):
     peak = 8000.0
     mk = lambda name, by, t: {'kernel': name, 'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': peak, 'unit': 'GB/s',   # noqa: E731
                               'frac': round(by / t / 1e9 / peak, 4), 'us': round(t * 1e6, 1), 'alg_bytes': int(by)}
-    return [mk('smpl layer forward (LBS as one launch + the joint selections as one)', by_f, t_f), mk('smpl layer backward (three LBS launches + the selections\' gradients as one)', by_b, max(t_fb - t_f, 1e-9)),
+    return [mk('smpl layer forward (LBS as one launch + the joint selections as one)', by_f, t_f), mk('smpl layer backward (LBS as one launch + the selections\' gradients as one)', by_b, max(t_fb - t_f, 1e-9)),
             mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 

@@ -39,6 +39,7 @@ extern "C" long danet_knob(int id, long value) {
         case DANET_KNOB_C3_ENABLE: case DANET_KNOB_C3_MT: case DANET_KNOB_C3_KW: case DANET_KNOB_C3_BLOCKS: case DANET_KNOB_C3_WANT:
             return conv3x3_knob(id, value);
         case DANET_KNOB_C3S_ENABLE: case DANET_KNOB_C3S_BLOCKS: case DANET_KNOB_C3S_KW: case DANET_KNOB_C3S_WANT:
+        case DANET_KNOB_C3S_BALANCE: case DANET_KNOB_C3S_TILE_COST:
             return conv3x3s_knob(id, value);
         case DANET_KNOB_PW: return conv_pw_knob(value);
         case DANET_KNOB_PW_WGRAD: return conv_pw_wgrad_knob(value);

@@ -80,7 +80,12 @@ struct S3Prob {
     float rc_nnbg;
     int x_bytes, y_bytes;
     int TH, NI, Wp, Sp, tiles_h, nnb, nks, nc16;
-    int tile0, ntiles, tile0m;                           // tile0m = tile0 % grid (filled at launch)
+    int tile0, ntiles;
+    // The problem's tiles are dealt round-robin to the nwg workgroups wg0, wg0 + 1, ... (modulo the grid): workgroup wg0 + d takes tiles
+    // d, d + nwg, ...  (filled at launch: s3_assign).  Rounds 2-4 dealt the launch's concatenated tile list over ALL workgroups, which gave
+    // a workgroup of the four-branch launch 3 or 5 units of work (a 48-channel tile = 1) where 4 is the average, 5 / 3 / 1 in the
+    // three-branch launches, 3 / 1 in the two-branch ones; now every problem gets a share of the workgroups in proportion to its work.
+    int wg0, nwg;
     float rc_nnb, rc_th;                                 // 1 / nnb, 1 / tiles_h (division-free tile coordinates)
     int lw, lthw;                                        // log2(W), log2(TH * W) when both are powers of two, else -1
     int flip, relu, out_fp32, swz, has_idle, kw, nt, nst, nent;
@@ -248,18 +253,20 @@ __device__ inline void tile_coords(const S3Prob& p, int tt, int& img0, int& y0, 
     img0 = __builtin_amdgcn_readfirstlane(bi * p.NI); y0 = __builtin_amdgcn_readfirstlane(tb * p.TH);
     nb = __builtin_amdgcn_readfirstlane(nb);
 }
-__device__ inline int first_tile_of(int tile0m, int bid, int nblk) {      // ids congruent to bid modulo nblk over the launch's list
-    const int tau = bid - tile0m;
-    return tau < 0 ? tau + nblk : tau;
+__device__ inline int first_tile_of(int wg0, int nwg, int bid, int nblk) {      // the workgroup's first tile of a problem (>= ntiles: none)
+    int d = bid - wg0;
+    if (d < 0) d += nblk;
+    return d < nwg ? d : 0x3fffffff;
 }
 // statistics leave the registers after a tile when the workgroup's next tile of the problem has another channel block
 __device__ inline bool flush_after(const S3Prob& p, int tau, int nblk) {
     if (!p.stats) return false;
-    if (tau + nblk >= p.ntiles) return true;
+    (void)nblk;
+    if (tau + p.nwg >= p.ntiles) return true;
     if (p.nnb == 1) return false;
     int i0, y0, nb0, nb1;
     tile_coords(p, tau, i0, y0, nb0);
-    tile_coords(p, tau + nblk, i0, y0, nb1);
+    tile_coords(p, tau + p.nwg, i0, y0, nb1);
     return nb0 != nb1;
 }
 
@@ -357,7 +364,7 @@ __device__ inline Pos pos_first(int nprob, int bid, int nblk, int rot, int ii0) 
     Pos q{ii0, 0, 0, false, true};
     for (; q.ii < nprob; ++q.ii) {
         const int idx = wrap_idx(q.ii + rot, nprob);
-        q.tau = first_tile_of(S3_FIELD(idx, tile0m), bid, nblk);
+        q.tau = first_tile_of(S3_FIELD(idx, wg0), S3_FIELD(idx, nwg), bid, nblk);
         if (q.tau < S3_FIELD(idx, ntiles)) { q.valid = true; return q; }
     }
     return q;
@@ -368,7 +375,7 @@ __device__ inline Pos pos_next(int nprob, int bid, int nblk, int rot, const Pos&
     q.newprob = false;
     if (c.s + 1 < S3_FIELD(idx, nst)) { q.s = c.s + 1; return q; }
     q.s = 0;
-    if (c.tau + nblk < S3_FIELD(idx, ntiles)) { q.tau = c.tau + nblk; return q; }
+    if (c.tau + S3_FIELD(idx, nwg) < S3_FIELD(idx, ntiles)) { q.tau = c.tau + S3_FIELD(idx, nwg); return q; }
     return pos_first(nprob, bid, nblk, rot, c.ii + 1);
 }
 // np: problem visits started so far (the table slot of the problem being computed is (np - 1) & 1, a new one's np & 1)
@@ -591,7 +598,7 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
 #pragma unroll
     for (int k = S3_MAXST - 1; k >= 0; --k) if (k < nst) { int a, b; range_of(k, kw, a, b); if (a < b) { jb0 = a; je0 = b; } }
 
-    Pos cur{ii, first_tile_of(p.tile0m, bid, nblk), 0, true, true};
+    Pos cur{ii, first_tile_of(p.wg0, p.nwg, bid, nblk), 0, true, true};
     // The ring lives across the tiles of a problem visit: the refills issued during a tile's last D k-steps follow the table's
     // wrap-around links and fetch the FIRST D k-steps of the next tile (same weights whenever the workgroup's next tile has the
     // same channel block -- always for the grids used: the tile stride is a multiple of the channel-block count), so that tile
@@ -847,7 +854,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch 
     int dsum[3] = {0, 0, 0};
     for (int ii = first.ii; ii < nprob; ++ii) {
         const int idx = wrap_idx(ii + rot, nprob);
-        if (first_tile_of(S3_FIELD(idx, tile0m), bid, nblk) >= S3_FIELD(idx, ntiles)) continue;
+        if (first_tile_of(S3_FIELD(idx, wg0), S3_FIELD(idx, nwg), bid, nblk) >= S3_FIELD(idx, ntiles)) continue;
         ++np;
         s3_problem<NT>(nprob, ii, rot, bid, nblk, g, np, s3_smem, dbg, dsum);
     }
@@ -951,6 +958,47 @@ bool s3_plan(const ConvP& p, S3Prob& q, int nprob) {
     return true;
 }
 
+// Which workgroups take which problem's tiles (S3Prob.wg0 / nwg).  A tile's cost ~ its k-steps per wave (nks / KW) plus a fixed
+// share for staging, exchange and epilogue (g_s3_tile_cost k-step equivalents).  Every problem starts with one block of 32
+// workgroups (32: a multiple of the 8 XCDs and of every channel-block count, which the kernel's weight prefetch across tiles and the
+// XCD swizzle of tile_coords rely on); the remaining blocks go, one at a time, to the problem whose workgroups currently carry the
+// most work -- exclusive ranges, so a workgroup stays with one problem (one tap table, one set of weights).  A launch with a
+// single problem, or with fewer than 32 workgroups per problem, keeps the plain deal (the concatenated list over all workgroups).
+// Measured at B = 32 (tools/c3s_balance.py, profiles/r05_c3s_balance.txt; us per launch, plain deal -> this one, outputs bit-identical):
+// two branches 25.4 -> 21.8 forward + statistics, 22.8 -> 20.6 data gradient; four branches 38.5 -> 35.9 and 35.7 -> 33.8; THREE
+// branches 31.5 -> 31.3 and 28.6 -> 29.9 -- there the plain deal already gives every workgroup one 48-channel tile plus one tile of
+// a deeper branch, and keeps it: balance = 1 skips three-problem launches, 2 applies it to every launch (A-B knob).
+int g_s3_balance = getenv("DANET_C3S_BALANCE") ? atoi(getenv("DANET_C3S_BALANCE")) : 1;
+int g_s3_tile_cost = getenv("DANET_C3S_TILE_COST") ? atoi(getenv("DANET_C3S_TILE_COST")) : 16;
+void s3_assign(S3Launch& L, int grid) {
+    const int n = L.n;
+    constexpr int BLK = 32;
+    bool ok = g_s3_balance != 0 && n > 1 && (n != 3 || g_s3_balance == 2) && grid % BLK == 0 && grid / BLK >= n;
+    int nwg[S3_MAXP];
+    double cost[S3_MAXP];
+    if (ok) {
+        int left = grid / BLK - n;
+        for (int i = 0; i < n; ++i) { nwg[i] = BLK; cost[i] = (double)L.p[i].nks / L.p[i].kw + g_s3_tile_cost; }
+        auto load = [&](int i) { return (double)((L.p[i].ntiles + nwg[i] - 1) / nwg[i]) * cost[i]; };
+        while (left > 0) {
+            int worst = -1;
+            for (int i = 0; i < n; ++i)
+                if (nwg[i] < L.p[i].ntiles && (worst < 0 || load(i) > load(worst))) worst = i;
+            if (worst < 0) break;                                  // every problem already has a workgroup per tile
+            // (a block more only helps when it lowers the tiles-per-workgroup count: keep adding until it does, or give up on this problem)
+            nwg[worst] += BLK; --left;
+        }
+        for (int i = 0; i < n; ++i) if (nwg[i] > L.p[i].ntiles) nwg[i] = (L.p[i].ntiles + 7) / 8 * 8 > nwg[i] ? nwg[i] : (L.p[i].ntiles + 7) / 8 * 8;
+    }
+    if (ok) {
+        int w = 0;
+        for (int i = 0; i < n; ++i) { L.p[i].wg0 = w; L.p[i].nwg = nwg[i]; w += nwg[i]; }
+        if (w > grid) ok = false;
+    }
+    if (!ok)
+        for (int i = 0; i < n; ++i) { L.p[i].wg0 = L.p[i].tile0 % grid; L.p[i].nwg = L.p[i].ntiles < grid ? L.p[i].ntiles : grid; }
+}
+
 template <int NT>
 void s3_launch_nt(const S3Launch& L, int grid, hipStream_t st) {
     static bool attr_set = false;
@@ -1004,7 +1052,12 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
         fprintf(stderr, "\n");
     }
     const int grid = L.total < g_s3_blocks ? L.total : g_s3_blocks;
-    for (int i = 0; i < n; ++i) L.p[i].tile0m = L.p[i].tile0 % grid;
+    s3_assign(L, grid);
+    if (verbose) {
+        fprintf(stderr, "[c3s] workgroups:");
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %d+%d", L.p[i].wg0, L.p[i].nwg);
+        fprintf(stderr, " of %d\n", grid);
+    }
     switch (NT) {
         case 1: s3_launch_nt<1>(L, grid, st); return 0;
         case 2: s3_launch_nt<2>(L, grid, st); return 0;
@@ -1040,6 +1093,8 @@ long danet_conv::conv3x3s_knob(int id, long v) {
         case DANET_KNOB_C3S_BLOCKS: prev = g_s3_blocks; if (v > 0) g_s3_blocks = (int)v; break;
         case DANET_KNOB_C3S_KW: prev = g_s3_kw; if (v >= 0) g_s3_kw = (int)v; break;
         case DANET_KNOB_C3S_WANT: prev = g_s3_want; if (v >= 0) g_s3_want = (int)v; break;
+        case DANET_KNOB_C3S_BALANCE: prev = g_s3_balance; if (v >= 0) g_s3_balance = (int)v; break;
+        case DANET_KNOB_C3S_TILE_COST: prev = g_s3_tile_cost; if (v >= 0) g_s3_tile_cost = (int)v; break;
         default: break;
     }
     return prev;

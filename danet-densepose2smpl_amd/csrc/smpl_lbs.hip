@@ -817,12 +817,16 @@ __device__ __forceinline__ void finalize_bwd_body(const int b,
         // flight per lane: 512 outputs in two passes.  (8 lanes per output and 32 outputs per pass was 16 passes of
         // dependent load batches: 43 us.)
         auto tsum = [&](const float* part, size_t tile_stride, int n) {
+            // (36 agent-scope loads in flight per lane: they are served past the L2, ~2 us a round trip -- with 12 the 108 tiles were
+            // nine dependent rounds, 35 us of the one-launch kernel)
             float s = 0.f;
-            for (int t0 = 0; t0 < n; t0 += 12) {
-                float v[12];
+            for (int t0 = 0; t0 < n; t0 += 36) {
+                float v[36];
 #pragma unroll
-                for (int u = 0; u < 12; ++u) v[u] = t0 + u < n ? ld_agent(part + (size_t)(t0 + u) * tile_stride) : 0.f;
-                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + ((v[8] + v[9]) + (v[10] + v[11]));
+                for (int u = 0; u < 36; ++u) v[u] = t0 + u < n ? ld_agent(part + (size_t)(t0 + u) * tile_stride) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 36; u += 12)
+                    s += ((v[u] + v[u + 1]) + (v[u + 2] + v[u + 3])) + ((v[u + 4] + v[u + 5]) + (v[u + 6] + v[u + 7])) + ((v[u + 8] + v[u + 9]) + (v[u + 10] + v[u + 11]));
             }
             return s;
         };
@@ -928,12 +932,16 @@ __global__ __launch_bounds__(256, 2) void smpl_fused_bwd_kernel(LbsBwdArgs a)
     lbs_bwd_phase1(a, bid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's agent-scope stores have been performed
     danet::grid_barrier(a.bar, (unsigned)nblk);
+    if (bid == 0 && threadIdx.x == 0) g_lbs_dbg[7] = clock64();
     // phase 2: pose-feature contraction, job = (half tile, batch half)
     for (int job = bid; job < a.npf * a.ny; job += nblk) lbs_bwd_phase2(a, job);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (bid == 0 && threadIdx.x == 0) g_lbs_dbg[14] = clock64();
     danet::grid_barrier(a.bar, (unsigned)nblk);
+    if (bid == 0 && threadIdx.x == 0) g_lbs_dbg[15] = clock64();
     // phase 3: one batch item per job
     for (int b = bid; b < a.B; b += nblk) lbs_bwd_phase3(a, b);
+    if (bid == 0 && threadIdx.x == 0) g_lbs_dbg[8] = clock64();
 }
 
 }  // namespace

@@ -319,14 +319,16 @@ int danet_conv_forward_multi_kernel(const void* jobs, int n);      /* the kernel
  *          planner's choice); BLOCKS = workgroup cap (> 0); WANT = tiles per problem the planner aims for (0 = 512 / problems)
  *   C3S_*  the streamed 3x3 kernel (csrc/conv3x3s.hip), which takes the 3x3 / stride-1 problems with at most 48 output channels
  *          per block ahead of the tile kernel: ENABLE; BLOCKS; KW = forced K split over the four waves 1/2/4 (0 = planner);
- *          WANT as above.  A forced register tiling (C3_MT / C3_KW) keeps a problem on conv3x3.hip.
+ *          WANT as above; BALANCE 0/1 = workgroups dealt to the problems of a launch in proportion to their work (1, the default) or
+ *          the launch's concatenated tile list dealt over all workgroups (0, rounds 2-4); TILE_COST = the fixed cost of a tile in that
+ *          model, in k-steps.  A forced register tiling (C3_MT / C3_KW) keeps a problem on conv3x3.hip.
  *   PW, PW_WGRAD, STEM, STEM_DGRAD, C3A   0/1: the pointwise forward / data-gradient kernel, the pointwise weight gradient, the
  *          7x7 stem forward and data gradient on LDS row tiles, the 64-channel row-tile 3x3 kernel (their sections below)
  *   BN_BLOCK_BYTES   bytes of the tensor one workgroup of the BatchNorm kernels handles at least (default 24576; > 0 sets) */
 enum { DANET_KNOB_C3_ENABLE = 1, DANET_KNOB_C3_MT = 2, DANET_KNOB_C3_KW = 3, DANET_KNOB_C3_BLOCKS = 4, DANET_KNOB_C3_WANT = 5,
        DANET_KNOB_C3S_ENABLE = 6, DANET_KNOB_C3S_BLOCKS = 7, DANET_KNOB_C3S_KW = 8, DANET_KNOB_C3S_WANT = 9,
        DANET_KNOB_PW = 10, DANET_KNOB_PW_WGRAD = 11, DANET_KNOB_STEM = 12, DANET_KNOB_STEM_DGRAD = 13, DANET_KNOB_C3A = 14,
-       DANET_KNOB_BN_BLOCK_BYTES = 15 };
+       DANET_KNOB_BN_BLOCK_BYTES = 15, DANET_KNOB_C3S_BALANCE = 16, DANET_KNOB_C3S_TILE_COST = 17 };
 long danet_knob(int id, long value);
 /* danet_conv3x3_stream_plan: KW*100 + stages*10 + NT the streamed 3x3 kernel (csrc/conv3x3s.hip) would use for a problem in a launch of
  * nprob problems (0: not taken). */

@@ -29,3 +29,10 @@ for i, n in enumerate(['forward: load A / W', 'forward: pose blend (incl. featur
     print('%-46s %8d ticks' % (n, fw[i + 1] - fw[i]))
 print('forward total %d ticks' % (fw[5] - fw[0]))
 
+# the one-launch backward (smpl_fused_bwd_kernel, workgroup 0): phase 1 ends at stamp 6, barrier 1 at 7, phase 2 at 14, barrier 2 at 15, the kernel at 8
+b = list(buf)
+if b[7] > b[6] > 0:
+    print('one-launch backward, workgroup 0 (ticks of the 100 MHz clock: 10 ns each):')
+    for name, a, z in (('phase 1 (seeds, d v_posed, partials)', 0, 6), ('barrier 1 (incl. waiting for the slowest workgroup)', 6, 7),
+                       ('phase 2 (pose-feature contraction)', 7, 14), ('barrier 2', 14, 15), ('phase 3 (reduction + chain)', 15, 8), ('kernel', 0, 8)):
+        print('  %-52s %8d' % (name, b[z] - b[a]))
