@@ -22,7 +22,15 @@ __device__ inline float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 1
 // so a wide layer keeps fewer of them: the product replicas x channels -- what a consumer block reads before it can
 // start -- stays ~2 K values (with 32 copies a block of the 384-channel BatchNorm read 98 KB to normalise 1.5 KB).
 constexpr int BN_NCOPY = 32;                        // copies a workspace has room for
-__host__ __device__ inline int bn_ncopy(int C) { return C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); }   // (8/4 and 16/8/4 measured the same step time)
+#ifndef DANET_BN_NCOPY_DIV
+#define DANET_BN_NCOPY_DIV 2
+#endif
+// (round 5: with 8-byte accumulators half as many replicas for the narrow layers -- 16 / 8 / 4 / 4 -- measured -0.25 ms/step against
+// 32 / 16 / 8 / 4: a consumer workgroup's prologue reads replicas x 2C x 8 bytes before it can start; DANET_BN_NCOPY_DIV = 1 / 2 / 4: A-B builds)
+__host__ __device__ inline int bn_ncopy(int C) {
+    const int n = (C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4))) / DANET_BN_NCOPY_DIV;
+    return n < 4 ? 4 : n;
+}   // (8/4 and 16/8/4 measured the same step time)
 
 // The accumulators are DOUBLES (DANET_BN_ACC32: floats, the round-1..4 form, kept for A-B timing).  A workgroup's partial sum is an
 // fp32 value; up to 2^4 of them (workgroups / replicas) are added into one replica with global_atomic_add_f64.  Every such
