@@ -90,6 +90,8 @@ _SIGNATURES = {
     'danet_sum_relu_forward': (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i), c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_sum_relu_backward_all': (c_i, [c_f, c_f] + [c_i] * 5 + [c_f] * 5),
+    'danet_sum_relu_forward_multi': (c_i, [c_f, c_i, c_f]),
+    'danet_sum_relu_backward_all_multi': (c_i, [c_f, c_i, c_f]),
     'danet_maxpool3x3s2_forward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'danet_maxpool3x3s2_backward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'danet_stn_gather_forward': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f, c_f]),
@@ -120,9 +122,20 @@ _SIGNATURES = {
 
 # fp32 instantiations (csrc/norm_act_f32.hip, stn.hip): same arguments, fp32 NHWC activations
 for _n in ('danet_bn_forward', 'danet_bn_backward', 'danet_bn_forward_multi', 'danet_bn_backward_multi', 'danet_sum_relu_forward',
-           'danet_sum_relu_backward', 'danet_sum_relu_backward_all', 'danet_stn_gather_forward', 'danet_stn_gather_backward',
+           'danet_sum_relu_backward', 'danet_sum_relu_backward_all', 'danet_sum_relu_forward_multi', 'danet_sum_relu_backward_all_multi', 'danet_stn_gather_forward', 'danet_stn_gather_backward',
            'danet_maxpool3x3s2_forward', 'danet_maxpool3x3s2_backward', 'danet_channel_sum'):
     _SIGNATURES[_n + '_f32'] = _SIGNATURES[_n]
+
+
+class SumFwdJob(ctypes.Structure):
+    """One output of danet_sum_relu_forward_multi (include/danet_hip.h)."""
+    _fields_ = [('terms', ctypes.c_void_p * 4), ('shifts', c_i * 4), ('nterms', c_i), ('B', c_i), ('H', c_i), ('W', c_i), ('C', c_i), ('relu', c_i),
+                ('y', ctypes.c_void_p)]
+
+
+class SumBwdJob(ctypes.Structure):
+    """One output's gradients of danet_sum_relu_backward_all_multi."""
+    _fields_ = [('gy', ctypes.c_void_p), ('y', ctypes.c_void_p), ('B', c_i), ('H', c_i), ('W', c_i), ('C', c_i), ('relu', c_i), ('d', ctypes.c_void_p * 4)]
 
 
 class Wg3Job(ctypes.Structure):

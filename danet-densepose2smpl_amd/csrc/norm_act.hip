@@ -750,11 +750,11 @@ struct SumP {
     int B, H, W, C;
 };
 
-__global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, elem_t* __restrict__ y, int relu)
+__device__ __forceinline__ void sum_relu_body(const SumP& p, elem_t* __restrict__ y, int relu, const int lb, const int nb)
 {
     const int CV = p.C / VW;
     const long nvec = (long)p.B * p.H * p.W * CV;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+    for (long v = (long)lb * 256 + threadIdx.x; v < nvec; v += (long)nb * 256) {
         const int cv = (int)(v % CV);
         long pix = v / CV;
         const int w = (int)(pix % p.W); pix /= p.W;
@@ -776,6 +776,20 @@ __global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, elem_t* __restric
         }
         store_bf(y + v * VW, s);
     }
+}
+__global__ __launch_bounds__(256) void sum_relu_kernel(SumP p, elem_t* __restrict__ y, int relu)
+{
+    sum_relu_body(p, y, relu, blockIdx.x, gridDim.x);
+}
+// The fuse sums of ONE HighResolutionModule (up to four outputs, one per branch) in one launch: they are independent of each other
+// and the low-resolution ones are far too small to fill a launch of their own (4.9 - 11.6 us each at B = 32, mostly launch).
+constexpr int NSM = 4;
+struct SumMulti { SumP p[NSM]; elem_t* y[NSM]; int relu[NSM]; int start[NSM + 1]; int n; };
+__global__ __launch_bounds__(256) void sum_relu_multi_kernel(SumMulti m)
+{
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    sum_relu_body(m.p[i], m.y[i], m.relu[i], blockIdx.x - m.start[i], m.start[i + 1] - m.start[i]);
 }
 
 // d_term[b,h',w',c] = sum over the 2^sh x 2^sh window of gy * (y > 0)
@@ -816,13 +830,13 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_kernel(const elem_t* __restr
 // 4x4, 8x8 group completes consecutively: gy and y are read ONCE (the per-shift kernel read them once per shift: 4 launches
 // and 8 tensor passes for the highest-resolution output of a 4-branch module).
 struct SumBwdAll { elem_t* d[4]; };
-__global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const elem_t* __restrict__ gy, const elem_t* __restrict__ y,
-                                                               int B, int H, int W, int C, int smax, int relu, SumBwdAll out)
+__device__ __forceinline__ void sum_relu_bwd_all_body(const elem_t* __restrict__ gy, const elem_t* __restrict__ y,
+                                                      int B, int H, int W, int C, int smax, int relu, const SumBwdAll& out, const int lb, const int nb)
 {
     const int CV = C / VW;
     const int F = 1 << smax, Hc = H >> smax, Wc = W >> smax;
     const long nvec = (long)B * Hc * Wc * CV;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+    for (long v = (long)lb * 256 + threadIdx.x; v < nvec; v += (long)nb * 256) {
         const int cv = (int)(v % CV);
         long pix = v / CV;
         const int wc = (int)(pix % Wc); pix /= Wc;
@@ -861,6 +875,20 @@ __global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const elem_t* __r
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void sum_relu_bwd_all_kernel(const elem_t* __restrict__ gy, const elem_t* __restrict__ y,
+                                                               int B, int H, int W, int C, int smax, int relu, SumBwdAll out)
+{
+    sum_relu_bwd_all_body(gy, y, B, H, W, C, smax, relu, out, blockIdx.x, gridDim.x);
+}
+struct SumBwdMultiOne { const elem_t* gy; const elem_t* y; int B, H, W, C, smax, relu; SumBwdAll out; };
+struct SumBwdMulti { SumBwdMultiOne a[NSM]; int start[NSM + 1]; int n; };
+__global__ __launch_bounds__(256) void sum_relu_bwd_all_multi_kernel(SumBwdMulti m)
+{
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const SumBwdMultiOne& a = m.a[i];
+    sum_relu_bwd_all_body(a.gy, a.y, a.B, a.H, a.W, a.C, a.smax, a.relu, a.out, blockIdx.x - m.start[i], m.start[i + 1] - m.start[i]);
 }
 
 }  // namespace
@@ -1038,6 +1066,60 @@ extern "C" int NA_NAME(danet_sum_relu_backward_all)(const void* gy, const void* 
     hipLaunchKernelGGL(sum_relu_bwd_all_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gy,
                        (const elem_t*)y, B, H, W, C, smax, relu, out);
     DANET_CHECK_LAUNCH("sum_relu_bwd_all_kernel");
+    return DANET_OK;
+}
+
+// Multi-problem forms (host job arrays, n <= 4): the fuse sums of one HighResolutionModule / their gradients in ONE launch each.
+//  forward job  { const void* terms[4]; int shifts[4]; int nterms, B, H, W, C, relu; void* y; }
+//  backward job { const void* gy; const void* y; int B, H, W, C, relu; void* d[4]; }      d[s] = gradient of the terms with shift s (NULL: none)
+struct SumFwdJob { const void* terms[4]; int shifts[4]; int nterms, B, H, W, C, relu; void* y; };
+struct SumBwdJob { const void* gy; const void* y; int B, H, W, C, relu; void* d[4]; };
+
+extern "C" int NA_NAME(danet_sum_relu_forward_multi)(const void* jobs_, int n, void* stream)
+{
+    DANET_ENTER();
+    const SumFwdJob* jobs = (const SumFwdJob*)jobs_;
+    DANET_CHECK_ARG(jobs && n >= 1 && n <= NSM, "sum_relu_forward_multi: 1..%d jobs", NSM);
+    SumMulti m; m.n = n; m.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const SumFwdJob& j = jobs[i];
+        DANET_CHECK_ARG(j.y && j.nterms >= 1 && j.nterms <= 4 && j.C % VW == 0 && j.B > 0, "sum_relu_forward_multi: job %d: bad arguments", i);
+        SumP& p = m.p[i];
+        p.nterms = j.nterms; p.B = j.B; p.H = j.H; p.W = j.W; p.C = j.C;
+        for (int t = 0; t < 4; ++t) { p.in[t] = t < j.nterms ? (const elem_t*)j.terms[t] : nullptr; p.shift[t] = t < j.nterms ? j.shifts[t] : 0; }
+        for (int t = 0; t < j.nterms; ++t)
+            DANET_CHECK_ARG(p.in[t] && p.shift[t] >= 0 && (j.H % (1 << p.shift[t])) == 0 && (j.W % (1 << p.shift[t])) == 0, "sum_relu_forward_multi: job %d term %d", i, t);
+        m.y[i] = (elem_t*)j.y; m.relu[i] = j.relu;
+        const long nvec = (long)j.B * j.H * j.W * (j.C / VW);
+        long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+        m.start[i + 1] = m.start[i] + (int)blocks;
+    }
+    hipLaunchKernelGGL(sum_relu_multi_kernel, dim3((unsigned)m.start[n]), dim3(256), 0, (hipStream_t)stream, m);
+    DANET_CHECK_LAUNCH("sum_relu_multi_kernel");
+    return DANET_OK;
+}
+
+extern "C" int NA_NAME(danet_sum_relu_backward_all_multi)(const void* jobs_, int n, void* stream)
+{
+    DANET_ENTER();
+    const SumBwdJob* jobs = (const SumBwdJob*)jobs_;
+    DANET_CHECK_ARG(jobs && n >= 1 && n <= NSM, "sum_relu_backward_all_multi: 1..%d jobs", NSM);
+    SumBwdMulti m; m.n = n; m.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const SumBwdJob& j = jobs[i];
+        int smax = -1;
+        for (int s_ = 0; s_ < 4; ++s_) if (j.d[s_]) smax = s_;
+        DANET_CHECK_ARG(j.gy && (!j.relu || j.y) && j.C % VW == 0 && smax >= 0 && j.H % (1 << smax) == 0 && j.W % (1 << smax) == 0,
+                        "sum_relu_backward_all_multi: job %d: bad arguments", i);
+        SumBwdMultiOne& a = m.a[i];
+        a.gy = (const elem_t*)j.gy; a.y = (const elem_t*)j.y; a.B = j.B; a.H = j.H; a.W = j.W; a.C = j.C; a.smax = smax; a.relu = j.relu;
+        for (int s_ = 0; s_ < 4; ++s_) a.out.d[s_] = (elem_t*)j.d[s_];
+        const long nvec = (long)j.B * (j.H >> smax) * (j.W >> smax) * (j.C / VW);
+        long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+        m.start[i + 1] = m.start[i] + (int)blocks;
+    }
+    hipLaunchKernelGGL(sum_relu_bwd_all_multi_kernel, dim3((unsigned)m.start[n]), dim3(256), 0, (hipStream_t)stream, m);
+    DANET_CHECK_LAUNCH("sum_relu_bwd_all_multi_kernel");
     return DANET_OK;
 }
 

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import segments
 from .config import cfg
-from .nn import fan_out, sum_relu, multi_batch_norm
+from .nn import fan_out, sum_relu, sum_relu_multi, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
 from .conv import multi_conv, ResLink
@@ -37,6 +37,7 @@ class _Chain(nn.Module):
 LOCKSTEP_BRANCHES = bool(int(os.environ.get('DANET_LOCKSTEP', '1')))    # one multi-tensor BatchNorm launch per block level
 LOCKSTEP_CONVS = bool(int(os.environ.get('DANET_LOCKSTEP_CONVS', '1')))     # ... and one multi-problem conv launch
 FUSE_GROUP = int(os.environ.get('DANET_FUSE_GROUP', '8'))     # exchange paths per multi-problem launch (the kernels take up to 8)
+SUM_MULTI = bool(int(os.environ.get('DANET_SUM_MULTI', '1')))       # a module's fuse sums (and their gradients) in one launch each
 BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)
 _SIDE = {}
 
@@ -149,12 +150,13 @@ class HighResolutionModule(nn.Module):
         else:
             fused = {(i, j): self.fuse_layers[i][j](xin[(i, j)]) for i in range(nout)
                      for j in range(self.num_branches) if j != i}
-        out = []
+        groups = []
         for i in range(len(self.fuse_layers)):
             terms = [use(j) if j == i else fused[(i, j)] for j in range(self.num_branches)]
             shifts = [j - i if j > i else 0 for j in range(self.num_branches)]
-            out.append(sum_relu(terms, shifts, relu=True))
-        return out
+            groups.append((terms, shifts))
+        # the module's fuse sums are independent of each other: one launch per pass (nn.sum_relu_multi) instead of one per output
+        return sum_relu_multi(groups, relu=True) if SUM_MULTI else [sum_relu(t, s, relu=True) for t, s in groups]
 
     def _fuse_paths_in_lockstep(self, x):
         """Every (output i, input j) exchange path is a chain of 1..3 conv+BN stages; the paths are independent, so

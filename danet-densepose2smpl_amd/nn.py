@@ -434,6 +434,85 @@ class SumReluFunction(torch.autograd.Function):
         return (None, None) + tuple(outs)
 
 
+class SumReluMultiFunction(torch.autograd.Function):
+    """n (<= 4) fuse sums -- the outputs of ONE HighResolutionModule (hr_module.py:166-177) -- in one launch forward
+    (csrc/norm_act.hip sum_relu_multi_kernel) and one backward (sum_relu_bwd_all_multi_kernel): the low-resolution outputs are far too
+    small to fill launches of their own.  meta = [(shifts, nterms)] per output; terms flattened behind it."""
+
+    @staticmethod
+    def forward(ctx, relu, meta, *terms):
+        L = _lib.lib()
+        terms = [nhwc_act(t) for t in terms]
+        dt = terms[0].dtype
+        n = len(meta)
+        jobs = (_lib.SumFwdJob * n)()
+        ys, k, cfg = [], 0, []
+        for i, (shifts, nt) in enumerate(meta):
+            ts = terms[k:k + nt]
+            k += nt
+            B, C = ts[0].shape[0], ts[0].shape[1]
+            H = max(t.shape[2] << s for t, s in zip(ts, shifts))
+            W = max(t.shape[3] << s for t, s in zip(ts, shifts))
+            for t, s in zip(ts, shifts):
+                if t.shape[1] != C or (t.shape[2] << s) != H or (t.shape[3] << s) != W:
+                    raise ValueError('sum_relu_multi: term %s with shift %d does not match output %dx%dx%d' % (tuple(t.shape), s, C, H, W))
+            y = _empty_nhwc(B, C, H, W, dt, ts[0].device)
+            j = jobs[i]
+            for q, (t, s) in enumerate(zip(ts, shifts)):
+                j.terms[q] = t.data_ptr()
+                j.shifts[q] = int(s)
+            j.nterms, j.B, j.H, j.W, j.C, j.relu, j.y = nt, B, H, W, C, int(relu), y.data_ptr()
+            ys.append(y)
+            cfg.append((tuple(shifts), B, C, H, W))
+        check(_k(L, 'danet_sum_relu_forward_multi', dt)(ctypes.addressof(jobs), n, stream()), 'danet_sum_relu_forward_multi')
+        ctx.save_for_backward(*(ys if relu else []))
+        ctx.cfg = (relu, cfg, dt)
+        ctx.set_materialize_grads(False)         # an output nobody differentiates through contributes no job (not a tensor of zeros)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        L = _lib.lib()
+        relu, cfg, dt = ctx.cfg
+        ys = ctx.saved_tensors if relu else [None] * len(cfg)
+        outs = []
+        jobs = (_lib.SumBwdJob * len(cfg))()
+        nj, keep = 0, []
+        per_out = []
+        for i, (shifts, B, C, H, W) in enumerate(cfg):
+            if gys[i] is None:
+                per_out.append(None)
+                continue
+            gy = nhwc_as(gys[i], dt)
+            cache = {s: _empty_nhwc(B, C, H >> s, W >> s, dt, gy.device) for s in sorted(set(shifts))}
+            j = jobs[nj]
+            nj += 1
+            j.gy, j.y = gy.data_ptr(), None if ys[i] is None else ys[i].data_ptr()
+            j.B, j.H, j.W, j.C, j.relu = B, H, W, C, int(relu)
+            for s in range(4):
+                j.d[s] = cache[s].data_ptr() if s in cache else None
+            keep.append(gy)
+            per_out.append(cache)
+        if nj:
+            check(_k(L, 'danet_sum_relu_backward_all_multi', dt)(ctypes.addressof(jobs), nj, stream()), 'danet_sum_relu_backward_all_multi')
+        for i, (shifts, B, C, H, W) in enumerate(cfg):
+            for s in shifts:
+                outs.append(None if per_out[i] is None else per_out[i][s])
+        return (None, None) + tuple(outs)
+
+
+def sum_relu_multi(groups, relu=True):
+    """[sum_relu(terms, shifts) for terms, shifts in groups] in one launch per pass when the set qualifies (<= 4 outputs of <= 4 terms,
+    shifts <= 3; terms of one output that share a shift share their gradient tensor, as in SumReluFunction); otherwise output by output."""
+    ok = 1 <= len(groups) <= 4 and all(1 <= len(t) <= 4 and all(0 <= s <= 3 for s in sh) for t, sh in groups) and groups[0][0][0].is_cuda \
+        and SUM_BWD_ALL
+    if not ok or len(groups) == 1:
+        return [sum_relu(t, sh, relu) for t, sh in groups]
+    meta = [(tuple(sh), len(t)) for t, sh in groups]
+    flat = [x for t, _ in groups for x in t]
+    return list(SumReluMultiFunction.apply(relu, meta, *flat))
+
+
 class FanOutFunction(torch.autograd.Function):
     """n aliases of x for n consumers; the backward sums the n incoming gradients in ONE launch (the fuse-layer sum
     kernel without ReLU or shifts) instead of autograd's n - 1 pairwise adds: (n + 1) instead of 3 (n - 1) tensor passes.

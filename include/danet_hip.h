@@ -489,6 +489,11 @@ int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nter
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
                             void* d_term, void* stream);
 /* every requested shift in one launch: d0..d3 (NULL = not needed) <- [B, H >> s, W >> s, C]; gy and y are read once */
+/* Multi-problem forms (host job arrays, n <= 4): the fuse sums of ONE HighResolutionModule, or their gradients, in one launch.
+ *  forward job  { const void* terms[4]; int shifts[4]; int nterms, B, H, W, C, relu; void* y; }
+ *  backward job { const void* gy; const void* y; int B, H, W, C, relu; void* d[4]; }   d[s]: gradient of the terms with shift s, NULL = none */
+int danet_sum_relu_forward_multi(const void* jobs, int n, void* stream);
+int danet_sum_relu_backward_all_multi(const void* jobs, int n, void* stream);
 int danet_sum_relu_backward_all(const void* gy, const void* y, int B, int H, int W, int C, int relu,
                                 void* d0, void* d1, void* d2, void* d3, void* stream);
 /* fp32 instantiation of the entry points above (csrc/norm_act_f32.hip: the same kernels with 4-byte elements; BASELINE
@@ -509,6 +514,8 @@ int danet_sum_relu_forward_f32(const void* const* terms, const int* shifts, int 
                                int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward_f32(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,
                                 void* d_term, void* stream);
+int danet_sum_relu_forward_multi_f32(const void* jobs, int n, void* stream);
+int danet_sum_relu_backward_all_multi_f32(const void* jobs, int n, void* stream);
 int danet_sum_relu_backward_all_f32(const void* gy, const void* y, int B, int H, int W, int C, int relu,
                                     void* d0, void* d1, void* d2, void* d3, void* stream);
 

@@ -56,6 +56,45 @@ def test_bn_train_forward_backward(C, H, B, relu, use_res):
     _close(ye, yre, 1e-2, 'eval')
 
 
+def test_sum_relu_multi_equals_the_per_output_launches():
+    """nn.sum_relu_multi (round 5): the four fuse sums of a 4-branch HighResolutionModule -- shifts (0,1,2,3), (0,0,1,2), (0,0,0,1),
+    (0,0,0,0), several terms of an output sharing a shift -- in ONE launch forward and ONE backward: outputs and every term's gradient
+    equal the per-output launches bit for bit (same kernels' bodies, same fp32 sums)."""
+    from danet_densepose2smpl_amd import nn as dnn, conv as dconv
+    g = torch.Generator().manual_seed(3)
+    B, C = 2, 48
+    sizes = [32, 16, 8, 4]
+
+    def make():
+        groups, leaves = [], []
+        for i in range(4):
+            terms, shifts = [], []
+            for j in range(4):
+                s = j - i if j > i else 0
+                t = dconv.nhwc_bf16(torch.randn(B, C, sizes[i] >> s, sizes[i] >> s, generator=torch.Generator().manual_seed(10 * i + j)).cuda()).requires_grad_(True)
+                terms.append(t); shifts.append(s); leaves.append(t)
+            groups.append((terms, shifts))
+        return groups, leaves
+    gys = [dconv.nhwc_bf16(torch.randn(B, C, s, s, generator=g).cuda()) for s in sizes]
+    res = []
+    for multi in (True, False):
+        groups, leaves = make()
+        ys = dnn.sum_relu_multi(groups, relu=True) if multi else [dnn.sum_relu(t, sh, relu=True) for t, sh in groups]
+        torch.autograd.backward(ys, gys)
+        torch.cuda.synchronize()
+        res.append(([y.detach().clone() for y in ys], [t.grad.clone() for t in leaves]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    # only two of the outputs receive a gradient: the others' terms get None, the launch holds two jobs
+    groups, leaves = make()
+    ys = dnn.sum_relu_multi(groups, relu=True)
+    torch.autograd.backward([ys[0], ys[2]], [gys[0], gys[2]])
+    for k, t in enumerate(leaves):
+        assert (t.grad is not None) == (k // 4 in (0, 2))
+
+
 def test_sum_relu_fuse():
     from danet_densepose2smpl_amd import nn as dnn
     g = torch.Generator().manual_seed(0)
