@@ -37,6 +37,7 @@ class _Chain(nn.Module):
 LOCKSTEP_BRANCHES = bool(int(os.environ.get('DANET_LOCKSTEP', '1')))    # one multi-tensor BatchNorm launch per block level
 LOCKSTEP_CONVS = bool(int(os.environ.get('DANET_LOCKSTEP_CONVS', '1')))     # ... and one multi-problem conv launch
 FUSE_GROUP = int(os.environ.get('DANET_FUSE_GROUP', '8'))     # exchange paths per multi-problem launch (the kernels take up to 8)
+FUSE_SPLIT_RELU = bool(int(os.environ.get('DANET_FUSE_SPLIT_RELU', '0')))       # A-B knob: 1 = ReLU and non-ReLU exchange stages in separate launches (rounds 2-4)
 SUM_MULTI = bool(int(os.environ.get('DANET_SUM_MULTI', '1')))       # a module's fuse sums (and their gradients) in one launch each
 BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)
 _SIDE = {}
@@ -171,16 +172,18 @@ class HighResolutionModule(nn.Module):
         cur = {key: x[key] for key in paths}              # x: {(output i, input j): branch j's output for that path}
         depth = max(len(st) for st in paths.values())
         for k in range(depth):
-            for relu in (False, True):
-                keys = [key for key, st in paths.items() if len(st) > k and bool(st[k].relu) == relu]
-                # same output-tile count first, so that a group of four qualifies for the multi-problem conv launch
+            # stage k of every path that has one: paths that end here (BatchNorm without ReLU) and paths that go on (with ReLU) share
+            # launches -- the BatchNorm kernels take the ReLU flag per job (round 5; rounds 2-4 launched the two kinds separately)
+            for relu in ((False, True) if FUSE_SPLIT_RELU else (None,)):
+                keys = [key for key, st in paths.items() if len(st) > k and (relu is None or bool(st[k].relu) == relu)]
+                # same output-tile count first, so that a group qualifies for the multi-problem conv launch
                 keys.sort(key=lambda key: (paths[key][k]._modules['0'].out_channels % 48 == 0, paths[key][k]._modules['0'].out_channels))
                 for g0 in range(0, len(keys), FUSE_GROUP):
                     grp = keys[g0:g0 + FUSE_GROUP]
                     convs = [paths[key][k]._modules['0'] for key in grp]
                     bns = [paths[key][k]._modules['1'] for key in grp]
                     h = multi_conv(convs, [cur[key] for key in grp]) if LOCKSTEP_CONVS else [c(cur[key]) for c, key in zip(convs, grp)]
-                    h = multi_batch_norm(bns, h, None, relu=relu)
+                    h = multi_batch_norm(bns, h, None, relu=[bool(paths[key][k].relu) for key in grp])
                     for key, v in zip(grp, h):
                         cur[key] = v
         return cur

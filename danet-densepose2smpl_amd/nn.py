@@ -267,6 +267,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
     def forward(ctx, static, *tensors):
         L = _lib.lib()
         n, relu, momentum, eps, rms, rvs, fused, links = static
+        relus = list(relu) if isinstance(relu, (list, tuple)) else [bool(relu)] * n          # per job (the kernels take one flag per job)
         xs = [nhwc_act(t) for t in tensors[:n]]
         dt = xs[0].dtype
         ress = [None if t is None else nhwc_as(t, dt) for t in tensors[n:2 * n]]
@@ -287,7 +288,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
                     sums = torch.zeros(L.danet_bn_ws_floats(C), dtype=torch.float32, device=xs[i].device)
             keep.append(sums)
             mask = torch.empty(B * H * W * C // 4, dtype=torch.uint8, device=xs[i].device) \
-                if (relu and RELU_MASK and (ress[i] is not None or _conv.FUSE_BN_BWD_REDUCE)) else None
+                if (relus[i] and RELU_MASK and (ress[i] is not None or _conv.FUSE_BN_BWD_REDUCE)) else None
             masks.append(mask)
             j = jobs[i]
             j.mask = None if mask is None else mask.data_ptr()
@@ -296,21 +297,21 @@ class MultiBatchNormFunction(torch.autograd.Function):
             j.running_mean = None if rms[i] is None else rms[i].data_ptr()
             j.running_var = None if rvs[i] is None else rvs[i].data_ptr()
             j.saved, j.sums = saved.data_ptr(), sums.data_ptr()
-            j.M, j.C, j.sums_state, j.relu = B * H * W, C, state, int(relu)
+            j.M, j.C, j.sums_state, j.relu = B * H * W, C, state, int(relus[i])
             ys.append(y)
             saveds.append(saved)
         check(_k(L, 'danet_bn_forward_multi', dt)(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
-        modes = [((2 if r is None else (1 if m is not None else 0)) if RELU_MASK else 0) if relu else 0 for m, r in zip(masks, ress)]
-        ctx.save_for_backward(*xs, *[y if (relu and md == 0) else None for y, md in zip(ys, modes)], *gammas, *saveds, *betas, *masks)
-        ctx.cfg = (n, relu, [r is not None for r in ress], links, modes)
-        for y, x, saved, mask, md in zip(ys, xs, saveds, masks, modes):
-            y._bn_ctx = (x, bool(relu), saved, mask, md)
+        modes = [((2 if r is None else (1 if m is not None else 0)) if RELU_MASK else 0) if rl else 0 for m, r, rl in zip(masks, ress, relus)]
+        ctx.save_for_backward(*xs, *[y if (rl and md == 0) else None for y, md, rl in zip(ys, modes, relus)], *gammas, *saveds, *betas, *masks)
+        ctx.cfg = (n, relus, [r is not None for r in ress], links, modes)
+        for y, x, saved, mask, md, rl in zip(ys, xs, saveds, masks, modes, relus):
+            y._bn_ctx = (x, bool(rl), saved, mask, md)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *gys):
         L = _lib.lib()
-        n, relu, has_res, links, modes = ctx.cfg
+        n, relus, has_res, links, modes = ctx.cfg
         sv = ctx.saved_tensors
         xs, ys, gammas, saveds, betas, masks = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n], sv[4 * n:5 * n], sv[5 * n:6 * n]
         jobs = (_lib.BnBwdJob * n)()
@@ -335,7 +336,7 @@ class MultiBatchNormFunction(torch.autograd.Function):
             j.beta, j.mask, j.mask_mode = betas[i].data_ptr(), None if masks[i] is None else masks[i].data_ptr(), modes[i]
             j.gamma, j.saved = gammas[i].data_ptr(), saveds[i].data_ptr()
             j.dx, j.dres, j.dparam, j.red = dx.data_ptr(), None if dres is None else dres.data_ptr(), dparam.data_ptr(), red.data_ptr()
-            j.M, j.C, j.red_state, j.relu = B * H * W, C, state, int(relu)
+            j.M, j.C, j.red_state, j.relu = B * H * W, C, state, int(relus[i])
             dxs.append(dx)
             dress.append(dres)
             dparams.append(dparam)
@@ -357,14 +358,15 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
     n = len(bns)
     ress = list(ress) if ress is not None else [None] * n
+    relus = [bool(r) for r in relu] if isinstance(relu, (list, tuple)) else [bool(relu)] * n      # one flag per BatchNorm, or one for all
     ok = 1 <= n <= 8 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
     lks = list(links) if links is not None else [None] * n
     if not ok:
-        return [b(x, r, relu, link=lk) for b, x, r, lk in zip(bns, xs, ress, lks)]
+        return [b(x, r, rl, link=lk) for b, x, r, rl, lk in zip(bns, xs, ress, relus, lks)]
     mom = {0.1 if b.momentum is None else b.momentum for b in bns}
     eps = {b.eps for b in bns}
     if len(mom) != 1 or len(eps) != 1:
-        return [b(x, r, relu, link=lk) for b, x, r, lk in zip(bns, xs, ress, lks)]
+        return [b(x, r, rl, link=lk) for b, x, r, rl, lk in zip(bns, xs, ress, relus, lks)]
     for b in bns:
         b._count()
     rms = [b.running_mean if b.track_running_stats else None for b in bns]
@@ -372,7 +374,7 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     fused = [getattr(x, '_bn_sums', None) for x in xs]
     for f in fused:
         _conv.FUSION['bn_stats_fused' if f is not None else 'bn_stats_own'] += 1
-    static = (n, bool(relu), mom.pop(), eps.pop(), rms, rvs, fused, links)
+    static = (n, relus, mom.pop(), eps.pop(), rms, rvs, fused, links)
     return list(MultiBatchNormFunction.apply(static, *xs, *ress, *[b.weight for b in bns], *[b.bias for b in bns]))
 
 
