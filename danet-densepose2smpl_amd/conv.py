@@ -1054,7 +1054,7 @@ def multi_conv(convs, xs, links=None):
     import ctypes
     n = len(convs)
     L = _lib.lib()
-    ok = PRECISION != 'fp32' and 1 <= n <= 8 and xs[0].is_cuda and all(c.bias is None and not c.out_fp32 and c.stride[0] == c.stride[1] and
+    ok = PRECISION != 'fp32' and 1 <= n <= 12 and xs[0].is_cuda and all(c.bias is None and not c.out_fp32 and c.stride[0] == c.stride[1] and
                                                 c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1] for c in convs)
     if ok:
         jobs = (_lib.ConvJob * n)()

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(ConvP p)
 
 // Up to 4 independent convolutions with the same NT in one launch (HRNet branches in lockstep): workgroup id ->
 // problem through the prefix table, then the problem's own (MT, grid).
-constexpr int NCM = 8;      // problems per multi launch (kernel arguments: 8 x ~300 B)
+constexpr int NCM = 12;     // problems per multi launch (kernel arguments: 12 x ~300 B; 12 = the exchange paths of a four-branch module's first stage)
 struct ConvMulti { ConvP p[NCM]; int start[NCM + 1]; int gx[NCM], gy[NCM], mt[NCM]; int n; };
 static_assert(sizeof(ConvMulti) <= 4096, "kernel arguments");
 

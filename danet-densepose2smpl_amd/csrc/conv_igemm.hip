@@ -723,9 +723,9 @@ struct ConvJob { const void* x; const void* wp; void* y; float* bn_sums; const v
 
 // *all3 = every problem runs on the LDS-tile 3x3 kernel (then nt / mts are not needed)
 static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, int* nt_out, bool* all3) {
-    if (!jobs || n < 1 || n > 8) return -1;
+    if (!jobs || n < 1 || n > 12) return -1;
     int nt = -1;
-    *all3 = n <= 4;                         // (the LDS-tile 3x3 kernel takes up to 4 problems, the gather kernel up to 8)
+    *all3 = n <= 4;                         // (the LDS-tile 3x3 kernel takes up to 4 problems, the gather kernel up to 12)
     for (int i = 0; i < n && *all3; ++i) {
         const ConvJob& j = jobs[i];
         bool vec8;
@@ -758,7 +758,7 @@ static int conv_multi_prepare(const ConvJob* jobs, int n, ConvP* ps, int* mts, i
 
 extern "C" int danet_conv_forward_multi_ok(const void* jobs, int n)
 {
-    ConvP ps[8]; int mts[8], nt; bool all3;
+    ConvP ps[12]; int mts[12], nt; bool all3;
     if (conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt, &all3) != 0) return 0;
     return all3 ? 2 : 1;                  // 2: one conv3x3_tile_kernel launch, 1: one conv_fast_multi_kernel launch
 }
@@ -767,7 +767,7 @@ extern "C" int danet_conv_forward_multi_ok(const void* jobs, int n)
 // 3 conv3x3_stream_kernel (profilers label their records with it).
 extern "C" int danet_conv_forward_multi_kernel(const void* jobs, int n)
 {
-    ConvP ps[8]; int mts[8], nt; bool all3;
+    ConvP ps[12]; int mts[12], nt; bool all3;
     if (conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt, &all3) != 0) return 0;
     if (!all3) return 1;
     return conv3x3s_launch(ps, n, nullptr, true) == 0 && conv3x3_stream_first() ? 3 : 2;
@@ -776,7 +776,7 @@ extern "C" int danet_conv_forward_multi_kernel(const void* jobs, int n)
 extern "C" int danet_conv_forward_multi(const void* jobs, int n, void* stream)
 {
     DANET_ENTER();
-    ConvP ps[8]; int mts[8], nt; bool all3;
+    ConvP ps[12]; int mts[12], nt; bool all3;
     DANET_CHECK_ARG(conv_multi_prepare((const ConvJob*)jobs, n, ps, mts, &nt, &all3) == 0, "conv_forward_multi: unsupported set (see danet_conv_forward_multi_ok)");
     for (int i = 0; i < n; ++i) {
         DANET_CHECK_ARG(ps[i].x && ps[i].w && ps[i].y, "conv_forward_multi: job %d: null pointer", i);

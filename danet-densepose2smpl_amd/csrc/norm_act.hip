@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 // Up to 4 independent BatchNorms in one launch (the HRNet branches advance in lockstep: nn.multi_batch_norm): the
 // small branches' launches are dominated by the per-launch floor, one launch over all of them is not.
-constexpr int NBM = 8;
+constexpr int NBM = 12;
 struct BnFwdOne {
     const elem_t* x; const elem_t* res; elem_t* y; const bn_acc_t* sums; const float* gamma; const float* beta;
     float* running_mean; float* running_var; float* saved; unsigned char* mask; FlatMap fm; int C; float inv_count, unbias; int relu;

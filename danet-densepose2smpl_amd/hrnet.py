@@ -36,7 +36,7 @@ class _Chain(nn.Module):
 
 LOCKSTEP_BRANCHES = bool(int(os.environ.get('DANET_LOCKSTEP', '1')))    # one multi-tensor BatchNorm launch per block level
 LOCKSTEP_CONVS = bool(int(os.environ.get('DANET_LOCKSTEP_CONVS', '1')))     # ... and one multi-problem conv launch
-FUSE_GROUP = int(os.environ.get('DANET_FUSE_GROUP', '8'))     # exchange paths per multi-problem launch (the kernels take up to 8)
+FUSE_GROUP = int(os.environ.get('DANET_FUSE_GROUP', '12'))    # exchange paths per multi-problem launch (the kernels take up to 12: a four-branch module's first stage)
 FUSE_SPLIT_RELU = bool(int(os.environ.get('DANET_FUSE_SPLIT_RELU', '0')))       # A-B knob: 1 = ReLU and non-ReLU exchange stages in separate launches (rounds 2-4)
 SUM_MULTI = bool(int(os.environ.get('DANET_SUM_MULTI', '1')))       # a module's fuse sums (and their gradients) in one launch each
 BRANCH_STREAMS = False      # run the low-resolution branches on side streams (set by the trainer's hipGraph capture)

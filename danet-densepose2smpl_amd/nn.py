@@ -359,7 +359,7 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     n = len(bns)
     ress = list(ress) if ress is not None else [None] * n
     relus = [bool(r) for r in relu] if isinstance(relu, (list, tuple)) else [bool(relu)] * n      # one flag per BatchNorm, or one for all
-    ok = 1 <= n <= 8 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
+    ok = 1 <= n <= 12 and all(b.training and b.affine and b.num_features <= 1024 for b in bns) and xs[0].is_cuda
     lks = list(links) if links is not None else [None] * n
     if not ok:
         return [b(x, r, rl, link=lk) for b, x, r, rl, lk in zip(bns, xs, ress, relus, lks)]

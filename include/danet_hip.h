@@ -275,7 +275,7 @@ long danet_conv_pack_job_bricks(int Cout, int Cin_g, int R, int S, int groups, i
 long danet_conv_pack_job_fill(void* job_host, const float* w, void* wp, long start, long bstart,
                               int Cout, int Cin_g, int R, int S, int groups, int mode, int chunk);
 int danet_conv_pack_weights_batched(const void* jobs_dev, int njobs, long total_elems, long total_bricks, void* stream);
-/* Up to 8 independent convolutions (forward or data gradient) in one launch (4 on the LDS-tile 3x3 kernel) -- HRNet branches
+/* Up to 12 independent convolutions (forward or data gradient) in one launch (4 on the LDS-tile 3x3 kernel) -- HRNet branches
  * and fuse-layer exchange paths in lockstep.
  * job = { const void* x, *wp; void* y; float* bn_sums; const void* bn_x, *bn_y; const float* bn_saved; float* bn_red; const void* addend;
  *         int B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, bn_gate; }  (no bias / ReLU / fp32 output);
@@ -453,7 +453,7 @@ int danet_bn_backward(const void* dy, const void* x, const void* y, int64_t M, i
                       const float* gamma, const float* saved, int relu,
                       void* dx, void* dres, float* dparam, float* red_ws, int ws_is_zero,
                       int mask_mode, const void* relu_mask, const float* beta, void* stream);
-/* Up to 8 independent training-mode BatchNorms per launch (HRNet branches / exchange paths in lockstep); C <= 1024 each.
+/* Up to 12 independent training-mode BatchNorms per launch (HRNet branches / exchange paths in lockstep); C <= 1024 each.
  *  forward job  { const void* x, *res; void* y; const float* gamma, *beta; float* running_mean, *running_var, *saved, *sums;
  *                 void* mask; int64_t M; int C, sums_state, relu; }   sums_state 1: zeroed scratch, 2: accumulated by the conv epilogue
  *  backward job { const void* dy, *x, *y; const float* gamma, *saved; void* dx, *dres; float* dparam, *red; const float* beta;
