@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import segments
 from .config import cfg
-from .nn import fan_out, sum_relu, sum_relu_multi, multi_batch_norm
+from .nn import fan_out, fan_out_multi, sum_relu, sum_relu_multi, multi_batch_norm
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
 from .conv import multi_conv, ResLink
@@ -139,7 +139,8 @@ class HighResolutionModule(nn.Module):
         # branch j feeds the exchange path to every other output and its own fuse sum: its gradient is the sum of that many
         # contributions -- one kernel (nn.fan_out) instead of autograd's pairwise adds
         nout = len(self.fuse_layers)
-        fan = [fan_out(x[j], nout) for j in range(self.num_branches)]       # (nout - 1 paths + own sum, or nout paths)
+        # (nout - 1 paths + own sum, or nout paths; the branches' gradient sums share one launch: nn.fan_out_multi)
+        fan = fan_out_multi([x[j] for j in range(self.num_branches)], nout) if SUM_MULTI else [fan_out(x[j], nout) for j in range(self.num_branches)]
         take = [0] * self.num_branches
 
         def use(j):

@@ -553,7 +553,63 @@ class FanOutFunction(torch.autograd.Function):
         return total, None
 
 
+class FanOutMultiFunction(torch.autograd.Function):
+    """FanOutFunction for the m (<= 4) branch outputs of ONE HighResolutionModule at once: n aliases of each; the backward sums each
+    branch's incoming gradients, all branches in ONE launch (csrc/norm_act.hip sum_relu_multi_kernel, no ReLU, no shifts) instead of one
+    launch per branch."""
+
+    @staticmethod
+    def forward(ctx, n, *xs):
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        m = len(gs) // n
+        outs = [None] * m
+        jobs = (_lib.SumFwdJob * m)()
+        nj, keep, dt0 = 0, [], None
+        for i in range(m):
+            grp = [g for g in gs[i * n:(i + 1) * n] if g is not None]
+            if not grp:
+                continue
+            if len(grp) == 1:
+                outs[i] = grp[0]
+                continue
+            dt = torch.float32 if grp[0].dtype == torch.float32 else torch.bfloat16
+            if len(grp) > 4 or (dt0 is not None and dt != dt0):
+                outs[i] = FanOutFunction.backward(ctx, *grp)[0]
+                continue
+            dt0 = dt
+            terms = [nhwc_as(t, dt) for t in grp]
+            B, C, H, W = terms[0].shape
+            y = _empty_nhwc(B, C, H, W, dt, terms[0].device)
+            j = jobs[nj]
+            nj += 1
+            for q, t in enumerate(terms):
+                j.terms[q] = t.data_ptr()
+                j.shifts[q] = 0
+            j.nterms, j.B, j.H, j.W, j.C, j.relu, j.y = len(terms), B, H, W, C, 0, y.data_ptr()
+            keep.append(terms)
+            outs[i] = y
+        if nj:
+            check(_k(_lib.lib(), 'danet_sum_relu_forward_multi', dt0)(ctypes.addressof(jobs), nj, stream()), 'danet_sum_relu_forward_multi')
+        return (None,) + tuple(outs)
+
+
 FAN_OUT = bool(int(os.environ.get('DANET_FAN_OUT', '1')))
+
+
+def fan_out_multi(xs, n):
+    """[fan_out(x, n) for x in xs] with ONE gradient-sum launch for all of them (m <= 4 tensors that qualify for fan_out)."""
+    ok = FAN_OUT and n > 2 and 1 < len(xs) <= 4 and torch.is_grad_enabled() and \
+        all(x.is_cuda and x.requires_grad and x.dim() == 4 and x.shape[1] % 4 == 0 for x in xs)
+    if not ok:
+        return [fan_out(x, n) for x in xs]
+    flat = FanOutMultiFunction.apply(n, *xs)
+    return [list(flat[i * n:(i + 1) * n]) for i in range(len(xs))]
 
 
 def fan_out(x, n):
