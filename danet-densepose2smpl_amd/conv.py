@@ -601,12 +601,21 @@ class Conv2dFunction(torch.autograd.Function):
                 gw = new_wgrad(weight, (Cout, Cin_g, R, S), x.device)
                 _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, weight)
             else:
-                # at the padded widths, then cropped to the parameter's own shape (one launch of csrc/glue.hip)
+                # at the padded widths, then cropped to the parameter's own shape (one launch of csrc/glue.hip) -- queued like every
+                # other weight gradient (round 5: these ran inside the backward chain, ~35 us of launches per layer of the heads), the
+                # crop then follows the multi-problem launch and writes the tensor autograd already holds as .grad
                 gwp = torch.empty(Cout, Cin_g, R, S, dtype=torch.float32, device=x.device)
-                _wgrad_into(gwp, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, None)
-                from .glue import crop
                 so, si = weight.shape[0] // groups, weight.shape[1]
-                gw = crop(gwp, (groups, Cout // groups, Cin_g, R * S), (groups, so, si, R * S), tuple(weight.shape))
+                views = ((groups, Cout // groups, Cin_g, R * S), (groups, so, si, R * S))
+                gw = new_wgrad(weight, tuple(weight.shape), x.device) if (DEFER_WGRAD and DEFER_PADDED) else None
+                # (the queue keeps the ADDRESS of gw only: a second reference would make autograd clone it instead of adopting it as .grad)
+                if gw is None or not _enqueue_wgrad(gwp.data_ptr(), weight, x, gy, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups,
+                                                    post=(gwp, gw.data_ptr(), views[0], views[1])):
+                    if gw is not None and GRAD_STORE is not None and GRAD_STORE.has(weight) and gw.data_ptr() == GRAD_STORE.grad_ptr(weight):
+                        GRAD_STORE._handed.discard(id(weight))          # (the slot was taken for a gradient that is not queued after all)
+                    _wgrad_into(gwp, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad, dil, groups, None)
+                    from .glue import crop
+                    gw = crop(gwp, views[0], views[1], tuple(weight.shape))
         if ctx.needs_input_grad[0]:
             bn_bwd = None
             if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
@@ -671,6 +680,7 @@ CHSUM_ARENA = bool(int(os.environ.get('DANET_CHSUM_ARENA', '1')))       # A-B / 
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches
+DEFER_PADDED = bool(int(os.environ.get('DANET_DEFER_PADDED_WGRAD', '1')))       # ... those of channel-padded layers as well (A-B knob)
 _WQ = []                  # 3x3 / stride 1 or 2 problems (conv_wgrad3x3.hip)
 _WQG = []                 # everything else (conv_wgrad.hip)
 GRAD_STORE = None         # distributed.GradStore of the running trainer: weight gradients are written into its views
@@ -692,6 +702,8 @@ def _check_adopted(queue):
     accumulation into an existing .grad (shared weights, gradient accumulation), would have read garbage."""
     for q in queue:
         gptr, weight = q[0], q[1]
+        if q[-1] is not None:             # (a channel-padded layer: the kernel writes a padded temporary, .grad is the tensor it is cropped into)
+            gptr = q[-1][1]
         if weight.grad is None or weight.grad.data_ptr() != gptr:
             _WQ.clear()
             _WQG.clear()
@@ -710,11 +722,14 @@ def flush_wgrads(bucket=None, hold=None):
 
     def mine(q):
         return bucket is None or GRAD_STORE is None or GRAD_STORE.bucket_of.get(id(q[1]), -1) == bucket
-    wq = [q for q in _WQ if mine(q)]
-    if wq:
+    # (channel-padded layers -- post is not None -- go out in launches of their own: the multi-problem planners deal a fixed number of
+    # workgroups over the jobs of a call, and a dozen tiny layers in the same call took workgroups away from every other launch: +0.3 ms)
+    for wq in ([q for q in _WQ if mine(q) and q[-1] is None], [q for q in _WQ if mine(q) and q[-1] is not None]):
+        if not wq:
+            continue
         _check_adopted(wq)
         jobs = (_lib.Wg3Job * len(wq))()
-        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups, stride) in zip(jobs, wq):
+        for j, (gptr, weight, x, gy, B, H, W, Cin, Cout, groups, stride, _post) in zip(jobs, wq):
             j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
             j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = B, H, W, Cin, Cout, groups, stride
         n = len(wq)
@@ -725,14 +740,16 @@ def flush_wgrads(bucket=None, hold=None):
         check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad3x3_multi')
         if tok is not None:
             PROFILER.end(tok)
+        _crop_posts(wq)
         if hold is not None:
             hold.extend(wq)
-        _WQ[:] = [q for q in _WQ if not mine(q)]
-    wqg = [q for q in _WQG if mine(q)]
-    if wqg:
+    _WQ[:] = [q for q in _WQ if not mine(q)]
+    for wqg in ([q for q in _WQG if mine(q) and q[-1] is None], [q for q in _WQG if mine(q) and q[-1] is not None]):
+        if not wqg:
+            continue
         _check_adopted(wqg)
         jobs = (_lib.WgJob * len(wqg))()
-        for j, (gptr, weight, x, gy, dims) in zip(jobs, wqg):
+        for j, (gptr, weight, x, gy, dims, _post) in zip(jobs, wqg):
             j.x, j.dy, j.dw = x.data_ptr(), gy.data_ptr(), gptr
             (j.B, j.H, j.W, j.Cin, j.OH, j.OW, j.Cout, j.R, j.S, j.stride, j.pad, j.dil, j.groups) = dims
         n = len(wqg)
@@ -746,9 +763,35 @@ def flush_wgrads(bucket=None, hold=None):
         check(L.danet_conv_wgrad_multi(ctypes.addressof(jobs), n, ptr(ws), need, 0.0, stream()), 'danet_conv_wgrad_multi')
         if tok is not None:
             PROFILER.end(tok)
+        _crop_posts(wqg)
         if hold is not None:
             hold.extend(wqg)
-        _WQG[:] = [q for q in _WQG if not mine(q)]
+    _WQG[:] = [q for q in _WQG if not mine(q)]
+
+
+def _crop_posts(queue):
+    """The channel-padded layers of a flushed queue: their gradients, computed at the padded widths, are cropped into the tensors autograd
+    holds as .grad (one launch per 16 layers)."""
+    posts = [(q[-1], q[1].grad) for q in queue if q[-1] is not None]          # (.grad IS the tensor returned from the backward node: _check_adopted)
+    if posts:
+        from .glue import crop_into
+        crop_into([p[0] for p, _ in posts], [p[2] for p, _ in posts], [p[3] for p, _ in posts], [g for _, g in posts])
+
+
+def _enqueue_wgrad(gptr, weight, x, gy, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, post=None):
+    """Queue a weight gradient for flush_wgrads (the kernel will write at address gptr); False when this problem is not queued
+    (deferral off, the parameter already has a gradient, or the 7x7 stem kernel -- a chip-filling launch of its own)."""
+    L = _lib.lib()
+    if not (DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None):
+        return False
+    if L.danet_conv_wgrad_rows_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
+        return False
+    if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+        # only the ADDRESS of the target is kept: holding the tensor would make autograd clone it instead of adopting it as .grad
+        _WQ.append((gptr, weight, x, gy, B, H, W, Cin, Cout, groups, stride, post))      # x, gy stay alive until the flush
+    else:
+        _WQG.append((gptr, weight, x, gy, (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups), post))
+    return True
 
 
 def _wgrad_scratch(need, zero_from, device):
@@ -772,13 +815,7 @@ def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad,
         if tok is not None:
             PROFILER.end(tok)
         return
-    if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None and USE_WGRAD3X3 and \
-            L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
-        # only the ADDRESS of gw is kept: holding the tensor would make autograd clone it instead of adopting it as .grad
-        _WQ.append((gw.data_ptr(), weight, x, gy, B, H, W, Cin, Cout, groups, stride))      # x, gy stay alive until the flush
-        return
-    if DEFER_WGRAD and isinstance(weight, nn.Parameter) and weight.grad is None:
-        _WQG.append((gw.data_ptr(), weight, x, gy, (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups)))
+    if _enqueue_wgrad(gw.data_ptr(), weight, x, gy, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
         return
     if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
         nws = L.danet_conv_wgrad3x3_ws_floats(B, H, W, Cin, Cout, groups, stride)

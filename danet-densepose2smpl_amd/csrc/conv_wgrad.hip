@@ -433,7 +433,8 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
             if (!done[k] && danet_conv_wgrad_kernel_id(jobs[k].Cin, jobs[k].Cout, jobs[k].groups, jobs[k].R * jobs[k].S) == kid) { idx[cnt++] = k; done[k] = true; }
         const int ct = kid / 100, ni = (kid / 10) % 10, tgs = kid % 10;
         double tot = 0;
-        for (int k = 0; k < cnt; ++k) { const WgJob& j = jobs[idx[k]]; tot += (double)j.B * j.OH * j.OW * j.Cout * (j.Cin / j.groups) * j.R * j.S; }
+        auto cw = [](const WgJob& j) { const double p = (double)j.Cout * (j.Cin / j.groups); return p < 2304.0 ? 2304.0 : p; };      // (floor: see conv_wgrad3x3.hip wg3_weight)
+        for (int k = 0; k < cnt; ++k) { const WgJob& j = jobs[idx[k]]; tot += (double)j.B * j.OH * j.OW * cw(j) * j.R * j.S; }
         WgradMulti mp; UnpackMulti up;
         mp.n = cnt; up.n = cnt; up.beta = beta; mp.start[0] = 0; up.start[0] = 0;
         for (int k = 0; k < cnt; ++k) {
@@ -449,7 +450,7 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
             const int nco = (p.Cout_g + ct * 16 - 1) / (ct * 16), nci = (p.Cin_g + ni * 16 - 1) / (ni * 16);
             const long other = (long)nco * nci * p.ntapgroups * j.groups;
             const long nchunks = (p.M + CHUNK - 1) / CHUNK;
-            const double w = (double)p.M * j.Cout * p.Cin_g * taps;
+            const double w = (double)p.M * cw(j) * taps;
             long ms = (long)(target * (w / tot) / other + 0.5);
             if (ms > nchunks / 2) ms = nchunks / 2;
             if (ms < 1) ms = 1;

@@ -395,12 +395,16 @@ static long multi_target_blocks() {
     return 768;          // swept on MI355X (384 / 512 / 768 / 1024): three workgroups per CU
 }
 
+// A problem's share of a multi-problem launch ~ pixel chunks x channel products, with a floor on the channel product: a layer of 12 or
+// 16 channels (the channel-padded head layers, queued since round 5) is bound by reading its pixels, not by its few MFMAs, and with its
+// true product it got one or two workgroups for 4 096 chunks -- a serial tail the whole launch waited for.
+static inline double wg3_weight(int Cout, int Cin_g) { const double p = (double)Cout * Cin_g; return p < 2304.0 ? 2304.0 : p; }
 // msplit of every job when jobs [first, last) of one instance share a launch
 static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int ni, int* msplit) {
     double tot = 0;
     for (int k = 0; k < cnt; ++k) {
         const Wg3Job& j = jobs[idx[k]];
-        tot += (double)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW) * j.Cout * (j.Cin / j.groups);
+        tot += (double)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW) * wg3_weight(j.Cout, j.Cin / j.groups);
     }
     const long target = multi_target_blocks();
     for (int k = 0; k < cnt; ++k) {
@@ -408,7 +412,7 @@ static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int 
         const int Cout_g = j.Cout / j.groups, Cin_g = j.Cin / j.groups;
         const long other = (long)((Cout_g + ct * 16 - 1) / (ct * 16)) * ((Cin_g + ni * 16 - 1) / (ni * 16)) * j.groups;
         const long nchunks = (long)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW);
-        const double w = (double)nchunks * j.Cout * Cin_g;
+        const double w = (double)nchunks * wg3_weight(j.Cout, Cin_g);
         long ms = (long)(target * (w / tot) / other + 0.5);
         if (ms > nchunks / 4) ms = nchunks / 4;
         if (ms < 1) ms = 1;

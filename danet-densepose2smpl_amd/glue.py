@@ -17,10 +17,12 @@ def _dims4(shape):
     return (1,) * (4 - len(shape)) + shape
 
 
-def _launch(srcs, src_views, dst_views, out_shapes):
-    """srcs[k] (dense fp32, numel == prod(src_views[k])) -> new tensor of out_shapes[k] (numel == prod(dst_views[k]))."""
+def _launch(srcs, src_views, dst_views, out_shapes, outs=None):
+    """srcs[k] (dense fp32, numel == prod(src_views[k])) -> new tensor of out_shapes[k] (numel == prod(dst_views[k])), or into the given
+    dense fp32 tensors `outs`."""
     L = _lib.lib()
-    outs = [torch.empty(tuple(s), dtype=torch.float32, device=srcs[0].device) for s in out_shapes]
+    if outs is None:
+        outs = [torch.empty(tuple(s), dtype=torch.float32, device=srcs[0].device) for s in out_shapes]
     for k0 in range(0, len(srcs), PAD_MAX):
         n = min(PAD_MAX, len(srcs) - k0)
         sp = (ctypes.c_void_p * n)(*[srcs[k0 + k].data_ptr() for k in range(n)])
@@ -71,6 +73,12 @@ def pad_multi(items):
             spec.append((tuple(sv), tuple(dv), tuple(shape)))
         tensors.append(t)
     return PadMultiFunction.apply(tuple(spec), *tensors)
+
+
+def crop_into(srcs, src_views, dst_views, outs):
+    """crop for several tensors in one launch per 16, written into EXISTING dense fp32 tensors (the deferred weight gradients of
+    channel-padded layers: computed at the padded widths by the multi-problem launches, cropped into the parameters' gradient slots)."""
+    _launch(list(srcs), list(src_views), list(dst_views), None, outs=list(outs))
 
 
 def crop(t, src_view, dst_view, out_shape):

@@ -166,7 +166,10 @@ def test_deferred_multi_problem_wgrad_matches_immediate():
     from danet_densepose2smpl_amd import conv as dconv
     torch.manual_seed(0)
     cfgs = [(48, 48, 3, 1, 1, 32), (96, 96, 3, 1, 1, 16), (192, 192, 3, 1, 1, 8), (48, 96, 3, 2, 1, 32), (64, 256, 1, 1, 0, 16),
-            (256, 64, 1, 1, 0, 16), (64, 64, 7, 2, 3, 32), (48, 24, 3, 1, 1, 32)]
+            (256, 64, 1, 1, 0, 16), (64, 64, 7, 2, 3, 32), (48, 24, 3, 1, 1, 32),
+            # channel-padded layers (widths no multiple of 8: the IUV heads, the heat-map head's Bottleneck(48, 12)): computed at the padded
+            # widths by the same multi-problem launches and cropped into .grad afterwards (round 5; they used to run inside the backward chain)
+            (48, 25, 3, 1, 1, 32), (48, 12, 1, 1, 0, 32), (12, 12, 3, 1, 1, 32), (12, 48, 1, 1, 0, 32), (75, 64, 1, 1, 0, 16)]
     convs = [dconv.Conv2d(ci, co, k, s, p, bias=False).cuda() for ci, co, k, s, p, _ in cfgs]
     xs = [torch.randn(3, ci, h, h, device='cuda') for ci, _, _, _, _, h in cfgs]
 
