@@ -253,14 +253,49 @@ static int pwg_msplit(const WgJob& j, long total_px, long target) {
     return (int)ms;
 }
 
+// The problems idx[0..cnt) go out in launches of one kernel instance each (greedy, in order, at most PWG_NPM per launch): gpx[k] = the
+// pixels of all problems that share problem k's launch.  `target` workgroups are dealt over the problems of ONE LAUNCH (round 5; rounds
+// 3-4 dealt them over all problems of the call, so that each of its ~12 launches got a twelfth of the workgroups: 64 on 256 CUs).
+static void pwg_group_pixels(const WgJob* jobs, const int* idx, int cnt, long* gpx) {
+    static const bool per_call = getenv("DANET_PWG_PER_CALL") != nullptr;          // A-B timing knob: the rounds 3-4 deal
+    if (per_call) {
+        long total = 0;
+        for (int k = 0; k < cnt; ++k) total += (long)jobs[idx[k]].B * jobs[idx[k]].OH * jobs[idx[k]].OW;
+        for (int k = 0; k < cnt && k < 4096; ++k) gpx[k] = total;
+        return;
+    }
+    bool done[4096];
+    for (int k = 0; k < cnt && k < 4096; ++k) done[k] = false;
+    for (int k0 = 0; k0 < cnt && k0 < 4096; ++k0) {
+        if (done[k0]) continue;
+        PwgPlan pl0;
+        if (!pwg_plan(jobs[idx[k0]].Cout, jobs[idx[k0]].Cin, pl0)) { gpx[k0] = (long)jobs[idx[k0]].B * jobs[idx[k0]].OH * jobs[idx[k0]].OW; done[k0] = true; continue; }
+        int members[64], nm = 0;
+        long px = 0;
+        for (int k = k0; k < cnt && k < 4096 && nm < PWG_NPM; ++k) {
+            if (done[k]) continue;
+            PwgPlan pl;
+            if (!pwg_plan(jobs[idx[k]].Cout, jobs[idx[k]].Cin, pl) || pl.nbw_t != pl0.nbw_t || pl.kbw_t != pl0.kbw_t || pl.nkc != pl0.nkc) continue;
+            done[k] = true;
+            members[nm++] = k;
+            px += (long)jobs[idx[k]].B * jobs[idx[k]].OH * jobs[idx[k]].OW;
+        }
+        for (int m = 0; m < nm; ++m) gpx[members[m]] = px;
+    }
+}
+
 // Workspace floats the problems idx[0..cnt) need (partial sums [msplit][Cout][Cin] each).
 size_t conv_pw_wgrad_ws_floats(const WgJob* jobs, const int* idx, int cnt, long target) {
+    static long gpx_buf[4096];
+    if (cnt > 4096) return 0;
+    long* const gpx = gpx_buf;
+    pwg_group_pixels(jobs, idx, cnt, gpx);
     long total_px = 0;
     for (int k = 0; k < cnt; ++k) total_px += (long)jobs[idx[k]].B * jobs[idx[k]].OH * jobs[idx[k]].OW;
     size_t need = 0;
     for (int k = 0; k < cnt; ++k) {
         const WgJob& j = jobs[idx[k]];
-        need += ((size_t)pwg_msplit(j, total_px, target) * j.Cout * j.Cin + 15) / 16 * 16;
+        need += ((size_t)pwg_msplit(j, gpx[k], target) * j.Cout * j.Cin + 15) / 16 * 16;
     }
     return need;
 }
@@ -272,8 +307,10 @@ int conv_pw_wgrad_launch(const WgJob* jobs, const int* idx, int cnt, float* ws, 
     long total_px = 0;
     for (int k = 0; k < cnt; ++k) total_px += (long)jobs[idx[k]].B * jobs[idx[k]].OH * jobs[idx[k]].OW;
     bool done[4096];
+    static long gpx_launch[4096];
     if (cnt > 4096) return -1;
     for (int k = 0; k < cnt; ++k) done[k] = false;
+    pwg_group_pixels(jobs, idx, cnt, gpx_launch);
     size_t used = 0;
     for (int k0 = 0; k0 < cnt; ++k0) {
         if (done[k0]) continue;
@@ -292,7 +329,7 @@ int conv_pw_wgrad_launch(const WgJob* jobs, const int* idx, int cnt, float* ws, 
             const long M = (long)j.B * j.OH * j.OW;
             p.x = (const bf16_t*)j.x; p.dy = (const bf16_t*)j.dy; p.part = ws + used;
             p.M = (int)M; p.K = j.Cin; p.N = j.Cout; p.KB = pl.KB; p.NB = pl.NB; p.nsplit = pl.nsplit; p.ksplit = pl.ksplit;
-            p.msplit = pwg_msplit(j, total_px, target); p.nchunks = (int)((M + PWG_KS * pl.nkc - 1) / (PWG_KS * pl.nkc));
+            p.msplit = pwg_msplit(j, gpx_launch[k], target); p.nchunks = (int)((M + PWG_KS * pl.nkc - 1) / (PWG_KS * pl.nkc));
             p.x_bytes = (int)(M * j.Cin * 2); p.dy_bytes = (int)(M * j.Cout * 2);
             mp.start[mp.n + 1] = mp.start[mp.n] + p.msplit;
             rp.part[rp.n] = p.part; rp.dw[rp.n] = j.dw; rp.msplit[rp.n] = p.msplit;
