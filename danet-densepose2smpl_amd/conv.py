@@ -76,6 +76,7 @@ def bn_sums_total(ws, C):
 # dy and x read once, sums and apply in one launch) -- measured 34.7 vs 35.1 ms/step with both, 35.4 with the fused
 # reduction alone (the reduction costs the 3x3 data gradients +18 us per launch, as much as it saves elsewhere)
 FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '0')))
+FUSE_BN_BWD_STEM = bool(int(os.environ.get('DANET_FUSE_BN_BWD_STEM', '0')))      # ... for the 7x7 stems' data gradients only (conv2d; measured neutral in round 5: 26.70 vs 26.67 ms)
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
 TRACE = None           # debugging: a list that receives (tag, shape, mean |value|) for every conv / BN launch (tools/debug_flaky.py)
@@ -618,7 +619,8 @@ class Conv2dFunction(torch.autograd.Function):
                     gw = crop(gwp, views[0], views[1], tuple(weight.shape))
         if ctx.needs_input_grad[0]:
             bn_bwd = None
-            if FUSE_BN_BWD_REDUCE and ctx.bn_ctx is not None and \
+            # (ctx.bn_ctx is only there when conv2d decided for the fused reduction: FUSE_BN_BWD_REDUCE, or FUSE_BN_BWD_STEM for this layer)
+            if ctx.bn_ctx is not None and \
                     L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 in (1, 2):
                 bn_x, saved = ctx.bn_ctx[0], ctx.bn_ctx[2]
                 c3 = L.danet_conv_forward_kernel(B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, 1, 0) % 10 == 2
@@ -904,7 +906,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
         if keep_group_padding:       # [B, groups*(Cout_g+padn), OH, OW]: the caller consumes the padded layout (part_ops)
             return y
         if groups == 1:              # a view: channels stay at the epilogue's padded pixel stride (iuv_ops reads it as it is)
-            return y[:, :Cout]
+            yv = y[:, :Cout]
+            yv._padded_base = y      # (iuv_ops.iuv_global differentiates through the padded tensor itself when it gets this view)
+            return yv
         B, _, OH, OW = y.shape
         y = y.permute(0, 2, 3, 1).reshape(B, OH, OW, groups, Cout_g + padn)[..., :Cout_g]
         return y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
@@ -917,6 +921,16 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_
     # the BatchNorm that produced x (if any) leaves its tensors on x: the data gradient then also reduces that
     # BatchNorm's backward sums (saves one pass over dy, x, y per BatchNorm with a single consumer)
     bn_ctx = getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and torch.is_grad_enabled()) else None
+    if bn_ctx is None and FUSE_BN_BWD_STEM and torch.is_grad_enabled() and getattr(x, '_bn_ctx', None) is not None and x.dtype == torch.bfloat16:
+        # the 7x7 stems over the part crops: the BatchNorm in front of them normalises a 403 MB tensor, far beyond the one-pass
+        # backward's reach, so its backward is the two-kernel form (reduce 158 us + apply 209 us) -- unless the stem's data-gradient
+        # kernel (csrc/conv_stem_dgrad.hip), which has the gradient tile in registers anyway, accumulates the two sums in its epilogue
+        Bx, Cx, Hx, Wx = x.shape
+        R_, S_ = weight.shape[2], weight.shape[3]
+        st_, pd_, dl_ = int(stride), int(padding), int(dilation)
+        if _lib.lib().danet_conv_stem_dgrad_ok(Bx, Hx, Wx, Cx, conv_out_size(Hx, R_, st_, pd_, dl_), conv_out_size(Wx, S_, st_, pd_, dl_),
+                                                 Cout, R_, S_, st_, pd_, dl_, groups) and x._bn_ctx[0].shape == x.shape:
+            bn_ctx = x._bn_ctx
     y = Conv2dFunction.apply(x, weight, bias, stride, padding, dilation, groups, out_fp32, sums, bn_ctx, link, wpad)
     if sums is not None:
         y._bn_sums = sums              # picked up by the BatchNorm2d that consumes y (nn.BatchNorm2d.forward)

@@ -10,6 +10,7 @@ from . import _lib
 from ._lib import ptr, check, stream
 
 NP, NA, MAPC = 25, 15, 80
+PADDED_BASES = bool(int(__import__('os').environ.get('DANET_IUV_PADDED_BASES', '1')))       # A-B knob
 
 
 def _rows(t, valid, ld):
@@ -31,6 +32,9 @@ class IuvGlobalFunction(torch.autograd.Function):
     def forward(ctx, u, v, ix, an, gt, w, keep):
         L = _lib.lib()
         B, _, H, W = u.shape
+        # an input that IS the conv epilogue's padded output (all 32 / 16 channels: iuv_global hands those over when it can) gets
+        # its gradient back at that width -- no slice-backward (a fill + a copy of the padded tensor per head) in between
+        ctx.full = (u.shape[1] == 32, v.shape[1] == 32, ix.shape[1] == 32, an.shape[1] == 16)
         u, v, ix = _rows(u, NP, 32), _rows(v, NP, 32), _rows(ix, NP, 32)
         an = _rows(an, NA, 16)
         want = gt is not None
@@ -67,8 +71,9 @@ class IuvGlobalFunction(torch.autograd.Function):
         check(L.danet_iuv_global_backward(u.data_ptr(), v.data_ptr(), ix.data_ptr(), an.data_ptr(), 32, 16, ptr(gtc), ptr(wc), ptr(kc),
                                           ptr(am_drop), ptr(gm), ptr(coef), B, H, W, int(ctx.want and coef is not None),
                                           ptr(du), ptr(dv), ptr(di), ptr(da), stream()), 'danet_iuv_global_backward')
-        f = lambda t, n: t.permute(0, 3, 1, 2)[:, :n]        # noqa: E731
-        return f(du, NP), f(dv, NP), f(di, NP), f(da, NA), None, None, None
+        f = lambda t, n, full: t.permute(0, 3, 1, 2) if full else t.permute(0, 3, 1, 2)[:, :n]        # noqa: E731
+        fu = ctx.full
+        return f(du, NP, fu[0]), f(dv, NP, fu[1]), f(di, NP, fu[2]), f(da, NA, fu[3]), None, None, None
 
 
 def iuv_global(u, v, ix, an, gt=None, w=None, keep=None):
@@ -77,6 +82,14 @@ def iuv_global(u, v, ix, an, gt=None, w=None, keep=None):
     [B,80,H,W] tensor (the body regressor's padded first-conv operand); argmax = uint8 [B,H,W] of the raw index head."""
     if not u.is_cuda:
         raise RuntimeError('danet_hip ops run on the GPU only (got a %s tensor); there is no CPU path' % u.device)
+    if PADDED_BASES and torch.is_grad_enabled():
+        # head outputs that are [:, :25] / [:, :15] views of the conv epilogue's zero-padded fp32 NHWC output carry that tensor along
+        # (conv.conv2d `_padded_base`): taking IT as the differentiable input keeps autograd's slice-backward out of the backward pass
+        bases = [getattr(t, '_padded_base', None) for t in (u, v, ix, an)]
+        ok = all(b is not None and b.dtype == torch.float32 and b.shape[0] == t.shape[0] and b.shape[2:] == t.shape[2:] and
+                 b.data_ptr() == t.data_ptr() and b.shape[1] == ld for b, t, ld in zip(bases, (u, v, ix, an), (32, 32, 32, 16)))
+        if ok and all(_rows(b, n, ld) is b for b, n, ld in zip(bases, (NP, NP, NP, NA), (32, 32, 32, 16))):
+            return IuvGlobalFunction.apply(bases[0], bases[1], bases[2], bases[3], gt, w, keep)
     return IuvGlobalFunction.apply(u, v, ix, an, gt, w, keep)
 
 
