@@ -59,6 +59,8 @@ _SIGNATURES = {
     'danet_conv_forward_multi_ok': (c_i, [c_f, c_i]),
     'danet_conv_forward_multi_kernel': (c_i, [c_f, c_i]),
     'danet_conv_forward_multi': (c_i, [c_f, c_i, c_f]),
+    'danet_conv_bn_forward_multi_ok': (c_i, [c_f, c_i, c_f, c_f]),
+    'danet_conv_bn_forward_multi': (c_i, [c_f, c_i, c_f, c_fl, c_fl, c_f, c_f, c_f]),
     'danet_conv_forward_kernel': (c_i, [c_i] * 15),
     'danet_conv_forward': (c_i, [c_f] * 4 + [c_i] * 16 + [c_f] * 6 + [c_i, c_f]),
     'danet_conv_wgrad_rows_ok': (c_i, [c_i] * 13),

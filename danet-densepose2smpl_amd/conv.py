@@ -980,7 +980,8 @@ class MultiConvFunction(torch.autograd.Function):
     def forward(ctx, static, *tensors):
         import ctypes
         L = _lib.lib()
-        n, cfgs, want_stats, bn_ctxs, links = static
+        n, cfgs, want_stats, bn_ctxs, links = static[:5]
+        bn = static[5] if len(static) > 5 else None      # the BatchNorms that follow (nn.multi_conv_bn): applied by this launch when it can
         xs = [nhwc_bf16(t) for t in tensors[:n]]
         ws = tensors[n:2 * n]
         jobs = (_lib.ConvJob * n)()
@@ -1005,7 +1006,39 @@ class MultiConvFunction(torch.autograd.Function):
         if PROFILER is not None:
             tok = PROFILER.begin(_multi_kernel_name(jobs, n, dims_l[0][6] // dims_l[0][12]),
                                  sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in dims_l), ('fwd-multi', n))
-        check(L.danet_conv_forward_multi(ctypes.addressof(jobs), n, stream()), 'danet_conv_forward_multi')
+        done = None
+        if bn is not None and all(s_ is not None for s_ in sums_l):
+            # conv -> BatchNorm (+ residual) (+ ReLU) in ONE launch when the streamed 3x3 kernel takes the set (csrc/conv3x3s.hip
+            # s3_bn_tail), else the two launches from inside the same call: either way the BatchNorm's outputs exist afterwards and
+            # nn.MultiBatchNormFunction finds them on the convolution's output (`_bn_done`)
+            bjobs = (_lib.BnFwdJob * n)()
+            done = []
+            for i in range(n):
+                spec = bn['jobs'][i]
+                B, Cout, OH, OW = ys[i].shape
+                res = None if spec['res'] is None else nhwc_as(spec['res'], torch.bfloat16)
+                if res is not None and res.shape != ys[i].shape:
+                    raise ValueError('residual shape %s != %s' % (tuple(res.shape), tuple(ys[i].shape)))
+                out = _empty_nhwc(B, Cout, OH, OW, torch.bfloat16, ys[i].device)
+                saved = torch.empty(2, Cout, dtype=torch.float32, device=ys[i].device)
+                mask = torch.empty(B * OH * OW * Cout // 4, dtype=torch.uint8, device=ys[i].device) if spec['want_mask'] else None
+                j = bjobs[i]
+                j.x, j.res, j.y = ys[i].data_ptr(), None if res is None else res.data_ptr(), out.data_ptr()
+                j.gamma, j.beta = spec['gamma'].data_ptr(), spec['beta'].data_ptr()
+                j.running_mean = None if spec['running_mean'] is None else spec['running_mean'].data_ptr()
+                j.running_var = None if spec['running_var'] is None else spec['running_var'].data_ptr()
+                j.saved, j.sums, j.mask = saved.data_ptr(), sums_l[i].data_ptr(), None if mask is None else mask.data_ptr()
+                j.M, j.C, j.sums_state, j.relu = B * OH * OW, Cout, 2, int(spec['relu'])
+                done.append((out, saved, mask))
+                keep += [res, spec['gamma'], spec['beta']]
+            was_fused = ctypes.c_int(0)
+            check(L.danet_conv_bn_forward_multi(ctypes.addressof(jobs), n, ctypes.addressof(bjobs), float(bn['momentum']), float(bn['eps']),
+                                                ptr(bn['bar']), ctypes.addressof(was_fused), stream()), 'danet_conv_bn_forward_multi')
+            FUSION['conv_bn_one_launch' if was_fused.value else 'conv_bn_two_launches'] += n
+            if tok is not None and was_fused.value:          # (the record names the kernel that ran: convolution + BatchNorm tail)
+                tok = (tok[0].replace('conv3x3_stream_kernel', 'conv3x3_stream_bn_kernel'),) + tuple(tok[1:])
+        else:
+            check(L.danet_conv_forward_multi(ctypes.addressof(jobs), n, stream()), 'danet_conv_forward_multi')
         if tok is not None:
             PROFILER.end(tok)
         if TRACE is not None:
@@ -1020,6 +1053,9 @@ class MultiConvFunction(torch.autograd.Function):
         for y, sums in zip(ys, sums_l):
             if sums is not None:
                 y._bn_sums = sums
+        if done is not None:
+            for y, d in zip(ys, done):
+                y._bn_done = d
         return tuple(ys)
 
     @staticmethod
@@ -1099,9 +1135,10 @@ class MultiConvFunction(torch.autograd.Function):
         return (None, *gxs, *gws)
 
 
-def multi_conv(convs, xs, links=None):
+def multi_conv(convs, xs, links=None, bn=None):
     """[conv(x) for conv, x in zip(convs, xs)] for up to 4 bias-free Conv2d modules in one launch per pass; falls back
-    to the per-module path when the set does not qualify (channel padding, bias, mixed tile counts, fp32 outputs)."""
+    to the per-module path when the set does not qualify (channel padding, bias, mixed tile counts, fp32 outputs).
+    bn (nn.multi_conv_bn): the training-mode BatchNorms that follow, for the same launch to apply (MultiConvFunction.forward)."""
     import ctypes
     n = len(convs)
     L = _lib.lib()
@@ -1124,7 +1161,7 @@ def multi_conv(convs, xs, links=None):
     grad = torch.is_grad_enabled()
     cfgs = [(c.stride[0], c.padding[0], c.dilation[0], c.groups) for c in convs]
     bn_ctxs = [getattr(x, '_bn_ctx', None) if (FUSE_BN_BWD_REDUCE and grad) else None for x in xs]
-    static = (n, cfgs, all(c.training for c in convs), bn_ctxs, links)
+    static = (n, cfgs, all(c.training for c in convs), bn_ctxs, links, bn if (bn is not None and n <= 4 and all(c.training for c in convs)) else None)
     return list(MultiConvFunction.apply(static, *xs, *[c.weight for c in convs]))
 
 

@@ -29,6 +29,7 @@
 // branch's tile is computed, the first stage of the next branch's tile is already arriving.
 #include "common.h"
 #include "conv_common.h"
+#include "grid_barrier.h"
 #include <type_traits>
 #include <algorithm>
 #include <map>
@@ -104,6 +105,13 @@ static_assert(S3_TAB < 256 && sizeof(S3Prob) % 4 == 0, "S3Prob");
 // k-loop was serialised by exactly that.
 typedef __attribute__((address_space(1))) int* dbg_ptr;
 struct S3Launch { S3Prob p[S3_MAXP]; int n; int total; int* dbg; };     // dbg: optional [blocks][16] timestamps (tools/c3s_diag.py)
+// The BatchNorm that follows problem i, applied by the same launch (s3_bn_tail; conv_common.h BnApply): all problems of the launch or none.
+struct S3Bn {
+    const bf16_t* res; bf16_t* out; const float* gamma; const float* beta; float* running_mean; float* running_var; float* saved; unsigned char* mask;
+    float inv_count, unbias; int relu, pad_;
+};
+static_assert(sizeof(S3Bn) % 4 == 0, "S3Bn");
+struct S3LaunchBn { S3Launch c; S3Bn bn[S3_MAXP]; unsigned* bar; float momentum, eps; };
 
 // The kernel argument is indexed with run-time problem numbers.  Done on the by-value argument the compiler copies the
 // whole structure to scratch memory (600 bytes per lane, every access a counted vector load that drains the fragment
@@ -118,6 +126,16 @@ __device__ inline S3Prob desc_prob(int idx) {
     return u.v;
 }
 #define S3_FIELD(idx, field) (s3_args()->p[idx].field)
+// (the BatchNorm launch: the same kernel-argument segment, longer -- S3Launch is its first member)
+typedef const __attribute__((address_space(4))) S3LaunchBn* S3LaunchBnK;
+__device__ inline S3LaunchBnK s3_bn_args() { return (S3LaunchBnK)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ inline S3Bn desc_bn(int idx) {
+    union { S3Bn v; int w[sizeof(S3Bn) / 4]; } u;
+    const __attribute__((address_space(4))) int* const src = (const __attribute__((address_space(4))) int*)&s3_bn_args()->bn[idx];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(S3Bn) / 4); ++i) u.w[i] = src[i];
+    return u.v;
+}
 
 __device__ inline unsigned udiv24(unsigned n, unsigned d, float rcp) {      // n < 2^24
     unsigned q = (unsigned)((float)n * rcp);
@@ -827,8 +845,172 @@ __device__ __forceinline__ void s3_problem(const int nprob, const int ii, const 
     }
 }
 
+// ---- the BatchNorm that follows, applied by the same launch (conv -> train-mode BatchNorm -> [+ residual] -> [ReLU]) ----------
+// /root/reference/models/module/res_module.py:39-56 (BasicBlock: conv1 -> bn1 -> relu, conv2 -> bn2 -> + residual -> relu), the HRNet
+// branch layers of hr_module.py:155-177.  After a workgroup's last tile: every statistic of the launch has been added to the
+// replicas (agent-scope atomics, waited for), a grid-wide barrier (grid_barrier.h: no fences -- what crosses it are those atomics, read
+// back with agent-scope loads), then every workgroup walks ITS OWN tiles again -- the rounded bf16 outputs it stored minutes of
+// cycles ago sit in its XCD's L2 (a workgroup reads only what it wrote itself: plain loads are coherent) -- and writes
+// out = [relu](fmaf(y, sc, sh) [+ res]) and the ReLU gate bytes exactly as norm_act.hip's bn_apply_body would in a launch of its
+// own: same operand rounding, same expressions (the contraction of the variance is pinned to what that kernel compiles to: fma(-mean,
+// mean, E[x^2]); the running statistics are four rounded products and two rounded sums there).  The tile that holds a channel
+// block's first pixels (pixel tile 0) also writes mean / invstd for the backward pass and updates the running statistics: once per
+// channel.  The launch must be co-resident (<= 2 workgroups per compute unit, nothing else on the device): the caller's contract,
+// as for the one-pass BatchNorm backward, with the same bounded spin and error word.
+template <typename T> __device__ inline T ld_acc_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int NT>
-__global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch L)
+__device__ __forceinline__ void s3_bn_tail(const int nprob, const int rot, const int bid, const int nblk, unsigned char* smem, dbg_ptr dbg)
+{
+    constexpr int NC = 16 * NT, CG = 4 * NT, U = 4 * NT;                // channels / 4-channel groups of a channel block; items per lane of a full tile
+    constexpr int CMAX = 384, RMAX = BN_NCOPY / DANET_BN_NCOPY_DIV;     // channels per problem (checked at launch); replicas at most (bn_ncopy)
+    static_assert(S3_MAXP * 2 * CMAX * 4 <= S3_BUF, "s3_bn_tail scratch");
+    const int t = threadIdx.x;
+    float* const sTab = reinterpret_cast<float*>(smem + S3_FIXED);        // [problem visit][scale | shift][CMAX] (the ring is free now)
+    const float momentum = s3_bn_args()->momentum, eps = s3_bn_args()->eps;
+    // ---- every channel's scale and shift of the problems this workgroup has tiles of: ONE round of replica loads per problem ------
+    // (a workgroup usually stays with one problem: s3_assign.)  Lane = channel: its 2 x ncopy accumulators are requested at once and
+    // added in replica order in double precision, as reduce_replicas does (norm_act.hip).
+    for (int ii = 0; ii < nprob; ++ii) {
+        const int idx = wrap_idx(ii + rot, nprob);
+        const int tau0 = first_tile_of(S3_FIELD(idx, wg0), S3_FIELD(idx, nwg), bid, nblk);
+        if (tau0 >= S3_FIELD(idx, ntiles)) continue;
+        const S3Prob p = desc_prob(idx);
+        const S3Bn b = desc_bn(idx);
+        const int C = p.Cout_tot;
+        const bn_acc_t* const acc = reinterpret_cast<const bn_acc_t*>(p.stats);
+        const int ncopy = bn_ncopy(C);
+        for (int c = t; c < C; c += 256) {
+            bn_acc_t v1[RMAX], v2[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                v1[r] = r < ncopy ? ld_acc_agent(acc + (size_t)r * 2 * C + c) : (bn_acc_t)0;
+                v2[r] = r < ncopy ? ld_acc_agent(acc + (size_t)r * 2 * C + C + c) : (bn_acc_t)0;
+            }
+            bn_acc_t s1 = 0, s2 = 0;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) { s1 += v1[r]; s2 += v2[r]; }
+            float sc, sh, mean, var, invstd;
+            {
+#pragma clang fp contract(off)
+                mean = (float)s1 * b.inv_count;
+                const float ex2 = (float)s2 * b.inv_count;
+                var = fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f);
+                invstd = rsqrtf(var + eps);
+                sc = invstd * b.gamma[c];
+                sh = __builtin_fmaf(-mean, sc, b.beta[c]);
+            }
+            sTab[(ii * 2 + 0) * CMAX + c] = sc; sTab[(ii * 2 + 1) * CMAX + c] = sh;
+            // the workgroup that holds pixel tile 0 of the channel's block writes the saved statistics and the running averages: once per channel
+            const int nb = c / NC, tt0 = p.swz ? nb * 8 : nb;
+            int d = bid - p.wg0; if (d < 0) d += nblk;
+            if (tt0 % p.nwg == d) {
+#pragma clang fp contract(off)
+                b.saved[c] = mean; b.saved[C + c] = invstd;
+                if (b.running_mean) {
+                    const float keep = 1.f - momentum;
+                    const float a0 = keep * b.running_mean[c], a1 = momentum * mean;
+                    b.running_mean[c] = a0 + a1;
+                    const float q0 = keep * b.running_var[c], q1 = (momentum * var) * b.unbias;
+                    b.running_var[c] = q0 + q1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg && t == 0) dbg[5] = (int)clock64();
+    // ---- the workgroup's own tiles again: a tile's loads (U outputs + U residual pieces per lane) are all in flight before the first
+    // one is used, and the NEXT tile's are requested before this tile is computed (two register sets, the tile loop unrolled by two)
+    for (int ii = 0; ii < nprob; ++ii) {
+        const int idx = wrap_idx(ii + rot, nprob);
+        const int tau0 = first_tile_of(S3_FIELD(idx, wg0), S3_FIELD(idx, nwg), bid, nblk);
+        if (tau0 >= S3_FIELD(idx, ntiles)) continue;
+        const S3Prob p = desc_prob(idx);
+        const S3Bn b = desc_bn(idx);
+        const int Ctot = p.Cout_tot, clim = p.Cout;                     // (groups == 1: checked at launch)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(b.res ? b.res : (const bf16_t*)p.y), 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(b.out, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(b.mask ? (void*)b.mask : (void*)p.y, 0, b.mask ? p.y_bytes >> 3 : 0, 0x00020000);
+        const bool has_res = b.res != nullptr, has_mask = b.mask != nullptr, relu = b.relu != 0;
+        const int thw = p.TH * p.W, npix = p.NI * thw, hw = p.H * p.W, pixb = Ctot * 2;
+        const float rc_thw = 1.0f / (float)thw;
+        const int nitems = npix * CG;
+        const float* const tab = sTab + ii * 2 * CMAX;
+        // a lane's items of a tile: (pixel, channel group) does not depend on the tile -- offsets relative to the tile's first pixel and
+        // channel block, once per problem
+        int rel[U], cgo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = t + u * 256;
+            const int pix = i / CG, cg = i - pix * CG;
+            int sl, rem;
+            if (p.lw >= 0) { sl = pix >> p.lthw; rem = pix & (thw - 1); }
+            else { sl = (int)udiv24((unsigned)pix, (unsigned)thw, rc_thw); rem = pix - sl * thw; }
+            rel[u] = i < nitems ? (sl * hw + rem) * pixb + cg * 8 : OOB;
+            cgo[u] = cg * 4;
+        }
+        auto issue = [&](int tau, int (&off)[U], i32x2 (&xq)[U], i32x2 (&rq)[U], int& cb) {
+            int img0, y0, nb;
+            tile_coords(p, tau, img0, y0, nb);
+            cb = nb * NC;
+            const int base = ((img0 * p.H + y0) * p.W) * pixb + cb * 2;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                off[u] = (rel[u] != OOB && cb + cgo[u] < clim) ? base + rel[u] : OOB;
+                xq[u] = __builtin_amdgcn_raw_buffer_load_b64(xr, off[u], 0, 0);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) rq[u] = __builtin_amdgcn_raw_buffer_load_b64(rr, off[u], 0, 0);
+            }
+        };
+        auto finish = [&](const int (&off)[U], const i32x2 (&xq)[U], const i32x2 (&rq)[U], int cb) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c0 = min(cb + cgo[u], CMAX - 4);                 // (idle lanes read a valid slot)
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(&tab[c0]), sh = *reinterpret_cast<const f32x4*>(&tab[CMAX + c0]);
+                const float a[4] = {__uint_as_float((unsigned)xq[u].x << 16), __uint_as_float((unsigned)xq[u].x & 0xffff0000u),
+                                    __uint_as_float((unsigned)xq[u].y << 16), __uint_as_float((unsigned)xq[u].y & 0xffff0000u)};
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_res) {
+                    r[0] = __uint_as_float((unsigned)rq[u].x << 16); r[1] = __uint_as_float((unsigned)rq[u].x & 0xffff0000u);
+                    r[2] = __uint_as_float((unsigned)rq[u].y << 16); r[3] = __uint_as_float((unsigned)rq[u].y & 0xffff0000u);
+                }
+                int mb = 0;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = __builtin_fmaf(a[j], sc[j], sh[j]);
+                    if (has_res) v += r[j];
+                    mb |= (v > 0.f ? 1 : 0) << j;
+                    o[j] = relu ? fmaxf(v, 0.f) : v;
+                }
+                const i32x2 pk = {(int)f2bf_pk(o[0], o[1]), (int)f2bf_pk(o[2], o[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, yr, off[u], 0, 0);
+                if (has_mask) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)mb, mr, off[u] == OOB ? OOB : off[u] >> 3, 0, 0);
+            }
+        };
+        int offA[U], offB[U], cbA = 0, cbB = 0;
+        i32x2 xA[U], rA[U], xB[U], rB[U];
+        int tau = tau0;
+        issue(tau, offA, xA, rA, cbA);
+        for (;;) {
+            const int t1 = tau + p.nwg;
+            if (t1 < p.ntiles) issue(t1, offB, xB, rB, cbB);
+            finish(offA, xA, rA, cbA);
+            if (t1 >= p.ntiles) break;
+            const int t2 = t1 + p.nwg;
+            if (t2 < p.ntiles) issue(t2, offA, xA, rA, cbA);
+            finish(offB, xB, rB, cbB);
+            if (t2 >= p.ntiles) break;
+            tau = t2;
+        }
+    }
+}
+
+template <int NT, bool WITH_BN>
+__device__ __forceinline__ void s3_kernel_body()
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_smem[];
     const int bid = blockIdx.x, nblk = gridDim.x;
@@ -844,22 +1026,37 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch 
         dbg[15] = (int)((__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xff00u) | ((__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 16));   // CU: HW_ID cu / sh / se, XCC_ID
     }
     const Pos first = pos_first(nprob, bid, nblk, rot, 0);
-    if (!first.valid) return;
-    issue_pos(nprob, rot, first, s3_smem, s3_smem + S3_FIXED, 0, wave, lane);      // the very first stage: nothing to overlap it with
-    if (dbg && threadIdx.x == 0) dbg[9] = (int)clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();                                                                  // ... published
-    if (dbg && threadIdx.x == 0) dbg[10] = (int)clock64();
-    int g = 0, np = 0;
-    int dsum[3] = {0, 0, 0};
-    for (int ii = first.ii; ii < nprob; ++ii) {
-        const int idx = wrap_idx(ii + rot, nprob);
-        if (first_tile_of(S3_FIELD(idx, wg0), S3_FIELD(idx, nwg), bid, nblk) >= S3_FIELD(idx, ntiles)) continue;
-        ++np;
-        s3_problem<NT>(nprob, ii, rot, bid, nblk, g, np, s3_smem, dbg, dsum);
+    if (!WITH_BN && !first.valid) return;
+    if (first.valid) {
+        issue_pos(nprob, rot, first, s3_smem, s3_smem + S3_FIXED, 0, wave, lane);      // the very first stage: nothing to overlap it with
+        if (dbg && threadIdx.x == 0) dbg[9] = (int)clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                                                  // ... published
+        if (dbg && threadIdx.x == 0) dbg[10] = (int)clock64();
+        int g = 0, np = 0;
+        int dsum[3] = {0, 0, 0};
+        for (int ii = first.ii; ii < nprob; ++ii) {
+            const int idx = wrap_idx(ii + rot, nprob);
+            if (first_tile_of(S3_FIELD(idx, wg0), S3_FIELD(idx, nwg), bid, nblk) >= S3_FIELD(idx, ntiles)) continue;
+            ++np;
+            s3_problem<NT>(nprob, ii, rot, bid, nblk, g, np, s3_smem, dbg, dsum);
+        }
+        if (dbg && threadIdx.x == 0) { dbg[7] = (int)clock64(); dbg[1] = dsum[0]; dbg[13] = dsum[1]; dbg[14] = dsum[2]; }
     }
-    if (dbg && threadIdx.x == 0) { dbg[7] = (int)clock64(); dbg[1] = dsum[0]; dbg[13] = dsum[1]; dbg[14] = dsum[2]; }
+    if constexpr (WITH_BN) {
+        // every output and every statistic of this workgroup has left (stores, atomics and the inline-asm loads the compiler does not count)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        danet::grid_barrier(s3_bn_args()->bar, (unsigned)nblk);
+        if (dbg && threadIdx.x == 0) dbg[8] = (int)clock64();
+        s3_bn_tail<NT>(nprob, rot, bid, nblk, s3_smem, dbg);
+        if (dbg && threadIdx.x == 0) dbg[12] = (int)clock64();
+    }
 }
+template <int NT>
+__global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_kernel(S3Launch L) { s3_kernel_body<NT, false>(); }
+// the same kernel with the BatchNorm tail (a kernel of its own: the plain one keeps its code, and profiles tell the two apart)
+template <int NT>
+__global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_stream_bn_kernel(S3LaunchBn L) { s3_kernel_body<NT, true>(); }
 
 bool g_s3_on = getenv("DANET_NO_C3_STREAM") == nullptr;
 int g_s3_blocks = getenv("DANET_C3S_BLOCKS") ? atoi(getenv("DANET_C3S_BLOCKS")) : 512;
@@ -1008,6 +1205,24 @@ void s3_launch_nt(const S3Launch& L, int grid, hipStream_t st) {
     }
     hipLaunchKernelGGL((conv3x3_stream_kernel<NT>), dim3((unsigned)grid), dim3(S3_THREADS), (size_t)S3_LDS, st, L);
 }
+template <int NT>
+void s3_launch_nt(const S3LaunchBn& L, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_bn_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_stream_bn_kernel<NT>), dim3((unsigned)grid), dim3(S3_THREADS), (size_t)S3_LDS, st, L);
+}
+template <typename LaunchT>
+int s3_launch_any(int NT, const LaunchT& L, int grid, hipStream_t st) {
+    switch (NT) {
+        case 1: s3_launch_nt<1>(L, grid, st); return 0;
+        case 2: s3_launch_nt<2>(L, grid, st); return 0;
+        case 3: s3_launch_nt<3>(L, grid, st); return 0;
+        default: return -1;
+    }
+}
 
 }  // namespace
 
@@ -1021,6 +1236,19 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
     L.n = n;
     hipStream_t st = (hipStream_t)stream;
     int tile0 = 0, NT = 0;
+    // the BatchNorm tail: every problem of the launch or none; plain forward problems with statistics only
+    const bool with_bn = ps[0].bna != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const ConvP& p = ps[i];
+        if ((p.bna != nullptr) != with_bn) return -1;
+        if (with_bn) {
+            const BnApply& a = *p.bna;
+            if (!p.stats || p.groups != 1 || p.transposed || p.bias || p.addend || p.relu || p.out_fp32 || p.bn_red) return -1;
+            if (p.Cout > 384 || p.Cout % 4) return -1;                                  // (s3_bn_tail's scale / shift table: CMAX channels per problem)
+            if (!a.out || !a.gamma || !a.beta || !a.saved || !ps[0].bna->bar || (a.running_mean == nullptr) != (a.running_var == nullptr)) return -1;
+            if (a.momentum != ps[0].bna->momentum || a.eps != ps[0].bna->eps) return -1;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const ConvP& p = ps[i];
         if (!s3_shape_ok(p)) return -1;
@@ -1058,12 +1286,27 @@ int conv3x3s_launch(const ConvP* ps, int n, void* stream, bool dry) {
         for (int i = 0; i < n; ++i) fprintf(stderr, " %d+%d", L.p[i].wg0, L.p[i].nwg);
         fprintf(stderr, " of %d\n", grid);
     }
-    switch (NT) {
-        case 1: s3_launch_nt<1>(L, grid, st); return 0;
-        case 2: s3_launch_nt<2>(L, grid, st); return 0;
-        case 3: s3_launch_nt<3>(L, grid, st); return 0;
-        default: return -1;
+    if (with_bn) {
+        // the BatchNorm tail crosses a grid-wide barrier: every workgroup of the launch must be resident at once -- at most two per
+        // compute unit (the kernel's launch bound and its LDS), which the workgroup cap (512 on the 256 compute units of an MI355X)
+        // already says; a cap raised past that by a knob makes the set unfusable rather than a deadlock
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (grid > 2 * cus) return -1;
+        S3LaunchBn LB{};
+        LB.c = L;
+        for (int i = 0; i < n; ++i) {
+            const BnApply& a = *ps[i].bna;
+            S3Bn& b = LB.bn[i];
+            b.res = a.res; b.out = a.out; b.gamma = a.gamma; b.beta = a.beta; b.running_mean = a.running_mean; b.running_var = a.running_var;
+            b.saved = a.saved; b.mask = a.mask; b.relu = a.relu;
+            const long M = (long)ps[i].B * ps[i].OH * ps[i].OW;
+            b.inv_count = 1.0f / (float)M; b.unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;       // (norm_act.hip danet_bn_forward_multi)
+        }
+        LB.bar = ps[0].bna->bar; LB.momentum = ps[0].bna->momentum; LB.eps = ps[0].bna->eps;
+        return s3_launch_any(NT, LB, grid, st);
     }
+    return s3_launch_any(NT, L, grid, st);
 }
 
 }  // namespace danet_conv

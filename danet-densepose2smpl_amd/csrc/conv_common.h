@@ -54,6 +54,20 @@ __device__ inline void bn_acc_add(float* ws, int rep, int which, int Ctot, int c
     __hip_atomic_fetch_add((__attribute__((address_space(1))) bn_acc_t*)p, (bn_acc_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The BatchNorm (+ residual) (+ ReLU) a convolution launch applies to its own output after a grid-wide barrier (conv3x3s.hip
+// s3_bn_tail; /root/reference/models/module/res_module.py:39-56 conv -> bn -> relu): what norm_act.hip's bn_apply_body does in a
+// launch of its own, with the same arithmetic -- out = [relu](fmaf(y, sc, sh) [+ res]), sc = invstd * gamma, sh = fmaf(-mean, sc, beta).
+struct BnApply {
+    const bf16_t* res; bf16_t* out;                 // residual (optional) and result, both shaped like the convolution's output
+    const float* gamma; const float* beta;          // [C]
+    float* running_mean; float* running_var;        // [C], optional (updated with `momentum`)
+    float* saved;                                   // [2][C]: mean, invstd (the backward pass reads them)
+    unsigned char* mask;                            // optional: the ReLU gate, one byte per four channels (norm_act.hip stmask)
+    int relu;
+    float momentum, eps;                            // (one value per launch: the first problem's)
+    unsigned* bar;                                  // grid-barrier state (grid_barrier.h; one per launch: the first problem's)
+};
+
 struct ConvP {
     const bf16_t* x; const bf16_t* w; const float* bias; void* y;
     int B, H, W, Cin, OH, OW, Cout;
@@ -71,7 +85,9 @@ struct ConvP {
     int bn_gate;
     long x_bytes, y_bytes;   // extents of the gathered / written tensors (buffer resources of conv_fast.hip)
     const bf16_t* addend;    // optional (3x3 LDS kernels and conv_fast.hip; bf16 outputs): bf16 tensor shaped like y, added before rounding
+    const BnApply* bna;   // optional (streamed 3x3 kernel, forward with `stats`): the training-mode BatchNorm that follows, applied by the same launch
 };
+
 
 // conv_fast.hip: the lean kernel for the common cases (conv_igemm.hip keeps the general one)
 bool conv_fast_ok(const ConvP& p, bool vec8, int mt);

@@ -773,6 +773,57 @@ extern "C" int danet_conv_forward_multi_kernel(const void* jobs, int n)
     return conv3x3s_launch(ps, n, nullptr, true) == 0 && conv3x3_stream_first() ? 3 : 2;
 }
 
+// ---- convolutions + the training-mode BatchNorms that follow them, one launch when the streamed 3x3 kernel takes the set ----------
+// (conv3x3s.hip s3_bn_tail; /root/reference/models/module/res_module.py:39-56, hr_module.py:155-177.)  bn jobs: the forward jobs of
+// danet_bn_forward_multi (norm_act.hip), job i normalising convolution i's output -- x = that output, sums = its bn_sums, sums_state 2.
+struct BnFwdJobC { const void* x; const void* res; void* y; const float* gamma; const float* beta; float* running_mean; float* running_var;
+                   float* saved; float* sums; void* mask; int64_t M; int C, sums_state, relu; };
+
+// >= 0: the number of problems when the set runs as ONE launch (convolutions + BatchNorm tail), 0 when it does not qualify
+static int conv_bn_fusable(const ConvJob* jobs, int n, const BnFwdJobC* bn, ConvP* ps, BnApply* ba, float momentum, float eps, void* bar)
+{
+    static const bool off = getenv("DANET_NO_CONV_BN") != nullptr;          // A-B timing knob
+    if (off || !bar || !bn || n < 1 || n > 4 || !conv3x3_stream_first()) return 0;
+    int mts[12], nt; bool all3;
+    if (conv_multi_prepare(jobs, n, ps, mts, &nt, &all3) != 0 || !all3) return 0;
+    for (int i = 0; i < n; ++i) {
+        const BnFwdJobC& b = bn[i];
+        if (!ps[i].stats || jobs[i].transposed || jobs[i].bn_red || jobs[i].addend) return 0;
+        if (b.x != jobs[i].y || b.sums != jobs[i].bn_sums || b.sums_state != 2 || b.C != jobs[i].Cout) return 0;
+        if (b.M != (int64_t)jobs[i].B * jobs[i].OH * jobs[i].OW || !b.y || !b.saved || !b.gamma || !b.beta) return 0;
+        ba[i] = BnApply{(const bf16_t*)b.res, (bf16_t*)b.y, b.gamma, b.beta, b.running_mean, b.running_var, b.saved, (unsigned char*)b.mask, b.relu,
+                        momentum, eps, (unsigned*)bar};
+        ps[i].bna = &ba[i];
+    }
+    return conv3x3s_launch(ps, n, nullptr, true) == 0 ? n : 0;
+}
+
+extern "C" int danet_conv_bn_forward_multi_ok(const void* jobs, int n, const void* bn_jobs, void* bar)
+{
+    ConvP ps[12]; BnApply ba[4];
+    return conv_bn_fusable((const ConvJob*)jobs, n, (const BnFwdJobC*)bn_jobs, ps, ba, 0.1f, 1e-5f, bar) > 0 ? 1 : 0;
+}
+
+extern "C" int danet_conv_bn_forward_multi(const void* jobs, int n, const void* bn_jobs, float momentum, float eps, void* bar, int* fused, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(jobs && bn_jobs && n >= 1 && n <= 12, "conv_bn_forward_multi: 1..12 jobs with their BatchNorm jobs");
+    ConvP ps[12]; BnApply ba[4];
+    if (fused) *fused = 0;
+    if (conv_bn_fusable((const ConvJob*)jobs, n, (const BnFwdJobC*)bn_jobs, ps, ba, momentum, eps, bar) > 0) {
+        for (int i = 0; i < n; ++i) DANET_CHECK_ARG(ps[i].x && ps[i].w && ps[i].y, "conv_bn_forward_multi: job %d: null pointer", i);
+        if (conv3x3s_launch(ps, n, stream, false) == 0) {              // (-1: e.g. a tap table that is new while the stream captures)
+            DANET_CHECK_LAUNCH("conv3x3_stream_bn_kernel");
+            if (fused) *fused = 1;
+            return DANET_OK;
+        }
+    }
+    // two launches: the set as danet_conv_forward_multi runs it, then danet_bn_forward_multi
+    const int rc = danet_conv_forward_multi(jobs, n, stream);
+    if (rc != DANET_OK) return rc;
+    return danet_bn_forward_multi(bn_jobs, n, momentum, eps, stream);
+}
+
 extern "C" int danet_conv_forward_multi(const void* jobs, int n, void* stream)
 {
     DANET_ENTER();

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import segments
 from .config import cfg
-from .nn import fan_out, fan_out_multi, sum_relu, sum_relu_multi, multi_batch_norm
+from .nn import fan_out, fan_out_multi, sum_relu, sum_relu_multi, multi_batch_norm, multi_conv_bn
 from .resnet import BasicBlock, Bottleneck, ConvBN, IUV_predict_layer, make_res_layer, BN_MOMENTUM
 from .nn import Conv2d, BatchNorm2d
 from .conv import multi_conv, ResLink
@@ -104,10 +104,16 @@ class HighResolutionModule(nn.Module):
             blocks = [br[k] for br in self.branches]
             # identity shortcuts: their gradients ride on ResLinks into conv1's data-gradient epilogue (resnet.BasicBlock)
             links = [ResLink() if (v.requires_grad and torch.is_grad_enabled()) else None for v in xs]
-            h = multi_conv([b.conv1 for b in blocks], xs, links) if LOCKSTEP_CONVS else [b.conv1(v, link=lk) for b, v, lk in zip(blocks, xs, links)]
-            h = multi_batch_norm([b.bn1 for b in blocks], h, None, relu=True)
-            h = multi_conv([b.conv2 for b in blocks], h) if LOCKSTEP_CONVS else [b.conv2(v) for b, v in zip(blocks, h)]
-            xs = multi_batch_norm([b.bn2 for b in blocks], h, xs, relu=True, links=links)
+            if LOCKSTEP_CONVS:
+                # conv -> bn -> relu and conv -> bn -> + identity -> relu: one launch each when the streamed 3x3 kernel takes the level's
+                # convolutions (nn.multi_conv_bn: the BatchNorm is the tail of the convolutions' launch), two otherwise
+                h = multi_conv_bn([b.conv1 for b in blocks], xs, [b.bn1 for b in blocks], None, relu=True, conv_links=links)
+                xs = multi_conv_bn([b.conv2 for b in blocks], h, [b.bn2 for b in blocks], xs, relu=True, bn_links=links)
+            else:
+                h = [b.conv1(v, link=lk) for b, v, lk in zip(blocks, xs, links)]
+                h = multi_batch_norm([b.bn1 for b in blocks], h, None, relu=True)
+                h = [b.conv2(v) for b, v in zip(blocks, h)]
+                xs = multi_batch_norm([b.bn2 for b in blocks], h, xs, relu=True, links=links)
         return xs
 
     def _branches_on_streams(self, x):

@@ -266,7 +266,8 @@ class MultiBatchNormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, static, *tensors):
         L = _lib.lib()
-        n, relu, momentum, eps, rms, rvs, fused, links = static
+        n, relu, momentum, eps, rms, rvs, fused, links = static[:8]
+        done = static[8] if len(static) > 8 else None       # (out, saved, mask) per job when the producing convolution's launch applied the BatchNorm (multi_conv_bn)
         relus = list(relu) if isinstance(relu, (list, tuple)) else [bool(relu)] * n          # per job (the kernels take one flag per job)
         xs = [nhwc_act(t) for t in tensors[:n]]
         dt = xs[0].dtype
@@ -275,7 +276,11 @@ class MultiBatchNormFunction(torch.autograd.Function):
         betas = [t.detach().float().contiguous() for t in tensors[3 * n:4 * n]]
         jobs = (_lib.BnFwdJob * n)()
         ys, saveds, keep, masks = [], [], [], []
-        for i in range(n):
+        if done is not None:
+            # nothing to launch: conv -> BatchNorm ran as one call (conv.MultiConvFunction.forward); same outputs, same saved tensors
+            ys, saveds, masks = [d[0] for d in done], [d[1] for d in done], [d[2] for d in done]
+            _conv.FUSION['bn_forward_in_conv_launch'] += n
+        for i in range(n if done is None else 0):
             B, C, H, W = xs[i].shape
             if ress[i] is not None and ress[i].shape != xs[i].shape:
                 raise ValueError('residual shape %s != %s' % (tuple(ress[i].shape), tuple(xs[i].shape)))
@@ -300,7 +305,8 @@ class MultiBatchNormFunction(torch.autograd.Function):
             j.M, j.C, j.sums_state, j.relu = B * H * W, C, state, int(relus[i])
             ys.append(y)
             saveds.append(saved)
-        check(_k(L, 'danet_bn_forward_multi', dt)(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
+        if done is None:
+            check(_k(L, 'danet_bn_forward_multi', dt)(ctypes.addressof(jobs), n, float(momentum), float(eps), stream()), 'danet_bn_forward_multi')
         modes = [((2 if r is None else (1 if m is not None else 0)) if RELU_MASK else 0) if rl else 0 for m, r, rl in zip(masks, ress, relus)]
         ctx.save_for_backward(*xs, *[y if (rl and md == 0) else None for y, md, rl in zip(ys, modes, relus)], *gammas, *saveds, *betas, *masks)
         ctx.cfg = (n, relus, [r is not None for r in ress], links, modes)
@@ -353,6 +359,43 @@ class MultiBatchNormFunction(torch.autograd.Function):
         return (None, *dxs, *dress, *[d[1] for d in dparams], *[d[0] for d in dparams])
 
 
+# conv -> BatchNorm (+ residual) (+ ReLU) of the lockstep branch layers as ONE launch (csrc/conv3x3s.hip conv3x3_stream_bn_kernel).  Built, bit-identical
+# to the two launches (tests/test_gpu_conv.py::test_conv_bn_one_launch_equals_two_launches) and OFF: measured on MI355X in the benched step
+# (two A-B pairs in one gpurun call) 26.42 / 26.42 ms with two launches, 26.53 / 26.52 ms with one -- the workgroups' own outputs are no
+# longer in their XCD's L2 when they come back for them (tools/c3s_bn_phases.py, profiles/r05_conv_bn_phases.txt: barrier released 38 us
+# into the four-branch launch, statistics + 1.8 us, the apply pass + 10 us = 47 MB at 4.7 TB/s, the rate of the stand-alone
+# bn_apply_multi_kernel), so the tail costs what the second launch cost and the barrier eats the launch overhead saved.
+CONV_BN = bool(int(os.environ.get('DANET_CONV_BN', '0')))
+
+
+def _bn_mask_wanted(relu, has_res):
+    return bool(relu and RELU_MASK and (has_res or _conv.FUSE_BN_BWD_REDUCE))
+
+
+def multi_conv_bn(convs, xs, bns, ress=None, relu=False, conv_links=None, bn_links=None):
+    """multi_batch_norm(bns, multi_conv(convs, xs), ress, relu) -- conv -> bn -> [+ residual] -> [relu] of the lockstep branch layers
+    (/root/reference/models/module/res_module.py:39-56, hr_module.py:155-177) -- with the BatchNorm applied by the convolutions'
+    own launch when the set runs on the streamed 3x3 kernel (csrc/conv3x3s.hip s3_bn_tail: a grid-wide barrier after the last
+    tile, then every workgroup normalises the tiles it wrote); two launches otherwise.  Results are bit-identical either way."""
+    n = len(bns)
+    relus = [bool(r) for r in relu] if isinstance(relu, (list, tuple)) else [bool(relu)] * n
+    rs = list(ress) if ress is not None else [None] * n
+    spec = None
+    dev = xs[0].device
+    if (CONV_BN and 1 <= n <= 4 and xs[0].is_cuda and _conv.PRECISION != 'fp32' and _conv.FUSE_BN_STATS and torch.is_grad_enabled() and
+            all(b.training and b.affine and b.num_features <= 1024 for b in bns) and
+            len({0.1 if b.momentum is None else b.momentum for b in bns}) == 1 and len({b.eps for b in bns}) == 1):
+        bar = _onepass_bar(dev)
+        if bar is not None:
+            spec = {'bar': bar, 'momentum': 0.1 if bns[0].momentum is None else bns[0].momentum, 'eps': bns[0].eps,
+                    'jobs': [{'res': r, 'gamma': b.weight.detach().float().contiguous(), 'beta': b.bias.detach().float().contiguous(),
+                              'running_mean': b.running_mean if b.track_running_stats else None,
+                              'running_var': b.running_var if b.track_running_stats else None,
+                              'relu': rl, 'want_mask': _bn_mask_wanted(rl, r is not None)} for b, r, rl in zip(bns, rs, relus)]}
+    h = _conv.multi_conv(convs, xs, conv_links, bn=spec)
+    return multi_batch_norm(bns, h, ress, relu=relu, links=bn_links)
+
+
 def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     """[bn(x, res, relu) for bn, x, res in ...] for up to 4 training-mode BatchNorm2d modules in one launch per pass;
     falls back to the per-module path otherwise (eval mode, wide layers, more than 4)."""
@@ -374,7 +417,9 @@ def multi_batch_norm(bns, xs, ress=None, relu=False, links=None):
     fused = [getattr(x, '_bn_sums', None) for x in xs]
     for f in fused:
         _conv.FUSION['bn_stats_fused' if f is not None else 'bn_stats_own'] += 1
-    static = (n, relus, mom.pop(), eps.pop(), rms, rvs, fused, links)
+    done = [getattr(x, '_bn_done', None) for x in xs]
+    done = done if all(d is not None for d in done) else None
+    static = (n, relus, mom.pop(), eps.pop(), rms, rvs, fused, links, done)
     return list(MultiBatchNormFunction.apply(static, *xs, *ress, *[b.weight for b in bns], *[b.bias for b in bns]))
 
 

@@ -308,6 +308,17 @@ int danet_conv_f32m_wgrad(const float* x, const float* dy, float* dw, float* ws,
                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups,
                           int Cout_real, int Cin_g_real, void* stream);
 int danet_conv_forward_multi_ok(const void* jobs, int n);          /* 0 no, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel */
+/* The convolutions of danet_conv_forward_multi AND the training-mode BatchNorm (+ residual) (+ ReLU) that follows each of them
+ * (/root/reference/models/module/res_module.py:39-56 conv -> bn -> relu / conv -> bn -> + residual -> relu; hr_module.py:155-177):
+ * bn_jobs[i] is a forward job of danet_bn_forward_multi whose x is conv job i's y, whose sums is its bn_sums (sums_state 2) and
+ * whose M, C are that output's.  When the streamed 3x3 kernel takes the set (<= 4 plain forward problems) it is ONE launch: the
+ * workgroups cross a grid-wide barrier after their last tile and normalise the tiles they wrote themselves (conv3x3s.hip
+ * s3_bn_tail) -- results (y, saved, running statistics, mask) bit-identical to the two launches, which is what the call runs
+ * otherwise.  *fused (optional) says which.  bar: the grid-barrier state of danet_bn_backward_onepass (same contract: zeroed once,
+ * launches that use it must not overlap, the device otherwise idle so that all workgroups are resident; a barrier that times out
+ * sets the same error word).  NULL bar: always two launches.  _ok: 1 when the set would be one launch. */
+int danet_conv_bn_forward_multi_ok(const void* jobs, int n, const void* bn_jobs, void* bar);
+int danet_conv_bn_forward_multi(const void* jobs, int n, const void* bn_jobs, float momentum, float eps, void* bar, int* fused, void* stream);
 int danet_conv_forward_multi_kernel(const void* jobs, int n);      /* the kernel the set runs on: 0 none, 1 conv_fast_multi_kernel, 2 conv3x3_tile_kernel,
                                                                        3 conv3x3_stream_kernel (csrc/conv3x3s.hip) */
 /* ---------------------------------------------------------------------------------------

@@ -809,3 +809,72 @@ def test_packing_at_padded_widths_equals_packing_a_zero_padded_copy(shape, group
         yb.backward(gy)
         assert torch.equal(ya, yb) and torch.equal(gxa, x.grad)
         assert wa.grad.shape == w.shape and torch.equal(wa.grad, wb.grad[:Cout, :Cin_g])
+
+
+@pytest.mark.parametrize('B,chans,sizes', [(32, (48, 96, 192, 384), (64, 32, 16, 8)), (8, (48, 96, 192, 384), (64, 32, 16, 8)),
+                                           (32, (48, 96), (64, 32)), (32, (48, 96, 192), (64, 32, 16)), (16, (32, 64), (32, 16)), (8, (16,), (32,))])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_conv_bn_one_launch_equals_two_launches(B, chans, sizes, with_res):
+    """conv -> train-mode BatchNorm (+ identity) -> ReLU of the lockstep HRNet branch layers (/root/reference/models/module/
+    res_module.py:39-56, hr_module.py:155-177) as ONE launch (csrc/conv3x3s.hip s3_bn_tail: grid barrier after the last tile,
+    every workgroup normalises the tiles it wrote) against the two launches (streamed convolution, then bn_apply_multi): outputs,
+    saved mean / invstd, running statistics, ReLU gate bytes and every gradient BIT-IDENTICAL; the HRNet shape sets must actually
+    take the one-launch path (no silent fall-back), and the result is checked against a torch fp32 restatement."""
+    import copy
+    from danet_densepose2smpl_amd import conv as dconv, nn as dnn
+    g = torch.Generator().manual_seed(5 + B + len(chans))
+    n = len(chans)
+    convs = [dconv.Conv2d(c, c, 3, 1, 1, bias=False).cuda() for c in chans]
+    bns = [dnn.BatchNorm2d(c).cuda() for c in chans]
+    for cv, bn, c in zip(convs, bns, chans):
+        with torch.no_grad():
+            cv.weight.copy_((torch.randn(c, c, 3, 3, generator=g) / np.sqrt(9 * c)).bfloat16().float())
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    xs0 = [torch.randn(B, c, s, s, generator=g).bfloat16().cuda() for c, s in zip(chans, sizes)]
+    rs0 = [torch.randn(B, c, s, s, generator=g).bfloat16().cuda() for c, s in zip(chans, sizes)] if with_res else None
+    gys = [torch.randn(B, c, s, s, generator=g).bfloat16().cuda() for c, s in zip(chans, sizes)]
+
+    def run(fuse):
+        cv2, bn2 = copy.deepcopy(convs), copy.deepcopy(bns)
+        for m in cv2 + bn2:
+            m.train()
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        rs = None if rs0 is None else [r.clone().requires_grad_(True) for r in rs0]
+        prev, dnn.CONV_BN = dnn.CONV_BN, fuse
+        dconv.FUSION.clear()
+        try:
+            ys = dnn.multi_conv_bn(cv2, xs, bn2, rs, relu=True)
+        finally:
+            dnn.CONV_BN = prev
+        counts = dict(dconv.FUSION)
+        ctxs = [y._bn_ctx for y in ys]
+        torch.autograd.backward(ys, gys)
+        torch.cuda.synchronize()
+        return {'y': [y.detach() for y in ys], 'saved': [c_[2] for c_ in ctxs], 'mask': [c_[3] for c_ in ctxs],
+                'rm': [b.running_mean.clone() for b in bn2], 'rv': [b.running_var.clone() for b in bn2],
+                'gx': [x.grad for x in xs], 'gr': None if rs is None else [r.grad for r in rs],
+                'gw': [c_.weight.grad for c_ in cv2], 'gg': [b.weight.grad for b in bn2], 'gb': [b.bias.grad for b in bn2], 'counts': counts}
+
+    two, one = run(False), run(True)
+    assert two['counts'].get('conv_bn_one_launch', 0) == 0
+    if chans[0] == 48:
+        assert one['counts'].get('conv_bn_one_launch', 0) == n and one['counts'].get('bn_forward_in_conv_launch', 0) == n, one['counts']
+    for key in ('y', 'saved', 'rm', 'rv', 'gx', 'gw', 'gg', 'gb') + (('gr',) if with_res else ()):
+        for i, (a, b) in enumerate(zip(one[key], two[key])):
+            assert torch.equal(a, b), (key, i, float((a.float() - b.float()).abs().max()))
+    for i, (a, b) in enumerate(zip(one['mask'], two['mask'])):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), ('mask', i)
+    # ... and the values themselves: conv (bf16-rounded output) -> batch statistics -> affine -> + residual -> relu in fp32
+    for i, (cv, bn) in enumerate(zip(convs, bns)):
+        raw = F.conv2d(xs0[i].float(), cv.weight.detach(), None, 1, 1).bfloat16().float()
+        mean, var = raw.mean(dim=(0, 2, 3)), raw.var(dim=(0, 2, 3), unbiased=False)
+        ref = (raw - mean[None, :, None, None]) * torch.rsqrt(var + bn.eps)[None, :, None, None] * bn.weight.detach()[None, :, None, None] + bn.bias.detach()[None, :, None, None]
+        if with_res:
+            ref = ref + rs0[i].float()
+        ref = ref.clamp(min=0)
+        err = float((one['y'][i].float() - ref).abs().max())
+        assert err <= 3e-2 * max(1.0, float(ref.abs().max())), (i, err)
+        assert float((one['saved'][i][0] - mean).abs().max()) < 2e-3 and float((one['rm'][i] - (0.9 * bn.running_mean + 0.1 * mean)).abs().max()) < 1e-3
