@@ -39,7 +39,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
     if steps is None:
-        c = sum(int(r['Calls']) for r in rows if 'conv3x3_stream_kernel<3>' in r['Name'])
+        c = sum(int(r['Calls']) for r in rows if 'conv3x3_stream_kernel<3>' in r['Name'] or 'conv3x3_stream_bn_kernel<3>' in r['Name'])     # (DANET_CONV_BN=1: the forward launches carry the second name)
         steps = c / 132.0 if c else 1.0
     fam = {}
     for r in rows:
