@@ -37,3 +37,16 @@ def rand_pose_shape(B, seed=1234, pose_sigma=0.2):
     betas = np.clip(rng.normal(0, 1, (B, 10)), -3, 3)
     pose = rng.normal(0, pose_sigma, (B, 72))
     return betas, pose
+
+
+def record(name, values):
+    """Append one measured-error record of a parity test to gpurun_out/parity_measured.jsonl (scratch; the closing run copies
+    it to profiles/) -- tolerances in the tests are set from these measurements, not guessed."""
+    import json
+    d = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_measured.jsonl'), 'a') as f:
+            f.write(json.dumps({'test': name, 'measured': values}) + '\n')
+    except OSError:
+        pass

@@ -614,6 +614,89 @@ def g15_dp_producer():
 ALL['g15'] = g15_dp_producer
 
 
+def _sub(t, step=4):
+    """Every `step`-th pixel of a map plus its per-channel means: a 256^2 fixture stays small and still sees every pixel."""
+    return t.detach()[..., ::step, ::step].contiguous(), t.detach().double().mean(dim=(-2, -1)).float()
+
+
+def g16_hrnet256():
+    """Round-5 review item 5: the reference's own PoseHighResolutionNet at the BENCHED resolution (256 x 256 -> 64 x 64 maps, B = 2,
+    train-mode BatchNorm) -- every earlier reference fixture of the backbone is 64 x 64.  The expected values are the reference run
+    in DOUBLE precision (module.double()); `floor__<key>` is how far the reference's own fp32 run is from that (max abs) -- the
+    error floor of ANY fp32 implementation of this network with these parameters, which the fp32-mode tolerance is derived from."""
+    ref_env({'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from models.module.hr_module import PoseHighResolutionNet
+    torch.manual_seed(0)
+    net = PoseHighResolutionNet(part_out_dim=7)
+    formula_params(net)
+    net.train()
+    img = formula_input('g16.img', (2, 3, 256, 256), -2.0, 2.0)
+    with torch.no_grad():
+        out32 = net(img)
+    rm32 = net.bn1.running_mean.clone()
+    formula_params(net)                                                   # (the fp32 run moved the running statistics)
+    net = net.double().train()
+    with torch.no_grad():
+        out = net(img.double())
+    arrs = {}
+    for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd'):
+        arrs[k], arrs[k + '__mean'] = _sub(out[k].float())
+        arrs['floor__' + k] = (out32[k].double() - out[k]).abs().max().float()
+        arrs['scale__' + k] = out[k].abs().max().float()
+        print(k, 'fp32 reference vs fp64 reference: max abs %.3g at scale %.3g' % (float(arrs['floor__' + k]), float(arrs['scale__' + k])))
+    save('g16_hrnet256', bn1_running_mean=net.bn1.running_mean.float(), bn2_running_var=net.bn2.running_var.float(),
+         floor__bn1_running_mean=(rm32.double() - net.bn1.running_mean).abs().max().float(), **arrs)
+
+
+def g17_infer():
+    """SURVEY 8 row f2 on the device (round-5 review item 4): the reference's inference path danet.py:61-131 -- IUV_Estimator (eval)
+    -> iuvmap_clean -> per-part iuvmap_clean -> DecomposedPredictor (eval) -> para -- run with formula parameters; the GPU test
+    writes the same parameters as a reference-layout checkpoint FILE, loads it into the HIP DaNet and calls infer_net."""
+    ref_env({'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32, 'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.,
+             'DANET.PARTDROP_RATE': 0.})
+    import torch.nn.functional as F
+    ag, gs = F.affine_grid, F.grid_sample
+    # the reference was written for torch 1.1 (align_corners=True semantics, SURVEY Appendix D.1) -- the build's default
+    F.affine_grid = lambda theta, size, align_corners=None: ag(theta, size, align_corners=True)
+    F.grid_sample = lambda x, grid, mode='bilinear', padding_mode='zeros', align_corners=None: gs(x, grid, mode, padding_mode, align_corners=True)
+    try:
+        from models.danet.iuv_estimator import IUV_Estimator
+        from models.danet.smpl_regressor import DecomposedPredictor
+        from utils.iuvmap import iuvmap_clean
+        torch.manual_seed(0)
+        est = IUV_Estimator(pretrained=False)
+        formula_params(est, skip=('learned_ratio', 'learned_offset'))
+        pose6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(24).unsqueeze(0)
+        mean = (torch.tensor([[0.9, 0., 0.]]), torch.zeros(1, 10), pose6)
+        pred = DecomposedPredictor(None, mean, pretrained=False)
+        formula_params(pred, skip=('mean_', 'I_n', 'A_link', 'A_mask', 'A', 'r2p_A', 'p2r_A'))
+        est.eval(); pred.eval()
+        img = formula_input('g17.img', (2, 3, 128, 128), -2.0, 2.0)
+        with torch.no_grad():
+            uv = est(img)
+            u, v, idx, ann = iuvmap_clean(*uv['uvia_pred'])
+            iuv_map = torch.cat([u, v, idx], dim=1)
+            pp = uv['part_iuv_pred']
+            parts = []
+            for p in range(pp.size(1)):                                       # danet.py:93-100
+                pu, pv, pi, _ = iuvmap_clean(pp[:, p, 0], pp[:, p, 1], pp[:, p, 2])
+                parts.append(torch.stack([pu, pv, pi], dim=1))
+            part_iuv_map = torch.stack(parts, dim=1)
+            para = pred(iuv_map, part_iuv_map)['para']
+        # how decisive the arg-max planes are: the smallest top-1 / top-2 logit gap (a flip would change the regressor's input)
+        top = uv['uvia_pred'][2].topk(2, dim=1).values
+        save('g17_infer', learned_ratio=est.learned_ratio, learned_offset=est.learned_offset, para=para,
+             u_raw=uv['uvia_pred'][0], index_raw=uv['uvia_pred'][2], ann_raw=uv['uvia_pred'][3], stn_kps_pred=uv['stn_kps_pred'],
+             part_iuv_pred=pp[:, ::6].contiguous(), index_clean=idx.argmax(1).to(torch.uint8),
+             min_index_gap=(top[:, 0] - top[:, 1]).min())
+    finally:
+        F.affine_grid, F.grid_sample = ag, gs
+
+
+ALL['g16'] = g16_hrnet256
+ALL['g17'] = g17_infer
+
+
 def _main():
     names = sys.argv[1:] or list(ALL)
     for n in names:

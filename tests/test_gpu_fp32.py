@@ -220,6 +220,36 @@ def test_backbones_fp32_vs_reference_golden(name, cls):
     assert _rel(net.bn1.running_mean, g['bn1_running_mean']) < 1e-4
 
 
+def test_hrnet_fp32_vs_reference_golden_at_the_benched_resolution():
+    """g16 (round-5 review item 5): the reference's PoseHighResolutionNet at 256 x 256 / B = 2 / train-mode BatchNorm, expected
+    values from the reference evaluated in DOUBLE precision.  The fixture records the error of the reference's OWN fp32 run against
+    them (`floor__*`: 1.8e-4 .. 2.3e-4 max abs at output scale ~11 = 1.7e-5 of scale): SURVEY 8c's "1e-4 abs" for torch-only blocks is
+    below the reference's own rounding noise on this 90-layer net, so the bound here is 4 x that measured floor (~8e-4 abs, 7e-5 of
+    scale -- 14 x tighter than the 1e-3 of scale the 64 x 64 fixtures are held to).  Every pixel is covered by the per-channel means."""
+    _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from danet_densepose2smpl_amd import hrnet, conv
+    from conftest import record
+    g = golden('g16_hrnet256')
+    net = hrnet.PoseHighResolutionNet(part_out_dim=7)
+    formula_params(net)
+    net = net.cuda().train()
+    img = formula_input('g16.img', (2, 3, 256, 256), -2.0, 2.0).cuda()
+    meas = {}
+    with conv.precision('fp32'), torch.no_grad():
+        out = net(img)
+    for k in KEYS:
+        o = out[k].float()
+        e = float(np.abs(o[..., ::4, ::4].cpu().numpy() - g[k]).max())
+        em = float(np.abs(o.double().mean(dim=(-2, -1)).cpu().numpy() - g[k + '__mean']).max())
+        meas[k] = {'max_abs': e, 'mean_abs': em, 'reference_fp32_floor': float(g['floor__' + k]), 'scale': float(g['scale__' + k])}
+    record('hrnet256_fp32_mode_vs_reference_fp64', meas)
+    for k in KEYS:
+        tol = 4.0 * float(g['floor__' + k])
+        assert meas[k]['max_abs'] <= tol and meas[k]['mean_abs'] <= tol, (k, meas[k], tol)
+    assert np.abs(net.bn1.running_mean.cpu().numpy() - g['bn1_running_mean']).max() < 1e-6
+    assert np.abs(net.bn2.running_var.cpu().numpy() / g['bn2_running_var'] - 1).max() < 1e-5
+
+
 @pytest.mark.parametrize('align', [0, 1])
 def test_iuv_estimator_fp32_vs_reference_golden(align):
     _cfg(**{'DANET.INIMG_SIZE': 64, 'DANET.HEATMAP_SIZE': 16, 'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.,

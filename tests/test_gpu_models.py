@@ -123,10 +123,12 @@ def test_poseresnet_stages_teacher_forced_vs_fp32_oracle():
     assert max(worst.values()) < 4e-2, worst
 
 
-def test_hrnet_stages_teacher_forced_vs_fp32_oracle():
+@pytest.mark.parametrize('size,B', [(128, 4), (256, 2)])
+def test_hrnet_stages_teacher_forced_vs_fp32_oracle(size, B):
     """Every stage of the HIP HRNet, fed with the fp32 oracle's own input to that stage, must
-    reproduce the oracle's output of that stage (structure / wiring check without chaos)."""
-    _cfg(**{'DANET.INIMG_SIZE': 128, 'DANET.HEATMAP_SIZE': 32})
+    reproduce the oracle's output of that stage (structure / wiring check without chaos).  (256, 2) is the benched resolution:
+    the oracle is pinned to the reference there by golden g16 (tests/test_oracle_nets.py)."""
+    _cfg(**{'DANET.INIMG_SIZE': size, 'DANET.HEATMAP_SIZE': size // 4})
     from danet_densepose2smpl_amd import hrnet
     from oracle import torch_ref
     ref = torch_ref.HRNet(part_out_dim=7)
@@ -146,7 +148,7 @@ def test_hrnet_stages_teacher_forced_vs_fp32_oracle():
             cap[n] = (i[0], o)
         return f
     hs = [rmods[n].register_forward_hook(mk(n)) for n in names]
-    img = torch.randn(4, 3, 128, 128, generator=torch.Generator().manual_seed(3))
+    img = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         ref(img)
     for h in hs:
