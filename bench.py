@@ -25,14 +25,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+STEP_GFLOP_PER_IMAGE_256 = 180.4      # 30.07 GMAC/img forward = 60.1 GFLOP, x3 for forward + data + weight gradients (5.77 TFLOP per 32-image step)
 PEAK_FP32_MFMA_TFLOPS = 157.0         # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD (no reduced-precision path for fp32 inputs on gfx950)
+
+
+def whole_step_mfma(batch, size, ms_per_step, peak_tflops):
+    """The step's ALGORITHMIC convolution / linear FLOPs over its wall time against the dense MFMA peak: the number the
+    north star's '>= 40 % conv MFMA roofline' is read against as a whole (the `roofline` entry is the dominant kernel alone)."""
+    tflop = STEP_GFLOP_PER_IMAGE_256 * (size / 256.0) ** 2 * batch / 1e3
+    ach = tflop / (ms_per_step * 1e-3)
+    return {'alg_tflop_per_step': round(tflop, 3), 'achieved': round(ach, 1), 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tflops, 4),
+            'note': 'all convolution families + every non-MFMA kernel of the step in the denominator'}
 
 
 def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, source description) from this round's committed PMC summary
     (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a 512 MiB copy
     in the same run), or (None, reason).  The file records the commit it was measured at."""
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             f = json.load(open(path))
@@ -49,7 +59,7 @@ def rocprof_avg_us(kernel):
     """(average duration of `kernel` in us, source) from this round's committed `rocprofv3 --kernel-trace --stats` summary of the same
     command (profiles/r05_bench_kernel_stats.csv), to sit beside the live HIP-event figure; (None, reason) without one."""
     import csv
-    for name in ('r05_bench_kernel_stats.csv', 'r04_bench_kernel_stats.csv', 'r03_bench_bf16_only_kernel_stats.csv'):
+    for name in ('r06_bench_kernel_stats.csv', 'r05_bench_kernel_stats.csv', 'r04_bench_kernel_stats.csv', 'r03_bench_bf16_only_kernel_stats.csv'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             for row in csv.DictReader(open(path)):
@@ -193,7 +203,7 @@ def geometry_rooflines(tr, B, size, dev):
     peak = 8000.0
     mk = lambda name, by, t: {'kernel': name, 'bound': 'hbm', 'achieved': round(by / t / 1e9, 1), 'peak': peak, 'unit': 'GB/s',   # noqa: E731
                               'frac': round(by / t / 1e9 / peak, 4), 'us': round(t * 1e6, 1), 'alg_bytes': int(by)}
-    return [mk('smpl layer forward (LBS as one launch + the joint selections as one)', by_f, t_f), mk('smpl layer backward (LBS as one launch + the selections\' gradients as one)', by_b, max(t_fb - t_f, 1e-9)),
+    return [mk('smpl layer forward (LBS as one launch + the joint selections as one)', by_f, t_f), mk('smpl layer backward (LBS as three launches + the selections\' gradients as one)', by_b, max(t_fb - t_f, 1e-9)),
             mk('iuv_raster forward (project+faces+resolve)', by_r, t_r)]
 
 
@@ -246,6 +256,7 @@ def fp32_record(args, tr, batch, world, dev):
     finite = bool(all(torch.isfinite(v).all() for v in losses.values())) if isinstance(losses, dict) else None
     return {'dtype': 'f32', 'value': round(world * args.batch * steps / elapsed, 2), 'unit': 'images/sec', 'ms_per_step': round(elapsed / steps * 1e3, 2),
             'steps': steps, 'warmup': warm, 'exec': exec_mode, 'finite_losses': finite, 'roofline': roof,
+            'whole_step_mfma': whole_step_mfma(args.batch, args.size, elapsed / steps * 1e3, PEAK_FP32_MFMA_TFLOPS),
             'workload': 'BASELINE config C4 arithmetic: the same full train step with fp32 NHWC activations; convolutions on '
                         'v_mfma_f32_16x16x4_f32 (conv_f32m.hip), BatchNorm / fuse sums / STN on the fp32 instantiation of the HIP kernels'}
 
@@ -436,7 +447,8 @@ def main():
                                        'render + losses, fwd+bwd+Adam), %dx%d, %d img/GPU; convs bf16 MFMA fp32-acc, '
                                        'LBS/raster/losses fp32' % (args.size, args.size, B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world},
-                'roofline': roof, 'roofline_extra': extra}
+                'roofline': roof, 'whole_step_mfma': whole_step_mfma(B, args.size, elapsed / args.steps * 1e3, PEAK_BF16_DENSE_TFLOPS),
+                'roofline_extra': extra}
         if fp32 is not None:
             line['fp32'] = fp32
         if world == 1 and not args.no_cpu_baseline:

@@ -29,21 +29,29 @@ class ZeroArena(object):
         self.off = 0
         self.high = 0
         self.zeroed = 0             # extent the current step's begin_step cleared
+        self.dirty = 0              # extent that may hold non-zero data in MEMORY (a recorded clear has not run: captures do not reset it)
         self.refused = []           # (offset, floats, cleared extent) of the slices a capture was refused (diagnostics)
 
     def enable(self, device, floats=160 * 1024 * 1024):
         self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
         self.off = 0
         self.high = floats
+        self.dirty = 0
 
     def disable(self):
         self.buf = None
 
     def begin_step(self):
         if self.buf is not None:
-            if self.high > 0:
-                self.buf[:self.high].zero_()
-            self.zeroed = self.high
+            capturing = torch.cuda.is_current_stream_capturing()
+            # eager: clear everything that may be dirty in memory -- also what an ABORTED capture attempt's step or the warm-up step
+            # before it left beyond the last step's own extent (round-5 advisor: a retry recorded a clear of the partial extent only)
+            ext = self.high if capturing else max(self.high, self.dirty)
+            if ext > 0:
+                self.buf[:ext].zero_()
+            self.zeroed = ext
+            if not capturing:
+                self.dirty = 0
             self.high = 0
             self.off = 0
 
@@ -60,6 +68,7 @@ class ZeroArena(object):
         t = self.buf[self.off:self.off + n]
         self.off += n16
         self.high = max(self.high, self.off)
+        self.dirty = max(self.dirty, self.off)
         return t
 
 
@@ -246,8 +255,11 @@ class Conv2dF32Function(torch.autograd.Function):
             if mfma and L.danet_conv_f32m_ok(B, OH, OW, Cout_p, H, W, Cin_p, R, S, stride, pad, dil, groups, 1):
                 wp = _pack_weight_f32(ctx.weight, w, groups, 1, Cout_gp, Cin_gp)
                 gx = torch.empty(B, H, W, Cin_p, dtype=torch.float32, device=g.device)
+                tok = PROFILER.begin('conv_f32m_kernel', 2.0 * B * OH * OW * Cout * R * S * Cin_g, ('dgrad', B, H, W, Cin, Cout, R, stride, groups)) if PROFILER is not None else None
                 check(L.danet_conv_f32m_forward(ptr(gp), ptr(wp), None, ptr(gx), B, OH, OW, Cout_p, H, W, Cin_p, R, S, stride, pad, dil, groups, 1, 0,
                                                 stream()), 'danet_conv_f32m_forward')
+                if tok is not None:
+                    PROFILER.end(tok)
                 gx = gx[..., :Cin]
             else:
                 wr = w.view(groups, Cout_gp, Cin_g, R, S)[:, :Cout_g].reshape(Cout, Cin_g, R, S) if (mfma and gpad) else w

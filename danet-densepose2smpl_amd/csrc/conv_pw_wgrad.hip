@@ -286,7 +286,7 @@ static void pwg_group_pixels(const WgJob* jobs, const int* idx, int cnt, long* g
 
 // Workspace floats the problems idx[0..cnt) need (partial sums [msplit][Cout][Cin] each).
 size_t conv_pw_wgrad_ws_floats(const WgJob* jobs, const int* idx, int cnt, long target) {
-    static long gpx_buf[4096];
+    thread_local static long gpx_buf[4096];      // (per host thread: the library holds no shared mutable scratch)
     if (cnt > 4096) return 0;
     long* const gpx = gpx_buf;
     pwg_group_pixels(jobs, idx, cnt, gpx);
@@ -307,7 +307,7 @@ int conv_pw_wgrad_launch(const WgJob* jobs, const int* idx, int cnt, float* ws, 
     long total_px = 0;
     for (int k = 0; k < cnt; ++k) total_px += (long)jobs[idx[k]].B * jobs[idx[k]].OH * jobs[idx[k]].OW;
     bool done[4096];
-    static long gpx_launch[4096];
+    thread_local static long gpx_launch[4096];
     if (cnt > 4096) return -1;
     for (int k = 0; k < cnt; ++k) done[k] = false;
     pwg_group_pixels(jobs, idx, cnt, gpx_launch);

@@ -409,7 +409,7 @@ static int wg_multi(const WgJob* jobs, int n, float* ws, size_t ws_floats, float
     size_t used = 0;
     {
         // 1x1 / stride-1 problems: csrc/conv_pw_wgrad.hip (its partial sums need no zeroed workspace)
-        static int idx[4096];
+        thread_local static int idx[4096];
         int cnt = 0;
         for (int i = 0; i < n; ++i) if (conv_pw_wgrad_ok(jobs[i])) { idx[cnt++] = i; done[i] = true; }
         if (cnt > 0) {

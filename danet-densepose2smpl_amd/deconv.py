@@ -120,6 +120,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
             if x.is_cuda and _conv.F32_MFMA and L.danet_conv_f32m_ok(B, H, W, Cin, OH, OW, Cout, R, S, st, pd, 1, 1, 1) and \
                     L.danet_conv_f32m_ok(B, OH, OW, Cout, H, W, Cin, R, S, st, pd, 1, 1, 0):
                 return ConvTranspose2dF32Function.apply(x, self.weight, self.bias, st, pd, op)
-            import torch.nn.functional as F                 # channel counts the MFMA kernels do not take: the fp32 tensor op
-            return F.conv_transpose2d(x.float(), self.weight, self.bias, self.stride, self.padding, self.output_padding)
+            # no tensor-op fall-back: the path's transposed convolutions are 2048 -> 256 and 256 -> 256 (res_module.py:169-194)
+            raise RuntimeError('ConvTranspose2d (fp32 mode): %d -> %d channels, kernel %d, stride %d on %s is outside the fp32 MFMA kernels '
+                               '(csrc/conv_f32m.hip: channel counts in multiples of 4, device tensors)' % (Cin, Cout, R, st, x.device))
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], self.output_padding[0])

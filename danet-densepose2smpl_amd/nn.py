@@ -386,6 +386,11 @@ def multi_conv_bn(convs, xs, bns, ress=None, relu=False, conv_links=None, bn_lin
             all(b.training and b.affine and b.num_features <= 1024 for b in bns) and
             len({0.1 if b.momentum is None else b.momentum for b in bns}) == 1 and len({b.eps for b in bns}) == 1):
         bar = _onepass_bar(dev)
+        # the launch crosses a grid barrier with up to `c3s_blocks` workgroups (512): under a data-parallel trainer's co-residency
+        # budget (ONEPASS_MAX_BLOCKS = 2 x the compute units left beside the communication kernels) a grid that large may not be
+        # resident at once -- two launches then, like the one-pass backward and the one-launch SMPL backward (round-5 advisor)
+        if bar is not None and 0 < ONEPASS_MAX_BLOCKS < _lib.lib().knob('c3s_blocks'):
+            bar = None
         if bar is not None:
             spec = {'bar': bar, 'momentum': 0.1 if bns[0].momentum is None else bns[0].momentum, 'eps': bns[0].eps,
                     'jobs': [{'res': r, 'gamma': b.weight.detach().float().contiguous(), 'beta': b.bias.detach().float().contiguous(),
@@ -745,9 +750,12 @@ class MaxPool3x3S2Function(torch.autograd.Function):
 
 def maxpool3x3s2(x):
     """F.max_pool2d(x, 3, 2, 1) on the HIP kernel for device tensors whose channel count fits its 16-byte lanes."""
-    if x.is_cuda and x.dim() == 4 and x.shape[1] % (4 if _conv.PRECISION == 'fp32' else 8) == 0:
-        return MaxPool3x3S2Function.apply(x)
-    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    lanes = 4 if _conv.PRECISION == 'fp32' else 8
+    if not (x.is_cuda and x.dim() == 4 and x.shape[1] % lanes == 0):
+        # no tensor-op fall-back: every stem of the path has 64 channels (res_module.py:303; SmplResNet :404)
+        raise RuntimeError('maxpool3x3s2: needs a device tensor [B, C, H, W] with C a multiple of %d (csrc/pool.hip); got %s on %s'
+                           % (lanes, tuple(x.shape), x.device))
+    return MaxPool3x3S2Function.apply(x)
 
 
 def bump_batch_counters(module=None):

@@ -1,4 +1,6 @@
 """torch.autograd.Function wrappers over the C ABI (include/danet_hip.h)."""
+import os
+
 import torch
 
 from . import _lib
@@ -11,6 +13,7 @@ def _f32c(t):
 
 LBS_ONE_LAUNCH = True       # the SMPL forward as one kernel launch (csrc/smpl_lbs.hip smpl_fused_fwd_kernel); False: prep -> main -> finalize
 _LBS_TICKETS = {}
+SMPL_BWD_FUSED = bool(int(os.environ.get('DANET_LBS_BWD_FUSED', '0')))    # the SMPL backward as ONE launch (smpl_fused_bwd_kernel); default: three launches (faster)
 
 
 def lbs_ticket(device, words):
@@ -71,10 +74,12 @@ class SmplLbsFunction(torch.autograd.Function):
         g_rot = torch.empty(B, 24, 3, 3, device=dev, dtype=torch.float32)
         nws = L.danet_smpl_lbs_bwd_ws_floats(B, V, NB)
         ws = torch.empty(nws, device=dev, dtype=torch.float32)
-        # ONE launch when the grid fits the co-residency budget: the barrier state is the one-pass BatchNorm backward's (same stream,
-        # never concurrent; its error word already guards the optimizer step and Trainer.check_onepass) -- None on any other stream
+        # Three launches by default (126 us at B = 32 against 150 for the one-launch form, bench.py roofline_extra of round 5; neutral in
+        # the step).  SMPL_BWD_FUSED: ONE launch when the grid fits the co-residency budget; the barrier state is the one-pass BatchNorm
+        # backward's (same stream, never concurrent; its error word guards the optimizer step inside a Trainer -- outside one nothing
+        # reads it, which is why the one-launch form is opt-in)
         from . import nn as _nn, conv as _conv
-        bar = _nn._onepass_bar(dev)
+        bar = _nn._onepass_bar(dev) if SMPL_BWD_FUSED else None
         if bar is not None and L.danet_smpl_lbs_backward_fused_ok(B, V, _nn.ONEPASS_MAX_BLOCKS):
             _conv.FUSION['smpl_bwd_fused'] += 1
         else:

@@ -496,20 +496,44 @@ class Trainer(object):
         self._graph = graph
         return self
 
+    @staticmethod
+    def _loaded_hip_runtime():
+        """The libamdhip64 THIS process already runs on (the copy torch loaded), by the path the loader mapped it from: dlopen of
+        that path returns the same handle, where a bare soname could resolve to another installation's runtime and act on nothing."""
+        import ctypes
+        try:
+            for ln in open('/proc/self/maps'):
+                path = ln.rsplit(None, 1)[-1]
+                if 'libamdhip64.so' in os.path.basename(path):
+                    return ctypes.CDLL(path)
+        except OSError:
+            pass
+        return None
+
     def _end_stray_capture(self):
         """A capture that raised may leave the step's stream in capture mode (observed: hipStreamCaptureStatusActive after
-        torch.cuda.graph's own clean-up): end it through the runtime so that the next capture can begin.  Best effort."""
+        torch.cuda.graph's own clean-up): end it through the runtime so that the next capture can begin.  Best effort, and it says
+        so when it could not (torch's own capture bookkeeping is not reset either way: a failed capture is not recoverable in
+        general, DESIGN 6 lesson 13 -- this only makes the NEXT error name the real state)."""
+        import ctypes
+        import warnings
         try:
             if not self.stream.is_capturing():
                 return
-            import ctypes
-            hip = ctypes.CDLL('libamdhip64.so')
+            hip = self._loaded_hip_runtime()
+            if hip is None:
+                warnings.warn('trainer: the step stream is still capturing after a failed capture and the loaded HIP runtime was not found; '
+                              'the next capture will fail')
+                return
             g = ctypes.c_void_p()
-            hip.hipStreamEndCapture(ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(g))
+            rc = hip.hipStreamEndCapture(ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(g))
             if g.value:
                 hip.hipGraphDestroy(g)
-        except Exception:          # noqa: BLE001 -- nothing more to try; the second capture will report the state it finds
-            pass
+            if rc != 0 or self.stream.is_capturing():
+                warnings.warn('trainer: hipStreamEndCapture on the stray capture returned %d; the stream %s capturing' %
+                              (rc, 'is still' if self.stream.is_capturing() else 'stopped'))
+        except Exception as e:          # noqa: BLE001 -- nothing more to try; the second capture will report the state it finds
+            warnings.warn('trainer: could not end the stray capture (%r)' % (e,))
 
     def load_batch(self, in_dict):
         """Copy a new batch into the captured graph's static input tensors (nested dictionaries included)."""

@@ -164,8 +164,9 @@ def test_one_launch_backward_equals_three_launch_backward(smpl, smpl_model, B):
     assert dnn.ONEPASS and dnn._onepass_bar(torch.device('cuda')) is not None           # (default stream = the one-pass stream outside a trainer)
 
     def run(fused):
-        prev = dnn.ONEPASS
+        prev, prev_f = dnn.ONEPASS, ops.SMPL_BWD_FUSED
         dnn.ONEPASS = fused                        # no barrier state -> three launches
+        ops.SMPL_BWD_FUSED = fused                 # (the one-launch form is opt-in since round 6: DANET_LBS_BWD_FUSED)
         try:
             dconv.FUSION.clear()
             tb, tr = _t(betas).requires_grad_(True), _t(rot).requires_grad_(True)
@@ -174,7 +175,7 @@ def test_one_launch_backward_equals_three_launch_backward(smpl, smpl_model, B):
             torch.cuda.synchronize()
             return tb.grad.clone(), tr.grad.clone(), dconv.FUSION.get('smpl_bwd_fused', 0)
         finally:
-            dnn.ONEPASS = prev
+            dnn.ONEPASS, ops.SMPL_BWD_FUSED = prev, prev_f
     one = [run(True) for _ in range(3)]
     three = run(False)
     assert three[2] == 0 and all(o[2] == (1 if fits else 0) for o in one)

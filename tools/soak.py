@@ -56,6 +56,7 @@ with torch.no_grad():
 # SMPL backward as ONE launch (round 5: three phases, two fence-free grid barriers, partials written and read at agent scope): a stale
 # read across a barrier would show as a mismatch against the first call's gradients
 from danet_densepose2smpl_amd import ops, nn as dnn    # noqa: E402
+ops.SMPL_BWD_FUSED = True       # (opt-in since round 6; this soak is about the one-launch kernel)
 gvs, gjs = torch.randn(32, 6890, 3, device='cuda') * 1e-2, torch.randn(32, 54, 3, device='cuda')
 
 
