@@ -418,7 +418,7 @@ bool supported(const ConvF& p) {
     if (p.M >= (1L << 24) || p.Kp >= (1 << 22)) return false;
     if (p.x_bytes >= (1L << 31) || p.y_bytes >= (1L << 31)) return false;
     if ((long)p.groups * p.Cout_pad * p.Kp * 4 >= (1L << 31)) return false;
-    if ((size_t)p.Kp * 2 > 60 * 1024) return false;                   // tap table in LDS
+    if ((size_t)p.Kp * 2 > 128 * 1024) return false;                  // tap table in LDS (> 64 KB: launch<> raises the kernel's dynamic-LDS limit; 2048 -> 256 / 4x4 deconv: 64 KB)
     return true;
 }
 
@@ -431,7 +431,12 @@ void launch(const ConvF& p, hipStream_t st) {
         nz *= p.stride * p.stride;
     }
     const dim3 grid((unsigned)((mblk + 64 * MT - 1) / (64 * MT)), (unsigned)(p.Cout_pad / (16 * NT)), (unsigned)nz);
-    hipLaunchKernelGGL((conv_f32m_kernel<MT, NT>), grid, dim3(256), (size_t)(p.Kp / 4) * sizeof(i32x2), st, p);
+    const size_t lds = (size_t)(p.Kp / 4) * sizeof(i32x2);
+    if (lds > 60 * 1024) {                                   // once per instantiation: the 160 KB of a gfx950 compute unit are opt-in above 64 KB
+        static bool raised = false;
+        if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32m_kernel<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); raised = true; }
+    }
+    hipLaunchKernelGGL((conv_f32m_kernel<MT, NT>), grid, dim3(256), lds, st, p);
 }
 
 bool wg_plan(WgF& p, int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S, int stride, int pad, int dil, int groups,

@@ -10,6 +10,7 @@
 //             axis-aligned thetas [[sx,0,cx],[0,sy,cy]], so the sample position is separable and
 //             monotone in (oh, ow); each input pixel sums tent(iy-y)*tent(ix-x)*dy over the output
 //             window that can reach it.
+#include <cstdlib>
 #include "common.h"
 #include "conv_common.h"
 
@@ -53,8 +54,152 @@ __device__ inline void store8(float* p, const V8& a) {
 }
 
 // x [B,H,W,C] (T = bf16 or fp32), theta [B,P,2,3] f32 -> y [B,OH,OW,P*C].  C % 8 == 0.
+// One workgroup per output row (b, oh); its OW * P * C/8 items (8 channels each) lie contiguously in y in item order, and a lane
+// walks them with a stride of 256 -- (ow, p, cv) advance incrementally (round 6: the per-item 64-bit divisions of the first version
+// were ~10x the useful instructions: 151 us for a 302 MB write).  The thetas of image b sit in LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void stn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ theta,
+                                                      int B, int H, int W, int C, int P, int OH, int OW, int align,
+                                                      T* __restrict__ y)
+{
+    extern __shared__ float stn_smem[];
+    float* const sTh = stn_smem;                                   // [P][6]
+    const int b = (int)blockIdx.x / OH, oh = (int)blockIdx.x - b * OH;
+    const int t = threadIdx.x;
+    for (int i = t; i < P * 6; i += 256) sTh[i] = theta[(size_t)b * P * 6 + i];
+    __syncthreads();
+    const int CV = C / 8, PC = P * CV, n = OW * PC;
+    const float inv_cv = 1.0f / (float)CV;
+    const float yn = norm_coord(oh, OH, align);
+    const int dq = 256 / PC, dr = 256 - dq * PC;
+    int ow = t / PC, pc = t - ow * PC;
+    const T* const xb = x + (size_t)b * H * W * C;
+    T* const yrow = y + ((size_t)b * OH + oh) * OW * ((size_t)P * C);
+    for (int i = t; i < n; i += 256) {
+        const int p = (int)(((float)pc + 0.5f) * inv_cv);           // pc / CV (exact: pc < 2^20)
+        const int cv = pc - p * CV;
+        const float* th = sTh + p * 6;
+        const float xn = norm_coord(ow, OW, align);
+        const float gx = th[0] * xn + th[1] * yn + th[2];
+        const float gy = th[3] * xn + th[4] * yn + th[5];
+        const float ix = unnorm_coord(gx, W, align), iy = unnorm_coord(gy, H, align);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        V8 acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int yy = y0 + dy, xx = x0 + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float w = (dy ? wy1 : wy0) * (dx ? wx1 : wx0);
+                    const V8 a = load8(xb + ((size_t)yy * W + xx) * C + cv * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.v[j] += w * a.v[j];
+                }
+            }
+        store8(yrow + (size_t)i * 8, acc);                          // item i = (ow, p, cv) IS the layout order of the row
+        pc += dr; ow += dq;
+        if (pc >= PC) { pc -= PC; ++ow; }
+    }
+}
+
+// range of output indices o in [0,n_out) with |a*o + b0 - target| < 1
+__device__ inline void reach(float a, float b0, float target, int n_out, int* lo, int* hi) {
+    if (fabsf(a) < 1e-12f) {
+        if (fabsf(b0 - target) < 1.0f) { *lo = 0; *hi = n_out - 1; } else { *lo = 1; *hi = 0; }
+        return;
+    }
+    float l = (target - 1.0f - b0) / a, h = (target + 1.0f - b0) / a;
+    if (l > h) { const float t = l; l = h; h = t; }
+    // one-index slack on both sides; the tent weight zeroes anything outside
+    const float lf = floorf(l) - 1.0f, hf = ceilf(h) + 1.0f;
+    *lo = lf < 0.0f ? 0 : (lf > (float)n_out ? n_out : (int)lf);
+    *hi = hf > (float)(n_out - 1) ? n_out - 1 : (hf < -1.0f ? -1 : (int)hf);
+}
+
+// dx [B,H,W,C] from dy [B,OH,OW,P*C]; axis-aligned thetas only.
+// One workgroup per input row (b, yy), a lane per (xx, 8 channels).  Per part the sample coordinates ix(ow) / iy(oh) -- evaluated with
+// exactly the forward's expressions -- are tabulated in LDS once per workgroup, and so is the window of output rows that can reach
+// row yy together with their row weights: the lanes' loops hold one table read, the tent weight and one independent 16-byte load per
+// candidate (no branch inside: a candidate outside the tent gets weight 0, which adds an exact zero), round 6: the first version
+// recomputed coordinates and window bounds (two float divisions per part) in every lane and serialised its loads behind `continue`s
+// -- 323 us for a 302 MB read.
+template <typename T>
+__global__ __launch_bounds__(1024) void stn_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ theta,
+                                                       int B, int H, int W, int C, int P, int OH, int OW, int align,
+                                                       T* __restrict__ dx)
+{
+    extern __shared__ float stn_smem[];
+    float* const sIx = stn_smem;                                    // [P][OW]
+    float* const sWy = sIx + P * OW;                                // [P][OH]: weight of output row oh on input row yy (0: out of reach)
+    float* const sXa = sWy + P * OH;                                // [P][2]: ix(ow) = x_at0 + (x_at1 - x_at0) * ow, as (slope, offset)
+    int* const sOh = reinterpret_cast<int*>(sXa + 2 * P);           // [P][2]: first / last output row with a non-zero weight
+    const int b = (int)blockIdx.x / H, yy = (int)blockIdx.x - b * H;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const float* const thb = theta + (size_t)b * P * 6;
+    for (int i = t; i < P * OW; i += nt) {
+        const int p = i / OW, ow = i - p * OW;
+        sIx[i] = unnorm_coord(thb[p * 6 + 0] * norm_coord(ow, OW, align) + thb[p * 6 + 2], W, align);
+    }
+    for (int i = t; i < P * OH; i += nt) {
+        const int p = i / OH, oh = i - p * OH;
+        const float iy = unnorm_coord(thb[p * 6 + 4] * norm_coord(oh, OH, align) + thb[p * 6 + 5], H, align);
+        // bilinear corner weights as the forward computes them (floor-based), so that the gradient matches the forward bit pattern
+        const float fy = floorf(iy);
+        sWy[i] = (int)fy == yy ? 1.0f - (iy - fy) : ((int)fy + 1 == yy ? iy - fy : 0.0f);
+    }
+    for (int p = t; p < P; p += nt) {
+        const float x_at0 = unnorm_coord(thb[p * 6 + 0] * norm_coord(0, OW, align) + thb[p * 6 + 2], W, align);
+        const float x_at1 = unnorm_coord(thb[p * 6 + 0] * norm_coord(OW > 1 ? 1 : 0, OW, align) + thb[p * 6 + 2], W, align);
+        const float y_at0 = unnorm_coord(thb[p * 6 + 4] * norm_coord(0, OH, align) + thb[p * 6 + 5], H, align);
+        const float y_at1 = unnorm_coord(thb[p * 6 + 4] * norm_coord(OH > 1 ? 1 : 0, OH, align) + thb[p * 6 + 5], H, align);
+        sXa[2 * p] = x_at1 - x_at0; sXa[2 * p + 1] = x_at0;
+        int oh0, oh1;
+        reach(y_at1 - y_at0, y_at0, (float)yy, OH, &oh0, &oh1);
+        sOh[2 * p] = oh0; sOh[2 * p + 1] = oh1;
+    }
+    __syncthreads();
+    const int CV = C / 8;
+    const size_t PCs = (size_t)P * C;
+    for (int i = t; i < W * CV; i += nt) {
+        const int xx = i / CV, cv = i - xx * CV;
+        V8 acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const int oh0 = sOh[2 * p], oh1 = sOh[2 * p + 1];      // (workgroup-uniform)
+            if (oh0 > oh1) continue;
+            int ow0, ow1;
+            reach(sXa[2 * p], sXa[2 * p + 1], (float)xx, OW, &ow0, &ow1);
+            const float* const ixp = sIx + p * OW;
+            for (int oh = oh0; oh <= oh1; ++oh) {
+                const float wy = sWy[p * OH + oh];
+                if (wy == 0.0f) continue;                           // (uniform: the same row for every lane)
+                const T* const drow = dy + (((size_t)b * OH + oh) * OW) * PCs + (size_t)p * C + cv * 8;
+#pragma unroll 4
+                for (int ow = ow0; ow <= ow1; ++ow) {
+                    const float ix = ixp[ow];
+                    const float fx = floorf(ix);
+                    const float wx = (int)fx == xx ? 1.0f - (ix - fx) : ((int)fx + 1 == xx ? ix - fx : 0.0f);
+                    const float w = wy * wx;
+                    const V8 g = load8(drow + (size_t)ow * PCs);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.v[j] += w * g.v[j];
+                }
+            }
+        }
+        store8(dx + (((size_t)b * H + yy) * W + xx) * C + cv * 8, acc);
+    }
+}
+
+// ---- the round-1 kernels (grid-stride, one item per lane with 64-bit index arithmetic), kept selectable for A-B timing: DANET_STN_V1=1
+// x [B,H,W,C] (T = bf16 or fp32), theta [B,P,2,3] f32 -> y [B,OH,OW,P*C].  C % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void stn_fwd_kernel_v1(const T* __restrict__ x, const float* __restrict__ theta,
                                                       int B, int H, int W, int C, int P, int OH, int OW, int align,
                                                       T* __restrict__ y)
 {
@@ -94,23 +239,9 @@ __global__ __launch_bounds__(256) void stn_fwd_kernel(const T* __restrict__ x, c
     }
 }
 
-// range of output indices o in [0,n_out) with |a*o + b0 - target| < 1
-__device__ inline void reach(float a, float b0, float target, int n_out, int* lo, int* hi) {
-    if (fabsf(a) < 1e-12f) {
-        if (fabsf(b0 - target) < 1.0f) { *lo = 0; *hi = n_out - 1; } else { *lo = 1; *hi = 0; }
-        return;
-    }
-    float l = (target - 1.0f - b0) / a, h = (target + 1.0f - b0) / a;
-    if (l > h) { const float t = l; l = h; h = t; }
-    // one-index slack on both sides; the tent weight zeroes anything outside
-    const float lf = floorf(l) - 1.0f, hf = ceilf(h) + 1.0f;
-    *lo = lf < 0.0f ? 0 : (lf > (float)n_out ? n_out : (int)lf);
-    *hi = hf > (float)(n_out - 1) ? n_out - 1 : (hf < -1.0f ? -1 : (int)hf);
-}
-
 // dx [B,H,W,C] from dy [B,OH,OW,P*C]; axis-aligned thetas only.
 template <typename T>
-__global__ __launch_bounds__(256) void stn_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ theta,
+__global__ __launch_bounds__(256) void stn_bwd_kernel_v1(const T* __restrict__ dy, const float* __restrict__ theta,
                                                       int B, int H, int W, int C, int P, int OH, int OW, int align,
                                                       T* __restrict__ dx)
 {
@@ -170,9 +301,16 @@ int stn_forward(const void* x, const float* theta, int B, int H, int W, int C, i
     DANET_ENTER();
     DANET_CHECK_ARG(x && theta && y && B > 0 && H > 0 && W > 0 && P > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0,
                     "stn_gather_forward: bad arguments (C=%d must be a multiple of 8)", C);
-    const long total = (long)B * OH * OW * P * (C / 8);
-    long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(stn_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+    static const bool v1 = getenv("DANET_STN_V1") != nullptr && atoi(getenv("DANET_STN_V1")) != 0;
+    if (v1) {
+        const long total = (long)B * OH * OW * P * (C / 8);
+        long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(stn_fwd_kernel_v1<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, theta, B, H, W, C, P, OH, OW, align_corners, (T*)y);
+        DANET_CHECK_LAUNCH("stn_fwd_kernel_v1");
+        return DANET_OK;
+    }
+    DANET_CHECK_ARG((long)OW * P * (C / 8) < (1L << 20) && P * 6 * 4 <= 48 * 1024, "stn_gather_forward: row of %d x %d x %d items is too long", OW, P, C / 8);
+    hipLaunchKernelGGL(stn_fwd_kernel<T>, dim3((unsigned)(B * OH)), dim3(256), (size_t)P * 6 * sizeof(float), (hipStream_t)stream, (const T*)x,
                        theta, B, H, W, C, P, OH, OW, align_corners, (T*)y);
     DANET_CHECK_LAUNCH("stn_fwd_kernel");
     return DANET_OK;
@@ -184,9 +322,19 @@ int stn_backward(const void* dy, const float* theta, int B, int H, int W, int C,
     DANET_ENTER();
     DANET_CHECK_ARG(dy && theta && dx && B > 0 && H > 0 && W > 0 && P > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0,
                     "stn_gather_backward: bad arguments");
-    const long total = (long)B * H * W * (C / 8);
-    long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(stn_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+    static const bool v1 = getenv("DANET_STN_V1") != nullptr && atoi(getenv("DANET_STN_V1")) != 0;
+    if (v1) {
+        const long total = (long)B * H * W * (C / 8);
+        long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(stn_bwd_kernel_v1<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, theta, B, H, W, C, P, OH, OW, align_corners, (T*)dx);
+        DANET_CHECK_LAUNCH("stn_bwd_kernel_v1");
+        return DANET_OK;
+    }
+    const size_t lds = ((size_t)P * OW + (size_t)P * OH + 4 * (size_t)P) * sizeof(float);
+    DANET_CHECK_ARG(lds <= 60 * 1024, "stn_gather_backward: %d parts x %d x %d outputs do not fit the coordinate tables", P, OH, OW);
+    int threads = (W * (C / 8) + 63) / 64 * 64;                     // a lane per (xx, 8 channels) of the row, whole waves, <= 1024
+    if (threads > 1024) threads = 1024;
+    hipLaunchKernelGGL(stn_bwd_kernel<T>, dim3((unsigned)(B * H)), dim3((unsigned)threads), lds, (hipStream_t)stream, (const T*)dy,
                        theta, B, H, W, C, P, OH, OW, align_corners, (T*)dx);
     DANET_CHECK_LAUNCH("stn_bwd_kernel");
     return DANET_OK;

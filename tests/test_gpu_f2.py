@@ -6,7 +6,9 @@ The file is what /root/reference/utils/saver.py:24-70 writes and /root/reference
 Its parameters are the closed-form `formula_tensor` of each key -- the same values the reference itself was run with when
 tests/golden/make_golden.py produced g7 (IUV_Estimator, train mode) and g17 (the whole inference path danet.py:61-131 in eval mode),
 so what comes out of `checkpoint.load_pretrained` + `DaNet.infer_net` is compared with the REFERENCE's own results.  Tolerances are
-the fp32 mode's (conv.precision('fp32'), the reference's arithmetic type): 1e-3 of scale on maps, 2e-3 abs on para."""
+the fp32 mode's (conv.precision('fp32'), the reference's arithmetic type), set from the measured errors (gpurun_out/parity_measured.jsonl
+-> profiles/r06_parity_measured.jsonl: maps 1.1e-6 .. 1.5e-6 of scale, STN centres 1.8e-7, para 1.2e-7, no arg-max flip): 2e-5 of scale on
+maps, 2e-6 on the centres, 5e-6 abs on para; the bf16 production path from the same file: para within 5e-3 (measured 2.5e-4)."""
 import os
 import sys
 
@@ -101,11 +103,11 @@ def test_reference_layout_checkpoint_drives_infer_net_to_the_reference_result(lo
     for a, k in zip(uv['uvia_pred'], ('u_raw', None, 'index_raw', 'ann_raw')):
         if k:
             errs[k] = _rel(a, g[k])
-            assert errs[k] < 1e-3, (k, errs[k])
+            assert errs[k] < 2e-5, (k, errs[k])
     errs['stn_kps_pred'] = float(np.abs(uv['stn_kps_pred'].cpu().numpy() - g['stn_kps_pred']).max())
-    assert errs['stn_kps_pred'] < 1e-4
+    assert errs['stn_kps_pred'] < 2e-6
     errs['part_iuv_pred'] = _rel(uv['part_iuv_pred'][:, ::6], g['part_iuv_pred'])
-    assert errs['part_iuv_pred'] < 1e-3
+    assert errs['part_iuv_pred'] < 2e-5
     # the cleaned part-index plane (integer work, danet.py:84 -> utils/iuvmap.py:6-38): equal wherever the reference's own top-2
     # logits are further apart than the raw maps' measured error (elsewhere the arg-max is not defined at fp32 resolution)
     idx = rd['visualization']['iuv_pred'][2].argmax(1).cpu().numpy().astype(np.uint8)
@@ -118,13 +120,13 @@ def test_reference_layout_checkpoint_drives_infer_net_to_the_reference_result(lo
     para = rd['para']
     assert para.shape == (2, 229)
     errs['para'] = float(np.abs(para.cpu().numpy() - g['para']).max())
-    assert errs['para'] < 2e-3, errs
+    assert errs['para'] < 5e-6, errs
     record('f2_infer_net_fp32_vs_reference', errs)
     # the bf16 production path from the same file: the regressor's output stays close (random-weight-net noise bound of test_gpu_models)
     rb = model.infer_net(img)['para']
     eb = float(np.abs(rb.cpu().numpy() - g['para']).max())
     record('f2_infer_net_bf16_vs_reference', {'para': eb})
-    assert torch.isfinite(rb).all() and eb < 0.25, eb
+    assert torch.isfinite(rb).all() and eb < 5e-3, eb
     rot = rb[:, 13:].reshape(-1, 3, 3)
     assert (torch.bmm(rot, rot.transpose(1, 2)) - torch.eye(3, device='cuda')).abs().max() < 1e-4
 
@@ -153,9 +155,10 @@ def test_reference_layout_checkpoint_drives_the_estimator_to_golden_g7(loaded, a
         # train mode moved the running statistics: restore them from the file so the module-scoped model stays what the file says
         from danet_densepose2smpl_amd import checkpoint
         checkpoint.load_pretrained(model, path)
-    for a, k in zip(rd['uvia_pred'], ('u', 'v', 'index', 'ann')):
-        assert _rel(a, g[k]) < 1e-3, (k, _rel(a, g[k]))
-    assert _rel(rd['part_iuv_pred'], g['part_iuv_pred']) < 1e-3
+    meas = {k: _rel(a, g[k]) for a, k in zip(rd['uvia_pred'], ('u', 'v', 'index', 'ann'))}
+    meas['part_iuv_pred'] = _rel(rd['part_iuv_pred'], g['part_iuv_pred'])
+    record('f2_estimator_from_file_fp32_vs_g7', meas)
+    assert max(meas.values()) < 1e-3, meas
     for k in g.files:
         if k.startswith('loss__'):
             ours, ref = float(rd['losses'][k[6:]].detach().sum()), float(g[k].sum())

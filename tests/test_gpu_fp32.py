@@ -12,12 +12,16 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, GOLDEN
+from conftest import golden, GOLDEN, record
 sys.path.insert(0, GOLDEN)
 from make_golden import formula_params, formula_input, damp_residual_branches    # noqa: E402
 
 pytestmark = pytest.mark.gpu
 KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
+# whole-network outputs in fp32 mode against the reference's fp32 goldens, as a fraction of the output scale (set from the errors
+# measured on MI355X, profiles/r06_parity_measured.jsonl; SURVEY 8c's 1e-4 ABS is below the reference's own fp32 rounding noise on
+# these nets, see test_hrnet_fp32_vs_reference_golden_at_the_benched_resolution)
+FP32_NET_TOL = 1e-4    # measured: HRNet g6 3.4e-5, estimator g7 3.1e-5, PoseResNet g6 1.0e-5, predictor g9 9.4e-6
 
 
 def _cfg(**kw):
@@ -173,9 +177,10 @@ def test_fp32_conv_transpose_vs_torch():
     from danet_densepose2smpl_amd import conv
     from danet_densepose2smpl_amd.deconv import ConvTranspose2d
     torch.manual_seed(3)
-    for (cin, cout, k, pad, op) in ((64, 32, 4, 1, 0), (32, 48, 3, 1, 1)):
+    # (2048 -> 256: PoseResNet's first deconv, res_module.py:169-194 -- K = 16 taps x 2048 channels needs a 64 KB tap table in LDS)
+    for (cin, cout, k, pad, op) in ((64, 32, 4, 1, 0), (32, 48, 3, 1, 1), (2048, 256, 4, 1, 0)):
         m = ConvTranspose2d(cin, cout, k, 2, pad, op, bias=True).cuda()
-        x = torch.randn(2, cin, 6, 5, device='cuda')
+        x = torch.randn(2, cin, 6, 5, device='cuda') if cin < 2048 else torch.randn(4, cin, 2, 2, device='cuda')
         xs = [x.clone().requires_grad_(True) for _ in range(2)]
         yr = F.conv_transpose2d(xs[0], m.weight, m.bias, 2, pad, op)
         gy = torch.randn_like(yr)
@@ -203,9 +208,12 @@ def test_backbones_fp32_vs_reference_golden(name, cls):
     # so this comparison no longer needs the one-workgroup-per-tensor configuration it used to run in)
     with conv.precision('fp32'):
         out = net(img)
+        meas = {}
         for k in KEYS:
             o = out[k] if (k != 'xd' or cls == 'hrnet') else out[k][:, ::4]
-            assert o.dtype == torch.float32 and _rel(o, g[k]) < 1e-3, (k, _rel(o, g[k]))
+            meas[k] = _rel(o, g[k])
+            assert o.dtype == torch.float32 and meas[k] < FP32_NET_TOL, (k, meas[k])
+        record('fp32_mode_%s_vs_reference' % name, meas)
         loss = sum((out[k].float() * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32, device='cuda').view_as(out[k]) * 0.37)).sum() for k in KEYS[:5])
         loss.backward()
     gw = {k: p.grad for k, p in net.named_parameters()}
@@ -224,8 +232,9 @@ def test_hrnet_fp32_vs_reference_golden_at_the_benched_resolution():
     """g16 (round-5 review item 5): the reference's PoseHighResolutionNet at 256 x 256 / B = 2 / train-mode BatchNorm, expected
     values from the reference evaluated in DOUBLE precision.  The fixture records the error of the reference's OWN fp32 run against
     them (`floor__*`: 1.8e-4 .. 2.3e-4 max abs at output scale ~11 = 1.7e-5 of scale): SURVEY 8c's "1e-4 abs" for torch-only blocks is
-    below the reference's own rounding noise on this 90-layer net, so the bound here is 4 x that measured floor (~8e-4 abs, 7e-5 of
-    scale -- 14 x tighter than the 1e-3 of scale the 64 x 64 fixtures are held to).  Every pixel is covered by the per-channel means."""
+    below the reference's own rounding noise on this 90-layer net, so the bound here is 2.5 x that measured floor (~5e-4 abs, 4.5e-5 of
+    scale -- 20 x tighter than the 1e-3 of scale the 64 x 64 fixtures are held to; measured on MI355X: 1.4 .. 1.8 x the floor, per-channel
+    means within 7e-6, profiles/r06_parity_measured.jsonl).  Every pixel is covered by the per-channel means."""
     _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
     from danet_densepose2smpl_amd import hrnet, conv
     from conftest import record
@@ -244,8 +253,8 @@ def test_hrnet_fp32_vs_reference_golden_at_the_benched_resolution():
         meas[k] = {'max_abs': e, 'mean_abs': em, 'reference_fp32_floor': float(g['floor__' + k]), 'scale': float(g['scale__' + k])}
     record('hrnet256_fp32_mode_vs_reference_fp64', meas)
     for k in KEYS:
-        tol = 4.0 * float(g['floor__' + k])
-        assert meas[k]['max_abs'] <= tol and meas[k]['mean_abs'] <= tol, (k, meas[k], tol)
+        tol = 2.5 * float(g['floor__' + k])
+        assert meas[k]['max_abs'] <= tol and meas[k]['mean_abs'] <= 0.2 * tol, (k, meas[k], tol)
     assert np.abs(net.bn1.running_mean.cpu().numpy() - g['bn1_running_mean']).max() < 1e-6
     assert np.abs(net.bn2.running_var.cpu().numpy() / g['bn2_running_var'] - 1).max() < 1e-5
 
@@ -266,10 +275,12 @@ def test_iuv_estimator_fp32_vs_reference_golden(align):
     t = lambda k: torch.from_numpy(g[k]).cuda()
     with conv.precision('fp32'):
         rd = est(t('img'), t('iuv_gt'), t('kps'), has_iuv=torch.ones(2, device='cuda'))
-    for a, k in zip(rd['uvia_pred'], ('u', 'v', 'index', 'ann')):
-        assert _rel(a, g[k]) < 1e-3, (k, _rel(a, g[k]))
-    assert np.abs(rd['stn_kps_pred'].cpu().numpy() - g['stn_kps_pred']).max() < 1e-4
-    assert _rel(rd['part_iuv_pred'], g['part_iuv_pred']) < 1e-3
+    meas = {k: _rel(a, g[k]) for a, k in zip(rd['uvia_pred'], ('u', 'v', 'index', 'ann'))}
+    meas['stn_kps_pred_abs'] = float(np.abs(rd['stn_kps_pred'].cpu().numpy() - g['stn_kps_pred']).max())
+    meas['part_iuv_pred'] = _rel(rd['part_iuv_pred'], g['part_iuv_pred'])
+    record('fp32_mode_g7_align%d_vs_reference' % align, meas)
+    assert all(meas[k] < FP32_NET_TOL for k in ('u', 'v', 'index', 'ann', 'part_iuv_pred')), meas
+    assert meas['stn_kps_pred_abs'] < 1e-4
     assert np.abs(rd['part_iuv_gt'].cpu().numpy() - g['part_iuv_gt']).max() < 1e-4
     n = 0
     for k in g.files:
@@ -294,13 +305,15 @@ def test_decomposed_predictor_fp32_vs_reference_golden():
     with conv.precision('fp32'):
         net.train()
         rd = net(iuv, part)
-        assert np.abs(rd['para'].detach().cpu().numpy() - g['para_train']).max() < 1e-3
-        assert _rel(rd['joint_position'][0], g['jp0']) < 1e-3 and _rel(rd['joint_position'][1], g['jp1']) < 1e-3
-        assert np.abs(rd['joint_rotation'][0].detach().cpu().numpy() - g['jr0']).max() < 1e-3
+        meas = {'para_train_abs': float(np.abs(rd['para'].detach().cpu().numpy() - g['para_train']).max()),
+                'jp0': _rel(rd['joint_position'][0], g['jp0']), 'jp1': _rel(rd['joint_position'][1], g['jp1']),
+                'jr0_abs': float(np.abs(rd['joint_rotation'][0].detach().cpu().numpy() - g['jr0']).max())}
         net.eval()
         with torch.no_grad():
             pe = net(iuv, part)['para']
-    assert np.abs(pe.cpu().numpy() - g['para_eval']).max() < 1e-3
+    meas['para_eval_abs'] = float(np.abs(pe.cpu().numpy() - g['para_eval']).max())
+    record('fp32_mode_g9_predictor_vs_reference', meas)
+    assert max(meas.values()) < FP32_NET_TOL, meas
 
 
 def test_train_step_runs_in_fp32_mode_and_agrees_with_bf16():
