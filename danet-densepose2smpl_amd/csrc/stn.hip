@@ -138,6 +138,7 @@ __global__ __launch_bounds__(1024) void stn_bwd_kernel(const T* __restrict__ dy,
     float* const sWy = sIx + P * OW;                                // [P][OH]: weight of output row oh on input row yy (0: out of reach)
     float* const sXa = sWy + P * OH;                                // [P][2]: ix(ow) = x_at0 + (x_at1 - x_at0) * ow, as (slope, offset)
     int* const sOh = reinterpret_cast<int*>(sXa + 2 * P);           // [P][2]: first / last output row with a non-zero weight
+    int* const sOw = sOh + 2 * P;                                   // [P][W]: first | last << 16 output column with a non-zero weight on input column xx
     const int b = (int)blockIdx.x / H, yy = (int)blockIdx.x - b * H;
     const int t = threadIdx.x, nt = blockDim.x;
     const float* const thb = theta + (size_t)b * P * 6;
@@ -163,6 +164,19 @@ __global__ __launch_bounds__(1024) void stn_bwd_kernel(const T* __restrict__ dy,
         sOh[2 * p] = oh0; sOh[2 * p + 1] = oh1;
     }
     __syncthreads();
+    // exact column windows (the same for every row of image b; recomputed per workgroup: 1 536 short scans): reach() brackets the
+    // candidates with slack, the tent test of the forward's floor-based weights trims them -- ix(ow) is monotone, the set is contiguous
+    for (int i = t; i < P * W; i += nt) {
+        const int p = i / W, xx = i - p * W;
+        int lo, hi;
+        reach(sXa[2 * p], sXa[2 * p + 1], (float)xx, OW, &lo, &hi);
+        const float* const ixp = sIx + p * OW;
+        auto hit = [&](int ow) { const int f = (int)floorf(ixp[ow]); return f == xx || f + 1 == xx; };
+        while (lo <= hi && !hit(lo)) ++lo;
+        while (hi >= lo && !hit(hi)) --hi;
+        sOw[i] = lo <= hi ? (lo | (hi << 16)) : (1 | (0 << 16));
+    }
+    __syncthreads();
     const int CV = C / 8;
     const size_t PCs = (size_t)P * C;
     for (int i = t; i < W * CV; i += nt) {
@@ -173,22 +187,31 @@ __global__ __launch_bounds__(1024) void stn_bwd_kernel(const T* __restrict__ dy,
         for (int p = 0; p < P; ++p) {
             const int oh0 = sOh[2 * p], oh1 = sOh[2 * p + 1];      // (workgroup-uniform)
             if (oh0 > oh1) continue;
-            int ow0, ow1;
-            reach(sXa[2 * p], sXa[2 * p + 1], (float)xx, OW, &ow0, &ow1);
+            const int oww = sOw[p * W + xx];
+            const int ow0 = oww & 0xffff, ow1 = oww >> 16;
             const float* const ixp = sIx + p * OW;
             for (int oh = oh0; oh <= oh1; ++oh) {
                 const float wy = sWy[p * OH + oh];
                 if (wy == 0.0f) continue;                           // (uniform: the same row for every lane)
                 const T* const drow = dy + (((size_t)b * OH + oh) * OW) * PCs + (size_t)p * C + cv * 8;
-#pragma unroll 4
-                for (int ow = ow0; ow <= ow1; ++ow) {
-                    const float ix = ixp[ow];
-                    const float fx = floorf(ix);
-                    const float wx = (int)fx == xx ? 1.0f - (ix - fx) : ((int)fx + 1 == xx ? ix - fx : 0.0f);
-                    const float w = wy * wx;
-                    const V8 g = load8(drow + (size_t)ow * PCs);
+                // four candidates at a time, their loads in flight together (a window is 2 / scale + 1 columns: mostly ONE group);
+                // a slot past the window reads the window's last column with weight 0 (adds an exact zero)
+                for (int ow = ow0; ow <= ow1; ow += 4) {
+                    V8 g[4];
+                    float w[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc.v[j] += w * g.v[j];
+                    for (int k = 0; k < 4; ++k) {
+                        const int o = ow + k <= ow1 ? ow + k : ow1;
+                        const float ix = ixp[o];
+                        const float fx = floorf(ix);
+                        const float wx = (int)fx == xx ? 1.0f - (ix - fx) : ((int)fx + 1 == xx ? ix - fx : 0.0f);
+                        w[k] = ow + k <= ow1 ? wy * wx : 0.0f;
+                        g[k] = load8(drow + (size_t)o * PCs);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc.v[j] += w[k] * g[k].v[j];
                 }
             }
         }
@@ -330,8 +353,8 @@ int stn_backward(const void* dy, const float* theta, int B, int H, int W, int C,
         DANET_CHECK_LAUNCH("stn_bwd_kernel_v1");
         return DANET_OK;
     }
-    const size_t lds = ((size_t)P * OW + (size_t)P * OH + 4 * (size_t)P) * sizeof(float);
-    DANET_CHECK_ARG(lds <= 60 * 1024, "stn_gather_backward: %d parts x %d x %d outputs do not fit the coordinate tables", P, OH, OW);
+    const size_t lds = ((size_t)P * OW + (size_t)P * OH + 4 * (size_t)P + (size_t)P * W) * sizeof(float);
+    DANET_CHECK_ARG(lds <= 60 * 1024 && OW < 32768, "stn_gather_backward: %d parts x %d x %d outputs do not fit the coordinate tables", P, OH, OW);
     int threads = (W * (C / 8) + 63) / 64 * 64;                     // a lane per (xx, 8 channels) of the row, whole waves, <= 1024
     if (threads > 1024) threads = 1024;
     hipLaunchKernelGGL(stn_bwd_kernel<T>, dim3((unsigned)(B * H)), dim3((unsigned)threads), lds, (hipStream_t)stream, (const T*)dy,

@@ -69,17 +69,21 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+from danet_densepose2smpl_amd import _lib                    # noqa: E402
+from danet_densepose2smpl_amd._lib import ptr, check, stream    # noqa: E402
+L = _lib.lib()
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, C, H, H, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+x = torch.randn(B, H, H, C, generator=g).to(dev).bfloat16().contiguous()           # NHWC
+y = torch.empty(B, H, H, P * C, dtype=torch.bfloat16, device=dev)
+gy = torch.randn(B, H, H, P * C, generator=g).to(dev).bfloat16().contiguous()
+dx = torch.empty_like(x)
 tag = 'v1' if os.environ.get('DANET_STN_V1', '0') not in ('', '0') else 'round 6'
 for nm, th in (('thetas of the benched step', step_thetas()), ('spread thetas', spread_thetas())):
     th = th.reshape(B, P, 2, 3).float().contiguous()
     sc = th[:, :, 0, 0]
-    xr = x.clone().requires_grad_(True)
-    y = dnn.stn_gather(xr, th, align_corners=True)
-    gy = torch.randn_like(y)
-    t_f = timed(lambda: dnn.stn_gather(x, th, align_corners=True))
-    t_fb = timed(lambda: torch.autograd.grad(dnn.stn_gather(xr, th, align_corners=True), xr, gy))
+    fwd = lambda: check(L.danet_stn_gather_forward(ptr(x), ptr(th), B, H, H, C, P, H, H, 1, ptr(y), stream()), 'fwd')     # noqa: E731
+    bwd = lambda: check(L.danet_stn_gather_backward(ptr(gy), ptr(th), B, H, H, C, P, H, H, 1, ptr(dx), stream()), 'bwd')   # noqa: E731
+    t_f, t_b = timed(fwd), timed(bwd)
     mb = y.numel() * 2 / 1e6
-    print('[%s] %s (scale min %.3f median %.3f max %.3f): forward %.1f us (%.2f TB/s written), backward %.1f us (%.2f TB/s read)' %
-          (tag, nm, float(sc.min()), float(sc.median()), float(sc.max()), t_f, mb / t_f, t_fb - t_f, mb / max(t_fb - t_f, 1e-9)))
+    print('[%s] %s (scale min %.3f median %.3f max %.3f): forward %.1f us (%.2f TB/s written), backward %.1f us (%.2f TB/s read)  dx checksum %.6g' %
+          (tag, nm, float(sc.min()), float(sc.median()), float(sc.max()), t_f, mb / t_f, t_b, mb / t_b, float(dx.float().abs().sum())))
