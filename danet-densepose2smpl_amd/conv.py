@@ -734,8 +734,14 @@ def flush_wgrads(bucket=None, hold=None):
     import ctypes
     L = _lib.lib()
 
+    if bucket is not None and not isinstance(bucket, int):
+        bucket = frozenset(bucket)                          # a run of buckets released together (GradStore.release_ready_group)
+
     def mine(q):
-        return bucket is None or GRAD_STORE is None or GRAD_STORE.bucket_of.get(id(q[1]), -1) == bucket
+        if bucket is None or GRAD_STORE is None:
+            return True
+        b = GRAD_STORE.bucket_of.get(id(q[1]), -1)
+        return b == bucket if isinstance(bucket, int) else b in bucket
     # (channel-padded layers -- post is not None -- go out in launches of their own: the multi-problem planners deal a fixed number of
     # workgroups over the jobs of a call, and a dozen tiny layers in the same call took workgroups away from every other launch: +0.3 ms)
     for wq in ([q for q in _WQ if mine(q) and q[-1] is None], [q for q in _WQ if mine(q) and q[-1] is not None]):

@@ -540,7 +540,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMulti m)
 // not started -- and launches of this kernel never overlap each other (the caller issues them on ONE stream).  The spin
 // is bounded: if the barrier is not met in time the launch sets an error flag instead of hanging (results are then
 // garbage; bar[2] reports it).
-constexpr int OP_NV = 10;             // rows (8-byte channel vectors of dy and x) per lane held in registers ...
+constexpr int OP_NV = 10;             // rows (8-byte channel vectors of dy and x) per lane held in registers: the instantiation for the whole device ...
+constexpr int OP_NV_BIG = 14;         // ... and the one a smaller co-residency budget asks for (177 instead of 128 registers; its four extra row slots cost a
+                                      // full-size launch ~1.5 us when they are not needed, so the planner only picks it when it saves a launch)
 constexpr int OP_NL = 15;             // ... and in the lane's private LDS slots (17 bytes per row: 64 KB per workgroup; with the 12 KB of
                                       // reduction scratch two workgroups fit a CU's 160 KB)
 #ifndef DANET_OP_CH
@@ -548,7 +550,7 @@ constexpr int OP_NL = 15;             // ... and in the lane's private LDS slots
 #endif
 constexpr int OP_CH = DANET_OP_CH;              // LDS rows loaded per batch
 static_assert(OP_NL % OP_CH == 0, "OP_NL");
-constexpr int OP_ROWS = OP_NV + OP_NL;
+constexpr int OP_ROWS = OP_NV + OP_NL, OP_ROWS_BIG = OP_NV_BIG + OP_NL;     // 25 / 29 rows per lane
 constexpr int OP_MAX_BLOCKS = 512;    // 2 workgroups per CU (<= 256 VGPRs each)
 
 using danet::grid_barrier;
@@ -581,8 +583,9 @@ __device__ inline void reduce_replicas_sc1(const bn_acc_t* __restrict__ rep, int
     __syncthreads();
 }
 
-struct BnOnePass { BnBwdOne a[NBM]; int start[NBM + 1]; int n; unsigned* bar; int dbg; };
+struct BnOnePass { BnBwdOne a[NBM]; int start[NBM + 1]; int n; unsigned* bar; int dbg; int big; };
 
+template <int NV>
 __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
 {
     int ji = 0;
@@ -605,13 +608,13 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     // ---- phase 0: everything this lane owns goes into registers (independent loads, all in flight)
     // (no branches inside the unrolled loops: wave-uniform options become selects / out-of-range offsets, otherwise
     // the loops split into ~100 basic blocks and the register allocator spills)
-    i32x2 gq[OP_NV], xq[OP_NV];
-    unsigned gate[(OP_NV + 7) / 8];                // 4 gate bits per row, 8 rows per register
+    i32x2 gq[NV], xq[NV];
+    unsigned gate[(NV + 7) / 8];                // 4 gate bits per row, 8 rows per register
 #pragma unroll
-    for (int w = 0; w < (OP_NV + 7) / 8; ++w) gate[w] = 0u;
+    for (int w = 0; w < (NV + 7) / 8; ++w) gate[w] = 0u;
     const bool use_mask = a.relu && a.mask_mode == 1, recompute = a.relu && a.mask_mode == 2;
 #pragma unroll
-    for (int k = 0; k < OP_NV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int off = live ? it.offset(k) : OOB;
         gq[k] = __builtin_amdgcn_raw_buffer_load_b64(gr, off, 0, 0);
         xq[k] = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
         int tm[OP_CH];
 #pragma unroll
         for (int u = 0; u < OP_CH; ++u) {
-            const int off = live ? it.offset(OP_NV + l0 + u) : OOB;
+            const int off = live ? it.offset(NV + l0 + u) : OOB;
             tg[u] = __builtin_amdgcn_raw_buffer_load_b64(gr, off, 0, 0);
             tx[u] = __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0);
             tm[u] = ldmask(mr, use_mask ? off : OOB);
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
 #pragma unroll
     for (int j = 0; j < VW; ++j) { s1.v[j] = 0.f; s2.v[j] = 0.f; }
 #pragma unroll
-    for (int k = 0; k < OP_NV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         float g[VW], x[VW];
         unpack(gq[k], g); unpack(xq[k], x);
         unsigned bits = 0;
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     // the packed registers cross the barrier as they are: without this the compiler keeps the UNPACKED floats of phase 1
     // alive for phase 2 (14 instead of 4 registers per row)
 #pragma unroll
-    for (int k = 0; k < OP_NV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         int q0 = gq[k].x, q1 = gq[k].y, q2 = xq[k].x, q3 = xq[k].y;
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
         gq[k].x = q0; gq[k].y = q1; xq[k].x = q2; xq[k].y = q3;
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
         if (bid == 0 && t < fm.CV && a.dparam) { a.dparam[c0 + j] = q0; a.dparam[C + c0 + j] = q1; }
     }
 #pragma unroll
-    for (int k = 0; k < OP_NV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int off = it.offset(k);
         float g[VW], x[VW];
         unpack(gq[k], g); unpack(xq[k], x);
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     }
 #pragma unroll 2
     for (int l = 0; l < OP_NL; ++l) {
-        const int off = it.offset(OP_NV + l);
+        const int off = it.offset(NV + l);
         const uint4 rw = sRow[l][t];
         float g[VW], x[VW];
         unpack(i32x2{(int)rw.x, (int)rw.y}, g); unpack(i32x2{(int)rw.z, (int)rw.w}, x);
@@ -1239,7 +1242,23 @@ static int onepass_max_blocks() {
 // cap (> 0): the caller's co-residency budget -- fewer workgroups than the device could hold when other kernels may occupy
 // compute units while these launches run (a data-parallel trainer reserves the communication library's channels, see
 // danet_hip.h); <= 0: the whole device.
+static int onepass_plan_rows(const BnBwdJob* jobs, int n, BnOnePass* ms, int cap, int rows_per_lane);
+// Rows per lane: 25 (OP_ROWS, bn_bwd_onepass_kernel<OP_NV>) unless the 29-row instantiation packs the set into FEWER launches: on the whole
+// device the four-branch level is 489 workgroups at 25 rows -- one launch --; beside a data-parallel trainer's 24 communication channels
+// the budget is 464 workgroups, which 25 rows would split in two and 29 rows fit in one (422 workgroups; round 6: -0.26 ms/step on the
+// N > 1 path, the single-process step untouched).
 static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */, int cap) {
+    BnOnePass alt[NBM];
+    const int nl_small = onepass_plan_rows(jobs, n, alt, cap, OP_ROWS);
+    const int nl_big = onepass_plan_rows(jobs, n, ms, cap, OP_ROWS_BIG);
+    if (nl_small > 0 && (nl_big == 0 || nl_small <= nl_big)) {
+        for (int l = 0; l < nl_small; ++l) { ms[l] = alt[l]; ms[l].big = 0; }
+        return nl_small;
+    }
+    for (int l = 0; l < nl_big; ++l) ms[l].big = 1;
+    return nl_big;
+}
+static int onepass_plan_rows(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */, int cap, int rows_per_lane) {
     if (!jobs || n < 1 || n > NBM || getenv("DANET_NO_BN_ONEPASS")) return 0;
     int max_blocks = onepass_max_blocks();
     if (cap > 0 && cap < max_blocks) max_blocks = cap;
@@ -1253,9 +1272,9 @@ static int onepass_plan(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM] */, 
         BnBwdOne a;
         int grid;
         if (make_map(j.M, j.C, 0, j.C, &a.fm, &grid) != 0) return 0;
-        // rows per lane <= OP_ROWS: blocks >= rows / (rows per block step * OP_ROWS)
+        // rows per lane <= rows_per_lane: blocks >= rows / (rows per block step * rows_per_lane)
         const long rows_per_block = a.fm.span / a.fm.CV;
-        long blocks = (j.M + rows_per_block * OP_ROWS - 1) / (rows_per_block * OP_ROWS);
+        long blocks = (j.M + rows_per_block * rows_per_lane - 1) / (rows_per_block * rows_per_lane);
         if (blocks < 1) blocks = 1;
         if (blocks > max_blocks) return 0;
         a.fm.rstep = (int)(rows_per_block * blocks);
@@ -1289,7 +1308,8 @@ extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, int
     BnOnePass ms[NBM];
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OP_NL * 256 * 17);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_onepass_kernel<OP_NV>), hipFuncAttributeMaxDynamicSharedMemorySize, OP_NL * 256 * 17);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_onepass_kernel<OP_NV_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, OP_NL * 256 * 17);
         attr_set = true;
     }
     const int nl = onepass_plan((const BnBwdJob*)jobs, n, ms, max_blocks);
@@ -1297,7 +1317,8 @@ extern "C" int danet_bn_backward_onepass(const void* jobs, int n, void* bar, int
     for (int l = 0; l < nl; ++l) {
         ms[l].bar = (unsigned*)bar;
         ms[l].dbg = getenv("DANET_BN_ONEPASS_DBG") ? atoi(getenv("DANET_BN_ONEPASS_DBG")) : 0;
-        hipLaunchKernelGGL(bn_bwd_onepass_kernel, dim3(ms[l].start[ms[l].n]), dim3(256), OP_NL * 256 * 17, (hipStream_t)stream, ms[l]);
+        if (ms[l].big) hipLaunchKernelGGL(bn_bwd_onepass_kernel<OP_NV_BIG>, dim3(ms[l].start[ms[l].n]), dim3(256), OP_NL * 256 * 17, (hipStream_t)stream, ms[l]);
+        else hipLaunchKernelGGL(bn_bwd_onepass_kernel<OP_NV>, dim3(ms[l].start[ms[l].n]), dim3(256), OP_NL * 256 * 17, (hipStream_t)stream, ms[l]);
         DANET_CHECK_LAUNCH("bn_bwd_onepass_kernel");
     }
     return DANET_OK;

@@ -248,6 +248,22 @@ class GradStore(object):
             n += 1
         return n
 
+    def release_ready_group(self, fn):
+        """release_ready for callers that take a RUN of buckets at once: fn(b0, b1) for the complete buckets b0 .. b1 - 1 (consecutive
+        by construction) -- one weight-gradient flush, one multi-tensor copy and ONE all-reduce over the run's contiguous slice of the
+        store instead of one of each per bucket (round 6: the regressor segment alone completes five 32 MB buckets at once; 13 bucket-sized
+        flushes cost the N > 1 path 0.5 ms/step over the single flush of a one-process step).  Same order on every rank as release_ready:
+        which buckets are complete after a segment depends on the model and on the global usage mask only."""
+        if self._pending is None or not self._in_backward:
+            return 0
+        b0 = self._next
+        while self._next < len(self.buckets) - 1 and self._pending[self._next] == 0:
+            self._next += 1
+            self.issued_early += 1
+        if self._next > b0:
+            fn(b0, self._next)
+        return self._next - b0
+
     def next_bucket(self):
         """First bucket the backward pass did not release (the trainer's tail loop continues from here)."""
         return self._next if self._pending is not None else 0
@@ -255,7 +271,7 @@ class GradStore(object):
     def collect(self, bi=None):
         """Gradients autograd produced elsewhere (BatchNorm / bias / Linear / GCN parameters) are copied into their
         slots (multi-tensor copy) and .grad is pointed at the slot; conv weight gradients are already there."""
-        rng = range(len(self.buckets)) if bi is None else (bi,)
+        rng = range(len(self.buckets)) if bi is None else ((bi,) if isinstance(bi, int) else bi)
         dst, src, moved = [], [], []
         for b in rng:
             _, _, i0, i1 = self.buckets[b]
@@ -291,6 +307,23 @@ class GradStore(object):
         self.issued.append(bi)
         if bi == len(self.buckets) - 1 and not self._mask_fresh:
             self.used.fill_(1.0)            # a step outside backward_scope: no mask, every parameter with a gradient pointer is updated
+        if self.wire is None:
+            work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.wire[s:e].copy_(self.flat[s:e])
+            work = dist.all_reduce(self.wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((work, s, e))
+
+    def reduce_buckets(self, b0, b1):
+        """reduce_bucket for the run b0 .. b1 - 1 as ONE collective: the run's slots are contiguous in the flat store."""
+        if b1 - b0 == 1:
+            return self.reduce_bucket(b0)
+        if self.world == 1 and self.group is None and not (dist.is_available() and dist.is_initialized()):
+            return
+        s, e = self.buckets[b0][0], self.buckets[b1 - 1][1]
+        self.issued.extend(range(b0, b1))
+        if b1 == len(self.buckets) and not self._mask_fresh:
+            self.used.fill_(1.0)
         if self.wire is None:
             work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

@@ -44,6 +44,8 @@ WGRAD_OVERLAP = bool(int(os.environ.get('DANET_WGRAD_OVERLAP', '0')))
 # two-kernel BatchNorm backward (a warning says so).  Trade-off: 24 channels leave the all-reduce 24 of 256 compute units;
 # DANET_COMM_CHANNELS chooses another number (tools/scale_sweep.sh sweeps it), NCCL_MAX_NCHANNELS set by hand wins.
 COMM_CHANNELS = int(os.environ.get('DANET_COMM_CHANNELS', '24'))
+# Buckets that complete together are flushed / copied / all-reduced as ONE run (GradStore.release_ready_group); 0: one bucket at a time (A-B)
+GROUP_RELEASE = bool(int(os.environ.get('DANET_GROUP_RELEASE', '1')))
 
 
 def reserve_comm_channels():
@@ -348,7 +350,7 @@ class Trainer(object):
                 st.backward_scope(True, early=reduce_now)
             try:
                 if segments.level() > 0:
-                    segments.backward(losses, (lambda k: st.release_ready(self._release_bucket)) if reduce_now else
+                    segments.backward(losses, (lambda k: st.release_ready_group(self._release_buckets)) if reduce_now else
                                       ((lambda k: self._flush_on_side_stream()) if overlap else None))
                 else:
                     # (every loss is a 1-element tensor, models/danet/danet.py:359-364: views + one cat + one sum)
@@ -375,8 +377,8 @@ class Trainer(object):
             _conv.GRAD_STORE = st
             try:
                 if reduce_now:
-                    for bi in range(st.next_bucket(), len(st.buckets)):      # what the backward pass did not release
-                        self._release_bucket(bi)
+                    if st.next_bucket() < len(st.buckets):                   # what the backward pass did not release, as one run
+                        self._release_buckets(st.next_bucket(), len(st.buckets))
                 else:
                     # one process: no all-reduce to overlap with, so all queued weight gradients go out in the fewest, largest
                     # multi-problem launches (-0.15 ms against 13 bucket-sized flushes) -- or, with WGRAD_OVERLAP, segment by segment on
@@ -415,6 +417,23 @@ class Trainer(object):
             _conv.GRAD_STORE = prev
         st.collect(bi)
         st.reduce_bucket(bi)
+
+    def _release_buckets(self, b0, b1):
+        """_release_bucket for the consecutive complete buckets b0 .. b1 - 1 at once: one flush of their queued weight gradients
+        (fewer, larger multi-problem launches), one multi-tensor copy, one all-reduce over their contiguous slice of the store."""
+        if not GROUP_RELEASE:
+            for bi in range(b0, b1):
+                self._release_bucket(bi)
+            return
+        st = self.store
+        run = range(b0, b1)
+        prev, _conv.GRAD_STORE = _conv.GRAD_STORE, st
+        try:
+            _conv.flush_wgrads(bucket=run)
+        finally:
+            _conv.GRAD_STORE = prev
+        st.collect(run)
+        st.reduce_buckets(b0, b1)
 
     def train_step(self, in_dict):
         self.model.train()

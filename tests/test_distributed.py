@@ -75,14 +75,24 @@ def _worker(rank, world, port, tmp):
     # thread; never-used parameters are not waited for after the first step; the last bucket (it carries the usage mask) always
     # goes out in the tail; and the bf16 wire format
     from danet_densepose2smpl_amd import segments
-    for wire in (torch.float32, torch.bfloat16):
+    # grouped: the buckets that are complete together go out as ONE run (release_ready_group / reduce_buckets: one collective over their
+    # contiguous slice of the store) -- what the Trainer does since round 6; the results must not depend on the grouping
+    for wire, grouped in ((torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, True)):
+        torch.manual_seed(300 + rank)                # the same initial parameters for the four runs
         net2 = _Net()
         st2 = GradStore(net2.parameters(), bucket_mb=0.0002, device=torch.device('cpu'), wire_dtype=wire)
         st2.broadcast_parameters(net2)
+        ncoll = []
 
         def release(bi, st2=st2):
             st2.collect(bi)
             st2.reduce_bucket(bi)
+            ncoll.append(1)
+
+        def release_run(b0, b1, st2=st2):
+            st2.collect(range(b0, b1))
+            st2.reduce_buckets(b0, b1)
+            ncoll.append(b1 - b0)
         log = []
         for step in range(3):
             net2.zero_grad(set_to_none=True)
@@ -92,11 +102,19 @@ def _worker(rank, world, port, tmp):
             loss = {'l': net2.b(h).pow(2).mean()}
             assert segments.level() == 1
             st2.backward_scope(True)
-            segments.backward(loss, lambda k: st2.release_ready(release))
+            del ncoll[:]
+            if grouped:
+                segments.backward(loss, lambda k: st2.release_ready_group(release_run))
+            else:
+                segments.backward(loss, lambda k: st2.release_ready(release))
             st2.backward_scope(False)
             segments.end()
-            for bi in range(st2.next_bucket(), len(st2.buckets)):
-                release(bi)
+            if grouped:
+                release_run(st2.next_bucket(), len(st2.buckets))
+                assert sum(ncoll) == len(st2.buckets) and len(ncoll) <= 2          # one run between the segments (from step 1 on), one in the tail
+            else:
+                for bi in range(st2.next_bucket(), len(st2.buckets)):
+                    release(bi)
             st2.wait()
             used = st2.used.clone()
             st2.scale_()
@@ -105,7 +123,7 @@ def _worker(rank, world, port, tmp):
         torch.save({'log': log, 'nb': len(st2.buckets), 'grads': {k: p.grad.clone() for k, p in net2.named_parameters()},
                     'params': {k: p.detach().clone() for k, p in net2.named_parameters()},
                     'order': [k for p in st2.params for k, q in net2.named_parameters() if q is p]},
-                   os.path.join(tmp, 'e%d_%s.pt' % (rank, 'bf16' if wire == torch.bfloat16 else 'fp32')))
+                   os.path.join(tmp, 'e%d_%s%s.pt' % (rank, 'bf16' if wire == torch.bfloat16 else 'fp32', '_grouped' if grouped else '')))
     # a parameter that receives a gradient on ONE rank only: the mask is summed with the last bucket, so both ranks see it in use
     net3 = _Net()
     st3 = GradStore(net3.parameters(), bucket_mb=0.0002, device=torch.device('cpu'))
@@ -182,7 +200,7 @@ def test_two_rank_gradient_average_matches_single_process(tmp_path):
     # segmented backward (fp32 and bf16 wire): every step issues all buckets in index order on both ranks; the first step cannot
     # release past the never-used module, later steps release the buckets of segment 1 (the layer behind the cut) between the
     # segments; the usage mask counts the ranks
-    for wire, tol in (('fp32', 1e-6), ('bf16', 2e-2)):
+    for wire, tol in (('fp32', 1e-6), ('bf16', 2e-2), ('fp32_grouped', 1e-6), ('bf16_grouped', 2e-2)):
         e0, e1 = torch.load(tmp_path / ('e0_%s.pt' % wire)), torch.load(tmp_path / ('e1_%s.pt' % wire))
         nb = e0['nb']
         for e in (e0, e1):
@@ -201,8 +219,12 @@ def test_two_rank_gradient_average_matches_single_process(tmp_path):
             ref.append({k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in net.named_parameters()})
         for k in e0['grads']:
             mean = (ref[0][k] + ref[1][k]) / 2
-            assert torch.allclose(e0['grads'][k], mean, atol=tol * float(mean.abs().max() + 1e-6) if wire == 'bf16' else tol), (wire, k)
+            assert torch.allclose(e0['grads'][k], mean, atol=tol * float(mean.abs().max() + 1e-6) if wire.startswith('bf16') else tol), (wire, k)
             assert torch.equal(e0['grads'][k], e1['grads'][k]), (wire, k)
+    # grouping changes how many collectives carry the buckets, not one bit of the result
+    for wire in ('fp32', 'bf16'):
+        a, b = torch.load(tmp_path / ('e0_%s.pt' % wire)), torch.load(tmp_path / ('e0_%s_grouped.pt' % wire))
+        assert all(torch.equal(a['grads'][k], b['grads'][k]) for k in a['grads']), wire
 
 
 def test_grad_store_usage_mask_and_single_handout():
