@@ -432,8 +432,10 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         int ct, ni, dummy;
         const int stride = jobs[i].stride;
         plan3(jobs[i].B, jobs[i].H / stride, jobs[i].W / stride, jobs[i].Cin, jobs[i].Cout, jobs[i].groups, &ct, &ni, &dummy);
+        static const int npm_env = getenv("DANET_WGRAD3_NPM") ? atoi(getenv("DANET_WGRAD3_NPM")) : 0;      // problems per launch (A-B knob)
+        const int npm = npm_env > 0 && npm_env < NPM ? npm_env : NPM;
         int idx[NPM], cnt = 0;
-        for (int k = i; k < n && cnt < NPM; ++k) {
+        for (int k = i; k < n && cnt < npm; ++k) {
             if (done[k] || jobs[k].stride != stride) continue;
             int c2, n2;
             plan3(jobs[k].B, jobs[k].H / stride, jobs[k].W / stride, jobs[k].Cin, jobs[k].Cout, jobs[k].groups, &c2, &n2, &dummy);
