@@ -322,6 +322,9 @@ static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, i
     *ct = tiles3(Cout_g); *ni = tiles3(Cin_g);
     if (*ct == 4) *ct = 2;                      // accumulators: ceil(9*NI/4)*CT tiles per wave
     if (*ni == 4) *ni = 2;
+    // (round 6, measured and dropped: 96 x 48 blocks for the 96 / 192 / 384-channel layers -- x staged half as often, 42 instead of 21
+    //  MFMAs per wave between two barriers, but 265 registers = ONE workgroup per compute unit instead of three: the 12-problem flush of
+    //  tools/wgrad3_bench.py took 229 us against 107, the step 26.58 ms against 26.20)
     const long other = (long)((Cout_g + *ct * 16 - 1) / (*ct * 16)) * ((Cin_g + *ni * 16 - 1) / (*ni * 16)) * groups;
     const long nchunks = (long)B * (H / TH) * (W / TW);
     long target = 256;
