@@ -231,14 +231,25 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
 // the prefix table, then (bx, by, bz) within the problem.  Fewer, longer workgroups per problem amortise the
 // per-workgroup prologue / partial-sum traffic that dominates a single 17 us launch.
 constexpr int NPM = 20;
-struct Wg3Multi { Wg3P p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; };
+struct Wg3Multi { Wg3P p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; int xcd; };
 
 template <int CT, int NI, int ST>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
 {
+    // XCD-contiguous order (round 6 experiment, DANET_WGRAD3_XCD=1; measured slower -- the 256 MB infinity cache already absorbs the
+    // cross-XCD re-reads, as conv_fast.hip found for its halos): hardware workgroup b runs on XCD b % 8 (observed, grid_barrier.h).  With the plain order a
+    // problem's workgroups are dealt round-robin over all eight XCDs, so each of the eight L2s fetches the problem's x and dy slices
+    // for itself: a 384-channel layer's 3.2 MB of operands cross the fabric as ~26 MB.  Here XCD x takes the x-th eighth of the
+    // virtual ids, i.e. a problem's (consecutive) workgroups share one or two L2s.
+    int vb = (int)blockIdx.x;
+    if (mp.xcd) {
+        const int G = (int)gridDim.x, q = G >> 3, r = G & 7;
+        const int x = vb & 7, slot = vb >> 3;
+        vb = x * q + (x < r ? x : r) + slot;
+    }
     int i = 0;
-    while (i + 1 < mp.n && (int)blockIdx.x >= mp.start[i + 1]) ++i;
-    const int l = blockIdx.x - mp.start[i];
+    while (i + 1 < mp.n && vb >= mp.start[i + 1]) ++i;
+    const int l = vb - mp.start[i];
     const Wg3P& p = mp.p[i];
     const int bx = l % p.msplit, rest = l / p.msplit;
     wgrad3x3_body<CT, NI, ST>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
@@ -447,7 +458,8 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         int msplit[NPM];
         plan_multi(jobs, idx, cnt, ct, ni, msplit);
         Wg3Multi mp; Red3Multi rp;
-        mp.n = cnt; rp.n = cnt; rp.beta = beta;
+        static const bool xcd_order = getenv("DANET_WGRAD3_XCD") && atoi(getenv("DANET_WGRAD3_XCD")) != 0;      // A-B knob, OFF: measured 117.7 vs 110.1 us per 12-problem flush, step 26.26 vs 26.21 ms
+        mp.n = cnt; rp.n = cnt; rp.beta = beta; mp.xcd = xcd_order ? 1 : 0;
         mp.start[0] = 0; rp.start[0] = 0;
         for (int k = 0; k < cnt; ++k) {
             const Wg3Job& j = jobs[idx[k]];
