@@ -67,6 +67,7 @@ _SIGNATURES = {
     'danet_conv_wgrad_rows_ws_floats': (c_sz, [c_i] * 8),
     'danet_conv_wgrad_rows': (c_i, [c_f] * 4 + [c_sz] + [c_i] * 12 + [c_fl, c_f]),
     'danet_conv_wgrad3x3_ok': (c_i, [c_i] * 10),
+    'danet_conv_wgrad3x3_pair_ok': (c_i, [c_i] * 11),
     'danet_conv_wgrad3x3_ws_floats': (c_sz, [c_i] * 7),
     'danet_conv_wgrad_multi_ws_floats': (c_sz, [c_f, c_i]),
     'danet_conv_wgrad_multi_ws_zero_from': (c_sz, [c_f, c_i]),

@@ -806,7 +806,8 @@ def _enqueue_wgrad(gptr, weight, x, gy, B, H, W, Cin, OH, OW, Cout, R, S, stride
         return False
     if L.danet_conv_wgrad_rows_ok(B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups):
         return False
-    if USE_WGRAD3X3 and L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups):
+    if USE_WGRAD3X3 and (L.danet_conv_wgrad3x3_ok(H, W, Cin, Cout, R, S, stride, pad, dil, groups) or
+                         L.danet_conv_wgrad3x3_pair_ok(B, H, W, Cin, Cout, R, S, stride, pad, dil, groups)):      # (4 x 4 maps: two images per chunk)
         # only the ADDRESS of the target is kept: holding the tensor would make autograd clone it instead of adopting it as .grad
         _WQ.append((gptr, weight, x, gy, B, H, W, Cin, Cout, groups, stride, post))      # x, gy stay alive until the flush
     else:

@@ -49,10 +49,17 @@ __device__ inline v2u tr_read(unsigned lds_byte_addr) {
 }
 
 // One workgroup's share of one problem: (bx of msplit pixel ranges, by = cout-block x cin-block, bz = group).
-template <int CT, int NI, int ST>
+// PAIR (round 6): 4 x 4 maps (the regressor tails: limb_net layer3 over the 768 part crops, /root/reference/models/module/res_module.py:393-464)
+// do not hold a 4 x 8 chunk, so they ran on the generic gather kernel at 3 % of the peak (0.56 ms per step).  Here a chunk is TWO
+// images side by side: the caller describes the tensors as [B / 2, 4, 8] (chunk c = images 2c, 2c + 1 = 32 consecutive pixels in
+// memory), pixel (ty, tx) of the chunk is pixel (ty, tx & 3) of image tx >> 2, and each image gets a halo tile of its own (6 x 6,
+// every border cell outside its image = zero): the staged strip is 6 x 12 and the second half of a fragment starts 6 columns on.
+template <int CT, int NI, int ST, bool PAIR = false>
 __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const int by, const int bz)
 {
-    constexpr int HH = halo_h(ST), HW = halo_w(ST);
+    static_assert(!PAIR || ST == 1, "pair mode: stride 1 only");
+    constexpr int HH = halo_h(ST), HW = PAIR ? 12 : halo_w(ST);
+    constexpr int HALF = PAIR ? 6 : ST * 4;                      // staged columns between the two 4-pixel halves of a fragment
     constexpr int BCO = CT * 16, BCI = NI * 16;
     constexpr int PXY = BCO * 2, PXX = BCI * 2;                  // bytes per staged pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -104,16 +111,27 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
     for (int u = 0; u < NRY; ++u) {
         const int pc = t + u * 256;
         const int c8 = pc % (BCO / 8), q = pc / (BCO / 8);
-        yrel[u] = (pc < NPY && co0 + c8 * 8 < p.Cout_g) ? (((q / TW) * p.W + q % TW) * p.Cout + c8 * 8) * 2 : OOB;
+        const int ty = q / TW, tx = q % TW;
+        const int ypix = PAIR ? (tx >> 2) * 16 + ty * 4 + (tx & 3) : ty * p.W + tx;
+        yrel[u] = (pc < NPY && co0 + c8 * 8 < p.Cout_g) ? (ypix * p.Cout + c8 * 8) * 2 : OOB;
     }
 #pragma unroll
     for (int u = 0; u < NRX; ++u) {
         const int pc = t + u * 256;
         const int c8 = pc % (BCI / 8), q = pc / (BCI / 8);
-        xrel[u] = (((q / HW - 1) * p.IW + q % HW - 1) * p.Cin + c8 * 8) * 2;
         const bool live = pc < NPX && ci0 + c8 * 8 < p.Cin_g;
-        xhy[u] = live ? q / HW : -100000;                                 // (-100000: never inside the image)
-        xhx[u] = q % HW;
+        if (PAIR) {
+            // halo cell (hy, hx): image hx / 6, its pixel (hy - 1, hx % 6 - 1) -- inside the 4 x 4 image or a zero; static per piece
+            const int hy = q / HW - 1, img = (q % HW) / 6, hc = (q % HW) % 6 - 1;
+            const bool inside = live && (unsigned)hy < 4u && (unsigned)hc < 4u;
+            xrel[u] = ((img * 16 + hy * 4 + hc) * p.Cin + c8 * 8) * 2;
+            xhy[u] = inside ? 1 : -100000;                                // (row test of fetch(): 0 <= -1 + 1 < IH)
+            xhx[u] = 1;
+        } else {
+            xrel[u] = (((q / HW - 1) * p.IW + q % HW - 1) * p.Cin + c8 * 8) * 2;
+            xhy[u] = live ? q / HW : -100000;                             // (-100000: never inside the image)
+            xhx[u] = q % HW;
+        }
     }
     // tile position of the current fetch (block-uniform), advanced chunk by chunk
     int f_tw = c_begin % p.tiles_w, f_th = (c_begin / p.tiles_w) % p.tiles_h, f_b = c_begin / (p.tiles_w * p.tiles_h);
@@ -128,7 +146,8 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
             ystage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yr, yrel[u] != OOB ? by + yrel[u] : OOB, 0, 0));
 #pragma unroll
         for (int u = 0; u < NRX; ++u) {
-            const bool ok = (unsigned)(ST * oh0 - 1 + xhy[u]) < (unsigned)p.IH && (unsigned)(ST * ow0 - 1 + xhx[u]) < (unsigned)p.IW;
+            const bool ok = PAIR ? xhy[u] > 0
+                                 : ((unsigned)(ST * oh0 - 1 + xhy[u]) < (unsigned)p.IH && (unsigned)(ST * ow0 - 1 + xhx[u]) < (unsigned)p.IW);
             xstage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? bx + xrel[u] : OOB, 0, 0));
         }
         if (++f_tw == p.tiles_w) { f_tw = 0; if (++f_th == p.tiles_h) { f_th = 0; ++f_b; } }
@@ -162,7 +181,7 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
 #pragma unroll
         for (int pi = 0; pi < MAXP; ++pi) {
             blo[pi] = tr_read(xbase + boff[pi]);
-            bhi[pi] = tr_read(xbase + boff[pi] + ST * 4 * PXX);
+            bhi[pi] = tr_read(xbase + boff[pi] + HALF * PXX);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
 constexpr int NPM = 20;
 struct Wg3Multi { Wg3P p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; int xcd; };
 
-template <int CT, int NI, int ST>
+template <int CT, int NI, int ST, bool PAIR = false>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
 {
     // XCD-contiguous order (round 6 experiment, DANET_WGRAD3_XCD=1; measured slower -- the 256 MB infinity cache already absorbs the
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
     const int l = vb - mp.start[i];
     const Wg3P& p = mp.p[i];
     const int bx = l % p.msplit, rest = l / p.msplit;
-    wgrad3x3_body<CT, NI, ST>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
+    wgrad3x3_body<CT, NI, ST, PAIR>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
 }
 
 struct Red3Multi { const float* part[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], msplit[NPM]; long start[NPM + 1]; int n; float beta; };
@@ -326,6 +345,18 @@ extern "C" int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, in
     if (H % stride != 0 || W % stride != 0) return 0;
     return (H / stride) % TH == 0 && (W / stride) % TW == 0 && (Cin / groups) % 8 == 0 && (Cout / groups) % 8 == 0;
 }
+
+// Pair mode (wgrad3x3_body<..., PAIR>): 4 x 4 maps, two images per chunk -- through danet_conv_wgrad3x3_multi only.
+extern "C" int danet_conv_wgrad3x3_pair_ok(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups) {
+    static const bool off = getenv("DANET_NO_WGRAD3_PAIR") != nullptr;         // A/B knob
+    if (off || !(R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && H == 4 && W == 4 && B > 0 && B % 2 == 0 && groups > 0)) return 0;
+    if (Cin % groups != 0 || Cout % groups != 0) return 0;
+    const int ci = Cin / groups, co = Cout / groups;
+    if (ci % 8 != 0 || co % 8 != 0) return 0;
+    // instantiated for 32- and 48-wide blocks (tiles3: 32 < c and c % 48 != 0 -> 2 tiles; c % 48 == 0 or c <= 48 -> 3)
+    return 1;
+}
+static inline bool wg3_is_pair(int B, int H, int W, int stride) { return H == 4 && W == 4 && stride == 1 && B % 2 == 0; }
 
 // (H, W): OUTPUT size
 static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, int* ni, int* msplit) {
@@ -415,17 +446,20 @@ static long multi_target_blocks() {
 static inline double wg3_weight(int Cout, int Cin_g) { const double p = (double)Cout * Cin_g; return p < 2304.0 ? 2304.0 : p; }
 // msplit of every job when jobs [first, last) of one instance share a launch
 static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int ni, int* msplit) {
+    auto chunks_of = [](const Wg3Job& j) -> long {
+        return wg3_is_pair(j.B, j.H, j.W, j.stride) ? (long)(j.B / 2) : (long)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW);
+    };
     double tot = 0;
     for (int k = 0; k < cnt; ++k) {
         const Wg3Job& j = jobs[idx[k]];
-        tot += (double)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW) * wg3_weight(j.Cout, j.Cin / j.groups);
+        tot += (double)chunks_of(j) * wg3_weight(j.Cout, j.Cin / j.groups);
     }
     const long target = multi_target_blocks();
     for (int k = 0; k < cnt; ++k) {
         const Wg3Job& j = jobs[idx[k]];
         const int Cout_g = j.Cout / j.groups, Cin_g = j.Cin / j.groups;
         const long other = (long)((Cout_g + ct * 16 - 1) / (ct * 16)) * ((Cin_g + ni * 16 - 1) / (ni * 16)) * j.groups;
-        const long nchunks = (long)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW);
+        const long nchunks = chunks_of(j);
         const double w = (double)nchunks * wg3_weight(j.Cout, Cin_g);
         long ms = (long)(target * (w / tot) / other + 0.5);
         if (ms > nchunks / 4) ms = nchunks / 4;
@@ -445,12 +479,13 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         if (done[i]) continue;
         int ct, ni, dummy;
         const int stride = jobs[i].stride;
+        const bool pair = wg3_is_pair(jobs[i].B, jobs[i].H, jobs[i].W, stride);
         plan3(jobs[i].B, jobs[i].H / stride, jobs[i].W / stride, jobs[i].Cin, jobs[i].Cout, jobs[i].groups, &ct, &ni, &dummy);
         static const int npm_env = getenv("DANET_WGRAD3_NPM") ? atoi(getenv("DANET_WGRAD3_NPM")) : 0;      // problems per launch (A-B knob)
         const int npm = npm_env > 0 && npm_env < NPM ? npm_env : NPM;
         int idx[NPM], cnt = 0;
         for (int k = i; k < n && cnt < npm; ++k) {
-            if (done[k] || jobs[k].stride != stride) continue;
+            if (done[k] || jobs[k].stride != stride || wg3_is_pair(jobs[k].B, jobs[k].H, jobs[k].W, stride) != pair) continue;
             int c2, n2;
             plan3(jobs[k].B, jobs[k].H / stride, jobs[k].W / stride, jobs[k].Cin, jobs[k].Cout, jobs[k].groups, &c2, &n2, &dummy);
             if (c2 == ct && n2 == ni) { idx[cnt++] = k; done[k] = true; }
@@ -470,10 +505,11 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
             p.direct = direct ? j.dw : nullptr;
             p.IH = j.H; p.IW = j.W;
             p.B = j.B; p.H = j.H / stride; p.W = j.W / stride; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
+            if (pair) { p.B = j.B / 2; p.H = p.IH = 4; p.W = p.IW = 8; }      // two images = one 4 x 8 chunk (32 consecutive pixels)
             p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
             p.tiles_h = p.H / TH; p.tiles_w = p.W / TW;
-            p.nchunks = (long)j.B * p.tiles_h * p.tiles_w;
-            p.x_bytes = (long)j.B * j.H * j.W * j.Cin * 2; p.dy_bytes = (long)j.B * p.H * p.W * j.Cout * 2;
+            p.nchunks = (long)p.B * p.tiles_h * p.tiles_w;
+            p.x_bytes = (long)j.B * j.H * j.W * j.Cin * 2; p.dy_bytes = (long)j.B * (j.H / stride) * (j.W / stride) * j.Cout * 2;
             p.msplit = msplit[k];
             const int nyb = ((p.Cout_g + ct * 16 - 1) / (ct * 16)) * ((p.Cin_g + ni * 16 - 1) / (ni * 16));
             mp.nyb[k] = nyb;
@@ -487,8 +523,14 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         }
         if (!ws) continue;                                   // sizing pass
         if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3_multi: workspace too small");
-        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + halo_h(stride) * halo_w(stride) * ni * 32);
+        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + halo_h(stride) * (pair ? 12 : halo_w(stride)) * ni * 32);
         const dim3 grid((unsigned)mp.start[cnt]);
+        if (pair) {
+#define W3P(a, b) if (ct == a && ni == b) { hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1, true>), grid, dim3(256), lds, st, mp); } else
+            W3P(2, 2) W3P(2, 3) W3P(3, 2) W3P(3, 3) W3P(1, 1) W3P(1, 2) W3P(2, 1) W3P(1, 3) W3P(3, 1)
+            return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: no pair-mode kernel for tiles %dx%d", ct, ni);
+#undef W3P
+        } else
 #define W3M(a, b) if (ct == a && ni == b) { \
             if (stride == 1) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1>), grid, dim3(256), lds, st, mp); \
             else hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 2>), grid, dim3(256), lds, st, mp); } else
@@ -520,7 +562,8 @@ extern "C" int danet_conv_wgrad3x3_multi(const void* jobs, int n, float* ws, siz
     const Wg3Job* jb = (const Wg3Job*)jobs;
     for (int i = 0; i < n; ++i)
         DANET_CHECK_ARG(jb[i].x && jb[i].dy && jb[i].dw && jb[i].B > 0 &&
-                        danet_conv_wgrad3x3_ok(jb[i].H, jb[i].W, jb[i].Cin, jb[i].Cout, 3, 3, jb[i].stride, 1, 1, jb[i].groups),
+                        (danet_conv_wgrad3x3_ok(jb[i].H, jb[i].W, jb[i].Cin, jb[i].Cout, 3, 3, jb[i].stride, 1, 1, jb[i].groups) ||
+                         danet_conv_wgrad3x3_pair_ok(jb[i].B, jb[i].H, jb[i].W, jb[i].Cin, jb[i].Cout, 3, 3, jb[i].stride, 1, 1, jb[i].groups)),
                         "conv_wgrad3x3_multi: job %d is not a supported 3x3 problem", i);
     return multi_foreach_launch(jb, n, ws, ws_floats, beta, (hipStream_t)stream, nullptr);
 }

@@ -395,6 +395,9 @@ int danet_conv_forward(const void* x, const void* wp, const float* bias, void* y
  * danet_conv_wgrad3x3_ok(...) != 0, with danet_conv_wgrad3x3_ws_floats(...) floats of scratch.  (H, W) is the INPUT
  * size; dy is [B, H/stride, W/stride, Cout]. */
 int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
+/* 4 x 4 maps (the regressor tails, reference models/module/res_module.py:393-464 at 768 part crops): two images share one 4 x 8 chunk;
+ * such problems are accepted by danet_conv_wgrad3x3_multi only (B even). */
+int danet_conv_wgrad3x3_pair_ok(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups);
 size_t danet_conv_wgrad3x3_ws_floats(int B, int H, int W, int Cin, int Cout, int groups, int stride);
 /* Batched 3x3 weight gradients: weight gradients are only needed by the optimizer, so a trainer may queue them during the
  * backward pass and compute them with a few multi-problem launches (up to 20 problems per launch, grouped by kernel instance).

@@ -169,9 +169,11 @@ def test_deferred_multi_problem_wgrad_matches_immediate():
             (256, 64, 1, 1, 0, 16), (64, 64, 7, 2, 3, 32), (48, 24, 3, 1, 1, 32),
             # channel-padded layers (widths no multiple of 8: the IUV heads, the heat-map head's Bottleneck(48, 12)): computed at the padded
             # widths by the same multi-problem launches and cropped into .grad afterwards (round 5; they used to run inside the backward chain)
-            (48, 25, 3, 1, 1, 32), (48, 12, 1, 1, 0, 32), (12, 12, 3, 1, 1, 32), (12, 48, 1, 1, 0, 32), (75, 64, 1, 1, 0, 16)]
+            (48, 25, 3, 1, 1, 32), (48, 12, 1, 1, 0, 32), (12, 12, 3, 1, 1, 32), (12, 48, 1, 1, 0, 32), (75, 64, 1, 1, 0, 16),
+            # 4 x 4 maps (the regressor tails): the transpose-read kernel's pair mode when the batch is even, the generic kernel otherwise
+            (256, 256, 3, 1, 1, 4), (64, 128, 3, 1, 1, 4)]
     convs = [dconv.Conv2d(ci, co, k, s, p, bias=False).cuda() for ci, co, k, s, p, _ in cfgs]
-    xs = [torch.randn(3, ci, h, h, device='cuda') for ci, _, _, _, _, h in cfgs]
+    xs = [torch.randn(4 if h == 4 else 3, ci, h, h, device='cuda') for ci, _, _, _, _, h in cfgs]
 
     def run(defer):
         for c in convs:
@@ -226,6 +228,49 @@ def test_multi_problem_wgrad3x3_direct_and_reduced_jobs():
         assert (o - r).abs().max().item() <= 2e-4 * r.abs().max().item(), sh
     for o, r, sh in zip(run(1.0, 0.5), refs, shapes):
         assert (o - (r + 0.5)).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-5, sh
+
+
+@pytest.mark.parametrize('B,Cin,Cout,groups', [(768, 256, 256, 1), (32, 256, 256, 1), (6, 64, 32, 1), (10, 48, 96, 1), (4, 96, 48, 2), (2, 16, 16, 1)],
+                         ids=lambda v: str(v))
+def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups):
+    """csrc/conv_wgrad3x3.hip PAIR mode (round 6): 3x3 / stride-1 weight gradients on 4 x 4 maps -- limb_net layer3 over the 768 part
+    crops (res_module.py:393-464; 0.56 ms per step on the generic gather kernel before) -- with two images sharing one 4 x 8 chunk, each
+    behind a zero halo of its own.  Against torch's fp32 weight gradient on the bf16-rounded operands; alone, next to ordinary jobs in
+    the same call, accumulated (beta = 1), and twice (bit-identical)."""
+    import ctypes
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    from danet_densepose2smpl_amd._lib import ptr, stream, check
+    L = _lib.lib()
+    assert L.danet_conv_wgrad3x3_pair_ok(B, 4, 4, Cin, Cout, 3, 3, 1, 1, 1, groups) == 1
+    assert L.danet_conv_wgrad3x3_ok(4, 4, Cin, Cout, 3, 3, 1, 1, 1, groups) == 0
+    assert L.danet_conv_wgrad3x3_pair_ok(B + 1, 4, 4, Cin, Cout, 3, 3, 1, 1, 1, groups) == 0          # an odd batch has no partner image
+    torch.manual_seed(B + Cin)
+    x = dconv.nhwc_bf16(torch.randn(B, Cin, 4, 4, device='cuda'))
+    g = dconv.nhwc_bf16(torch.randn(B, Cout, 4, 4, device='cuda') * 0.1)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin // groups, 3, 3), g.float(), stride=1, padding=1, groups=groups)
+    # an ordinary 8-wide job of the same instance family rides in the same call
+    x2 = dconv.nhwc_bf16(torch.randn(4, Cin, 8, 8, device='cuda'))
+    g2 = dconv.nhwc_bf16(torch.randn(4, Cout, 8, 8, device='cuda') * 0.1)
+    ref2 = torch.nn.grad.conv2d_weight(x2.float(), (Cout, Cin // groups, 3, 3), g2.float(), stride=1, padding=1, groups=groups)
+
+    def run(beta, init):
+        o = torch.full((Cout, Cin // groups, 3, 3), init, device='cuda')
+        o2 = torch.full((Cout, Cin // groups, 3, 3), init, device='cuda')
+        jobs = (_lib.Wg3Job * 2)()
+        for j, (xx, gg, oo, bb, hh) in zip(jobs, ((x, g, o, B, 4), (x2, g2, o2, 4, 8))):
+            j.x, j.dy, j.dw = xx.data_ptr(), gg.data_ptr(), oo.data_ptr()
+            j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = bb, hh, hh, Cin, Cout, groups, 1
+        need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), 2)
+        ws = torch.full((max(int(need), 1),), float('nan'), device='cuda')
+        check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), 2, ptr(ws), need, beta, stream()), 'wgrad3x3_multi')
+        torch.cuda.synchronize()
+        return o, o2
+    a, b = run(0.0, float('nan')), run(0.0, 3.0)
+    assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert (a[0] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), float((a[0] - ref).abs().max() / ref.abs().max())
+    assert (a[1] - ref2).abs().max().item() <= 2e-4 * ref2.abs().max().item()
+    c = run(1.0, 0.5)
+    assert (c[0] - (ref + 0.5)).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
 
 
 # (Cin, Cout, H, W, B): HRNet branch shapes at 256^2 and 224^2 inputs (row widths 64..8 and 56..7), the regressor
