@@ -49,17 +49,18 @@ __device__ inline v2u tr_read(unsigned lds_byte_addr) {
 }
 
 // One workgroup's share of one problem: (bx of msplit pixel ranges, by = cout-block x cin-block, bz = group).
-// PAIR (round 6): 4 x 4 maps (the regressor tails: limb_net layer3 over the 768 part crops, /root/reference/models/module/res_module.py:393-464)
+// PAIR (round 6): 4 x 4 OUTPUT maps (the regressor tails: limb_net layer3 over the 768 part crops, /root/reference/models/module/res_module.py:393-464)
 // do not hold a 4 x 8 chunk, so they ran on the generic gather kernel at 3 % of the peak (0.56 ms per step).  Here a chunk is TWO
 // images side by side: the caller describes the tensors as [B / 2, 4, 8] (chunk c = images 2c, 2c + 1 = 32 consecutive pixels in
 // memory), pixel (ty, tx) of the chunk is pixel (ty, tx & 3) of image tx >> 2, and each image gets a halo tile of its own (6 x 6,
-// every border cell outside its image = zero): the staged strip is 6 x 12 and the second half of a fragment starts 6 columns on.
+// every border cell outside its image = zero): the staged strip is 6 x 12 and the second half of a fragment starts 6 columns on
+// (stride 2: 8 x 8 inputs, 9 x 18 strip).
 template <int CT, int NI, int ST, bool PAIR = false>
 __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const int by, const int bz)
 {
-    static_assert(!PAIR || ST == 1, "pair mode: stride 1 only");
-    constexpr int HH = halo_h(ST), HW = PAIR ? 12 : halo_w(ST);
-    constexpr int HALF = PAIR ? 6 : ST * 4;                      // staged columns between the two 4-pixel halves of a fragment
+    constexpr int PHW = ST * 3 + 3;                              // pair mode: halo columns of ONE image (4 output columns at stride ST)
+    constexpr int HH = halo_h(ST), HW = PAIR ? 2 * PHW : halo_w(ST);
+    constexpr int HALF = PAIR ? PHW : ST * 4;                    // staged columns between the two 4-pixel halves of a fragment
     constexpr int BCO = CT * 16, BCI = NI * 16;
     constexpr int PXY = BCO * 2, PXX = BCI * 2;                  // bytes per staged pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -121,10 +122,11 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
         const int c8 = pc % (BCI / 8), q = pc / (BCI / 8);
         const bool live = pc < NPX && ci0 + c8 * 8 < p.Cin_g;
         if (PAIR) {
-            // halo cell (hy, hx): image hx / 6, its pixel (hy - 1, hx % 6 - 1) -- inside the 4 x 4 image or a zero; static per piece
-            const int hy = q / HW - 1, img = (q % HW) / 6, hc = (q % HW) % 6 - 1;
-            const bool inside = live && (unsigned)hy < 4u && (unsigned)hc < 4u;
-            xrel[u] = ((img * 16 + hy * 4 + hc) * p.Cin + c8 * 8) * 2;
+            // halo cell (hy, hx): image hx / PHW, its input pixel (hy - 1, hx % PHW - 1) -- inside the (4 ST) x (4 ST) image or a zero;
+            // static per piece
+            const int hy = q / HW - 1, img = (q % HW) / PHW, hc = (q % HW) % PHW - 1;
+            const bool inside = live && (unsigned)hy < (unsigned)(4 * ST) && (unsigned)hc < (unsigned)(4 * ST);
+            xrel[u] = ((img * (16 * ST * ST) + hy * (4 * ST) + hc) * p.Cin + c8 * 8) * 2;
             xhy[u] = inside ? 1 : -100000;                                // (row test of fetch(): 0 <= -1 + 1 < IH)
             xhx[u] = 1;
         } else {
@@ -349,14 +351,15 @@ extern "C" int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, in
 // Pair mode (wgrad3x3_body<..., PAIR>): 4 x 4 maps, two images per chunk -- through danet_conv_wgrad3x3_multi only.
 extern "C" int danet_conv_wgrad3x3_pair_ok(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups) {
     static const bool off = getenv("DANET_NO_WGRAD3_PAIR") != nullptr;         // A/B knob
-    if (off || !(R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && H == 4 && W == 4 && B > 0 && B % 2 == 0 && groups > 0)) return 0;
+    if (off || !(R == 3 && S == 3 && (stride == 1 || stride == 2) && pad == 1 && dil == 1 && H == 4 * stride && W == 4 * stride && B > 0 && B % 2 == 0 &&
+                 groups > 0)) return 0;
     if (Cin % groups != 0 || Cout % groups != 0) return 0;
     const int ci = Cin / groups, co = Cout / groups;
     if (ci % 8 != 0 || co % 8 != 0) return 0;
     // instantiated for 32- and 48-wide blocks (tiles3: 32 < c and c % 48 != 0 -> 2 tiles; c % 48 == 0 or c <= 48 -> 3)
     return 1;
 }
-static inline bool wg3_is_pair(int B, int H, int W, int stride) { return H == 4 && W == 4 && stride == 1 && B % 2 == 0; }
+static inline bool wg3_is_pair(int B, int H, int W, int stride) { return (stride == 1 || stride == 2) && H == 4 * stride && W == 4 * stride && B % 2 == 0; }
 
 // (H, W): OUTPUT size
 static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, int* ni, int* msplit) {
@@ -505,7 +508,7 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
             p.direct = direct ? j.dw : nullptr;
             p.IH = j.H; p.IW = j.W;
             p.B = j.B; p.H = j.H / stride; p.W = j.W / stride; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
-            if (pair) { p.B = j.B / 2; p.H = p.IH = 4; p.W = p.IW = 8; }      // two images = one 4 x 8 chunk (32 consecutive pixels)
+            if (pair) { p.B = j.B / 2; p.H = 4; p.W = 8; p.IH = 4 * stride; p.IW = 8 * stride; }      // two images = one 4 x 8 chunk (32 consecutive output pixels)
             p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
             p.tiles_h = p.H / TH; p.tiles_w = p.W / TW;
             p.nchunks = (long)p.B * p.tiles_h * p.tiles_w;
@@ -523,10 +526,12 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         }
         if (!ws) continue;                                   // sizing pass
         if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3_multi: workspace too small");
-        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + halo_h(stride) * (pair ? 12 : halo_w(stride)) * ni * 32);
+        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + halo_h(stride) * (pair ? 2 * (stride * 3 + 3) : halo_w(stride)) * ni * 32);
         const dim3 grid((unsigned)mp.start[cnt]);
         if (pair) {
-#define W3P(a, b) if (ct == a && ni == b) { hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1, true>), grid, dim3(256), lds, st, mp); } else
+#define W3P(a, b) if (ct == a && ni == b) { \
+            if (stride == 1) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1, true>), grid, dim3(256), lds, st, mp); \
+            else hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 2, true>), grid, dim3(256), lds, st, mp); } else
             W3P(2, 2) W3P(2, 3) W3P(3, 2) W3P(3, 3) W3P(1, 1) W3P(1, 2) W3P(2, 1) W3P(1, 3) W3P(3, 1)
             return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: no pair-mode kernel for tiles %dx%d", ct, ni);
 #undef W3P

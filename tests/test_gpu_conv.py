@@ -230,9 +230,10 @@ def test_multi_problem_wgrad3x3_direct_and_reduced_jobs():
         assert (o - (r + 0.5)).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-5, sh
 
 
-@pytest.mark.parametrize('B,Cin,Cout,groups', [(768, 256, 256, 1), (32, 256, 256, 1), (6, 64, 32, 1), (10, 48, 96, 1), (4, 96, 48, 2), (2, 16, 16, 1)],
-                         ids=lambda v: str(v))
-def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups):
+@pytest.mark.parametrize('stride', [1, 2])
+@pytest.mark.parametrize('B,Cin,Cout,groups', [(768, 256, 256, 1), (32, 256, 256, 1), (6, 64, 32, 1), (10, 48, 96, 1), (4, 96, 48, 2), (2, 16, 16, 1),
+                                               (768, 128, 256, 1)], ids=lambda v: str(v))
+def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups, stride):
     """csrc/conv_wgrad3x3.hip PAIR mode (round 6): 3x3 / stride-1 weight gradients on 4 x 4 maps -- limb_net layer3 over the 768 part
     crops (res_module.py:393-464; 0.56 ms per step on the generic gather kernel before) -- with two images sharing one 4 x 8 chunk, each
     behind a zero halo of its own.  Against torch's fp32 weight gradient on the bf16-rounded operands; alone, next to ordinary jobs in
@@ -241,25 +242,26 @@ def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups):
     from danet_densepose2smpl_amd import conv as dconv, _lib
     from danet_densepose2smpl_amd._lib import ptr, stream, check
     L = _lib.lib()
-    assert L.danet_conv_wgrad3x3_pair_ok(B, 4, 4, Cin, Cout, 3, 3, 1, 1, 1, groups) == 1
-    assert L.danet_conv_wgrad3x3_ok(4, 4, Cin, Cout, 3, 3, 1, 1, 1, groups) == 0
-    assert L.danet_conv_wgrad3x3_pair_ok(B + 1, 4, 4, Cin, Cout, 3, 3, 1, 1, 1, groups) == 0          # an odd batch has no partner image
+    S = 4 * stride                                  # input size: 4 x 4 OUTPUT maps (stride 2: limb_net layer3's first block, 8 x 8 -> 4 x 4)
+    assert L.danet_conv_wgrad3x3_pair_ok(B, S, S, Cin, Cout, 3, 3, stride, 1, 1, groups) == 1
+    assert L.danet_conv_wgrad3x3_ok(S, S, Cin, Cout, 3, 3, stride, 1, 1, groups) == 0
+    assert L.danet_conv_wgrad3x3_pair_ok(B + 1, S, S, Cin, Cout, 3, 3, stride, 1, 1, groups) == 0          # an odd batch has no partner image
     torch.manual_seed(B + Cin)
-    x = dconv.nhwc_bf16(torch.randn(B, Cin, 4, 4, device='cuda'))
+    x = dconv.nhwc_bf16(torch.randn(B, Cin, S, S, device='cuda'))
     g = dconv.nhwc_bf16(torch.randn(B, Cout, 4, 4, device='cuda') * 0.1)
-    ref = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin // groups, 3, 3), g.float(), stride=1, padding=1, groups=groups)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin // groups, 3, 3), g.float(), stride=stride, padding=1, groups=groups)
     # an ordinary 8-wide job of the same instance family rides in the same call
-    x2 = dconv.nhwc_bf16(torch.randn(4, Cin, 8, 8, device='cuda'))
+    x2 = dconv.nhwc_bf16(torch.randn(4, Cin, 8 * stride, 8 * stride, device='cuda'))
     g2 = dconv.nhwc_bf16(torch.randn(4, Cout, 8, 8, device='cuda') * 0.1)
-    ref2 = torch.nn.grad.conv2d_weight(x2.float(), (Cout, Cin // groups, 3, 3), g2.float(), stride=1, padding=1, groups=groups)
+    ref2 = torch.nn.grad.conv2d_weight(x2.float(), (Cout, Cin // groups, 3, 3), g2.float(), stride=stride, padding=1, groups=groups)
 
     def run(beta, init):
         o = torch.full((Cout, Cin // groups, 3, 3), init, device='cuda')
         o2 = torch.full((Cout, Cin // groups, 3, 3), init, device='cuda')
         jobs = (_lib.Wg3Job * 2)()
-        for j, (xx, gg, oo, bb, hh) in zip(jobs, ((x, g, o, B, 4), (x2, g2, o2, 4, 8))):
+        for j, (xx, gg, oo, bb, hh) in zip(jobs, ((x, g, o, B, S), (x2, g2, o2, 4, 8 * stride))):
             j.x, j.dy, j.dw = xx.data_ptr(), gg.data_ptr(), oo.data_ptr()
-            j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = bb, hh, hh, Cin, Cout, groups, 1
+            j.B, j.H, j.W, j.Cin, j.Cout, j.groups, j.stride = bb, hh, hh, Cin, Cout, groups, stride
         need = L.danet_conv_wgrad3x3_multi_ws_floats(ctypes.addressof(jobs), 2)
         ws = torch.full((max(int(need), 1),), float('nan'), device='cuda')
         check(L.danet_conv_wgrad3x3_multi(ctypes.addressof(jobs), 2, ptr(ws), need, beta, stream()), 'wgrad3x3_multi')
