@@ -108,6 +108,7 @@ _SIGNATURES = {
     'danet_softargmax_forward': (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),
     'danet_softargmax_backward': (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f, c_f]),
     'danet_pad_multi': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f]),
+    'danet_loss_finalize': (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f]),
     'danet_smpl_joints_forward': (c_i, [c_f, c_f, c_f] + [c_i] * 4 + [c_f] * 4),
     'danet_smpl_joints_backward': (c_i, [c_f] * 5 + [c_i] * 4 + [c_f, c_f]),
     'danet_stn_theta_forward': (c_i, [c_f] * 8 + [c_i] * 4 + [c_fl, c_fl, c_f, c_f]),

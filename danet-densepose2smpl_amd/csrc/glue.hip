@@ -213,3 +213,41 @@ extern "C" int danet_smpl_joints_backward(const float* g49, const float* g19, co
     DANET_CHECK_LAUNCH("smpl_joints_bwd_kernel");
     return DANET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Loss bookkeeping of the estimator (round 6): the fused loss kernels leave raw DOUBLE sums (rows of replicas: sums[r][n], added in
+// index order); the reference then scales each by a constant and / or divides by the number of labelled samples
+// (/root/reference/models/danet/iuv_estimator.py:325-339, 233-256).  As tensor ops that was ~6 launches per loss and pass
+// (select, mul / div, their backward, select-backward = fill + copy, gradient adds): here ONE launch turns the sums into the n
+// finished losses  out[i] = sum_r sums[r][i] * a[i] / (b[i] > 0 ? max(sum(w), 1) * b[i] : 1)   (w = per-sample weights, or nw ones)
+// and ONE launch turns the n incoming gradients (null = no gradient) into the coefficients the backward kernels multiply by.
+struct LossFin { const double* sums; int rows, n; float a[8], b[8]; const float* w; int nw; float* out; const float* g[8]; };
+
+__global__ void loss_finalize_kernel(LossFin p)
+{
+    const int i = threadIdx.x;
+    if (i >= p.n) return;
+    float ws = (float)p.nw;
+    if (p.w) { ws = 0.f; for (int k = 0; k < p.nw; ++k) ws += p.w[k]; ws = fmaxf(ws, 1.0f); }
+    const float f = p.a[i] / (p.b[i] > 0.f ? ws * p.b[i] : 1.0f);
+    if (p.sums) {                                   // forward: the finished losses
+        double s = 0.0;
+        for (int r = 0; r < p.rows; ++r) s += p.sums[(size_t)r * p.n + i];
+        p.out[i] = (float)s * f;
+    } else {                                        // backward: d loss_i / d sum_i times the incoming gradient
+        p.out[i] = p.g[i] ? p.g[i][0] * f : 0.f;
+    }
+}
+
+extern "C" int danet_loss_finalize(const void* sums, int rows, int n, const float* a, const float* b, const float* w, int nw,
+                                   const void* const* grads, float* out, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(out && n >= 1 && n <= 8 && a && b && nw >= 1 && (sums ? rows >= 1 : grads != nullptr), "loss_finalize: bad arguments");
+    LossFin p{};
+    p.sums = (const double*)sums; p.rows = rows; p.n = n; p.w = w; p.nw = nw; p.out = out;
+    for (int i = 0; i < n; ++i) { p.a[i] = a[i]; p.b[i] = b[i]; p.g[i] = grads ? (const float*)grads[i] : nullptr; }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    DANET_CHECK_LAUNCH("loss_finalize_kernel");
+    return DANET_OK;
+}

@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, stream
+from ._lib import check, stream, ptr
 
 PAD_MAX = 16
 
@@ -85,3 +85,27 @@ def crop(t, src_view, dst_view, out_shape):
     """The leading block of a dense fp32 tensor: t viewed as src_view -> new tensor of out_shape (viewed as dst_view <= src_view in every
     dimension); one launch, no autograd (the backward of a pad, used on weight gradients computed at padded widths)."""
     return _launch([t.contiguous()], [src_view], [dst_view], [out_shape])[0]
+
+
+def loss_finalize(n, scales, w, nw, sums=None, rows=1, grads=None):
+    """csrc/glue.hip danet_loss_finalize: the n finished losses from raw double sums (forward: `sums`, rows x n doubles) or the n
+    backward coefficients from the incoming gradients (`grads`: list of 1-element tensors / None).  scales = ((a_i, b_i), ...):
+    loss_i = sum_i * a_i / (max(sum(w), 1) * b_i) where b_i > 0, sum_i * a_i otherwise; w = per-sample weights [nw] or None (= ones)."""
+    import ctypes
+    dev = (sums if sums is not None else next(g for g in grads if g is not None)).device
+    a = (ctypes.c_float * 8)(*([float(x[0]) for x in scales] + [0.0] * (8 - n)))
+    b = (ctypes.c_float * 8)(*([float(x[1]) for x in scales] + [0.0] * (8 - n)))
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    gp = None
+    keep = []
+    if grads is not None:
+        arr = (ctypes.c_void_p * 8)()
+        for i, g in enumerate(grads):
+            if g is not None:
+                g = g.detach().to(torch.float32).contiguous()
+                keep.append(g)
+                arr[i] = g.data_ptr()
+        gp = ctypes.addressof(arr)
+    check(_lib.lib().danet_loss_finalize(ptr(sums), int(rows), int(n), ctypes.addressof(a), ctypes.addressof(b), ptr(w), int(nw), gp, ptr(out), stream()),
+          'danet_loss_finalize')
+    return out

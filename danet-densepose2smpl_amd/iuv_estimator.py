@@ -53,6 +53,7 @@ def load_learned_ratio(path=None):
 
 
 FUSED_STN_THETA = True       # visibility score + affine_para as one HIP launch (False: the tensor-op formulation)
+LOSS_FINALIZE = bool(int(os.environ.get('DANET_LOSS_FINALIZE', '1')))     # the estimator's losses leave their fused ops finished (glue.loss_finalize); 0: tensor-op scaling (A-B)
 
 
 def _sample_points(maps, pts, align):
@@ -255,10 +256,15 @@ class IUV_Estimator(nn.Module):
             from . import iuv_ops
             want = self.training and iuv_image_gt is not None
             w = None if has_iuv is None else has_iuv.to(torch.float32)
-            sums, rd['iuv_map'], am_raw = iuv_ops.iuv_global(u_pred, v_pred, index_pred, ann_pred, iuv_image_gt if want else None, w, keep25)
+            B, S2 = u_pred.shape[0], u_pred.shape[-1] * u_pred.shape[-2]
+            # the four losses leave the op finished (iuv_estimator.py:325-339: U / V sums x weight / batch; index / ann sums / (labelled samples
+            # x pixels)): scales = (a, b) per loss, loss = sum * a / (max(sum w, 1) * b)
+            scales = ((cfg.DANET.POINT_REGRESSION_WEIGHTS / B, 0.), (cfg.DANET.POINT_REGRESSION_WEIGHTS / B, 0.), (1., S2), (1., S2)) if (want and LOSS_FINALIZE) else None
+            sums, rd['iuv_map'], am_raw = iuv_ops.iuv_global(u_pred, v_pred, index_pred, ann_pred, iuv_image_gt if want else None, w, keep25, scales=scales)
             rd['iuv_argmax'] = am_raw
-            if want:
-                B, S2 = u_pred.shape[0], u_pred.shape[-1] * u_pred.shape[-2]
+            if want and scales is not None:
+                rd['losses'].update({'loss_U': sums[0], 'loss_V': sums[1], 'loss_IndexUV': sums[2], 'loss_segAnn': sums[3]})
+            elif want:
                 wsum = float(B) if w is None else w.sum().clamp(min=1.0)
                 rd['losses'].update({'loss_U': sums[0] * (cfg.DANET.POINT_REGRESSION_WEIGHTS / B), 'loss_V': sums[1] * (cfg.DANET.POINT_REGRESSION_WEIGHTS / B),
                                      'loss_IndexUV': sums[2] / (wsum * S2), 'loss_segAnn': sums[3] / (wsum * S2)})
@@ -337,12 +343,18 @@ class IUV_Estimator(nn.Module):
             # rd['part_iuv_gt'] (visualisation only in the reference) is not materialised on this path
             B = part_pred.shape[0]
             w = None if has_iuv is None else has_iuv.to(torch.float32)
-            sums = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align)
-            wsum = torch.tensor(float(B), device=sums.device) if w is None else w.sum().clamp(min=1.0)
-            lU = sums[0] / B * cfg.DANET.POINT_REGRESSION_WEIGHTS
-            lV = sums[1] / B * cfg.DANET.POINT_REGRESSION_WEIGHTS
-            lI = sums[2] / (wsum * (24 * Sp * Sp))
-            rd['losses'].update({'loss_pU': lU / 24., 'loss_pV': lV / 24., 'loss_pIndexUV': lI})
+            if LOSS_FINALIZE:
+                pr = cfg.DANET.POINT_REGRESSION_WEIGHTS / (24. * B)          # (sum / B * weight) / 24 joints
+                lU, lV, lI = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align,
+                                                  scales=((pr, 0.), (pr, 0.), (1., 24. * Sp * Sp)))
+                rd['losses'].update({'loss_pU': lU, 'loss_pV': lV, 'loss_pIndexUV': lI})
+            else:
+                sums = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align)
+                wsum = torch.tensor(float(B), device=sums.device) if w is None else w.sum().clamp(min=1.0)
+                lU = sums[0] / B * cfg.DANET.POINT_REGRESSION_WEIGHTS
+                lV = sums[1] / B * cfg.DANET.POINT_REGRESSION_WEIGHTS
+                lI = sums[2] / (wsum * (24 * Sp * Sp))
+                rd['losses'].update({'loss_pU': lU / 24., 'loss_pV': lV / 24., 'loss_pIndexUV': lI})
         elif self.training and iuv_image_gt is not None:
             if uvia_list is None:
                 uvia_list = iuv_img2map(iuv_image_gt)

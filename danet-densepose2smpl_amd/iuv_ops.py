@@ -29,7 +29,10 @@ class IuvGlobalFunction(torch.autograd.Function):
     argmax [B,H,W] uint8 of the raw index logits)."""
 
     @staticmethod
-    def forward(ctx, u, v, ix, an, gt, w, keep):
+    def forward(ctx, u, v, ix, an, gt, w, keep, scales=None):
+        """scales (round 6) = four (a, b) pairs: the op returns the four FINISHED losses sum_i * a_i / (max(sum w, 1) * b_i) (b_i = 0: no
+        division) as separate one-element tensors instead of the raw sum vector -- one launch (glue.loss_finalize) where the selects,
+        multiplications / divisions, their backward and the select-backward fills cost ~6 launches per loss and pass."""
         L = _lib.lib()
         B, _, H, W = u.shape
         # an input that IS the conv epilogue's padded output (all 32 / 16 channels: iuv_global hands those over when it can) gets
@@ -50,15 +53,29 @@ class IuvGlobalFunction(torch.autograd.Function):
                                          B, H, W, int(want), ptr(mp), ptr(am_raw), ptr(am_drop), ptr(sums), stream()), 'danet_iuv_global_forward')
         ctx.save_for_backward(u, v, ix, an, gtc, wc, kc, am_drop)
         ctx.want = want
+        ctx.scales = scales
         ctx.mark_non_differentiable(am_raw)
+        if scales is not None:
+            from .glue import loss_finalize
+            out = loss_finalize(4, scales, wc, B, sums=sums, rows=1)
+            ctx.set_materialize_grads(False)
+            return out[0:1], out[1:2], out[2:3], out[3:4], mp.permute(0, 3, 1, 2), am_raw
         return sums.float(), mp.permute(0, 3, 1, 2), am_raw
 
     @staticmethod
-    def backward(ctx, gsums, gmap, _g_am):
+    def backward(ctx, *grads):
         L = _lib.lib()
         u, v, ix, an, gtc, wc, kc, am_drop = ctx.saved_tensors
         B, _, H, W = u.shape
         dev = u.device
+        if ctx.scales is not None:
+            g4, gmap = grads[:4], grads[4]
+            gsums = None
+            if ctx.want and any(g is not None for g in g4):
+                from .glue import loss_finalize
+                gsums = loss_finalize(4, ctx.scales, wc, B, grads=list(g4))
+        else:
+            gsums, gmap = grads[0], grads[1]
         du = torch.empty(B, H, W, 32, dtype=torch.float32, device=dev)
         dv, di = torch.empty_like(du), torch.empty_like(du)
         da = torch.empty(B, H, W, 16, dtype=torch.float32, device=dev)
@@ -73,13 +90,14 @@ class IuvGlobalFunction(torch.autograd.Function):
                                           ptr(du), ptr(dv), ptr(di), ptr(da), stream()), 'danet_iuv_global_backward')
         f = lambda t, n, full: t.permute(0, 3, 1, 2) if full else t.permute(0, 3, 1, 2)[:, :n]        # noqa: E731
         fu = ctx.full
-        return f(du, NP, fu[0]), f(dv, NP, fu[1]), f(di, NP, fu[2]), f(da, NA, fu[3]), None, None, None
+        return f(du, NP, fu[0]), f(dv, NP, fu[1]), f(di, NP, fu[2]), f(da, NA, fu[3]), None, None, None, None
 
 
-def iuv_global(u, v, ix, an, gt=None, w=None, keep=None):
+def iuv_global(u, v, ix, an, gt=None, w=None, keep=None, scales=None):
     """sums = (sum smooth-L1 U, sum smooth-L1 V, sum CE index, sum CE ann) over the batch, weighted per sample by w
     (zeros when gt is None); iuv_map = [U_clean | V_clean | one-hot | 5 zero channels] as a bf16 channels_last
-    [B,80,H,W] tensor (the body regressor's padded first-conv operand); argmax = uint8 [B,H,W] of the raw index head."""
+    [B,80,H,W] tensor (the body regressor's padded first-conv operand); argmax = uint8 [B,H,W] of the raw index head.
+    scales = ((a, b),) * 4: the first result is the tuple of the four finished losses sums_i * a_i / (max(sum w, 1) * b_i) instead."""
     if not u.is_cuda:
         raise RuntimeError('danet_hip ops run on the GPU only (got a %s tensor); there is no CPU path' % u.device)
     if PADDED_BASES and torch.is_grad_enabled():
@@ -89,8 +107,13 @@ def iuv_global(u, v, ix, an, gt=None, w=None, keep=None):
         ok = all(b is not None and b.dtype == torch.float32 and b.shape[0] == t.shape[0] and b.shape[2:] == t.shape[2:] and
                  b.data_ptr() == t.data_ptr() and b.shape[1] == ld for b, t, ld in zip(bases, (u, v, ix, an), (32, 32, 32, 16)))
         if ok and all(_rows(b, n, ld) is b for b, n, ld in zip(bases, (NP, NP, NP, NA), (32, 32, 32, 16))):
-            return IuvGlobalFunction.apply(bases[0], bases[1], bases[2], bases[3], gt, w, keep)
-    return IuvGlobalFunction.apply(u, v, ix, an, gt, w, keep)
+            return _pack(IuvGlobalFunction.apply(bases[0], bases[1], bases[2], bases[3], gt, w, keep, scales), scales)
+    return _pack(IuvGlobalFunction.apply(u, v, ix, an, gt, w, keep, scales), scales)
+
+
+def _pack(out, scales):
+    """(sums, map, argmax), with `scales` the four finished losses as a tuple in place of the sum vector."""
+    return out if scales is None else (tuple(out[:4]), out[4], out[5])
 
 
 class SoftArgmaxFunction(torch.autograd.Function):

@@ -73,7 +73,7 @@ def padded_part_view(x24):
 
 class PartLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, iuv_img, theta, sample_w, sel, align):
+    def forward(ctx, pred, iuv_img, theta, sample_w, sel, align, scales=None):
         pred = nhwc_bf16(pred)
         B, C, H, W = pred.shape
         img = iuv_img.detach().to(torch.float32).contiguous()
@@ -90,24 +90,37 @@ class PartLossFunction(torch.autograd.Function):
                                                  ptr(sums), stream()), 'danet_part_loss_forward')
         ctx.save_for_backward(pred, img, th, w, sel)
         ctx.align = int(align)
+        ctx.scales = scales
+        if scales is not None:               # the three finished losses, one launch (glue.loss_finalize; see iuv_ops.IuvGlobalFunction)
+            from .glue import loss_finalize
+            out = loss_finalize(3, scales, w, B, sums=sums, rows=32)
+            ctx.set_materialize_grads(False)
+            return out[0:1], out[1:2], out[2:3]
         return sums.view(torch.float64).view(32, 3).sum(dim=0, dtype=torch.float64).float()
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *grads):
         pred, img, th, w, sel = ctx.saved_tensors
         B, C, H, W = pred.shape
         gp = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
-        scale = g.detach().to(torch.float32).contiguous()
+        if ctx.scales is not None:
+            from .glue import loss_finalize
+            if all(g is None for g in grads):
+                return None, None, None, None, None, None, None
+            scale = loss_finalize(3, ctx.scales, w, B, grads=list(grads))
+        else:
+            scale = grads[0].detach().to(torch.float32).contiguous()
         check(_lib.lib().danet_part_loss_backward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), ptr(scale),
                                                   B, H, W, ctx.align, ctx.cpj, ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_loss_backward')
-        return gp, None, None, None, None, None
+        return gp, None, None, None, None, None, None
 
 
-def part_losses(pred, iuv_img, theta, sample_w, sel, align):
+def part_losses(pred, iuv_img, theta, sample_w, sel, align, scales=None):
     """-> tensor [3]: sum over (b, joint, class, pixel) of fg * smooth_l1(U), same for V, and the sum over
     (b, joint, pixel) of w_b * cross-entropy of the index map; ground truth = the 3-channel IUV image
-    resampled per joint by `theta` [B,24,2,3] (sel [24,6]: DensePose parts of each joint)."""
+    resampled per joint by `theta` [B,24,2,3] (sel [24,6]: DensePose parts of each joint).
+    scales = ((a, b),) * 3: the three FINISHED losses sums_i * a_i / (max(sum w, 1) * b_i) as a tuple of one-element tensors instead."""
     if pred.dim() == 6:
         B, J, T, K, H, W = pred.shape
         pred = getattr(pred, '_padded', None) if getattr(pred, '_padded', None) is not None else pred.reshape(B, J * T * K, H, W)
-    return PartLossFunction.apply(pred, iuv_img, theta, sample_w, sel, align)
+    return PartLossFunction.apply(pred, iuv_img, theta, sample_w, sel, align, scales)

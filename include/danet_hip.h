@@ -153,6 +153,12 @@ int danet_softargmax_backward(const float* hm, int ld, int B, int J, int H, int 
  *   gradient (theta is detached before affine_grid, iuv_estimator.py:197).
  */
 int danet_pad_multi(const void* const* src, void* const* dst, const int* sdims, const int* ddims, int n, void* stream);
+/* Loss bookkeeping of the estimator (reference models/danet/iuv_estimator.py:325-339, 233-256) as one launch per pass:
+ * forward  (sums != NULL): out[i] = (sum over rows r of sums[r][i], DOUBLES) * a[i] / (b[i] > 0 ? max(sum(w[0..nw)), 1) * b[i] : 1);
+ * backward (sums == NULL): out[i] = (grads[i] ? *grads[i] : 0) * a[i] / (the same divisor) -- the coefficient vector of the loss kernels'
+ * backward.  n <= 8; a, b, grads are HOST arrays; w (device, or NULL = nw ones) are the per-sample weights. */
+int danet_loss_finalize(const void* sums, int rows, int n, const float* a, const float* b, const float* w, int nw,
+                        const void* const* grads, float* out, void* stream);
 /* /root/reference/models/smpl.py:31-37 (joints = joints54[:, JOINT_MAP]; smpl_joints = joints54[:, :24]; joints_J19 = joints[:, -24:][:, J24_TO_J19]):
  * one launch forward, one backward (the three gradients scattered and summed into g54; NULL = zero). */
 int danet_smpl_joints_forward(const float* j54, const long* map49, const long* map19, int B, int NJ54, int N49, int N19,
