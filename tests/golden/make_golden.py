@@ -648,6 +648,108 @@ def g16_hrnet256():
          floor__bn1_running_mean=(rm32.double() - net.bn1.running_mean).abs().max().float(), **arrs)
 
 
+def g18_hrnet256_b32():
+    """The BENCHED workload's backbone (32 images, 256 x 256, train-mode BatchNorm) through the reference in double precision, with the
+    reference's own fp32 floor (round-5 review, missing 5: "every reference golden is 64^2 / B = 2 or one 256^2 predictor input").  Every
+    16th pixel of the six maps + per-image-and-channel means over all pixels."""
+    ref_env({'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from models.module.hr_module import PoseHighResolutionNet
+    torch.manual_seed(0)
+    net = PoseHighResolutionNet(part_out_dim=7)
+    formula_params(net)
+    net.train()
+    img = formula_input('g18.img', (32, 3, 256, 256), -2.0, 2.0)
+    with torch.no_grad():
+        out32 = net(img)
+    formula_params(net)
+    net = net.double().train()
+    with torch.no_grad():
+        out = net(img.double())
+    arrs = {}
+    for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd'):
+        arrs[k], arrs[k + '__mean'] = _sub(out[k].float(), 16)
+        arrs['floor__' + k] = (out32[k].double() - out[k]).abs().max().float()
+        arrs['scale__' + k] = out[k].abs().max().float()
+        print(k, 'fp32 reference vs fp64 reference: max abs %.3g at scale %.3g' % (float(arrs['floor__' + k]), float(arrs['scale__' + k])))
+    save('g18_hrnet256_b32', bn1_running_mean=net.bn1.running_mean.float(), **arrs)
+
+
+def g19_inputs(B=32, S=64):
+    """Closed-form inputs of g19 (nothing stored): image, ground-truth IUV image (4 x 4 blobs of one part, top rows background) and
+    joint centres with visibility."""
+    img = formula_input('g19.img', (B, 3, 256, 256), -2.0, 2.0)
+    part = (formula_input('g19.part', (B, S // 4, S // 4)) * 25).floor().clamp(0, 24).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    part[:, :6] = 0
+    gt = torch.cat([(part / 24.).unsqueeze(1), formula_input('g19.uv', (B, 2, S, S))], 1)
+    gt[:, 1:] *= (part > 0).float().unsqueeze(1)
+    kps = torch.cat([formula_input('g19.kps', (B, 24, 2), -0.8, 0.8), torch.ones(B, 24, 1)], -1)
+    kps[0, 3, 2] = 0.0
+    return img, gt, kps
+
+
+def g19_grad_sample(gw):
+    """What g19 keeps of a weight gradient: all of a small one, every 4th output and 2nd input channel of a large one."""
+    return gw if gw.numel() <= 50000 else gw[::4, ::2].contiguous()
+
+
+def g19_estimator256_b32():
+    """The estimator half of the BENCHED train step on the reference itself: IUV_Estimator.forward in train mode at 32 x 256 x 256
+    (HRNet-W48 -> heads -> soft-argmax -> 24 STN crops -> grouped partial head -> all eight IUV losses, jitters 0,
+    align_corners = True as torch 1.1) and its backward pass: the loss scalars, the STN centres, sub-sampled predictions and four
+    sentinel weight gradients (stem, a stage-3 branch conv, a global head, the grouped partial head)."""
+    cfg = ref_env({'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64, 'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.,
+                   'DANET.PARTDROP_RATE': 0.})
+    import torch.nn.functional as F
+    ag, gs = F.affine_grid, F.grid_sample
+    F.affine_grid = lambda theta, size, align_corners=None: ag(theta, size, align_corners=True)
+    F.grid_sample = lambda x, grid, mode='bilinear', padding_mode='zeros', align_corners=None: gs(x.to(grid.dtype), grid, mode, padding_mode, align_corners=True)
+    try:
+        from models.danet.iuv_estimator import IUV_Estimator
+        torch.manual_seed(0)
+        est = IUV_Estimator(pretrained=False)
+        formula_params(est, skip=('learned_ratio', 'learned_offset'))
+        est.train()
+        B, S = 32, 64
+        img, gt, kps = g19_inputs(B, S)
+        has_iuv = torch.ones(B, dtype=torch.uint8).bool()
+        names = ('iuv_est.conv1.weight', 'iuv_est.stage3.1.branches.2.1.conv2.weight', 'iuv_est.final_pred.predict_u.weight',
+                 'iuv_est.final_pred.predict_partial_iuv.weight')
+        # the same pass in DOUBLE first: how far the reference's own fp32 gradients are from it is the floor of any fp32 implementation
+        # (the backward pass of a random-weight 90-layer ReLU net amplifies rounding: ~2 % on the stem's weight gradient)
+        est.double()
+        torch.set_default_dtype(torch.float64)
+        try:
+            rd64 = est(img.double(), gt.double(), kps.double(), has_iuv=has_iuv)
+            sum(v.sum() for v in rd64['losses'].values()).backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        g64 = {n: p.grad.clone() for n, p in est.named_parameters() if n in names}
+        l64 = {k: v.detach().reshape(-1).float() for k, v in rd64['losses'].items()}
+        del rd64
+        est.zero_grad(set_to_none=True)
+        est.float()
+        formula_params(est, skip=('learned_ratio', 'learned_offset'))         # (the double pass moved the running statistics)
+        rd = est(img, gt, kps, has_iuv=has_iuv)
+        total = sum(v.sum() for v in rd['losses'].values())
+        total.backward()
+        pd = dict(est.named_parameters())
+        floors = {}
+        for n in names:
+            d = (pd[n].grad.double() - g64[n]).abs().max() / g64[n].abs().max()
+            floors['gfloor__' + n.replace('.', '__')] = d.float()
+            print(n, 'fp32 reference gradient vs fp64: %.3g of scale' % float(d))
+        for k in l64:
+            print(k, 'fp32 loss vs fp64: rel %.3g' % float((rd['losses'][k].detach().reshape(-1)[0] - l64[k][0]).abs() / l64[k][0].abs()))
+        save('g19_estimator256_b32', learned_ratio=est.learned_ratio, learned_offset=est.learned_offset, **floors,
+             **{'grad64__' + n.replace('.', '__'): g19_grad_sample(g64[n].float()) for n in names},
+             index=_sub(rd['uvia_pred'][2], 16)[0], u=_sub(rd['uvia_pred'][0], 16)[0],
+             stn_kps_pred=rd['stn_kps_pred'], part_iuv_pred=rd['part_iuv_pred'].detach()[:, ::6, :, :, ::16, ::16].contiguous(),
+             **{'loss__' + k: v.detach().reshape(-1) for k, v in rd['losses'].items()},
+             **{'grad__' + n.replace('.', '__'): g19_grad_sample(pd[n].grad) for n in names})
+    finally:
+        F.affine_grid, F.grid_sample = ag, gs
+
+
 def g17_infer():
     """SURVEY 8 row f2 on the device (round-5 review item 4): the reference's inference path danet.py:61-131 -- IUV_Estimator (eval)
     -> iuvmap_clean -> per-part iuvmap_clean -> DecomposedPredictor (eval) -> para -- run with formula parameters; the GPU test
@@ -695,6 +797,8 @@ def g17_infer():
 
 ALL['g16'] = g16_hrnet256
 ALL['g17'] = g17_infer
+ALL['g18'] = g18_hrnet256_b32
+ALL['g19'] = g19_estimator256_b32
 
 
 def _main():

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from conftest import golden, GOLDEN, record
 sys.path.insert(0, GOLDEN)
-from make_golden import formula_params, formula_input, damp_residual_branches    # noqa: E402
+from make_golden import formula_params, formula_input, damp_residual_branches, g19_inputs, g19_grad_sample    # noqa: E402
 
 pytestmark = pytest.mark.gpu
 KEYS = ['predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index', 'predict_hm', 'xd']
@@ -257,6 +257,113 @@ def test_hrnet_fp32_vs_reference_golden_at_the_benched_resolution():
         assert meas[k]['max_abs'] <= tol and meas[k]['mean_abs'] <= 0.2 * tol, (k, meas[k], tol)
     assert np.abs(net.bn1.running_mean.cpu().numpy() - g['bn1_running_mean']).max() < 1e-6
     assert np.abs(net.bn2.running_var.cpu().numpy() / g['bn2_running_var'] - 1).max() < 1e-5
+
+
+def test_hrnet_vs_reference_golden_at_the_benched_batch_and_resolution():
+    """g18: the reference's PoseHighResolutionNet on the BENCHED workload's shape -- 32 images of 256 x 256, train-mode BatchNorm -- in
+    double precision, with the reference's own fp32 floor.  (a) The HIP fp32 mode (the reference's arithmetic type) within 2.5 x that
+    floor on every 16th pixel and on the per-image-and-channel means over ALL pixels; (b) the bf16 production path -- the benched
+    kernels at the benched sizes: four-branch lockstep launches of 512 workgroups, one-pass BatchNorm backward not involved in a
+    forward -- against the same reference values, with the whole-network bf16 bounds of tests/test_gpu_models.py (a random-weight
+    90-layer ReLU net amplifies bf16 rounding: measured values recorded in profiles/r06_parity_measured.jsonl)."""
+    _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from danet_densepose2smpl_amd import hrnet, conv
+    g = golden('g18_hrnet256_b32')
+    net = hrnet.PoseHighResolutionNet(part_out_dim=7)
+    formula_params(net)
+    net = net.cuda().train()
+    img = formula_input('g18.img', (32, 3, 256, 256), -2.0, 2.0).cuda()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    meas = {}
+    with conv.precision('fp32'), torch.no_grad():
+        out = net(img)
+    for k in KEYS:
+        o = out[k].float()
+        e = float(np.abs(o[..., ::16, ::16].cpu().numpy() - g[k]).max())
+        em = float(np.abs(o.double().mean(dim=(-2, -1)).cpu().numpy() - g[k + '__mean']).max())
+        meas[k] = {'max_abs': e, 'mean_abs': em, 'reference_fp32_floor': float(g['floor__' + k]), 'scale': float(g['scale__' + k])}
+    record('hrnet256_b32_fp32_mode_vs_reference_fp64', meas)
+    for k in KEYS:
+        tol = 2.5 * float(g['floor__' + k])
+        assert meas[k]['max_abs'] <= tol and meas[k]['mean_abs'] <= 0.2 * tol, (k, meas[k], tol)
+    net.load_state_dict(sd)                                   # (the fp32 pass moved the running statistics)
+    with torch.no_grad():
+        out = net(img)
+    mb = {}
+    for k in KEYS:
+        a = out[k].float()[..., ::16, ::16].flatten().double().cpu()
+        r = torch.from_numpy(g[k]).flatten().double()
+        mb[k] = {'rel_rms': float((a - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()), 'cos': float((a * r).sum() / (a.norm() * r.norm()))}
+    record('hrnet256_b32_bf16_vs_reference_fp64', mb)
+    for k in KEYS:
+        assert mb[k]['rel_rms'] < 0.35 and mb[k]['cos'] > 0.93, (k, mb[k])
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_estimator_train_pass_vs_reference_golden_at_the_benched_size(mode):
+    """g19: the estimator half of the BENCHED train step on the reference itself -- IUV_Estimator.forward (train mode) + backward at
+    32 x 256 x 256: HRNet-W48, the heads, soft-argmax, 24 STN crops, the grouped partial head and all eight IUV losses
+    (iuv_estimator.py:58-260, jitters 0).  fp32 mode (the reference's arithmetic): losses to 1e-4, STN centres to 1e-5, sub-sampled
+    predictions to 1e-4 of scale, the four sentinel weight gradients (stem, a stage-3 branch conv, a global head, the grouped partial
+    head) against the reference's DOUBLE-precision gradients within 3 x the reference's own fp32 floor.  bf16 (the benched kernels: streamed 3x3 launches, fused global / partial loss kernels, STN gather,
+    deferred multi-problem weight gradients): losses within 5 % (measured <= 0.9 %), head gradients by cosine, deep gradients by
+    magnitude (see the comment at the assertion)."""
+    _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64, 'DANET.STN_CENTER_JITTER': 0., 'DANET.STN_SCALE_JITTER': 0.,
+            'DANET.PARTDROP_RATE': 0., 'DANET.ALIGN_CORNERS': True})
+    import contextlib
+    from danet_densepose2smpl_amd.iuv_estimator import IUV_Estimator
+    from danet_densepose2smpl_amd import conv
+    g = golden('g19_estimator256_b32')
+    est = IUV_Estimator(pretrained=False)
+    formula_params(est, skip=('learned_ratio', 'learned_offset', '_'))
+    with torch.no_grad():
+        est.learned_ratio.copy_(torch.from_numpy(g['learned_ratio']))
+        est.learned_offset.copy_(torch.from_numpy(g['learned_offset']))
+    est = est.cuda().train()
+    img, gt, kps = (t.cuda() for t in g19_inputs())
+    with (conv.precision('fp32') if mode == 'fp32' else contextlib.nullcontext()):
+        rd = est(img, gt, kps, has_iuv=torch.ones(32, device='cuda'))
+        sum(v.sum() for v in rd['losses'].values()).backward()
+        conv.flush_wgrads()
+    torch.cuda.synchronize()
+    meas = {}
+    for k in g.files:
+        if k.startswith('loss__'):
+            ours, ref = float(rd['losses'][k[6:]].detach().sum()), float(g[k].sum())
+            meas[k[6:]] = abs(ours - ref) / abs(ref)
+    meas['stn_kps_pred_abs'] = float(np.abs(rd['stn_kps_pred'].cpu().numpy() - g['stn_kps_pred']).max())
+    meas['index'] = _rel(rd['uvia_pred'][2][..., ::16, ::16], g['index'])
+    meas['u'] = _rel(rd['uvia_pred'][0][..., ::16, ::16], g['u'])
+    meas['part_iuv_pred'] = _rel(rd['part_iuv_pred'].float()[:, ::6, :, :, ::16, ::16], g['part_iuv_pred'])
+    pd = dict(est.named_parameters())
+    # gradients against the reference's DOUBLE-precision pass; `gfloor__*` = how far the reference's own fp32 gradients are from it
+    # (0.8 % of scale on the stem, 1.2 % on the stage-3 conv, 1e-6 .. 1e-5 on the heads: the backward pass of a random-weight 90-layer
+    # ReLU net amplifies rounding) -- the floor of any fp32 implementation
+    for k in g.files:
+        if k.startswith('grad64__'):
+            gw = g19_grad_sample(pd[k[8:].replace('__', '.')].grad.float()).cpu().flatten().double()
+            r = torch.from_numpy(g[k]).flatten().double()
+            meas['grad__' + k[8:]] = {'rel_max': float((gw - r).abs().max() / r.abs().max()), 'cos': float((gw * r).sum() / (gw.norm() * r.norm())),
+                                      'norm_ratio': float(gw.norm() / r.norm()), 'reference_fp32_floor': float(g['gfloor__' + k[8:]])}
+    record('estimator256_b32_%s_vs_reference' % mode, meas)
+    losses = [k[6:] for k in g.files if k.startswith('loss__')]
+    grads = ['grad__' + k[8:] for k in g.files if k.startswith('grad64__')]
+    assert len(losses) == 8 and len(grads) == 4
+    if mode == 'fp32':
+        assert all(meas[k] < 1e-4 for k in losses), meas
+        assert meas['stn_kps_pred_abs'] < 1e-5 and meas['index'] < 1e-4 and meas['u'] < 1e-4 and meas['part_iuv_pred'] < 1e-4, meas
+        assert all(meas[k]['rel_max'] < max(3.0 * meas[k]['reference_fp32_floor'], 1e-4) and meas[k]['cos'] > 0.999 for k in grads), meas
+    else:
+        # measured on MI355X: the eight losses within 0.01 .. 0.9 %, STN centres 0.011, head gradients cos 0.99986 / 0.994.  The DEEP
+        # weight gradients (stem, stage 3) are decorrelated from the reference's (cos ~0.4) on this net: its backward pass amplifies a
+        # relative rounding error by ~1e5 (the reference's OWN fp32 gradients are already 1 % off its fp64 ones), and bf16 rounds at
+        # 4e-3 -- a property of random formula weights, not of the kernels, which the fp32 mode above holds to 1.7 x the fp32 floor
+        # through the same graph; what is asserted for them here is that their magnitude is right.
+        assert all(meas[k] < 0.05 for k in losses), meas
+        assert meas['stn_kps_pred_abs'] < 0.05, meas
+        heads = [k for k in grads if 'final_pred' in k]
+        assert len(heads) == 2 and all(meas[k]['cos'] > 0.98 for k in heads), meas
+        assert all(0.5 < meas[k]['norm_ratio'] < 2.0 for k in grads), meas
 
 
 @pytest.mark.parametrize('align', [0, 1])
