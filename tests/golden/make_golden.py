@@ -688,8 +688,9 @@ def g19_inputs(B=32, S=64):
 
 
 def g19_grad_sample(gw):
-    """What g19 keeps of a weight gradient: all of a small one, every 4th output and 2nd input channel of a large one."""
-    return gw if gw.numel() <= 50000 else gw[::4, ::2].contiguous()
+    """What g19 / g20 keep of a weight gradient: all of a small one, every k-th element (~40 k of them) of a large one."""
+    flat = gw.reshape(-1)
+    return flat if flat.numel() <= 50000 else flat[::max(1, flat.numel() // 40000)].contiguous()
 
 
 def g19_estimator256_b32():
@@ -750,6 +751,62 @@ def g19_estimator256_b32():
         F.affine_grid, F.grid_sample = ag, gs
 
 
+def g20_inputs(B=32, S=64):
+    """Closed-form regressor inputs shaped like danet.py:247,276-283 produces them: cleaned global maps [B,75,S,S] (U | V | one-hot index)
+    and cleaned partial maps [B,24,3,7,S,S]; one-hot planes from an arg-max of formula logits, U / V masked by them."""
+    import torch.nn.functional as F
+    idx = F.one_hot(formula_input('g20.idx', (B, 25, S, S)).argmax(1), 25).permute(0, 3, 1, 2).float()
+    uv = formula_input('g20.uv', (B, 2, 25, S, S))
+    iuv = torch.cat([uv[:, 0] * idx, uv[:, 1] * idx, idx], 1)
+    pidx = F.one_hot(formula_input('g20.pidx', (B, 24, 7, S, S)).argmax(2), 7).permute(0, 1, 4, 2, 3).float()
+    puv = formula_input('g20.puv', (B, 24, 2, 7, S, S))
+    part = torch.stack([puv[:, :, 0] * pidx, puv[:, :, 1] * pidx, pidx], 2)
+    return iuv, part
+
+
+def g20_predictor_b32():
+    """The regressor half of the BENCHED train step on the reference: DecomposedPredictor.forward (train mode) + backward at B = 32 --
+    body_net on [32,75,64,64], limb_net on the 768 part maps, the grouped limb layer4, the three GCNs and the grouped regressors
+    (smpl_regressor.py:397-928) -- para / joint positions / rotation, and sentinel weight gradients with the reference's own fp32 floor."""
+    ref_env({'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from models.danet.smpl_regressor import DecomposedPredictor
+    torch.manual_seed(0)
+    pose6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(24).unsqueeze(0)
+    mean = (torch.tensor([[0.9, 0., 0.]]), torch.zeros(1, 10), pose6)
+    names = ('limb_net.0.weight', 'limb_net.3.conv1.weight', 'limb_net.3.layer3.1.conv2.weight', 'body_net.3.layer4.1.conv2.weight',
+             'limb_reslayer.layer4.0.conv1.weight', 'refine_gcn.gc.1.weight')
+    skip = ('mean_', 'I_n', 'A_link', 'A_mask', 'A', 'r2p_A', 'p2r_A')
+    iuv, part = g20_inputs()
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        net = DecomposedPredictor(None, mean, pretrained=False)
+        formula_params(net, skip=skip)
+        net = net.to(dt).train()
+        torch.set_default_dtype(dt)
+        try:
+            rd = net(iuv.to(dt), part.to(dt))
+            w = torch.cos(torch.arange(rd['para'].numel(), dtype=dt).view_as(rd['para']) * 0.37)
+            loss = (rd['para'] * w).sum() + sum(t.sum() for t in rd['joint_position']) + rd['joint_rotation'][0].sum()
+            loss.backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        pd = dict(net.named_parameters())
+        res[dt] = ({'para': rd['para'].detach(), 'jp0': rd['joint_position'][0].detach(), 'jp1': rd['joint_position'][1].detach(),
+                    'jr0': rd['joint_rotation'][0].detach()}, {n: pd[n].grad.clone() for n in names})
+    out64, g64 = res[torch.float64]
+    out32, g32 = res[torch.float32]
+    arrs = {k: v.float() for k, v in out64.items()}
+    for k in out64:
+        arrs['floor__' + k] = (out32[k].double() - out64[k]).abs().max().float()
+        print(k, 'fp32 vs fp64 reference: max abs %.3g' % float(arrs['floor__' + k]))
+    for n in names:
+        key = n.replace('.', '__')
+        arrs['grad64__' + key] = g19_grad_sample(g64[n].float())
+        arrs['gfloor__' + key] = ((g32[n].double() - g64[n]).abs().max() / g64[n].abs().max()).float()
+        print(n, 'fp32 reference gradient vs fp64: %.3g of scale' % float(arrs['gfloor__' + key]))
+    save('g20_predictor_b32', **arrs)
+
+
 def g17_infer():
     """SURVEY 8 row f2 on the device (round-5 review item 4): the reference's inference path danet.py:61-131 -- IUV_Estimator (eval)
     -> iuvmap_clean -> per-part iuvmap_clean -> DecomposedPredictor (eval) -> para -- run with formula parameters; the GPU test
@@ -799,6 +856,7 @@ ALL['g16'] = g16_hrnet256
 ALL['g17'] = g17_infer
 ALL['g18'] = g18_hrnet256_b32
 ALL['g19'] = g19_estimator256_b32
+ALL['g20'] = g20_predictor_b32
 
 
 def _main():
