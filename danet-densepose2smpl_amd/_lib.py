@@ -179,7 +179,7 @@ def exported_symbols():
 # include/danet_hip.h DANET_KNOB_*: the library's only run-time switches (A-B timing, tests)
 KNOBS = {'c3_enable': 1, 'c3_mt': 2, 'c3_kw': 3, 'c3_blocks': 4, 'c3_want': 5, 'c3s_enable': 6, 'c3s_blocks': 7, 'c3s_kw': 8, 'c3s_want': 9,
          'pw': 10, 'pw_wgrad': 11, 'stem': 12, 'stem_dgrad': 13, 'c3a': 14, 'bn_block_bytes': 15,
-         'c3s_balance': 16, 'c3s_tile_cost': 17}
+         'c3s_balance': 16, 'c3s_tile_cost': 17, 'g3': 18}
 
 
 class _Library(object):

@@ -434,6 +434,8 @@ def _kernel_name(kid, stream_dims=None):
         return 'conv_pw_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10)
     if kid % 10 == 4:
         return 'conv3x3_stream_kernel<%d>' % ((kid // 100) % 10)
+    if kid % 10 == 5:        # csrc/conv_g3.hip: <channels per group of the gathered tensor (48 forward: NT 2, 24 data gradient: NT 3), MT>
+        return 'conv_g3_kernel<%d, %d>' % (48 if (kid // 100) % 10 == 2 else 24, kid // 1000)
     if kid % 10 == 1:
         return 'conv_fast_kernel<%d, %d>' % (kid // 1000, (kid // 100) % 10)
     return 'conv_igemm_kernel<%d, %d, %s>' % (kid // 1000, (kid // 100) % 10, 'true' if (kid // 10) % 10 else 'false')

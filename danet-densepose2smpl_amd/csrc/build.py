@@ -29,6 +29,7 @@ UNITS = {
     'conv3x3.hip': MFMA_VGPR,
     'conv3x3s.hip': MFMA_VGPR,
     'conv_fast.hip': MFMA_VGPR,
+    'conv_g3.hip': MFMA_VGPR,
     'conv_pw.hip': MFMA_VGPR,
     'conv_pw_wgrad.hip': MFMA_VGPR,
     'conv3x3a.hip': [],

@@ -46,6 +46,7 @@ extern "C" long danet_knob(int id, long value) {
         case DANET_KNOB_STEM: return conv_stem_knob(value);
         case DANET_KNOB_STEM_DGRAD: return conv_stem_dgrad_knob(value);
         case DANET_KNOB_C3A: return conv3x3a_knob(value);
+        case DANET_KNOB_G3: return conv_g3_knob(value);
         case DANET_KNOB_BN_BLOCK_BYTES: return bn_block_bytes_knob(value);
         default: return -1;
     }

@@ -106,6 +106,10 @@ bool conv_pw_wgrad_ok(const WgJob& j);
 size_t conv_pw_wgrad_ws_floats(const WgJob* jobs, const int* idx, int cnt, long target);
 int conv_pw_wgrad_launch(const WgJob* jobs, const int* idx, int cnt, float* ws, float beta, long target, void* stream);
 
+// conv_g3.hip: grouped 3x3 / stride-1 layers with narrow groups (the 24-group partial-IUV head: 48 -> 24 forward, 24 -> 48 data gradient)
+bool conv_g3_ok(const ConvP& p, bool vec8);
+int conv_g3_launch(const ConvP& p, void* stream);
+
 // conv3x3.hip: 3x3 / stride-1 / pad-1 forward and data gradient on an LDS-resident halo tile (persistent workgroups)
 bool conv3x3_ok(const ConvP& p, bool vec8);
 int conv3x3_config(const ConvP& p, bool vec8, int nprob);      // MT*100 + NT*10 + KW, 0 = not supported
@@ -125,6 +129,7 @@ long conv_pw_wgrad_knob(long value);
 long conv_stem_knob(long value);
 long conv_stem_dgrad_knob(long value);
 long conv3x3a_knob(long value);
+long conv_g3_knob(long value);
 long bn_block_bytes_knob(long value);        // danet_conv3x3_debug's buffer (NULL: off); the streamed kernel writes 16 ints per workgroup
 
 }  // namespace danet_conv

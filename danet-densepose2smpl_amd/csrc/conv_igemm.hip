@@ -636,7 +636,8 @@ static bool fill_conv_params(ConvP& p, bool& vec8, int B, int H, int W, int Cin,
 
 // Which kernel danet_conv_forward launches for a problem: MT*1000 + NT*100 + vec8*10 + fast
 // (fast = 1: conv_fast_kernel<MT, NT>, 0: conv_igemm_kernel<MT, NT, vec8>, 2: the LDS-tile 3x3 kernels (MT, NT, KW in the other
-// digits), 3: conv_pw_kernel<NKS, NTB> (NKS, NTB in the first two), 4: a grouped 3x3 layer on conv3x3_stream_kernel<NT>); -1 for invalid sizes.
+// digits), 3: conv_pw_kernel<NKS, NTB> (NKS, NTB in the first two), 4: a grouped 3x3 layer on conv3x3_stream_kernel<NT>, 5: a narrow-group
+// 3x3 layer on conv_g3_kernel<Cin_g, MT> (MT in the first digit)); -1 for invalid sizes.
 extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, int OW, int Cout, int R, int S,
                                          int stride, int pad, int dil, int groups, int transposed, int out_fp32)
 {
@@ -644,6 +645,7 @@ extern "C" int danet_conv_forward_kernel(int B, int H, int W, int Cin, int OH, i
     bool vec8;
     if (!fill_conv_params(p, vec8, B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups, transposed, 0, out_fp32)) return -1;
     const int mt = danet_conv_kernel_id(B, OH, OW, Cin, Cout, groups) / 100;
+    if (conv_g3_ok(p, vec8)) return (p.W / 16) * 1000 + danet_conv_nt(p.Cout_g) * 100 + 10 + 5;                                   // conv_g3_kernel<Cin_g, MT>
     if (conv3x3_ok(p, vec8)) { const int c = conv3x3_config(p, vec8, 1); return (c / 100) * 1000 + ((c / 10) % 10) * 100 + (c % 10) * 10 + 2; }
     if (conv_pw_ok(p, vec8)) { const int c = conv_pw_config(p); return (c / 10) * 1000 + (c % 10) * 100 + 10 + 3; }      // conv_pw_kernel<NKS, NTB>
     if (p.groups > 1 && vec8 && conv3x3_stream_first() && conv3x3s_launch(&p, 1, nullptr, true) == 0)                       // grouped 3x3 on conv3x3_stream_kernel<NT>
@@ -684,6 +686,12 @@ extern "C" int danet_conv_forward(const void* x, const void* wp, const float* bi
     DANET_CHECK_ARG(!bn_sums || (!bias && !relu && !out_fp32), "conv_forward: fused BN statistics need a plain bf16 output");
     DANET_CHECK_ARG((size_t)(p.Kp / 8) * 16 <= 64 * 1024, "conv_forward: K=%d too large for the tap table", p.K);
     hipStream_t st = (hipStream_t)stream;
+    if (conv_g3_ok(p, vec8)) {
+        // the 24-group partial-IUV head and its data gradient (csrc/conv_g3.hip): one (image, group, row band) per workgroup
+        if (conv_g3_launch(p, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no narrow-group instantiation");
+        DANET_CHECK_LAUNCH("conv_g3_kernel");
+        return DANET_OK;
+    }
     if (c3) {
         if (conv3x3_launch(&p, 1, stream) != 0) return danet::fail(DANET_ERR_ARG, "conv_forward: no 3x3 tiling");
         DANET_CHECK_LAUNCH("conv3x3_tile_kernel");

@@ -345,7 +345,8 @@ int danet_conv_forward_multi_kernel(const void* jobs, int n);      /* the kernel
 enum { DANET_KNOB_C3_ENABLE = 1, DANET_KNOB_C3_MT = 2, DANET_KNOB_C3_KW = 3, DANET_KNOB_C3_BLOCKS = 4, DANET_KNOB_C3_WANT = 5,
        DANET_KNOB_C3S_ENABLE = 6, DANET_KNOB_C3S_BLOCKS = 7, DANET_KNOB_C3S_KW = 8, DANET_KNOB_C3S_WANT = 9,
        DANET_KNOB_PW = 10, DANET_KNOB_PW_WGRAD = 11, DANET_KNOB_STEM = 12, DANET_KNOB_STEM_DGRAD = 13, DANET_KNOB_C3A = 14,
-       DANET_KNOB_BN_BLOCK_BYTES = 15, DANET_KNOB_C3S_BALANCE = 16, DANET_KNOB_C3S_TILE_COST = 17 };
+       DANET_KNOB_BN_BLOCK_BYTES = 15, DANET_KNOB_C3S_BALANCE = 16, DANET_KNOB_C3S_TILE_COST = 17,
+       DANET_KNOB_G3 = 18 /* csrc/conv_g3.hip: narrow-group 3x3 layers (danet_conv_forward_kernel: last digit 5) */ };
 long danet_knob(int id, long value);
 /* danet_conv3x3_stream_plan: KW*100 + stages*10 + NT the streamed 3x3 kernel (csrc/conv3x3s.hip) would use for a problem in a launch of
  * nprob problems (0: not taken). */

@@ -638,13 +638,15 @@ def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
     x = torch.randn(B, G * Cg, H, H, generator=g).bfloat16().cuda()
     w = (torch.randn(G * Ng, Cg, 3, 3, generator=g) / np.sqrt(9 * Cg)).bfloat16().float().cuda()
     dconv.stream_tables(x.device)
-    assert L.danet_conv_forward_kernel(B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, 0, 0) % 10 == 4
+    with _lib.knobs(g3=0):          # (round 6: without fused statistics the narrow-group kernel, csrc/conv_g3.hip, takes the head first)
+        assert L.danet_conv_forward_kernel(B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, 0, 0) % 10 == 4
     yr = F.conv2d(x.float(), w, None, 1, 1, 1, G)
     xn, wp = dconv.nhwc_bf16(x), dconv.pack_weight(torch.nn.Parameter(w), G, 0)
     bias = torch.randn(G * Ng, generator=g).cuda()
     res = {}
     for on in (1, 0):
         prev = L.danet_conv3x3_stream_set(on, -1, -1, -1)
+        prev_g3 = L.knob('g3', 0)
         try:
             sums = torch.zeros(L.danet_bn_ws_floats(G * Ng), device='cuda')
             y = dconv._conv_fwd_raw(xn, wp, None, B, H, H, G * Cg, H, H, G * Ng, 3, 3, 1, 1, 1, G, False, False, False, sums)
@@ -653,6 +655,7 @@ def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
             res[on] = (y.float(), dconv.bn_sums_total(sums, G * Ng), yb.float())
         finally:
             L.danet_conv3x3_stream_set(prev, -1, -1, -1)
+            L.knob('g3', prev_g3)
     scale = yr.abs().max().item()
     assert (res[1][0] - yr).abs().max().item() <= 1e-2 * scale
     assert (res[1][0] - res[0][0]).abs().max().item() <= 1e-2 * scale
@@ -660,6 +663,46 @@ def test_grouped_partial_iuv_head_runs_on_the_streamed_kernel(B, H):
     st = res[1][1]
     assert (st[0] - yr.sum(dim=(0, 2, 3))).abs().max().item() <= 5e-3 * yr.sum(dim=(0, 2, 3)).abs().max().item() + 1e-3 * scale * B * H
     assert (st[1] - (yr * yr).sum(dim=(0, 2, 3))).abs().max().item() <= 3e-3 * (yr * yr).sum(dim=(0, 2, 3)).abs().max().item()
+
+
+@pytest.mark.parametrize('B,H,W', [(32, 64, 64), (3, 32, 32), (2, 20, 48), (2, 7, 16)])
+def test_narrow_group_3x3_kernel_forward_and_data_gradient(B, H, W):
+    """csrc/conv_g3.hip (round 6): the 24-group partial-IUV head (iuv_estimator.py:193-206, 24 x (48 -> 21, padded to 24) channels, 3x3)
+    forward WITH ITS BIAS and its data gradient (24 -> 48 per group, taps mirrored) -- one (image, group, row band) per workgroup, the
+    band in LDS, the group's weights in registers -- selected (kernel id ...5) and compared with F.conv2d / its input gradient in fp32 on
+    the bf16-rounded operands and with the kernels that ran these passes before (streamed kernel / gather kernel: knob g3 = 0); row
+    counts that do not fill a band, widths of 1 .. 4 fragments; two runs bit-identical."""
+    from danet_densepose2smpl_amd import conv as dconv, _lib
+    L = _lib.lib()
+    G, Cg, Ng = 24, 48, 24
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, G * Cg, H, W, generator=g).bfloat16().cuda()
+    w = (torch.randn(G * Ng, Cg, 3, 3, generator=g) / np.sqrt(9 * Cg)).bfloat16().float().cuda()
+    w.view(G, Ng, Cg, 3, 3)[:, 21:] = 0                                          # the head's three padding channels per group
+    bias = torch.randn(G * Ng, generator=g).cuda()
+    gy = (torch.randn(B, G * Ng, H, W, generator=g) * 0.1).bfloat16().cuda()
+    dconv.stream_tables(x.device)
+    assert L.danet_conv_forward_kernel(B, H, W, G * Cg, H, W, G * Ng, 3, 3, 1, 1, 1, G, 0, 0) % 10 == 5
+    assert L.danet_conv_forward_kernel(B, H, W, G * Ng, H, W, G * Cg, 3, 3, 1, 1, 1, G, 1, 0) % 10 == 5
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, w, bias, 1, 1, 1, G)
+    gxr, = torch.autograd.grad(yr, xr, gy.float())
+    wpar = torch.nn.Parameter(w)
+    xn, gn = dconv.nhwc_bf16(x), dconv.nhwc_bf16(gy)
+    wp0, wp1 = dconv.pack_weight(wpar, G, 0), dconv.pack_weight(wpar, G, 1)
+    out = {}
+    for on in (1, 1, 0):
+        with _lib.knobs(g3=on):
+            y = dconv._conv_fwd_raw(xn, wp0, bias, B, H, W, G * Cg, H, W, G * Ng, 3, 3, 1, 1, 1, G, False, False, False)
+            gx = dconv._conv_fwd_raw(gn, wp1, None, B, H, W, G * Ng, H, W, G * Cg, 3, 3, 1, 1, 1, G, True, False, False)
+            torch.cuda.synchronize()
+        out.setdefault(on, []).append((y.float(), gx.float()))
+    (y1, gx1), (y2, gx2) = out[1]
+    y0, gx0 = out[0][0]
+    assert torch.equal(y1, y2) and torch.equal(gx1, gx2)
+    sy, sg = yr.abs().max().item(), gxr.abs().max().item()
+    assert (y1 - yr).abs().max().item() <= 1e-2 * sy and (gx1 - gxr).abs().max().item() <= 1e-2 * sg
+    assert (y1 - y0).abs().max().item() <= 1e-2 * sy and (gx1 - gx0).abs().max().item() <= 1e-2 * sg
 
 
 @pytest.mark.parametrize('B,Cin', [(768, 64), (64, 64), (96, 32), (70, 16)])
