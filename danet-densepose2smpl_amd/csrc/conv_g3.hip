@@ -57,11 +57,12 @@ __global__ __launch_bounds__(256, 2) void conv_g3_kernel(ConvP p)
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (int)p.x_bytes, 0x00020000);
         const int npieces = (TH + 2) * WP * PC;
         const int pixb = p.Cin * 2;
-        for (int i0 = 0; i0 < npieces; i0 += 256 * 4) {
-            i32x4 v[4];
-            int dst[4];
+        constexpr int NB = 8;                                 // loads in flight per lane (a band is 14 - 16 pieces per lane: two batches)
+        for (int i0 = 0; i0 < npieces; i0 += 256 * NB) {
+            i32x4 v[NB];
+            int dst[NB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int i = i0 + u * 256 + t;
                 const int pc = i % PC, q = i / PC;
                 const int col = q % WP, row = q / WP;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_g3_kernel(ConvP p)
                 dst[u] = i < npieces ? (row * WP + col) * PS + pc * 16 : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NB; ++u)
                 if (dst[u] >= 0) *reinterpret_cast<i32x4*>(g3_smem + dst[u]) = v[u];
         }
     }
