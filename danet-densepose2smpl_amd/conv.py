@@ -88,6 +88,7 @@ FUSE_BN_BWD_REDUCE = bool(int(os.environ.get('DANET_FUSE_BN_BWD', '0')))
 FUSE_BN_BWD_STEM = bool(int(os.environ.get('DANET_FUSE_BN_BWD_STEM', '0')))      # ... for the 7x7 stems' data gradients only (conv2d; measured neutral in round 5: 26.70 vs 26.67 ms)
 FUSE_BN_STATS = True     # conv epilogue accumulates the following BatchNorm's batch statistics
 USE_WGRAD3X3 = True      # 3x3/s1 weight gradients through the LDS-transpose-read kernel
+MULTI_DGRAD_SUBSETS = bool(int(os.environ.get('DANET_MULTI_DGRAD_SUBSETS', '1')))     # data gradients of a multi-conv set that does not qualify as a whole: qualifying subsets in one launch each
 TRACE = None           # debugging: a list that receives (tag, shape, mean |value|) for every conv / BN launch (tools/debug_flaky.py)
 
 # How often each attribute-carried fusion was taken / missed since the last FUSION.clear().  The fusions ride on
@@ -1142,8 +1143,40 @@ class MultiConvFunction(torch.autograd.Function):
                         gxs[i]._bn_red = reds[k]
                     if adds[k] is not None:
                         FUSION['residual_grad_fused'] += 1
-            else:                                   # e.g. tile counts differ between the problems: per-layer launches
-                for k, i in enumerate(need):
+            else:
+                # The set as a whole does not qualify (the data gradients of a fuse-layer level mix output widths -- 48 / 96 / 192 channels =
+                # different channel-block counts per workgroup -- and the 48-channel strided ones have no parity classes): round 6 launches
+                # every SUBSET of equal channel-block count that qualifies as one multi-problem launch (the fuse chains' ~35 single
+                # data-gradient launches per step were 0.7 ms) and only the rest per layer.
+                left = list(range(len(need)))
+                if MULTI_DGRAD_SUBSETS and len(need) > 1 and not any(a is not None for a in adds):
+                    by_nt = {}
+                    for k, i in enumerate(need):
+                        d = dims_l[i]
+                        by_nt.setdefault(int(L.danet_conv_nt(d[3] // d[12])), []).append(k)
+                    for nt_, ks in by_nt.items():
+                        # drop members that do not run on the lean gather kernel by themselves, then try the rest together
+                        sub = [k for k in ks if L.danet_conv_forward_multi_ok(ctypes.addressof(jobs[k]), 1) == 1]
+                        if len(sub) < 2:
+                            continue
+                        sj = (_lib.ConvJob * len(sub))(*[jobs[k] for k in sub])
+                        if L.danet_conv_forward_multi_ok(ctypes.addressof(sj), len(sub)) != 1:
+                            continue
+                        tok = None
+                        if PROFILER is not None:
+                            dd = [dims_l[need[k]] for k in sub]
+                            tok = PROFILER.begin(_multi_kernel_name(sj, len(sub), dd[0][3] // dd[0][12]),
+                                                 sum(2.0 * d[0] * d[4] * d[5] * d[6] * (d[3] // d[12]) * d[7] * d[8] for d in dd), ('dgrad-multi', len(sub)))
+                        check(L.danet_conv_forward_multi(ctypes.addressof(sj), len(sub), stream()), 'danet_conv_forward_multi')
+                        if tok is not None:
+                            PROFILER.end(tok)
+                        FUSION['dgrad_subset_multi'] += len(sub)
+                        for k in sub:
+                            left.remove(k)
+                            if reds[k] is not None:
+                                gxs[need[k]]._bn_red = reds[k]
+                for k in left:                      # per-layer launches
+                    i = need[k]
                     (B, H, W, Cin, OH, OW, Cout, R, S, stride, pad, dil, groups) = dims_l[i]
                     gxs[i] = _conv_fwd_raw(gys[i], keep[k], None, B, OH, OW, Cout, H, W, Cin, R, S, stride, pad, dil, groups, True, False, False)
                     if adds[k] is not None:
