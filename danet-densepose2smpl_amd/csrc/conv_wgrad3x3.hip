@@ -55,12 +55,18 @@ __device__ inline v2u tr_read(unsigned lds_byte_addr) {
 // memory), pixel (ty, tx) of the chunk is pixel (ty, tx & 3) of image tx >> 2, and each image gets a halo tile of its own (6 x 6,
 // every border cell outside its image = zero): the staged strip is 6 x 12 and the second half of a fragment starts 6 columns on
 // (stride 2: 8 x 8 inputs, 9 x 18 strip).
-template <int CT, int NI, int ST, bool PAIR = false>
+// SM = 2 (round 6, same idea): 2 x 2 output maps (body_net layer4, the grouped limb layer4: `LimbResLayers`, res_module.py:500-535) -- a
+// chunk is EIGHT images, two rows of four, each behind its own 4 x 4 (stride 2: 5 x 5) halo; these layers' 2.4 M-element weight gradients
+// were 71 M atomic adds on the generic kernel (287 us + 150 us of unpacking per step).
+template <int CT, int NI, int ST, int SM = 0>
 __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const int by, const int bz)
 {
-    constexpr int PHW = ST * 3 + 3;                              // pair mode: halo columns of ONE image (4 output columns at stride ST)
-    constexpr int HH = halo_h(ST), HW = PAIR ? 2 * PHW : halo_w(ST);
-    constexpr int HALF = PAIR ? PHW : ST * 4;                    // staged columns between the two 4-pixel halves of a fragment
+    constexpr bool PAIR = SM != 0;                               // small-map mode: SM = output map side (4: two images per chunk, 2: eight)
+    constexpr int OS = SM ? SM : 4;                              // output rows / columns of one image
+    constexpr int PHW = ST * (OS - 1) + 3;                       // halo columns (and rows) of ONE image
+    constexpr int IMH = SM ? TH / OS : 1, IMW = SM ? TW / OS : 1; // images per chunk, vertically / horizontally
+    constexpr int HH = SM ? IMH * PHW : halo_h(ST), HW = SM ? IMW * PHW : halo_w(ST);
+    constexpr int HALF = SM ? (4 / OS) * PHW : ST * 4;           // staged columns between the two 4-pixel halves of a fragment
     constexpr int BCO = CT * 16, BCI = NI * 16;
     constexpr int PXY = BCO * 2, PXX = BCI * 2;                  // bytes per staged pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -90,7 +96,10 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
         const int r = tap / 3, s = tap - r * 3;
         // lane i of 16-lane group lg supplies output pixel (ty = lg, tx = 4h + (i>>2)) = halo pixel (ST*ty + r, ST*tx + s),
         // channels ni*16 + 4(i&3)
-        boff[pi] = (unsigned)(((ST * lg + r) * HW + ST * (li >> 2) + s) * PXX + (ni * 16 + 4 * (li & 3)) * 2);
+        // (small-map mode: pixel (ty, tx) lies in image (ty / OS, tx / OS), whose halo starts PHW cells further per image)
+        const int hrow = SM ? (lg / OS) * PHW + ST * (lg % OS) + r : ST * lg + r;
+        const int hcol = SM ? ((li >> 2) / OS) * PHW + ST * ((li >> 2) % OS) + s : ST * (li >> 2) + s;
+        boff[pi] = (unsigned)((hrow * HW + hcol) * PXX + (ni * 16 + 4 * (li & 3)) * 2);
     }
     const unsigned aoff = (unsigned)((lg * TW + (li >> 2)) * PXY + (4 * (li & 3)) * 2);   // dY fragment, h = 0, ct = 0
 
@@ -113,7 +122,7 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
         const int pc = t + u * 256;
         const int c8 = pc % (BCO / 8), q = pc / (BCO / 8);
         const int ty = q / TW, tx = q % TW;
-        const int ypix = PAIR ? (tx >> 2) * 16 + ty * 4 + (tx & 3) : ty * p.W + tx;
+        const int ypix = SM ? ((ty / OS) * IMW + tx / OS) * (OS * OS) + (ty % OS) * OS + tx % OS : ty * p.W + tx;
         yrel[u] = (pc < NPY && co0 + c8 * 8 < p.Cout_g) ? (ypix * p.Cout + c8 * 8) * 2 : OOB;
     }
 #pragma unroll
@@ -122,11 +131,11 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg3P& p, const int bx, const
         const int c8 = pc % (BCI / 8), q = pc / (BCI / 8);
         const bool live = pc < NPX && ci0 + c8 * 8 < p.Cin_g;
         if (PAIR) {
-            // halo cell (hy, hx): image hx / PHW, its input pixel (hy - 1, hx % PHW - 1) -- inside the (4 ST) x (4 ST) image or a zero;
-            // static per piece
-            const int hy = q / HW - 1, img = (q % HW) / PHW, hc = (q % HW) % PHW - 1;
-            const bool inside = live && (unsigned)hy < (unsigned)(4 * ST) && (unsigned)hc < (unsigned)(4 * ST);
-            xrel[u] = ((img * (16 * ST * ST) + hy * (4 * ST) + hc) * p.Cin + c8 * 8) * 2;
+            // halo cell (hq, hx): image (hq / PHW, hx / PHW), its input pixel (hq % PHW - 1, hx % PHW - 1) -- inside the (OS ST)^2 image or a
+            // zero; static per piece
+            const int hq = q / HW, img = (hq / PHW) * IMW + (q % HW) / PHW, hy = hq % PHW - 1, hc = (q % HW) % PHW - 1;
+            const bool inside = live && (unsigned)hy < (unsigned)(OS * ST) && (unsigned)hc < (unsigned)(OS * ST);
+            xrel[u] = ((img * (OS * OS * ST * ST) + hy * (OS * ST) + hc) * p.Cin + c8 * 8) * 2;
             xhy[u] = inside ? 1 : -100000;                                // (row test of fetch(): 0 <= -1 + 1 < IH)
             xhx[u] = 1;
         } else {
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wg3P p)
 constexpr int NPM = 20;
 struct Wg3Multi { Wg3P p[NPM]; int start[NPM + 1]; int nyb[NPM]; int n; int xcd; };
 
-template <int CT, int NI, int ST, bool PAIR = false>
+template <int CT, int NI, int ST, int SM = 0>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
 {
     // XCD-contiguous order (round 6 experiment, DANET_WGRAD3_XCD=1; measured slower -- the 256 MB infinity cache already absorbs the
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_multi_kernel(Wg3Multi mp)
     const int l = vb - mp.start[i];
     const Wg3P& p = mp.p[i];
     const int bx = l % p.msplit, rest = l / p.msplit;
-    wgrad3x3_body<CT, NI, ST, PAIR>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
+    wgrad3x3_body<CT, NI, ST, SM>(p, bx, rest % mp.nyb[i], rest / mp.nyb[i]);
 }
 
 struct Red3Multi { const float* part[NPM]; float* dw[NPM]; int G[NPM], Cout_g[NPM], Cin_g[NPM], msplit[NPM]; long start[NPM + 1]; int n; float beta; };
@@ -351,15 +360,22 @@ extern "C" int danet_conv_wgrad3x3_ok(int H, int W, int Cin, int Cout, int R, in
 // Pair mode (wgrad3x3_body<..., PAIR>): 4 x 4 maps, two images per chunk -- through danet_conv_wgrad3x3_multi only.
 extern "C" int danet_conv_wgrad3x3_pair_ok(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int groups) {
     static const bool off = getenv("DANET_NO_WGRAD3_PAIR") != nullptr;         // A/B knob
-    if (off || !(R == 3 && S == 3 && (stride == 1 || stride == 2) && pad == 1 && dil == 1 && H == 4 * stride && W == 4 * stride && B > 0 && B % 2 == 0 &&
-                 groups > 0)) return 0;
+    if (off || !(R == 3 && S == 3 && (stride == 1 || stride == 2) && pad == 1 && dil == 1 && H == W && B > 0 && groups > 0)) return 0;
+    if (!((H == 4 * stride && B % 2 == 0) || (H == 2 * stride && B % 8 == 0))) return 0;          // 4 x 4 outputs: image pairs; 2 x 2: octets
     if (Cin % groups != 0 || Cout % groups != 0) return 0;
     const int ci = Cin / groups, co = Cout / groups;
     if (ci % 8 != 0 || co % 8 != 0) return 0;
     // instantiated for 32- and 48-wide blocks (tiles3: 32 < c and c % 48 != 0 -> 2 tiles; c % 48 == 0 or c <= 48 -> 3)
     return 1;
 }
-static inline bool wg3_is_pair(int B, int H, int W, int stride) { return (stride == 1 || stride == 2) && H == 4 * stride && W == 4 * stride && B % 2 == 0; }
+// small-map mode of a problem: the output map side (4 or 2) when it runs with several images per chunk, 0 otherwise
+static inline int wg3_small(int B, int H, int W, int stride) {
+    if (!(stride == 1 || stride == 2) || H != W) return 0;
+    if (H == 4 * stride && B % 2 == 0) return 4;
+    if (H == 2 * stride && B % 8 == 0) return 2;
+    return 0;
+}
+static inline bool wg3_is_pair(int B, int H, int W, int stride) { return wg3_small(B, H, W, stride) != 0; }
 
 // (H, W): OUTPUT size
 static void plan3(int B, int H, int W, int Cin, int Cout, int groups, int* ct, int* ni, int* msplit) {
@@ -450,7 +466,8 @@ static inline double wg3_weight(int Cout, int Cin_g) { const double p = (double)
 // msplit of every job when jobs [first, last) of one instance share a launch
 static void plan_multi(const Wg3Job* jobs, const int* idx, int cnt, int ct, int ni, int* msplit) {
     auto chunks_of = [](const Wg3Job& j) -> long {
-        return wg3_is_pair(j.B, j.H, j.W, j.stride) ? (long)(j.B / 2) : (long)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW);
+        const int sm = wg3_small(j.B, j.H, j.W, j.stride);
+        return sm ? (long)(j.B / (sm == 4 ? 2 : 8)) : (long)j.B * (j.H / j.stride / TH) * (j.W / j.stride / TW);
     };
     double tot = 0;
     for (int k = 0; k < cnt; ++k) {
@@ -482,13 +499,14 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         if (done[i]) continue;
         int ct, ni, dummy;
         const int stride = jobs[i].stride;
-        const bool pair = wg3_is_pair(jobs[i].B, jobs[i].H, jobs[i].W, stride);
+        const int sm = wg3_small(jobs[i].B, jobs[i].H, jobs[i].W, stride);
+        const bool pair = sm != 0;
         plan3(jobs[i].B, jobs[i].H / stride, jobs[i].W / stride, jobs[i].Cin, jobs[i].Cout, jobs[i].groups, &ct, &ni, &dummy);
         static const int npm_env = getenv("DANET_WGRAD3_NPM") ? atoi(getenv("DANET_WGRAD3_NPM")) : 0;      // problems per launch (A-B knob)
         const int npm = npm_env > 0 && npm_env < NPM ? npm_env : NPM;
         int idx[NPM], cnt = 0;
         for (int k = i; k < n && cnt < npm; ++k) {
-            if (done[k] || jobs[k].stride != stride || wg3_is_pair(jobs[k].B, jobs[k].H, jobs[k].W, stride) != pair) continue;
+            if (done[k] || jobs[k].stride != stride || wg3_small(jobs[k].B, jobs[k].H, jobs[k].W, stride) != sm) continue;
             int c2, n2;
             plan3(jobs[k].B, jobs[k].H / stride, jobs[k].W / stride, jobs[k].Cin, jobs[k].Cout, jobs[k].groups, &c2, &n2, &dummy);
             if (c2 == ct && n2 == ni) { idx[cnt++] = k; done[k] = true; }
@@ -508,7 +526,7 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
             p.direct = direct ? j.dw : nullptr;
             p.IH = j.H; p.IW = j.W;
             p.B = j.B; p.H = j.H / stride; p.W = j.W / stride; p.Cin = j.Cin; p.Cout = j.Cout; p.groups = j.groups;
-            if (pair) { p.B = j.B / 2; p.H = 4; p.W = 8; p.IH = 4 * stride; p.IW = 8 * stride; }      // two images = one 4 x 8 chunk (32 consecutive output pixels)
+            if (pair) { p.B = j.B / (sm == 4 ? 2 : 8); p.H = 4; p.W = 8; p.IH = 4 * stride; p.IW = 8 * stride; }      // 2 (8) images = one 4 x 8 chunk (32 consecutive output pixels)
             p.Cin_g = j.Cin / j.groups; p.Cout_g = j.Cout / j.groups;
             p.tiles_h = p.H / TH; p.tiles_w = p.W / TW;
             p.nchunks = (long)p.B * p.tiles_h * p.tiles_w;
@@ -526,12 +544,15 @@ static int multi_foreach_launch(const Wg3Job* jobs, int n, float* ws, size_t ws_
         }
         if (!ws) continue;                                   // sizing pass
         if (used > ws_floats) return danet::fail(DANET_ERR_WORKSPACE, "conv_wgrad3x3_multi: workspace too small");
-        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + halo_h(stride) * (pair ? 2 * (stride * 3 + 3) : halo_w(stride)) * ni * 32);
+        const int phw = stride * ((sm ? sm : 4) - 1) + 3;                                   // halo side of one image in small-map mode
+        const size_t lds = 2 * (size_t)(TH * TW * ct * 32 + (sm ? (TH / sm) * phw * (TW / sm) * phw : halo_h(stride) * halo_w(stride)) * ni * 32);
         const dim3 grid((unsigned)mp.start[cnt]);
         if (pair) {
 #define W3P(a, b) if (ct == a && ni == b) { \
-            if (stride == 1) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1, true>), grid, dim3(256), lds, st, mp); \
-            else hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 2, true>), grid, dim3(256), lds, st, mp); } else
+            if (stride == 1 && sm == 4) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1, 4>), grid, dim3(256), lds, st, mp); \
+            else if (stride == 2 && sm == 4) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 2, 4>), grid, dim3(256), lds, st, mp); \
+            else if (stride == 1) hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 1, 2>), grid, dim3(256), lds, st, mp); \
+            else hipLaunchKernelGGL((conv_wgrad3x3_multi_kernel<a, b, 2, 2>), grid, dim3(256), lds, st, mp); } else
             W3P(2, 2) W3P(2, 3) W3P(3, 2) W3P(3, 3) W3P(1, 1) W3P(1, 2) W3P(2, 1) W3P(1, 3) W3P(3, 1)
             return danet::fail(DANET_ERR_ARG, "conv_wgrad3x3_multi: no pair-mode kernel for tiles %dx%d", ct, ni);
 #undef W3P

@@ -231,10 +231,13 @@ def test_multi_problem_wgrad3x3_direct_and_reduced_jobs():
 
 
 @pytest.mark.parametrize('stride', [1, 2])
-@pytest.mark.parametrize('B,Cin,Cout,groups', [(768, 256, 256, 1), (32, 256, 256, 1), (6, 64, 32, 1), (10, 48, 96, 1), (4, 96, 48, 2), (2, 16, 16, 1),
-                                               (768, 128, 256, 1)], ids=lambda v: str(v))
-def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups, stride):
-    """csrc/conv_wgrad3x3.hip PAIR mode (round 6): 3x3 / stride-1 weight gradients on 4 x 4 maps -- limb_net layer3 over the 768 part
+@pytest.mark.parametrize('B,Cin,Cout,groups,osz', [(768, 256, 256, 1, 4), (32, 256, 256, 1, 4), (6, 64, 32, 1, 4), (10, 48, 96, 1, 4), (4, 96, 48, 2, 4),
+                                                   (2, 16, 16, 1, 4), (768, 128, 256, 1, 4),
+                                                   # 2 x 2 output maps: eight images per chunk (body_net layer4, the grouped limb layer4)
+                                                   (32, 512, 512, 1, 2), (32, 3072, 3072, 24, 2), (8, 64, 32, 1, 2), (16, 256, 512, 1, 2), (24, 48, 48, 1, 2)],
+                         ids=lambda v: str(v))
+def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups, osz, stride):
+    """csrc/conv_wgrad3x3.hip small-map mode (round 6): 3x3 weight gradients on 4 x 4 (two images per chunk) and 2 x 2 (eight) output maps -- limb_net layer3 over the 768 part
     crops (res_module.py:393-464; 0.56 ms per step on the generic gather kernel before) -- with two images sharing one 4 x 8 chunk, each
     behind a zero halo of its own.  Against torch's fp32 weight gradient on the bf16-rounded operands; alone, next to ordinary jobs in
     the same call, accumulated (beta = 1), and twice (bit-identical)."""
@@ -242,13 +245,13 @@ def test_wgrad3x3_pair_mode_two_4x4_images_per_chunk(B, Cin, Cout, groups, strid
     from danet_densepose2smpl_amd import conv as dconv, _lib
     from danet_densepose2smpl_amd._lib import ptr, stream, check
     L = _lib.lib()
-    S = 4 * stride                                  # input size: 4 x 4 OUTPUT maps (stride 2: limb_net layer3's first block, 8 x 8 -> 4 x 4)
+    S = osz * stride                                # input size: osz x osz OUTPUT maps (stride 2: limb_net layer3's first block, 8 x 8 -> 4 x 4)
     assert L.danet_conv_wgrad3x3_pair_ok(B, S, S, Cin, Cout, 3, 3, stride, 1, 1, groups) == 1
     assert L.danet_conv_wgrad3x3_ok(S, S, Cin, Cout, 3, 3, stride, 1, 1, groups) == 0
     assert L.danet_conv_wgrad3x3_pair_ok(B + 1, S, S, Cin, Cout, 3, 3, stride, 1, 1, groups) == 0          # an odd batch has no partner image
     torch.manual_seed(B + Cin)
     x = dconv.nhwc_bf16(torch.randn(B, Cin, S, S, device='cuda'))
-    g = dconv.nhwc_bf16(torch.randn(B, Cout, 4, 4, device='cuda') * 0.1)
+    g = dconv.nhwc_bf16(torch.randn(B, Cout, osz, osz, device='cuda') * 0.1)
     ref = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin // groups, 3, 3), g.float(), stride=stride, padding=1, groups=groups)
     # an ordinary 8-wide job of the same instance family rides in the same call
     x2 = dconv.nhwc_bf16(torch.randn(4, Cin, 8 * stride, 8 * stride, device='cuda'))
