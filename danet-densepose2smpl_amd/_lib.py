@@ -83,7 +83,7 @@ _SIGNATURES = {
     'danet_bn_ws_floats': (c_sz, [c_i]),
     'danet_knob': (ctypes.c_long, [c_i, ctypes.c_long]),
     'danet_bn_acc_bytes': (c_i, []),
-    'danet_channel_sum': (c_i, [c_f, ctypes.c_int64, c_i, c_f, c_i, c_f]),
+    'danet_channel_sum': (c_i, [c_f, ctypes.c_int64, c_i, c_f, c_i, c_i, c_f]),
     'danet_bn_forward_multi': (c_i, [c_f, c_i, c_fl, c_fl, c_f]),
     'danet_bn_backward_multi': (c_i, [c_f, c_i, c_f]),
     'danet_bn_backward_onepass_ok': (c_i, [c_f, c_i, c_i]),

@@ -684,16 +684,19 @@ def channel_sum(gy):
     if not gy.is_cuda or C % 4 != 0 or gy.dtype not in (torch.bfloat16, torch.float32) or not gy.permute(0, 2, 3, 1).is_contiguous():
         return gy.sum(dim=(0, 2, 3), dtype=torch.float32)
     # double accumulators: order-independent (csrc/conv_common.h); a slice of the step's zeroed arena when there is one
-    out = ARENA.alloc(2 * C) if CHSUM_ARENA else None
+    # (round 6) 16 replicas for the large maps: 1 024 workgroups instead of 256 queueing on the same C addresses; summed here
+    ncopy = CHSUM_COPIES if B * H * W * C >= (1 << 21) else 1
+    out = ARENA.alloc(2 * C * ncopy) if CHSUM_ARENA else None
     zero = out is not None
-    out = out.view(torch.float64) if zero else torch.empty(C, dtype=torch.float64, device=gy.device)
+    out = out.view(torch.float64) if zero else torch.empty(C * ncopy, dtype=torch.float64, device=gy.device)
     L = _lib.lib()
     fn = L.danet_channel_sum_f32 if gy.dtype == torch.float32 else L.danet_channel_sum
-    check(fn(ptr(gy.permute(0, 2, 3, 1)), B * H * W, C, ptr(out), int(zero), stream()), 'danet_channel_sum')
-    return out.float()
+    check(fn(ptr(gy.permute(0, 2, 3, 1)), B * H * W, C, ptr(out), int(zero), ncopy, stream()), 'danet_channel_sum')
+    return out.float() if ncopy == 1 else out.view(ncopy, C).sum(0).float()
 
 
 CHSUM_ARENA = bool(int(os.environ.get('DANET_CHSUM_ARENA', '1')))       # A-B / debugging knob: 0 = a memset node per call
+CHSUM_COPIES = int(os.environ.get('DANET_CHSUM_COPIES', '16'))            # replicas of a bias-gradient sum over a large map (1: the old single copy)
 
 
 DEFER_WGRAD = False       # queue weight gradients during backward; flush_wgrads() computes them in multi-problem launches

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const elem_t* __restrict_
 
 // per-channel sums of a [M, C] tensor (bias gradients): one atomic per channel and block into out[C] (DOUBLES, zeroed by the host: the
 // additions of the workgroups' fp32 partial sums are exact, so the totals do not depend on their order -- conv_common.h)
-__global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restrict__ x, FlatMap fm, double* __restrict__ out)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restrict__ x, FlatMap fm, double* __restrict__ out, int ncopy, int Ctot)
 {
     __shared__ float sm[256][VW];
     const int t = threadIdx.x;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const elem_t* __restri
                 for (int j = 0; j < VW; ++j) s.v[j] += a[u].v[j];
         }
     }
-    block_channel_reduce(sm, s, t, fm.CV, fm.span, out);
+    block_channel_reduce(sm, s, t, fm.CV, fm.span, out + (size_t)(blockIdx.x % ncopy) * Ctot);
 }
 
 // mode 0: training (sums -> mean/invstd, update running stats); mode 1: eval (running stats)
@@ -1012,13 +1012,16 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
 
 // out[C] (doubles) = sum over the M rows of x [M, C] (the bias gradient of a convolution: gy.sum(dim = (0, 2, 3))); out is zeroed
 // here (memset node) and accumulated with one atomic per channel and workgroup.  C % 4 == 0, C <= 1024 per launch slab.
-extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, double* out, int out_is_zero, void* stream)
+// ncopy (round 6; 1 = the old form): out holds ncopy REPLICAS [ncopy][C], workgroup b adds into replica b % ncopy and the caller sums the
+// replicas -- with one copy 256 workgroups queued on the same C addresses and could not be made more (a 17 MB head gradient took 34 us:
+// 0.5 TB/s, four waves per compute unit); with 16 copies the launch runs 1 024 workgroups.
+extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, double* out, int out_is_zero, int ncopy, void* stream)
 {
     DANET_ENTER();
-    DANET_CHECK_ARG(x && out && M > 0 && C > 0 && C % VW == 0, "channel_sum: bad arguments (C=%d must be a multiple of %d)", C, VW);
+    DANET_CHECK_ARG(x && out && M > 0 && C > 0 && C % VW == 0 && ncopy >= 1 && ncopy <= 64, "channel_sum: bad arguments (C=%d must be a multiple of %d)", C, VW);
     hipStream_t st = (hipStream_t)stream;
     if (!out_is_zero) {
-        hipError_t err = danet::zero_async(out, sizeof(double) * (size_t)C, st);
+        hipError_t err = danet::zero_async(out, sizeof(double) * (size_t)C * ncopy, st);
         if (err != hipSuccess) return danet::fail(DANET_ERR_HIP, "channel_sum: memset: %s", hipGetErrorString(err));
     }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
@@ -1027,8 +1030,9 @@ extern "C" int NA_NAME(danet_channel_sum)(const void* x, int64_t M, int C, doubl
         DANET_CHECK_ARG(make_map(M, C, c0, Cs, &fm, &grid) == 0, "channel_sum: C=%d (M=%ld) unsupported", C, (long)M);
         // every workgroup ends with one atomic per channel on the SAME C addresses (no replicas here): 1024 workgroups serialised
         // there; one workgroup per compute unit reads as fast and queues a quarter of the atomics (A-B in the step: within noise)
-        if (grid > 256) { grid = 256; fm.rstep = (int)((long)fm.span * grid / fm.CV); }
-        hipLaunchKernelGGL(channel_sum_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, out + c0);
+        const int cap = ncopy >= 4 ? 1024 : 256;
+        if (grid > cap) { grid = cap; fm.rstep = (int)((long)fm.span * grid / fm.CV); }
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, fm, out + c0, ncopy, C);
         DANET_CHECK_LAUNCH("channel_sum_kernel");
     }
     return DANET_OK;

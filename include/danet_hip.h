@@ -503,8 +503,9 @@ int danet_bn_backward_onepass(const void* jobs, int n, void* bar, int max_blocks
 /* out[C] (DOUBLES: order-independent accumulation) = sum over the M rows of x [M, C] (bf16; _f32: fp32): the bias gradient of a convolution,
  * gy.sum(dim = (0, 2, 3)) in /root/reference's autograd.  out is zeroed here unless out_is_zero != 0 (a slice of the caller's
  * zeroed arena); C % 4 == 0. */
-int danet_channel_sum(const void* x, int64_t M, int C, double* out, int out_is_zero, void* stream);
-int danet_channel_sum_f32(const void* x, int64_t M, int C, double* out, int out_is_zero, void* stream);
+/* (ncopy: out is [ncopy][C] replicas, workgroup b adds into replica b % ncopy, the caller sums them; 1 = a plain [C] result) */
+int danet_channel_sum(const void* x, int64_t M, int C, double* out, int out_is_zero, int ncopy, void* stream);
+int danet_channel_sum_f32(const void* x, int64_t M, int C, double* out, int out_is_zero, int ncopy, void* stream);
 int danet_sum_relu_forward(const void* const* terms, const int* shifts, int nterms,
                            int B, int H, int W, int C, int relu, void* y, void* stream);
 int danet_sum_relu_backward(const void* gy, const void* y, int B, int H, int W, int C, int shift, int relu,

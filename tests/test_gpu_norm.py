@@ -373,7 +373,7 @@ def test_maxpool3x3s2_vs_torch(shape, mode):
     assert float((g.float() - gr).abs().max()) <= tol * float(gr.abs().max()) + 1e-12
 
 
-@pytest.mark.parametrize('shape', [(32, 576, 16, 16), (3, 24, 9, 7), (2, 2048, 4, 4), (5, 32, 33, 17)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('shape', [(32, 576, 16, 16), (3, 24, 9, 7), (2, 2048, 4, 4), (5, 32, 33, 17), (32, 32, 64, 64)], ids=lambda s: 'x'.join(map(str, s)))
 def test_channel_sum_vs_torch(shape):
     """danet_channel_sum (bias gradients) == gy.sum(dim=(0, 2, 3)) in fp32, for bf16 and fp32 NHWC tensors."""
     from danet_densepose2smpl_amd import conv
