@@ -19,7 +19,8 @@ echo "== full GPU suite, three times, tails kept"
 for i in 1 2 3; do
   timeout 900 python -m pytest tests -q -x -m gpu > gpurun_out/${R}_pytest_full_$i.log 2>&1
   echo "rc=$?" >> gpurun_out/${R}_pytest_full_$i.log
-  (echo "# python -m pytest tests -q -x -m gpu   (run $i of 3, one gpurun box, $(date -u +%FT%TZ))"; tail -12 gpurun_out/${R}_pytest_full_$i.log) > gpurun_out/${R}_pytest_gpu_$i.txt
+  # (the summary line first: RCCL prints its banner when the process exits, after pytest's last line)
+  (echo "# python -m pytest tests -q -x -m gpu   (run $i of 3, one gpurun box, $(date -u +%FT%TZ))"; grep -h "passed\|failed\|error" gpurun_out/${R}_pytest_full_$i.log | tail -3; tail -4 gpurun_out/${R}_pytest_full_$i.log) > gpurun_out/${R}_pytest_gpu_$i.txt
   tail -2 gpurun_out/${R}_pytest_gpu_$i.txt
 done
 cp gpurun_out/parity_measured.jsonl gpurun_out/${R}_parity_measured.jsonl 2>/dev/null
