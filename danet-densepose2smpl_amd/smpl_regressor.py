@@ -45,6 +45,7 @@ def _pool_conv1x1_grouped(cin, cout, groups):
 
 
 FUSED_SMPL_LOSSES = True    # SMPL-side losses through csrc/loss_ops.hip (False: the tensor-op formulation below)
+BODY_STREAM = bool(int(__import__('os').environ.get('DANET_BODY_STREAM', '1')))     # body_net on a side stream beside limb_net (A-B knob)
 
 
 def _masked_mean(per_sample_sum, mask, per_sample_count):
@@ -309,8 +310,22 @@ class DecomposedPredictor(nn.Module):
 
     def forward(self, body_iuv, limb_iuv):
         rd = {'visualization': {}, 'losses': {}}
-        global_para, _ = self.body_net(body_iuv)
-        global_para = global_para + self.mean_cam_shape
+        # body_net (32 images, tensors of <= 16 MB, most launches a handful of workgroups) is independent of limb_net (the 768 part
+        # crops: chip-filling launches) until `para` is assembled: on a side stream its latency-bound launches run beside the limb
+        # net's (round 6; autograd replays its backward on the same stream; its BatchNorms take the two-kernel backward there, the
+        # one-pass kernel being confined to the step's own stream, nn.ONEPASS_STREAM)
+        side = None
+        if BODY_STREAM and body_iuv.is_cuda and self.training and torch.is_grad_enabled():
+            from .hrnet import _side_streams
+            cur = torch.cuda.current_stream(body_iuv.device)
+            side = _side_streams(body_iuv.device, 1)[0]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                global_para, _ = self.body_net(body_iuv)
+                global_para = global_para + self.mean_cam_shape
+        else:
+            global_para, _ = self.body_net(body_iuv)
+            global_para = global_para + self.mean_cam_shape
         nbs, S = limb_iuv.size(0), limb_iuv.size(-1)
         # the fused part_clean op hands over the zero-padded 24-channel NHWC bf16 operand of the stem conv
         stacked = getattr(limb_iuv, '_nhwc_padded', None)
@@ -341,5 +356,8 @@ class DecomposedPredictor(nn.Module):
         rot_ref = self.p2r_gcn(pos_ref, self.p2r_A[0])
         pose6 = self._grouped_head(self.pose_regressors[-1], rot_ref).reshape(nbs, -1) + self.mean_pose
         smpl_pose = rot6d_to_rotmat(pose6).reshape(nbs, -1)
+        if side is not None:
+            cur.wait_stream(side)
+            global_para.record_stream(cur)
         rd['para'] = torch.cat([global_para, smpl_pose], dim=1)
         return rd
