@@ -21,6 +21,7 @@ import os as _os
 PAD_NARROW_BLOCKS = bool(int(_os.environ.get('DANET_PAD_NARROW_BLOCKS', '1')))
 BOTTLENECK_LINK = bool(int(_os.environ.get('DANET_BOTTLENECK_LINK', '1')))          # A-B knob: identity-shortcut gradient of a Bottleneck through conv1's dgrad epilogue
 HEAD_FAN_OUT = bool(int(_os.environ.get('DANET_HEAD_FAN_OUT', '1')))                # A-B knob: nn.fan_out over the six consumers of the final feature map      # A-B knob, see Bottleneck._forward_padded
+HEAD_STREAM = bool(int(_os.environ.get('DANET_HEAD_STREAM', '1')))      # the four global IUV heads on a side stream beside the heat-map head (A-B knob)
 
 
 class ConvBN(nn.Module):
@@ -147,6 +148,21 @@ class IUV_predict_layer(nn.Module):
         # the fuse-sum kernel (nn.fan_out: two launches) instead of five pairwise adds of autograd
         from .nn import fan_out
         xs = fan_out(x, 6) if HEAD_FAN_OUT else [x] * 6
+        if HEAD_STREAM and x.is_cuda and self.training and torch.is_grad_enabled():
+            # the four global heads are independent of the heat-map head's chain of ten narrow (12 / 16-channel) layers, whose launches
+            # are bound by their latency: side by side on two streams (round 6; autograd replays each on its own stream)
+            from .hrnet import _side_streams
+            cur = torch.cuda.current_stream(x.device)
+            side = _side_streams(x.device, 2)[1]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                heads = [self.predict_u(xs[0]), self.predict_v(xs[1]), self.predict_uv_index(xs[2]), self.predict_ann_index(xs[3])]
+            hm = self.predict_hm(xs[4])
+            cur.wait_stream(side)
+            for h in heads:
+                h.record_stream(cur)
+            return {'predict_u': heads[0], 'predict_v': heads[1], 'predict_uv_index': heads[2], 'predict_ann_index': heads[3],
+                    'predict_hm': hm, 'xd': xs[5]}
         return {'predict_u': self.predict_u(xs[0]), 'predict_v': self.predict_v(xs[1]),
                 'predict_uv_index': self.predict_uv_index(xs[2]), 'predict_ann_index': self.predict_ann_index(xs[3]),
                 'predict_hm': self.predict_hm(xs[4]), 'xd': xs[5]}
