@@ -932,6 +932,11 @@ inline int make_map(int64_t M, int C, int c_begin, int Cs, FlatMap* fm, int* gri
     fm->rstep = (int)((long)fm->span * blocks / fm->CV);
     return 0;
 }
+// slabs of a tensor wider than one slab that one multi-problem launch can take (1: not wide, or not a whole number of slabs)
+inline int wide_slabs(int C) {
+    static const bool off = getenv("DANET_BN_WIDE") && atoi(getenv("DANET_BN_WIDE")) == 0;       // A-B timing
+    return !off && C > SLAB && C % SLAB == 0 && C / SLAB <= 12 ? C / SLAB : 1;
+}
 
 }  // namespace
 
@@ -953,6 +958,31 @@ extern "C" int NA_NAME(danet_bn_forward)(const void* x, const void* res, void* y
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_forward: memset: %s", hipGetErrorString(e));
     }
     const float inv = 1.0f / (float)M, unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    if (wide_slabs(C) > 1) {
+        // a tensor wider than one slab is C / SLAB independent BatchNorms over the same rows: ONE launch over all of them (round 6: the
+        // grouped layer4 of the limb branch, [32, 2, 2, 3072], took three 11 us launches per BatchNorm in a stretch of the step where
+        // nothing else runs)
+        const int ns = wide_slabs(C);
+        BnFwdMulti m; m.n = ns; m.momentum = momentum; m.eps = eps; m.mode = training ? 0 : 1; m.start[0] = 0;
+        for (int s = 0; s < ns; ++s) {
+            const int c0 = s * SLAB;
+            BnFwdOne& a = m.a[s];
+            int grid;
+            DANET_CHECK_ARG(make_map(M, C, c0, SLAB, &a.fm, &grid) == 0, "bn_forward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
+            if (training && ws_is_zero != 2) {
+                hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, st, (const elem_t*)x, a.fm, (bn_acc_t*)sums_ws + c0, C);
+                DANET_CHECK_LAUNCH("bn_stats_kernel");
+            }
+            a.x = (const elem_t*)x; a.res = (const elem_t*)res; a.y = (elem_t*)y; a.sums = sums_ws ? (const bn_acc_t*)sums_ws + c0 : nullptr;
+            a.gamma = gamma ? gamma + c0 : nullptr; a.beta = beta ? beta + c0 : nullptr;
+            a.running_mean = running_mean ? running_mean + c0 : nullptr; a.running_var = running_var ? running_var + c0 : nullptr;
+            a.saved = saved ? saved + c0 : nullptr; a.mask = (unsigned char*)relu_mask; a.C = C; a.inv_count = inv; a.unbias = unbias; a.relu = relu;
+            m.start[s + 1] = m.start[s] + grid;
+        }
+        hipLaunchKernelGGL(bn_apply_multi_kernel, dim3(m.start[ns]), dim3(256), 0, st, m);
+        DANET_CHECK_LAUNCH("bn_apply_multi_kernel");
+        return DANET_OK;
+    }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
         FlatMap fm; int grid;
@@ -991,6 +1021,28 @@ extern "C" int NA_NAME(danet_bn_backward)(const void* dy, const void* x, const v
     if (!ws_is_zero) {
         hipError_t e = danet::zero_async(red_ws, sizeof(bn_acc_t) * 2 * C * NCOPY, st);
         if (e != hipSuccess) return danet::fail(DANET_ERR_HIP, "bn_backward: memset: %s", hipGetErrorString(e));
+    }
+    if (wide_slabs(C) > 1) {                       // as in bn_forward: the slabs of a wide tensor in one launch per phase
+        const int ns = wide_slabs(C);
+        BnBwdMulti m; m.n = ns; m.start[0] = 0;
+        for (int s = 0; s < ns; ++s) {
+            const int c0 = s * SLAB;
+            BnBwdOne& a = m.a[s];
+            int grid;
+            DANET_CHECK_ARG(make_map(M, C, c0, SLAB, &a.fm, &grid) == 0, "bn_backward: C=%d (M=%ld) unsupported: channels must be a multiple of 4 and the tensor < 2 GB", C, (long)M);
+            a.dy = (const elem_t*)dy; a.x = (const elem_t*)x; a.y = (const elem_t*)y; a.saved = saved + c0; a.gamma = gamma ? gamma + c0 : nullptr;
+            a.red = (bn_acc_t*)red_ws + c0; a.dx = (elem_t*)dx; a.dres = (elem_t*)dres; a.dparam = dparam ? dparam + c0 : nullptr; a.C = C;
+            a.inv_count = 1.0f / (float)M; a.relu = relu; a.have_red = ws_is_zero == 2; a.beta = beta ? beta + c0 : nullptr;
+            a.mask = (const unsigned char*)relu_mask; a.mask_mode = mask_mode;
+            m.start[s + 1] = m.start[s] + grid;
+        }
+        if (ws_is_zero != 2) {
+            hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(m.start[ns]), dim3(256), 0, st, m);
+            DANET_CHECK_LAUNCH("bn_bwd_reduce_multi_kernel");
+        }
+        hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(m.start[ns]), dim3(256), 0, st, m);
+        DANET_CHECK_LAUNCH("bn_bwd_apply_multi_kernel");
+        return DANET_OK;
     }
     for (int c0 = 0; c0 < C; c0 += SLAB) {
         const int Cs = C - c0 < SLAB ? C - c0 : SLAB;
@@ -1271,25 +1323,33 @@ static int onepass_plan_rows(const BnBwdJob* jobs, int n, BnOnePass* ms /* [NBM]
     BnOnePass* m = nullptr;
     for (int i = 0; i < n; ++i) {
         const BnBwdJob& j = jobs[i];
-        if (!(j.dy && j.x && j.dx && j.saved && j.red && j.M > 0 && j.C > 0 && j.C <= SLAB && j.red_state == 1)) return 0;
+        if (!(j.dy && j.x && j.dx && j.saved && j.red && j.M > 0 && j.C > 0 && (j.C <= SLAB || wide_slabs(j.C) > 1) && j.red_state == 1)) return 0;
         if (j.relu && !((j.mask_mode == 1 && j.mask) || (j.mask_mode == 2 && !j.dres))) return 0;
+      // a wide tensor: one entry per channel slab (same rows, per-channel buffers offset, the full width as their stride)
+      for (int s = 0, ns = wide_slabs(j.C); s < ns; ++s) {
+        const int c0 = s * SLAB, Cs = j.C < SLAB ? j.C : SLAB;
         BnBwdOne a;
         int grid;
-        if (make_map(j.M, j.C, 0, j.C, &a.fm, &grid) != 0) return 0;
+        if (make_map(j.M, j.C, c0, Cs, &a.fm, &grid) != 0) return 0;
         // rows per lane <= rows_per_lane: blocks >= rows / (rows per block step * rows_per_lane)
         const long rows_per_block = a.fm.span / a.fm.CV;
         long blocks = (j.M + rows_per_block * rows_per_lane - 1) / (rows_per_block * rows_per_lane);
         if (blocks < 1) blocks = 1;
         if (blocks > max_blocks) return 0;
         a.fm.rstep = (int)(rows_per_block * blocks);
-        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved; a.gamma = j.gamma; a.red = (bn_acc_t*)j.red;
-        a.dx = (elem_t*)j.dx; a.dres = (elem_t*)j.dres; a.dparam = j.dparam; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
-        a.have_red = 0; a.beta = j.beta; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
-        if (!m || m->start[m->n] + blocks > max_blocks) { m = &ms[nl++]; m->n = 0; m->start[0] = 0; }
+        a.dy = (const elem_t*)j.dy; a.x = (const elem_t*)j.x; a.y = (const elem_t*)j.y; a.saved = j.saved + c0; a.gamma = j.gamma ? j.gamma + c0 : nullptr;
+        a.red = (bn_acc_t*)j.red + c0;
+        a.dx = (elem_t*)j.dx; a.dres = (elem_t*)j.dres; a.dparam = j.dparam ? j.dparam + c0 : nullptr; a.C = j.C; a.inv_count = 1.0f / (float)j.M; a.relu = j.relu;
+        a.have_red = 0; a.beta = j.beta ? j.beta + c0 : nullptr; a.mask = (const unsigned char*)j.mask; a.mask_mode = j.mask_mode;
+        if (!m || m->n == NBM || m->start[m->n] + blocks > max_blocks) {
+            if (nl == NBM) return 0;
+            m = &ms[nl++]; m->n = 0; m->start[0] = 0;
+        }
         m->a[m->n] = a;
         m->start[m->n + 1] = m->start[m->n] + (int)blocks;
         ++m->n;
         total += blocks;
+      }
     }
     // small sets are launch-bound either way: in isolation the barrier (~9 us; 17 + 0.055 us per workgroup in all) costs
     // more than a second ~6 us launch, but inside the captured step a threshold did not pay (33.38 / 33.39 / 33.52 / 33.70

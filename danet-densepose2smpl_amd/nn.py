@@ -168,7 +168,7 @@ class BatchNormActFunction(torch.autograd.Function):
             if red is None:
                 red = torch.empty(L.danet_bn_ws_floats(C), dtype=torch.float32, device=x.device)
         dparam = torch.empty(2, C, dtype=torch.float32, device=x.device)      # rows: d beta, d gamma
-        bar = _onepass_bar(x.device) if (red_zero != 2 and C <= 1024 and dt == torch.bfloat16) else None
+        bar = _onepass_bar(x.device) if (red_zero != 2 and (C <= 1024 or (C % 1024 == 0 and C <= 12288)) and dt == torch.bfloat16) else None
         done = False
         if bar is not None:
             if red_zero is False:
