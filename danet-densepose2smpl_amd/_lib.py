@@ -122,6 +122,12 @@ _SIGNATURES = {
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_backward': (c_i, [c_f, c_f, c_i, c_f, c_f]),
+    'danet_gcn_tail_ws_floats': (c_sz, [c_i]),
+    'danet_gcn_tail_scratch_floats': (c_sz, [c_i]),
+    'danet_gcn_tail_max_batch': (c_i, []),
+    'danet_gcn_tail_debug': (c_i, [c_f]),
+    'danet_gcn_tail_forward': (c_i, [c_f, c_f]),
+    'danet_gcn_tail_backward': (c_i, [c_f, c_f]),
 }
 
 # fp32 instantiations (csrc/norm_act_f32.hip, stn.hip): same arguments, fp32 NHWC activations
@@ -164,6 +170,22 @@ class BnBwdJob(ctypes.Structure):
     """One tensor of danet_bn_backward_multi."""
     _fields_ = [(k, ctypes.c_void_p) for k in ('dy', 'x', 'y', 'gamma', 'saved', 'dx', 'dres', 'dparam', 'red', 'beta', 'mask')] + \
                [('M', ctypes.c_int64), ('C', c_i), ('red_state', c_i), ('relu', c_i), ('mask_mode', c_i)]
+
+
+class GcnLayer(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ('W', 'bias', 'gamma', 'beta', 'running_mean', 'running_var')]
+
+
+class GcnTailArgs(ctypes.Structure):
+    """struct danet_gcn_tail_args (include/danet_hip.h)."""
+    _fields_ = [('x', ctypes.c_void_p), ('L', GcnLayer * 5)] + \
+               [(k, ctypes.c_void_p) for k in ('A_r2p', 'A_p2r', 'A_mask', 'edge')] + \
+               [('Wp', ctypes.c_void_p * 2), ('bp', ctypes.c_void_p * 2), ('Wc', ctypes.c_void_p * 2), ('bc', ctypes.c_void_p * 2)] + \
+               [(k, ctypes.c_void_p) for k in ('mean_pose', 'ws', 'jr0', 'jp0', 'jp1', 'pose', 'g_jr0', 'g_jp0', 'g_jp1', 'g_pose', 'gx')] + \
+               [('gW', ctypes.c_void_p * 5), ('gb', ctypes.c_void_p * 5), ('ggamma', ctypes.c_void_p * 5), ('gbeta', ctypes.c_void_p * 5),
+                ('gedge', ctypes.c_void_p),
+                ('gWp', ctypes.c_void_p * 2), ('gbp', ctypes.c_void_p * 2), ('gWc', ctypes.c_void_p * 2), ('gbc', ctypes.c_void_p * 2),
+                ('scratch', ctypes.c_void_p), ('bar', ctypes.c_void_p), ('B', c_i), ('momentum', ctypes.c_float), ('eps', ctypes.c_float)]
 
 
 class ConvJob(ctypes.Structure):

@@ -46,6 +46,7 @@ UNITS = {
     'stn.hip': [],
     'pool.hip': [],
     'glue.hip': [],
+    'gcn_tail.hip': [],
 }
 INCLUDES = {'norm_act_f32.hip': ['norm_act.hip']}
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + os.path.join(ROOT, 'include'), '-I' + HERE,

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import assets
+from . import gcn_tail as _gcn_tail
 from .config import cfg
 from .gcn import GCN, adjacency, normalize_digraph, normalize_undigraph
 from .geometry import perspective_projection, rot6d_to_rotmat
@@ -338,6 +339,17 @@ class DecomposedPredictor(nn.Module):
 
         rd['joint_position'] = []
         rd['joint_rotation'] = []
+        # the whole graph tail below as ONE launch per direction when the configuration is the trained default (csrc/gcn_tail.hip, round 6)
+        fused = _gcn_tail.fused_tail(self, rot_feats)
+        if fused is not None:
+            jr0, jp0, jp1, smpl_pose = fused
+            rd['joint_rotation'].append(jr0)
+            rd['joint_position'] += [jp0, jp1]
+            if side is not None:
+                cur.wait_stream(side)
+                global_para.record_stream(cur)
+            rd['para'] = torch.cat([global_para, smpl_pose], dim=1)
+            return rd
         if self.training:
             p0 = self._grouped_head(self.pose_regressors[0], rot_feats).reshape(nbs, -1) + self.mean_pose
             rd['joint_rotation'].append(rot6d_to_rotmat(p0).reshape(nbs, -1))

@@ -120,6 +120,42 @@ int danet_rot6d_to_rotmat_forward(const float* x, int N, float* R, void* stream)
 int danet_rot6d_to_rotmat_backward(const float* x, const float* gR, int N, float* gx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The regressor's graph tail as ONE launch per direction (csrc/gcn_tail.hip).  Replaces the torch operations of
+ * /root/reference/models/danet/smpl_regressor.py:846-900 (training mode, REFINE_STRATEGY 'gcn', REFINE_ON, POS_INTERSUPV) with
+ * models/module/GCN.py:12-92 and utils/geometry.py:47-61 behind them: pose head 0 -> rot6d; r2p graph convolution; coordinate head 0;
+ * three refinement graph convolutions on D^-1/2 (I + A_mask relu(edge_importance)) D^-1/2 with the residual; coordinate head 1; p2r
+ * graph convolution; pose head 1 -> rot6d.  Every graph convolution is (adjacency x features) x W + b -> BatchNorm1d(24) (training
+ * mode: batch statistics, running statistics updated) -> ReLU.  All tensors fp32, contiguous.
+ * `args`: struct danet_gcn_tail_args below.  forward reads x .. mean_pose, writes ws, jr0 [B,216], jp0 / jp1 [B,24,3], pose [B,216]
+ * and the running statistics; backward reads the same inputs, ws as the forward left it and g_* (each may be NULL = zero), and
+ * writes every g* buffer completely.  bar: DANET grid-barrier state (danet_bn_backward_onepass_bar_words() uints, zeroed once; shared
+ * with the other barrier kernels of the SAME stream).  1 <= B <= danet_gcn_tail_max_batch() (a caller with more rows uses its
+ * unfused operations).  24 workgroups, one per joint. */
+struct danet_gcn_layer { const float* W; const float* bias; const float* gamma; const float* beta; float* running_mean; float* running_var; };
+struct danet_gcn_tail_args {
+    const float* x;                                   /* [B,24,128] limb features */
+    struct danet_gcn_layer L[5];                      /* r2p 128->128, refine 128->256->256->128, p2r 128->128; W [in][out] */
+    const float* A_r2p; const float* A_p2r; const float* A_mask; const float* edge;    /* [24,24] each */
+    const float* Wp[2]; const float* bp[2];           /* pose heads [24,6,128], [144] */
+    const float* Wc[2]; const float* bc[2];           /* coordinate heads [24,3,128], [72] */
+    const float* mean_pose;                           /* [144] */
+    float* ws;                                        /* danet_gcn_tail_ws_floats(B) floats: forward -> backward */
+    float* jr0; float* jp0; float* jp1; float* pose;
+    const float* g_jr0; const float* g_jp0; const float* g_jp1; const float* g_pose;
+    float* gx; float* gW[5]; float* gb[5]; float* ggamma[5]; float* gbeta[5]; float* gedge;
+    float* gWp[2]; float* gbp[2]; float* gWc[2]; float* gbc[2];
+    float* scratch;                                   /* danet_gcn_tail_scratch_floats(B) floats (backward only) */
+    unsigned* bar;
+    int B; float momentum, eps;
+};
+size_t danet_gcn_tail_ws_floats(int B);
+size_t danet_gcn_tail_scratch_floats(int B);
+int danet_gcn_tail_max_batch(void);
+int danet_gcn_tail_debug(long long* out32);          /* diagnostic: phase time stamps of the last launches (host array of 32) */
+int danet_gcn_tail_forward(const void* args, void* stream);
+int danet_gcn_tail_backward(const void* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Global (25-class) IUV glue (csrc/iuv_ops.hip).  Replaces utils/iuvmap.py:6-38,103-147 (iuvmap_clean, iuv_img2map),
  * models/danet/iuv_estimator.py:304-341 (body_uv_losses) and danet.py:194-205,247 (part drop, clean, concat), and
  * utils/keypoints.py:334-394 (soft-argmax of the joint heat-maps).
