@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int NJ = 24, BM = 32, NT = 1024, NLAY = 5, PADF = 4, MAXC = 256;      // 16 waves per workgroup: the loops are latency-bound, four waves per SIMD hide it
-constexpr int CHF = 32, CHB = 16;      // weight rows per LDS chunk, forward / backward (LDS budget: 131 KB / 115 KB of the 160)
 __host__ __device__ constexpr int lay_cin(int l) { return l == 2 || l == 3 ? 256 : 128; }
 __host__ __device__ constexpr int lay_cout(int l) { return l == 1 || l == 2 ? 256 : 128; }
 
@@ -76,14 +75,18 @@ __device__ inline float block_sum(float v, Small& s) {
     return r;
 }
 
-// the non-zeros of a row (stride 1) or a column (stride 24) of an adjacency into s.idx / s.val
+// the non-zeros of a row (stride 1) or a column (stride 24) of an adjacency into s.idx / s.val, in index order: 24 lanes of the first wave,
+// one load each (thread 0 walking the line alone paid 24 dependent round trips when the matrix is in global memory)
 __device__ inline void sparse_line(const float* A, int stride, Small& s) {
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int c = 0;
-        for (int m = 0; m < NJ; ++m) { const float v = A[m * stride]; if (v != 0.f) { s.idx[c] = m; s.val[c] = v; ++c; } }
-        s.nnz = c;
-        for (; c & 3; ++c) { s.idx[c] = s.idx[0]; s.val[c] = 0.f; }
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const float v = t < NJ ? A[t * stride] : 0.f;
+        const unsigned long long m = __ballot(v != 0.f);
+        const int pos = __popcll(m & ((1ull << t) - 1ull)), c = __popcll(m);
+        if (v != 0.f) { s.idx[pos] = t; s.val[pos] = v; }
+        if (t == 0) s.nnz = c;
+        if (t >= c && t < ((c + 3) & ~3)) { s.idx[t] = 0; s.val[t] = 0.f; }        // padding: weight 0 on joint 0
     }
     __syncthreads();
 }
@@ -104,6 +107,7 @@ __device__ inline void mix_rows(const float* src, int B, const Small& s, float* 
                 float4 q[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4*>(base + (size_t)s.idx[j + u] * C);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float a = s.val[j + u];
@@ -122,43 +126,26 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // sO[32][LD + PADF] = sA[32][K + PADF] x Wg[K][LD] on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: an fmaf chain,
 // bit for bit) -- with the FMA on the vector units the 32 rows of sA had to be re-read from LDS by every wave for every column (broadcast
 // reads, 2.3x the LDS bandwidth the arithmetic could use: the 256 x 256 layer took 30 us where the FMAs need 14).  Wave w owns the
-// 32-column tile w % (LD / 32) and one of 16 / (LD / 32) slices of K; the slices are added in a fixed order at the end.  Wg is staged
-// through LDS in chunks of CH rows (one contiguous block, 16-byte loads by the whole workgroup, the next chunk in flight while the
-// current one is used).  sW: 2 x CH x LD floats.  sO must not alias sA.
-template <int K, int LD, int CH>
-__device__ __forceinline__ void gemm_mfma(const float* sA, const float* __restrict__ Wg, float* sW, float* sO) {
-    constexpr int TOT4 = CH * LD / 4, F4 = (TOT4 + NT - 1) / NT, NCH = K / CH, NCT = LD / 32, KG = (NT / 64) / NCT, RPC = CH / KG;
-    static_assert(K % CH == 0 && RPC >= 2 && RPC % 2 == 0, "chunking");
+// 32-column tile w % (LD / 32) and one of 16 / (LD / 32) slices of K; the slices are added in a fixed order at the end.  Every element
+// of Wg is the B operand of exactly ONE MFMA of ONE wave: the lanes fetch their operands straight from global memory, all of a wave's
+// K / KG / 2 loads issued before the first MFMA (one round trip for the whole product; staged through LDS in chunks, each chunk's round
+// trip was exposed: 16 chunks x ~1 us in the backward).  sO must not alias sA.
+template <int K, int LD>
+__device__ __forceinline__ void gemm_mfma(const float* sA, const float* __restrict__ Wg, float* sO) {
+    constexpr int NCT = LD / 32, KG = (NT / 64) / NCT, KS = K / KG, NM = KS / 2;
+    static_assert(NM >= 1 && NM <= 64 && KS % 2 == 0, "slicing");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, ct = wave % NCT, kg = wave / NCT, li = lane & 31, lk = lane >> 5;
-    float4 st[F4];
+    const float* wp = Wg + (size_t)(kg * KS + lk) * LD + ct * 32 + li;
+    float bv[NM];
 #pragma unroll
-    for (int u = 0; u < F4; ++u) if (t + u * NT < TOT4) st[u] = reinterpret_cast<const float4*>(Wg)[t + u * NT];
-#pragma unroll
-    for (int u = 0; u < F4; ++u) if (t + u * NT < TOT4) reinterpret_cast<float4*>(sW)[t + u * NT] = st[u];
-    __syncthreads();
+    for (int m = 0; m < NM; ++m) bv[m] = wp[(size_t)m * 2 * LD];
+    __builtin_amdgcn_sched_barrier(0);          // (left alone the scheduler sinks each load next to its MFMA: one round trip per MFMA)
+    const float* ap = sA + li * (K + PADF) + kg * KS + lk;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int ch = 0; ch < NCH; ++ch) {
-        const float* cur = sW + (ch & 1) * (CH * LD);
-        if (ch + 1 < NCH) {
 #pragma unroll
-            for (int u = 0; u < F4; ++u) if (t + u * NT < TOT4) st[u] = reinterpret_cast<const float4*>(Wg + (size_t)(ch + 1) * CH * LD)[t + u * NT];
-        }
-#pragma unroll
-        for (int kk = 0; kk < RPC; kk += 2) {
-            const int kr = kg * RPC + kk + lk;
-            const float av = sA[li * (K + PADF) + ch * CH + kr];
-            const float bv = cur[kr * LD + ct * 32 + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        if (ch + 1 < NCH) {
-            float* nxt = sW + ((ch + 1) & 1) * (CH * LD);
-#pragma unroll
-            for (int u = 0; u < F4; ++u) if (t + u * NT < TOT4) reinterpret_cast<float4*>(nxt)[t + u * NT] = st[u];
-        }
-        __syncthreads();
-    }
+    for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * m], bv[m], acc, 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         if (kg == g) {
@@ -300,7 +287,7 @@ __device__ inline void head_bwd(const float* sF, const float* __restrict__ W, co
 // One graph-convolution layer of joint n: mix (row of the adjacency) -> [32 x CIN] x [CIN x COUT] + bias -> BatchNorm over the joint's
 // (batch, channel) values -> ReLU.  Leaves the activation in sOut (row stride COUT + PADF, rows >= B zero) and in the workspace.
 template <int CIN, int COUT>
-__device__ inline void layer_fwd(const TailArgs& a, const WsMap& w, int l, const float* Aline, const float* xin, int n, float* sIn, float* sOut, float* sW, Small& s) {
+__device__ inline void layer_fwd(const TailArgs& a, const WsMap& w, int l, const float* Aline, const float* xin, int n, float* sIn, float* sOut, Small& s) {
     constexpr int RG = NT / COUT, RPT = BM / RG;
     const int t = threadIdx.x, B = a.B, c = t % COUT, r0 = (t / COUT) * RPT;
     sparse_line(Aline, 1, s);
@@ -313,7 +300,7 @@ __device__ inline void layer_fwd(const TailArgs& a, const WsMap& w, int l, const
             *reinterpret_cast<float4*>(ax + ((size_t)b * NJ + n) * CIN + k) = *reinterpret_cast<const float4*>(sIn + b * (CIN + PADF) + k);
         }
     }
-    gemm_mfma<CIN, COUT, CHF>(sIn, a.L[l].W, sW, sOut);
+    gemm_mfma<CIN, COUT>(sIn, a.L[l].W, sOut);
     float acc[RPT];
     const float bias = a.L[l].bias[c];
 #pragma unroll
@@ -349,8 +336,8 @@ __device__ inline void layer_fwd(const TailArgs& a, const WsMap& w, int l, const
     __syncthreads();
 }
 
-constexpr int SM_FLOATS = 2 * BM * (MAXC + PADF) + 2 * CHF * MAXC;            // forward: sIn + sOut + the weight chunks
-constexpr int SM_FLOATS_BWD = 2 * BM * (MAXC + PADF) + BM * (128 + PADF) + 2 * CHB * MAXC;       // backward: sG + sX + sRes + the weight chunks
+constexpr int SM_FLOATS = 2 * BM * (MAXC + PADF);            // forward: sIn + sOut
+constexpr int SM_FLOATS_BWD = 2 * BM * (MAXC + PADF) + BM * (128 + PADF);       // backward: sG + sX + sRes
 
 __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
 {
@@ -358,7 +345,6 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
     __shared__ Small s;
     float* sIn = smem;
     float* sOut = smem + BM * (MAXC + PADF);
-    float* sW = smem + 2 * BM * (MAXC + PADF);
     const int n = blockIdx.x, t = threadIdx.x, B = a.B;
     const WsMap w = ws_map(B);
     TAIL_STAMP(0);
@@ -370,6 +356,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int e = e0 + u * NJ * NT; v[u] = e < sz ? a.L[l].W[e] : 0.f; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int e = e0 + u * NJ * NT; if (e < sz) WT[(size_t)(e % cout) * cin + e / cout] = v[u]; }
         }
@@ -392,22 +379,22 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
 #pragma unroll
         for (int e = 0; e < 9; ++e) a.jr0[(size_t)t * (NJ * 9) + n * 9 + e] = R[e];
     }
-    layer_fwd<128, 128>(a, w, 0, a.A_r2p + n * NJ, a.x, n, sIn, sOut, sW, s);
+    layer_fwd<128, 128>(a, w, 0, a.A_r2p + n * NJ, a.x, n, sIn, sOut, s);
     head_fwd<3>(sOut, a.Wc[0] + (size_t)n * 3 * 128, a.bc[0] + n * 3, nullptr, s);
     if (t < B * 3) a.jp0[((size_t)(t / 3) * NJ + n) * 3 + t % 3] = s.h[(t / 3) * 8 + t % 3];
     TAIL_STAMP(2);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(3);
     // ---- phases 1 - 3: the refinement layers on norm_A
-    layer_fwd<128, 256>(a, w, 1, s.An + n * NJ, a.ws + w.act[0], n, sIn, sOut, sW, s);
+    layer_fwd<128, 256>(a, w, 1, s.An + n * NJ, a.ws + w.act[0], n, sIn, sOut, s);
     TAIL_STAMP(4);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(5);
-    layer_fwd<256, 256>(a, w, 2, s.An + n * NJ, a.ws + w.act[1], n, sIn, sOut, sW, s);
+    layer_fwd<256, 256>(a, w, 2, s.An + n * NJ, a.ws + w.act[1], n, sIn, sOut, s);
     TAIL_STAMP(6);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(7);
-    layer_fwd<256, 128>(a, w, 3, s.An + n * NJ, a.ws + w.act[2], n, sIn, sOut, sW, s);
+    layer_fwd<256, 128>(a, w, 3, s.An + n * NJ, a.ws + w.act[2], n, sIn, sOut, s);
     {   // pos_ref = pos_init + h3 (this joint's rows), coordinate head 1
         const float* act0 = a.ws + w.act[0];
         float* pr = a.ws + w.posref;
@@ -427,7 +414,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(9);
     // ---- phase 4: pos -> rot, pose head 1, rot6d
-    layer_fwd<128, 128>(a, w, 4, a.A_p2r + n * NJ, a.ws + w.posref, n, sIn, sOut, sW, s);
+    layer_fwd<128, 128>(a, w, 4, a.A_p2r + n * NJ, a.ws + w.posref, n, sIn, sOut, s);
     head_fwd<6>(sOut, a.Wp[1] + (size_t)n * 6 * 128, a.bp[1] + n * 6, a.mean_pose + n * 6, s);
     if (t < B) {
         float R[9];
@@ -446,7 +433,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
 // this joint's partial d W / d bias in the scratch, d gamma / d beta of the joint, and (refinement layers) its row of d norm_A.
 template <int CIN, int COUT>
 __device__ inline void layer_bwd(const TailArgs& a, const WsMap& w, const ScMap& sc, int l, const float* Aline, const float* xin, int n, bool want_dA,
-                                 float* sG, float* sX, float* sW, Small& s)
+                                 float* sG, float* sX, Small& s)
 {
     constexpr int RG = NT / COUT, RPT = BM / RG;
     const int t = threadIdx.x, B = a.B;
@@ -500,7 +487,7 @@ __device__ inline void layer_bwd(const TailArgs& a, const WsMap& w, const ScMap&
     wgrad_mfma<CIN, COUT>(sX, sG, a.scratch + sc.partW[l] + (size_t)n * CIN * COUT);
     __syncthreads();                                       // every wave is done with ax
     {   // d ax [32][CIN] = gy W^T
-        gemm_mfma<COUT, CIN, CHB>(sG, a.ws + w.WT[l], sW, sX);
+        gemm_mfma<COUT, CIN>(sG, a.ws + w.WT[l], sX);
         float* dax = a.scratch + sc.dax[l];
         for (int i = t; i < B * (CIN / 4); i += NT) {
             const int b = i / (CIN / 4), k = (i % (CIN / 4)) * 4;
@@ -524,6 +511,7 @@ __device__ inline void layer_bwd(const TailArgs& a, const WsMap& w, const ScMap&
                     float4 q[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4*>(base + (size_t)s.idx[j + u] * CIN);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc[j + u] += (d.x * q[u].x + d.y * q[u].y) + (d.z * q[u].z + d.w * q[u].w);
                 }
@@ -555,7 +543,6 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     float* sG = smem;
     float* sX = smem + BM * (MAXC + PADF);
     float* sRes = smem + 2 * BM * (MAXC + PADF);
-    float* sW = sRes + BM * (128 + PADF);
     const int n = blockIdx.x, t = threadIdx.x, B = a.B;
     const WsMap w = ws_map(B);
     const ScMap sc = sc_map(B);
@@ -572,7 +559,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     }
     __syncthreads();
     head_bwd<6, false>(sX, a.Wp[1] + (size_t)n * 6 * 128, s, sG, a.gWp[1] + (size_t)n * 6 * 128, a.gbp[1] + n * 6);
-    layer_bwd<128, 128>(a, w, sc, 4, a.A_p2r + n * NJ, a.ws + w.posref, n, false, sG, sX, sW, s);
+    layer_bwd<128, 128>(a, w, sc, 4, a.A_p2r + n * NJ, a.ws + w.posref, n, false, sG, sX, s);
     TAIL_STAMP(17);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(18);
@@ -590,7 +577,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     head_bwd<3, true>(sX, a.Wc[1] + (size_t)n * 3 * 128, s, sG, a.gWc[1] + (size_t)n * 3 * 128, a.gbc[1] + n * 3);
     for (int i = t; i < BM * 128; i += NT) sRes[(i >> 7) * (128 + PADF) + (i & 127)] = sG[(i >> 7) * (128 + PADF) + (i & 127)];
     __syncthreads();
-    layer_bwd<256, 128>(a, w, sc, 3, s.An + n * NJ, a.ws + w.act[2], n, true, sG, sX, sW, s);
+    layer_bwd<256, 128>(a, w, sc, 3, s.An + n * NJ, a.ws + w.act[2], n, true, sG, sX, s);
     TAIL_STAMP(19);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(20);
@@ -598,7 +585,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     sparse_line(s.An + n, NJ, s);
     mix_rows<256, false>(a.scratch + sc.dax[3], B, s, sG);
     __syncthreads();
-    layer_bwd<256, 256>(a, w, sc, 2, s.An + n * NJ, a.ws + w.act[1], n, true, sG, sX, sW, s);
+    layer_bwd<256, 256>(a, w, sc, 2, s.An + n * NJ, a.ws + w.act[1], n, true, sG, sX, s);
     TAIL_STAMP(21);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(22);
@@ -606,7 +593,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     sparse_line(s.An + n, NJ, s);
     mix_rows<256, false>(a.scratch + sc.dax[2], B, s, sG);
     __syncthreads();
-    layer_bwd<128, 256>(a, w, sc, 1, s.An + n * NJ, a.ws + w.act[0], n, true, sG, sX, sW, s);
+    layer_bwd<128, 256>(a, w, sc, 1, s.An + n * NJ, a.ws + w.act[0], n, true, sG, sX, s);
     if (t < NJ) a.scratch[sc.dA + n * NJ + t] = s.dA[t];
     TAIL_STAMP(23);
     danet::grid_barrier_fenced(a.bar, NJ);
@@ -625,7 +612,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     }
     __syncthreads();
     head_bwd<3, true>(sX, a.Wc[0] + (size_t)n * 3 * 128, s, sG, a.gWc[0] + (size_t)n * 3 * 128, a.gbc[0] + n * 3);
-    layer_bwd<128, 128>(a, w, sc, 0, a.A_r2p + n * NJ, a.x, n, false, sG, sX, sW, s);
+    layer_bwd<128, 128>(a, w, sc, 0, a.A_r2p + n * NJ, a.x, n, false, sG, sX, s);
     TAIL_STAMP(25);
     danet::grid_barrier_fenced(a.bar, NJ);
     TAIL_STAMP(26);
@@ -651,6 +638,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
             float v[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) v[j] = pW[(size_t)j * sz + e];
+            __builtin_amdgcn_sched_barrier(0);
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc += v[j];
