@@ -273,6 +273,12 @@ def fp32_line(args, tr, batch, world, rank, dev):
                           'finite_losses': rec['finite_losses'], 'roofline': rec.get('roofline')}), flush=True)
 
 
+def _barrier_word():
+    """The grid-barrier error word(s): 0, or the code of the wait that expired (csrc/grid_barrier.h)."""
+    from danet_densepose2smpl_amd import nn as _dnn
+    return [int(b[2]) for b in _dnn._ONEPASS_BAR.values()]
+
+
 def _dnn_error():
     from danet_densepose2smpl_amd import nn as _dnn
     return _dnn.onepass_error()
@@ -350,12 +356,19 @@ def main():
     # One eager step with every conv launch bracketed by HIP events (on the launch stream) finds the
     # dominant kernel instance and gives its per-launch durations -- the same kernels, shapes and
     # data as the timed steps (which replay them from a hipGraph, where events cannot be recorded).
+    def stage(tag):              # DANET_BENCH_STAGES=1: the grid-barrier error word after each stage (stderr)
+        if os.environ.get('DANET_BENCH_STAGES'):
+            torch.cuda.synchronize(dev)
+            from danet_densepose2smpl_amd import nn as _n
+            sys.stderr.write('stage %-16s t=%.3f onepass_error=%s word=%s\n' % (tag, time.time(), _dnn_error(), [hex(int(b[2])) for b in _n._ONEPASS_BAR.values()]))
     tr.train_step(batch)
     tr.train_step(batch)
     torch.cuda.synchronize(dev)
+    stage('two eager steps')
     summ, dominant = {}, None
     if not args.dry:
         summ, dominant = profile_step(tr, batch, dev)
+    stage('profile_step')
     use_graph = not args.no_graph
     if use_graph:
         try:
@@ -366,9 +379,11 @@ def main():
             use_graph = False
     if not use_graph:
         step = lambda: tr.train_step(batch)
+    stage('capture')
     for _ in range(args.warmup):
         step()
     sync()
+    stage('warmup')
     _flush_c_stdio()      # RCCL's start-up banner sits in the C stdio buffer of every rank: emit it now, not after the JSON line
     t0 = time.time()
     for _ in range(args.steps):
@@ -376,6 +391,7 @@ def main():
     sync()
     elapsed = time.time() - t0
     elapsed_local = elapsed
+    stage('timed steps')
     # what the timed steps computed must be numbers: the last step's losses and a sample of the parameters the optimizer has
     # updated W + K times by now (round 5 found replays of the round-4 graph turning NaN after a few steps: a memset node racing the
     # bias-gradient kernel -- the timing was unaffected, the training was not)
@@ -387,6 +403,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    stage('before extras')
     roof = None
     if dominant is not None:
         if dominant in summ:
@@ -439,7 +456,7 @@ def main():
         line = {'metric': 'images/sec fwd+bwd HRNet-W48+SMPL+IUV 256x256 bs32/GPU', 'value': round(ips, 2), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-                'exec': 'hipgraph' if use_graph else 'eager', 'finite_losses_and_parameters': finite, 'onepass_error': bool(_dnn_error()),
+                'exec': 'hipgraph' if use_graph else 'eager', 'finite_losses_and_parameters': finite, 'onepass_error': bool(_dnn_error()), 'barrier_error_word': _barrier_word(),
                 'dry': bool(args.dry),
                 'allreduce': allreduce_info,
                 'config': {'workload': 'full DaNet train step (HRNet-W48 + global and part-wise IUV heads + regressor nets + SMPL LBS '

@@ -122,6 +122,8 @@ _SIGNATURES = {
     'danet_rodrigues_smplx': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_forward': (c_i, [c_f, c_i, c_f, c_f]),
     'danet_rot6d_to_rotmat_backward': (c_i, [c_f, c_f, c_i, c_f, c_f]),
+    'danet_regroup_parts': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    'danet_pack_image': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'danet_gcn_tail_ws_floats': (c_sz, [c_i]),
     'danet_gcn_tail_scratch_floats': (c_sz, [c_i]),
     'danet_gcn_tail_max_batch': (c_i, []),

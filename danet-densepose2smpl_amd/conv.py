@@ -878,9 +878,15 @@ def _wgrad_into(gw, x, gy, B, H, W, Cin, OH, OW, Cout, Cin_g, R, S, stride, pad,
         PROFILER.end(tok)
 
 
+PACK_IMAGE = bool(int(os.environ.get('DANET_PACK_IMAGE', '1')))      # A-B knob
+
+
 def _pad_channels_nhwc(x, mult=8):
     """bf16 NHWC tensor whose channel count is padded with zeros to a multiple of `mult`
     (autograd-tracked, so the gradient is sliced back)."""
+    if PACK_IMAGE and mult == 8 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] < 8 and x.is_contiguous() and not x.requires_grad:
+        from .glue import pack_image            # the input image: cast + channels-last + zero channels in one launch (csrc/glue.hip)
+        return pack_image(x)
     x = nhwc_bf16(x)
     padc = (-x.shape[1]) % mult
     if padc == 0:

@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void s3_kernel_body()
     if constexpr (WITH_BN) {
         // every output and every statistic of this workgroup has left (stores, atomics and the inline-asm loads the compiler does not count)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        danet::grid_barrier(s3_bn_args()->bar, (unsigned)nblk);
+        danet::grid_barrier(s3_bn_args()->bar, (unsigned)nblk, 0x40000u + (unsigned)nblk);
         if (dbg && threadIdx.x == 0) dbg[8] = (int)clock64();
         s3_bn_tail<NT>(nprob, rot, bid, nblk, s3_smem, dbg);
         if (dbg && threadIdx.x == 0) dbg[12] = (int)clock64();

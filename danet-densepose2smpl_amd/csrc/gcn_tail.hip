@@ -383,16 +383,16 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
     head_fwd<3>(sOut, a.Wc[0] + (size_t)n * 3 * 128, a.bc[0] + n * 3, nullptr, s);
     if (t < B * 3) a.jp0[((size_t)(t / 3) * NJ + n) * 3 + t % 3] = s.h[(t / 3) * 8 + t % 3];
     TAIL_STAMP(2);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 257u);
     TAIL_STAMP(3);
     // ---- phases 1 - 3: the refinement layers on norm_A
     layer_fwd<128, 256>(a, w, 1, s.An + n * NJ, a.ws + w.act[0], n, sIn, sOut, s);
     TAIL_STAMP(4);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 258u);
     TAIL_STAMP(5);
     layer_fwd<256, 256>(a, w, 2, s.An + n * NJ, a.ws + w.act[1], n, sIn, sOut, s);
     TAIL_STAMP(6);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 259u);
     TAIL_STAMP(7);
     layer_fwd<256, 128>(a, w, 3, s.An + n * NJ, a.ws + w.act[2], n, sIn, sOut, s);
     {   // pos_ref = pos_init + h3 (this joint's rows), coordinate head 1
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_fwd_kernel(TailArgs a)
         if (t < B * 3) a.jp1[((size_t)(t / 3) * NJ + n) * 3 + t % 3] = s.h[(t / 3) * 8 + t % 3];
     }
     TAIL_STAMP(8);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 260u);
     TAIL_STAMP(9);
     // ---- phase 4: pos -> rot, pose head 1, rot6d
     layer_fwd<128, 128>(a, w, 4, a.A_p2r + n * NJ, a.ws + w.posref, n, sIn, sOut, s);
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     head_bwd<6, false>(sX, a.Wp[1] + (size_t)n * 6 * 128, s, sG, a.gWp[1] + (size_t)n * 6 * 128, a.gbp[1] + n * 6);
     layer_bwd<128, 128>(a, w, sc, 4, a.A_p2r + n * NJ, a.ws + w.posref, n, false, sG, sX, s);
     TAIL_STAMP(17);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 513u);
     TAIL_STAMP(18);
     // ---- d pos_ref = p2r_A^T d ax4 + coordinate head 1; layer 3
     sparse_line(a.A_p2r + n, NJ, s);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     __syncthreads();
     layer_bwd<256, 128>(a, w, sc, 3, s.An + n * NJ, a.ws + w.act[2], n, true, sG, sX, s);
     TAIL_STAMP(19);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 514u);
     TAIL_STAMP(20);
     // ---- layer 2
     sparse_line(s.An + n, NJ, s);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     __syncthreads();
     layer_bwd<256, 256>(a, w, sc, 2, s.An + n * NJ, a.ws + w.act[1], n, true, sG, sX, s);
     TAIL_STAMP(21);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 515u);
     TAIL_STAMP(22);
     // ---- layer 1
     sparse_line(s.An + n, NJ, s);
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     layer_bwd<128, 256>(a, w, sc, 1, s.An + n * NJ, a.ws + w.act[0], n, true, sG, sX, s);
     if (t < NJ) a.scratch[sc.dA + n * NJ + t] = s.dA[t];
     TAIL_STAMP(23);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 516u);
     TAIL_STAMP(24);
     // ---- d pos_init = (through the residual) + norm_A^T d ax1 + coordinate head 0; layer 0
     sparse_line(s.An + n, NJ, s);
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(NT) void gcn_tail_bwd_kernel(TailArgs a)
     head_bwd<3, true>(sX, a.Wc[0] + (size_t)n * 3 * 128, s, sG, a.gWc[0] + (size_t)n * 3 * 128, a.gbc[0] + n * 3);
     layer_bwd<128, 128>(a, w, sc, 0, a.A_r2p + n * NJ, a.x, n, false, sG, sX, s);
     TAIL_STAMP(25);
-    danet::grid_barrier_fenced(a.bar, NJ);
+    danet::grid_barrier_fenced(a.bar, NJ, 517u);
     TAIL_STAMP(26);
     // ---- d rot_feats = r2p_A^T d ax0 + pose head 0
     sparse_line(a.A_r2p + n, NJ, s);

@@ -251,3 +251,62 @@ extern "C" int danet_loss_finalize(const void* sums, int rows, int n, const floa
     DANET_CHECK_LAUNCH("loss_finalize_kernel");
     return DANET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 24 part crops of an image as 24 channel groups of ONE map, and back: x [NB * J][HW][V] 16-byte vectors (an NHWC tensor of NB * J
+// small maps) <-> y [NB][HW][J][V] (the NHWC tensor [NB, J * C, H, W] the grouped layer4 of the limb branch reads,
+// /root/reference/models/danet/smpl_regressor.py:826 `limb_feat.view(nbs, -1, h, w)`).  As tensor operations the view of a channels-last
+// tensor was three copies forward and three backward (NCHW-contiguous reshape, back to channels-last, cast).
+__global__ __launch_bounds__(256) void regroup_parts_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int J, int HW, int V, long n, int inverse)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // index in the grouped layout [b][p][j][v]
+    if (i >= n) return;
+    const int v = (int)(i % V);
+    long r = i / V;
+    const int j = (int)(r % J); r /= J;
+    const int p = (int)(r % HW);
+    const long b = r / HW;
+    const long k = ((b * J + j) * HW + p) * V + v;                // index in the per-crop layout [b][j][p][v]
+    if (inverse) y[k] = x[i]; else y[i] = x[k];
+}
+
+extern "C" int danet_regroup_parts(const void* x, void* y, int NB, int J, int HW, int row_bytes, int inverse, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && y && NB > 0 && J > 0 && HW > 0 && row_bytes > 0 && row_bytes % 16 == 0, "regroup_parts: bad arguments (a pixel's channels must be a multiple of 16 bytes)");
+    const int V = row_bytes / 16;
+    const long n = (long)NB * J * HW * V;
+    hipLaunchKernelGGL(regroup_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, J, HW, V, n, inverse);
+    DANET_CHECK_LAUNCH("regroup_parts_kernel");
+    return DANET_OK;
+}
+
+// The input image [B, C, H, W] fp32 (NCHW) -> bf16 NHWC with the channels zero-padded to CP (a multiple of 8, <= 8): the operand of the
+// first convolution in one launch (as tensor operations: cast, channels-last copy, fill, pad copy).  No gradient (the image is data).
+__global__ __launch_bounds__(256) void pack_image_kernel(const float* __restrict__ x, uint4* __restrict__ y, int C, long HW, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // pixel index b * HW + p
+    if (i >= n) return;
+    const long b = i / HW, p = i % HW;
+    unsigned short h[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float f = c < C ? x[(b * C + c) * HW + p] : 0.f;
+        unsigned u = __builtin_bit_cast(unsigned, f);
+        // round to nearest even, NaN kept quiet (torch's float -> bfloat16)
+        h[c] = (f != f) ? (unsigned short)0x7fc0 : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    uint4 o;
+    o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16); o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+    y[i] = o;
+}
+
+extern "C" int danet_pack_image(const float* x, void* y, int B, int C, int H, int W, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(x && y && B > 0 && C >= 1 && C <= 8 && H > 0 && W > 0, "pack_image: bad arguments (1 <= C <= 8)");
+    const long n = (long)B * H * W;
+    hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (uint4*)y, C, (long)H * W, n);
+    DANET_CHECK_LAUNCH("pack_image_kernel");
+    return DANET_OK;
+}

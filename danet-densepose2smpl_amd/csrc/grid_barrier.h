@@ -6,11 +6,11 @@
 
 namespace danet {
 
-// State (GRID_BAR_WORDS uints, zeroed once by the caller): word 2 = error flag; group g (workgroups with id % 8 == g:
+// State (GRID_BAR_WORDS uints, zeroed once by the caller): word 2 = error flag (non-zero: a wait expired; the value is the caller's err_code); group g (workgroups with id % 8 == g:
 // observed to share an XCD, which only matters for speed) owns the 64-byte lines at 16 * (1 + g) (arrivals) and
 // 16 * (9 + g) (generation); the line at 16 * 17 counts the groups that are complete.
 constexpr int GRID_BAR_WORDS = 16 * 18;
-__device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
+__device__ inline void grid_barrier(unsigned* bar, unsigned nblocks, unsigned err_code = 1u) {
     // Two levels: a workgroup arrives at its group's counter; the last one of a group arrives at the top counter; the last
     // group bumps every group's generation word, on which that group's workgroups spin.  512 arrivals on one word and 512
     // pollers of one word cost 17 us per barrier (measured with the phase knob of tools/experiments/bn_micro.cpp); spread
@@ -44,7 +44,7 @@ __device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
             unsigned spins = 0;
             while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) { __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (++spins > (1u << 22)) { __hip_atomic_store(&bar[2], err_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
     }
@@ -57,9 +57,9 @@ __device__ inline void grid_barrier(unsigned* bar, unsigned nblocks) {
 // acquires after the barrier (stale lines are dropped).  The write-back costs time in proportion to the dirty lines of the XCD's L2
 // -- 78 us per barrier inside the 100 MB BatchNorm kernel, which is why grid_barrier itself carries no fences --, a few us in the SMPL
 // backward, whose kernels have written a few MB.
-__device__ inline void grid_barrier_fenced(unsigned* bar, unsigned nblocks) {
+__device__ inline void grid_barrier_fenced(unsigned* bar, unsigned nblocks, unsigned err_code = 1u) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    grid_barrier(bar, nblocks);
+    grid_barrier(bar, nblocks, err_code);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 

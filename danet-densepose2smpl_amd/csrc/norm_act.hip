@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(BnOnePass m)
     bn_acc_t* dst = a.red + (size_t)(bid % danet_conv::bn_ncopy(C)) * 2 * C;
     block_channel_reduce(sm, s1, t, fm.CV, fm.span, dst);
     block_channel_reduce(sm, s2, t, fm.CV, fm.span, dst + C);
-    if (!(m.dbg & 1)) grid_barrier(m.bar, gridDim.x);
+    if (!(m.dbg & 1)) grid_barrier(m.bar, gridDim.x, 0x30000u + gridDim.x);        // (error code: which launch gave up, by its grid)
     if (m.dbg & 2) return;
     // ---- phase 2: the complete sums (agent-scope loads), then dx / d_res from the registers
     reduce_replicas_sc1(a.red, C, fm.CV * VW, t, sStat);

@@ -109,3 +109,55 @@ def loss_finalize(n, scales, w, nw, sums=None, rows=1, grads=None):
     check(_lib.lib().danet_loss_finalize(ptr(sums), int(rows), int(n), ctypes.addressof(a), ctypes.addressof(b), ptr(w), int(nw), gp, ptr(out), stream()),
           'danet_loss_finalize')
     return out
+
+
+class RegroupPartsFunction(torch.autograd.Function):
+    """[NB * J, C, H, W] channels-last (the J part crops of each image) -> [NB, J * C, H, W] channels-last (J channel groups of one map):
+    /root/reference/models/danet/smpl_regressor.py:826 `limb_feat.view(nbs, -1, h, w)`, one launch each way (csrc/glue.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, NB):
+        BJ, C, H, W = x.shape
+        J = BJ // NB
+        xc = x.detach()
+        if not xc.permute(0, 2, 3, 1).is_contiguous():
+            xc = xc.contiguous(memory_format=torch.channels_last)
+            if not xc.permute(0, 2, 3, 1).is_contiguous():
+                xc = xc.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        y = torch.empty(NB, H, W, J * C, dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+        check(_lib.lib().danet_regroup_parts(ptr(xc.permute(0, 2, 3, 1)), ptr(y.permute(0, 2, 3, 1)), NB, J, H * W, C * x.element_size(), 0, stream()),
+              'danet_regroup_parts')
+        ctx.dims = (NB, J, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        NB, J, C, H, W = ctx.dims
+        g = gy
+        if not g.permute(0, 2, 3, 1).is_contiguous():
+            g = g.contiguous(memory_format=torch.channels_last)
+            if not g.permute(0, 2, 3, 1).is_contiguous():
+                g = g.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        gx = torch.empty(NB * J, H, W, C, dtype=g.dtype, device=g.device).permute(0, 3, 1, 2)
+        check(_lib.lib().danet_regroup_parts(ptr(g.permute(0, 2, 3, 1)), ptr(gx.permute(0, 2, 3, 1)), NB, J, H * W, C * g.element_size(), 1, stream()),
+              'danet_regroup_parts')
+        return gx, None
+
+
+def regroup_parts(x, NB):
+    """x [NB * J, C, H, W] -> [NB, J * C, H, W] (== x.reshape(NB, -1, H, W)); on the GPU with 16-byte pixel rows one launch, channels-last
+    in and out."""
+    if x.is_cuda and x.shape[0] % NB == 0 and (x.shape[1] * x.element_size()) % 16 == 0:
+        return RegroupPartsFunction.apply(x, NB)
+    return x.reshape(NB, -1, x.size(-2), x.size(-1))
+
+
+def pack_image(x):
+    """fp32 NCHW image batch [B, C <= 8, H, W] -> bf16 channels-last [B, 8, H, W] with zero channels behind C (no gradient)."""
+    B, C, H, W = x.shape
+    xc = x.detach()
+    if xc.dtype != torch.float32 or not xc.is_contiguous():
+        xc = xc.float().contiguous()
+    y = torch.empty(B, H, W, 8, dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    check(_lib.lib().danet_pack_image(ptr(xc), ptr(y.permute(0, 2, 3, 1)), B, C, H, W, stream()), 'danet_pack_image')
+    return y

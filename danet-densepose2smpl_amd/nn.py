@@ -31,7 +31,31 @@ ONEPASS_STREAM = None
 # on the communication stream WHILE the backward pass continues, and a grid barrier over more workgroups than fit beside them
 # could wait for ever (include/danet_hip.h, danet_bn_backward_onepass).
 ONEPASS_MAX_BLOCKS = 0
+# > 0 while another stream of the step may be running kernels beside the one-pass stream (the regressor's body_net branch between its fork
+# and its join, in the forward and in the backward pass: smpl_regressor.SideWindow).  A one-pass launch of more than ONE workgroup per
+# compute unit is then not safe: each workgroup takes 78 KB of a compute unit's 160 KB of LDS, and a block of LDS that a workgroup of the
+# other stream held while the first one-pass workgroup was placed can leave the remaining space in two pieces that are each too small
+# for the second -- for as long as the first one spins at the barrier, i.e. until the barrier's spin bound (round 6: a 492-workgroup
+# launch of limb_net's backward beside a 13 us pointwise convolution of body_net's, 0.6 s, `bn_bwd_onepass_kernel` error word 0x301ec;
+# caught by bench.py's host-ahead eager step, where the two branches meet at a different phase than in the replayed graph).  While the
+# window is open the budget is one workgroup per compute unit; launches that need more take the two-kernel path (four BatchNorms of
+# limb_net's first layer).
+SIDE_LIVE = 0
 _ONEPASS_BAR = {}
+_CUS = {}
+
+
+def onepass_budget(device=None):
+    """The co-residency budget a one-pass launch may use NOW (the `max_blocks` of danet_bn_backward_onepass): ONEPASS_MAX_BLOCKS, capped
+    at one workgroup per compute unit while a side stream is live."""
+    b = ONEPASS_MAX_BLOCKS
+    if SIDE_LIVE > 0 and b >= 0:
+        dev = torch.cuda.current_device() if device is None or getattr(device, 'index', None) is None else device.index
+        cus = _CUS.get(dev)
+        if cus is None:
+            cus = _CUS[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+        b = cus if b == 0 else min(b, cus)
+    return b
 
 
 def _onepass_bar(device):
@@ -180,8 +204,9 @@ class BatchNormActFunction(torch.autograd.Function):
             j.dx, j.dres, j.dparam, j.red = dx.data_ptr(), None if dres is None else dres.data_ptr(), dparam.data_ptr(), red.data_ptr()
             j.beta, j.mask, j.mask_mode = None if b is None else b.data_ptr(), None if mask is None else mask.data_ptr(), int(ctx.mask_mode)
             j.M, j.C, j.red_state, j.relu = M, C, 1, int(ctx.relu)
-            if L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1, ONEPASS_MAX_BLOCKS):
-                check(L.danet_bn_backward_onepass(ctypes.addressof(job), 1, ptr(bar), ONEPASS_MAX_BLOCKS, stream()), 'danet_bn_backward_onepass')
+            budget = onepass_budget(x.device)
+            if L.danet_bn_backward_onepass_ok(ctypes.addressof(job), 1, budget):
+                check(L.danet_bn_backward_onepass(ctypes.addressof(job), 1, ptr(bar), budget, stream()), 'danet_bn_backward_onepass')
                 _conv.FUSION['bn_bwd_onepass'] += 1
                 done = True
         if not done:
@@ -347,8 +372,9 @@ class MultiBatchNormFunction(torch.autograd.Function):
             dress.append(dres)
             dparams.append(dparam)
         bar = _onepass_bar(xs[0].device) if (dt == torch.bfloat16 and all(jobs[i].red_state == 1 for i in range(n))) else None
-        if bar is not None and L.danet_bn_backward_onepass_ok(ctypes.addressof(jobs), n, ONEPASS_MAX_BLOCKS):
-            check(L.danet_bn_backward_onepass(ctypes.addressof(jobs), n, ptr(bar), ONEPASS_MAX_BLOCKS, stream()), 'danet_bn_backward_onepass')
+        budget = onepass_budget(xs[0].device)
+        if bar is not None and L.danet_bn_backward_onepass_ok(ctypes.addressof(jobs), n, budget):
+            check(L.danet_bn_backward_onepass(ctypes.addressof(jobs), n, ptr(bar), budget, stream()), 'danet_bn_backward_onepass')
             _conv.FUSION['bn_bwd_onepass'] += n
         else:
             check(_k(L, 'danet_bn_backward_multi', dt)(ctypes.addressof(jobs), n, stream()), 'danet_bn_backward_multi')
@@ -389,7 +415,7 @@ def multi_conv_bn(convs, xs, bns, ress=None, relu=False, conv_links=None, bn_lin
         # the launch crosses a grid barrier with up to `c3s_blocks` workgroups (512): under a data-parallel trainer's co-residency
         # budget (ONEPASS_MAX_BLOCKS = 2 x the compute units left beside the communication kernels) a grid that large may not be
         # resident at once -- two launches then, like the one-pass backward and the one-launch SMPL backward (round-5 advisor)
-        if bar is not None and 0 < ONEPASS_MAX_BLOCKS < _lib.lib().knob('c3s_blocks'):
+        if bar is not None and 0 < onepass_budget(dev) < _lib.lib().knob('c3s_blocks'):
             bar = None
         if bar is not None:
             spec = {'bar': bar, 'momentum': 0.1 if bns[0].momentum is None else bns[0].momentum, 'eps': bns[0].eps,

@@ -80,7 +80,7 @@ class SmplLbsFunction(torch.autograd.Function):
         # reads it, which is why the one-launch form is opt-in)
         from . import nn as _nn, conv as _conv
         bar = _nn._onepass_bar(dev) if SMPL_BWD_FUSED else None
-        if bar is not None and L.danet_smpl_lbs_backward_fused_ok(B, V, _nn.ONEPASS_MAX_BLOCKS):
+        if bar is not None and L.danet_smpl_lbs_backward_fused_ok(B, V, _nn.onepass_budget(dev)):
             _conv.FUSION['smpl_bwd_fused'] += 1
         else:
             bar = None
@@ -88,7 +88,7 @@ class SmplLbsFunction(torch.autograd.Function):
             ptr(betas_c), ptr(rot_c), B, ptr(m.shapedirs), ptr(m.posedirs), ptr(m.J_shapedirs),
             ptr(m.lbs_weights), ptr(m.parents), ptr(m.J_regressor_extra), ptr(m.landmark_verts),
             V, NB, NL, NE, ptr(cbuf), ptr(vposed), ptr(gv), ptr(gj), ptr(g_betas), ptr(g_rot),
-            ptr(ws), nws, ptr(bar), int(_nn.ONEPASS_MAX_BLOCKS), stream()), 'danet_smpl_lbs_backward')
+            ptr(ws), nws, ptr(bar), int(_nn.onepass_budget(dev)), stream()), 'danet_smpl_lbs_backward')
         return g_betas, g_rot, None
 
 

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import assets
 from . import gcn_tail as _gcn_tail
+from . import glue as _glue
 from .config import cfg
 from .gcn import GCN, adjacency, normalize_digraph, normalize_undigraph
 from .geometry import perspective_projection, rot6d_to_rotmat
@@ -45,7 +46,38 @@ def _pool_conv1x1_grouped(cin, cout, groups):
     return seq
 
 
+class _SideWindowOpen(torch.autograd.Function):
+    """Identity on the joined result of the two branches: its backward is the FIRST node of the regressor's backward pass and opens the
+    side-stream window (nn.SIDE_LIVE) -- from here on body_net's backward kernels run beside limb_net's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import nn as _nn
+        _nn.SIDE_LIVE += 1
+        return g
+
+
+class _SideWindowClose(torch.autograd.Function):
+    """Identity on the two branches' inputs: its backward runs when BOTH branches have delivered their input gradients and closes the
+    window."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a.view_as(a), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        from . import nn as _nn
+        _nn.SIDE_LIVE = max(0, _nn.SIDE_LIVE - 1)
+        return ga, gb
+
+
 FUSED_SMPL_LOSSES = True    # SMPL-side losses through csrc/loss_ops.hip (False: the tensor-op formulation below)
+REGROUP_PARTS = bool(int(__import__('os').environ.get('DANET_REGROUP_PARTS', '1')))   # the crops -> channel groups view as one launch each way (A-B knob)
 BODY_STREAM = bool(int(__import__('os').environ.get('DANET_BODY_STREAM', '1')))     # body_net on a side stream beside limb_net (A-B knob)
 
 
@@ -316,10 +348,23 @@ class DecomposedPredictor(nn.Module):
         # net's (round 6; autograd replays its backward on the same stream; its BatchNorms take the two-kernel backward there, the
         # one-pass kernel being confined to the step's own stream, nn.ONEPASS_STREAM)
         side = None
-        if BODY_STREAM and body_iuv.is_cuda and self.training and torch.is_grad_enabled():
+        window = False
+        pad = getattr(limb_iuv, '_nhwc_padded', None)
+        # (only when both inputs carry gradients -- as in a train step --: the backward window below is bracketed by their gradient nodes)
+        if BODY_STREAM and body_iuv.is_cuda and self.training and torch.is_grad_enabled() and body_iuv.requires_grad and \
+                (pad if pad is not None else limb_iuv).requires_grad:
             from .hrnet import _side_streams
+            from . import nn as _nn
             cur = torch.cuda.current_stream(body_iuv.device)
             side = _side_streams(body_iuv.device, 1)[0]
+            # between this fork and the join below (and between their mirror images in the backward pass) kernels of two streams share
+            # the compute units: barrier kernels are held to one workgroup per compute unit meanwhile (nn.SIDE_LIVE)
+            if pad is not None:
+                body_iuv, pad = _SideWindowClose.apply(body_iuv, pad)          # (the padded operand is what limb_net reads, see below)
+            else:
+                body_iuv, limb_iuv = _SideWindowClose.apply(body_iuv, limb_iuv)
+            window = True
+            _nn.SIDE_LIVE += 1
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 global_para, _ = self.body_net(body_iuv)
@@ -329,12 +374,12 @@ class DecomposedPredictor(nn.Module):
             global_para = global_para + self.mean_cam_shape
         nbs, S = limb_iuv.size(0), limb_iuv.size(-1)
         # the fused part_clean op hands over the zero-padded 24-channel NHWC bf16 operand of the stem conv
-        stacked = getattr(limb_iuv, '_nhwc_padded', None)
+        stacked = pad
         if stacked is None:
             stacked = limb_iuv.reshape(nbs * 24, -1, S, S)
         _, lf = self.limb_net(stacked)
         lf = lf['x4']
-        lf = self.limb_reslayer(lf.reshape(nbs, -1, lf.size(-2), lf.size(-1)))      # [B,24*128,1,1]
+        lf = self.limb_reslayer(_glue.regroup_parts(lf, nbs) if REGROUP_PARTS else lf.reshape(nbs, -1, lf.size(-2), lf.size(-1)))      # [B,24*128,1,1]
         rot_feats = lf.reshape(nbs, 24, -1).float()                                   # [B,24,128]
 
         rd['joint_position'] = []
@@ -348,7 +393,10 @@ class DecomposedPredictor(nn.Module):
             if side is not None:
                 cur.wait_stream(side)
                 global_para.record_stream(cur)
+                _nn.SIDE_LIVE = max(0, _nn.SIDE_LIVE - 1)
             rd['para'] = torch.cat([global_para, smpl_pose], dim=1)
+            if window:
+                rd['para'] = _SideWindowOpen.apply(rd['para'])
             return rd
         if self.training:
             p0 = self._grouped_head(self.pose_regressors[0], rot_feats).reshape(nbs, -1) + self.mean_pose
@@ -371,5 +419,8 @@ class DecomposedPredictor(nn.Module):
         if side is not None:
             cur.wait_stream(side)
             global_para.record_stream(cur)
+            _nn.SIDE_LIVE = max(0, _nn.SIDE_LIVE - 1)
         rd['para'] = torch.cat([global_para, smpl_pose], dim=1)
+        if window:
+            rd['para'] = _SideWindowOpen.apply(rd['para'])
         return rd

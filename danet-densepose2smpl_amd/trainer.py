@@ -165,7 +165,9 @@ class Trainer(object):
             # step): 0 = the whole device; data-parallel: all-reduce kernels of earlier buckets run beside the backward pass, so the grid
             # barrier must fit next to them -- 2 * (compute units - channel limit); -1 = no limit known: two-kernel path
             self.onepass_blocks = 0
-            if self.distributed:
+            if os.environ.get('DANET_ONEPASS_BLOCKS'):            # experiment knob: an explicit budget
+                self.onepass_blocks = int(os.environ['DANET_ONEPASS_BLOCKS'])
+            elif self.distributed:
                 ch = comm_channel_limit()
                 if ch is None:
                     import warnings
@@ -323,6 +325,7 @@ class Trainer(object):
         from . import nn as _nn
         st = self.store
         prev_blocks, _nn.ONEPASS_MAX_BLOCKS = _nn.ONEPASS_MAX_BLOCKS, getattr(self, 'onepass_blocks', 0)
+        _nn.SIDE_LIVE = 0                      # (a backward pass that raised inside a side-stream window leaves it open)
         try:
             return self._core_body(batch, reduce, with_optimizer, segments, st)
         finally:

@@ -195,6 +195,12 @@ int danet_pad_multi(const void* const* src, void* const* dst, const int* sdims, 
  * backward.  n <= 8; a, b, grads are HOST arrays; w (device, or NULL = nw ones) are the per-sample weights. */
 int danet_loss_finalize(const void* sums, int rows, int n, const float* a, const float* b, const float* w, int nw,
                         const void* const* grads, float* out, void* stream);
+/* danet_regroup_parts: the 24 part crops of an image as 24 channel groups of one map (models/danet/smpl_regressor.py:826
+ *   `limb_feat.view(nbs, -1, h, w)`) on NHWC tensors: x [NB * J][HW][row_bytes] -> y [NB][HW][J][row_bytes]; inverse != 0: the other way
+ *   (its gradient).  row_bytes (a pixel's channels of one crop) % 16 == 0; any element type.
+ * danet_pack_image: x [B, C, H, W] fp32 NCHW (C <= 8) -> y [B, H, W, 8] bf16 NHWC, channels C .. 7 zero: the first convolution's operand. */
+int danet_regroup_parts(const void* x, void* y, int NB, int J, int HW, int row_bytes, int inverse, void* stream);
+int danet_pack_image(const float* x, void* y, int B, int C, int H, int W, void* stream);
 /* /root/reference/models/smpl.py:31-37 (joints = joints54[:, JOINT_MAP]; smpl_joints = joints54[:, :24]; joints_J19 = joints[:, -24:][:, J24_TO_J19]):
  * one launch forward, one backward (the three gradients scattered and summed into g54; NULL = zero). */
 int danet_smpl_joints_forward(const float* j54, const long* map49, const long* map19, int B, int NJ54, int N49, int N19,

@@ -525,3 +525,63 @@ def test_two_process_capture_falls_back_to_reduce_after_replay(tmp_path):
         assert torch.isfinite(c['p_after']).all() and not torch.equal(c['p_after'], c['p_before'])
     assert torch.equal(c0['p_before'], c1['p_before']) and torch.equal(c0['p_after'], c1['p_after'])
     assert torch.equal(c0['flat'], c1['flat'])
+
+
+def test_regroup_parts_equals_the_reshape_and_its_gradient():
+    """glue.regroup_parts (one launch each way) == x.reshape(NB, -1, H, W) on the logical NCHW tensor, bf16 and fp32."""
+    from danet_densepose2smpl_amd.glue import regroup_parts
+    for dt, (NB, J, C, H) in ((torch.bfloat16, (3, 24, 256, 4)), (torch.float32, (2, 24, 64, 2)), (torch.bfloat16, (2, 5, 8, 3))):
+        x = torch.randn(NB * J, C, H, H, device='cuda').to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = regroup_parts(x, NB)
+        ref = x.detach().reshape(NB, J * C, H, H)
+        assert y.shape == ref.shape and torch.equal(y, ref)
+        assert y.permute(0, 2, 3, 1).is_contiguous()
+        g = torch.randn_like(ref)
+        y.backward(g)
+        assert torch.equal(x.grad, g.reshape(NB * J, C, H, H))
+
+
+def test_pack_image_equals_cast_and_pad():
+    from danet_densepose2smpl_amd.glue import pack_image
+    x = torch.randn(3, 3, 20, 12, device='cuda') * 3
+    x[0, 0, 0, 0] = float('inf'); x[0, 1, 0, 1] = 1e-40
+    y = pack_image(x)
+    assert y.shape == (3, 8, 20, 12) and y.dtype == torch.bfloat16 and y.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(y[:, :3], x.bfloat16()) and float(y[:, 3:].abs().max()) == 0
+
+
+def test_side_stream_window_caps_the_barrier_budget_and_closes():
+    """smpl_regressor: while body_net runs on its side stream (forward: fork .. join; backward: the mirror image, bracketed by two
+    identity nodes) nn.onepass_budget() is one workgroup per compute unit; afterwards the window is closed again."""
+    _cfg(**{'DANET.INIMG_SIZE': 256, 'DANET.HEATMAP_SIZE': 64})
+    from danet_densepose2smpl_amd import nn as dnn, smpl_regressor as sr
+    from danet_densepose2smpl_amd.smpl_regressor import DecomposedPredictor
+    dnn.ONEPASS_STREAM = None
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert dnn.SIDE_LIVE == 0 and dnn.onepass_budget() == dnn.ONEPASS_MAX_BLOCKS
+    dnn.SIDE_LIVE = 1
+    try:
+        assert dnn.onepass_budget() == cus
+        keep, dnn.ONEPASS_MAX_BLOCKS = dnn.ONEPASS_MAX_BLOCKS, 64
+        assert dnn.onepass_budget() == 64
+        dnn.ONEPASS_MAX_BLOCKS = -1
+        assert dnn.onepass_budget() == -1
+        dnn.ONEPASS_MAX_BLOCKS = keep
+    finally:
+        dnn.SIDE_LIVE = 0
+    pose6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(24).unsqueeze(0)
+    net = DecomposedPredictor(None, (torch.tensor([[0.9, 0., 0.]]), torch.zeros(1, 10), pose6), pretrained=False).cuda().train()
+    seen = []
+    hook = net.limb_net[3].layer1[0].bn1.register_full_backward_hook(lambda m, gi, go: seen.append(dnn.SIDE_LIVE))
+    iuv = torch.randn(2, 75, 64, 64, device='cuda', requires_grad=True)
+    part = torch.randn(2, 24, 3, 7, 64, 64, device='cuda', requires_grad=True)
+    rd = net(iuv, part)
+    assert dnn.SIDE_LIVE == 0                                   # the forward window is closed at the join
+    (rd['para'].float().sum() + sum(t.float().sum() for t in rd['joint_position'])).backward()
+    hook.remove()
+    assert seen == [1] if sr.BODY_STREAM else seen == [0]       # limb_net's backward ran inside the window
+    assert dnn.SIDE_LIVE == 0 and iuv.grad is not None and part.grad is not None
+    from danet_densepose2smpl_amd import conv
+    conv.flush_wgrads()
+    torch.cuda.synchronize()
+    assert not dnn.onepass_error()

@@ -1,0 +1,5 @@
+#!/bin/bash
+exec < /dev/null
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+b() { timeout 300 python bench.py --no-cpu-baseline --no-fp32 --steps 6 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['finite_losses_and_parameters'], d['onepass_error'])"; }
+for i in 1 2 3 4 5 6; do b plain; DANET_SYNC_AFTER_CAPTURE=1 b sync_after_capture; done

@@ -1,0 +1,6 @@
+#!/bin/bash
+exec < /dev/null
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+b() { timeout 300 python bench.py --no-cpu-baseline --no-fp32 --steps 4 --warmup 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['onepass_error'], [hex(w) for w in d['barrier_error_word']])"; }
+for i in 1 2 3 4 5 6 7 8 9 10; do DANET_ONEPASS_BLOCKS=480 b budget480; done
+for i in 1 2 3 4 5 6 7 8 9 10; do DANET_ONEPASS_BLOCKS=464 b budget464; done
