@@ -41,6 +41,7 @@ ONEPASS_MAX_BLOCKS = 0
 # window is open the budget is one workgroup per compute unit; launches that need more take the two-kernel path (four BatchNorms of
 # limb_net's first layer).
 SIDE_LIVE = 0
+SIDE_CAP = bool(int(os.environ.get('DANET_SIDE_CAP', '1')))      # 0: A-B timing of the cap ONLY (the hazard above is real)
 _ONEPASS_BAR = {}
 _CUS = {}
 
@@ -49,7 +50,7 @@ def onepass_budget(device=None):
     """The co-residency budget a one-pass launch may use NOW (the `max_blocks` of danet_bn_backward_onepass): ONEPASS_MAX_BLOCKS, capped
     at one workgroup per compute unit while a side stream is live."""
     b = ONEPASS_MAX_BLOCKS
-    if SIDE_LIVE > 0 and b >= 0:
+    if SIDE_LIVE > 0 and b >= 0 and SIDE_CAP:
         dev = torch.cuda.current_device() if device is None or getattr(device, 'index', None) is None else device.index
         cus = _CUS.get(dev)
         if cus is None:
