@@ -100,6 +100,7 @@ class GcnTailFunction(torch.autograd.Function):
         a.ws, a.jr0, a.jp0, a.jp1, a.pose = ws.data_ptr(), jr0.data_ptr(), jp0.data_ptr(), jp1.data_ptr(), pose.data_ptr()
         a.bar, a.B, a.momentum, a.eps = bar.data_ptr(), B, float(bns[0].momentum), float(bns[0].eps)
         check(L.danet_gcn_tail_forward(ctypes.addressof(a), stream()), 'danet_gcn_tail_forward')
+        _nn.onepass_watch(dev)                        # (outside a Trainer: a barrier that gave up is reported by the next launch)
         for bn in bns:                                    # torch's per-module counter (nn.BatchNorm1d.forward)
             if _nn.BatchNorm2d.count_batches:
                 bn.num_batches_tracked.add_(1)
@@ -141,6 +142,7 @@ class GcnTailFunction(torch.autograd.Function):
         a.scratch, a.bar, a.B = scratch.data_ptr(), bar.data_ptr(), B
         a.momentum, a.eps = ctx.bn
         check(L.danet_gcn_tail_backward(ctypes.addressof(a), stream()), 'danet_gcn_tail_backward')
+        _nn.onepass_watch(dev)
         return (None, gx) + tuple(g.view(s) for g, s in zip(gp, ctx.shapes))
 
 

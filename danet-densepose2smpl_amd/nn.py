@@ -86,6 +86,34 @@ def onepass_poison(device):
     return _onepass_state(device)[2:3]
 
 
+_WATCH = {}
+
+
+def onepass_watch(device):
+    """For barrier launches OUTSIDE a Trainer (which checks the error word itself and keeps a timed-out step from being applied): a
+    non-blocking look at the error word.  Every call starts an asynchronous copy of the word into pinned memory and inspects the copy the
+    PREVIOUS call started, once its event has passed -- a launch that gave up at its barrier (its results are garbage, and the stale arrival
+    counts make later barriers release early) is reported by the next barrier launch or by `onepass_error()`, not silently.  Nothing is
+    done while the stream is capturing."""
+    if ONEPASS_STREAM is not None or torch.cuda.is_current_stream_capturing():
+        return
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _WATCH.get(idx)
+    if st is not None and st[1].query():
+        code = int(st[0][0])
+        if code != 0:
+            _WATCH.pop(idx, None)
+            raise RuntimeError('a grid-barrier kernel gave up waiting (error word 0x%x: csrc/grid_barrier.h); results since then are invalid -- '
+                               'nn.onepass_recover() resets the barrier state' % code)
+    if st is None:
+        st = _WATCH[idx] = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+    elif not st[1].query():
+        return                                   # the previous look is still in flight
+    st[0].copy_(_onepass_state(device)[2:3], non_blocking=True)
+    st[1].record(torch.cuda.current_stream(device))
+
+
 def _on_device(d, device):
     """d (a key of _ONEPASS_BAR, always with an index) is `device` (None = any; 'cuda' without an index = any GPU)."""
     if device is None:

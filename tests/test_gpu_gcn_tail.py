@@ -165,3 +165,27 @@ def test_fused_tail_is_not_taken_outside_its_configuration():
     net.train()
     with torch.no_grad():
         assert not gcn_tail.applicable(net, torch.zeros(4, 24, 128, device='cuda'))
+
+
+def test_a_barrier_that_gave_up_is_reported_outside_a_trainer():
+    """nn.onepass_watch: with no Trainer to read the barrier's error word, the next barrier launch after a time-out raises."""
+    _cfg()
+    from danet_densepose2smpl_amd import nn as dnn
+    dnn.ONEPASS_STREAM = None
+    net = _net(2)
+    x = (torch.randn(4, 24, 128).abs() * 0.5).cuda()
+    _tail(net, x.clone().requires_grad_(True))
+    torch.cuda.synchronize()
+    bar = dnn._onepass_state(x.device)
+    bar[2] = 0x301ec                                    # as a timed-out one-pass launch leaves it
+    try:
+        with pytest.raises(RuntimeError, match='0x301ec'):
+            for _ in range(3):                            # (the look is one launch behind)
+                _tail(net, x.clone().requires_grad_(True))
+                torch.cuda.synchronize()
+    finally:
+        bar.zero_()
+        dnn._WATCH.clear()
+    _tail(net, x.clone().requires_grad_(True))
+    torch.cuda.synchronize()
+    assert not dnn.onepass_error()
