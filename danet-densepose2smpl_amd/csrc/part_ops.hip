@@ -41,6 +41,28 @@ __device__ inline Pred load_pred(const bf16_t* __restrict__ src) {
     return p;
 }
 
+// the same from the zero-padded layout (cpj == 24: 48 bytes per (pixel, joint), 16-byte aligned): three 16-byte loads instead of 21
+// two-byte ones
+__device__ inline Pred load_pred24(const bf16_t* __restrict__ src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    const unsigned w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    float f[24];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { f[2 * i] = __builtin_bit_cast(float, w[i] << 16); f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+    Pred p;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { p.u[k] = f[k]; p.v[k] = f[NC + k]; p.ix[k] = f[2 * NC + k]; }
+    return p;
+}
+__device__ inline void store24(bf16_t* __restrict__ dst, const float* f /* [24] */) {
+    unsigned w[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) w[i] = (unsigned)(unsigned short)f2bf(f[2 * i]) | ((unsigned)(unsigned short)f2bf(f[2 * i + 1]) << 16);
+    uint4* q = reinterpret_cast<uint4*>(dst);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]); q[2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+
 __device__ inline int argmax7(const float* x) {          // first maximum, like torch.argmax
     int am = 0; float best = x[0];
 #pragma unroll
@@ -152,22 +174,38 @@ __device__ inline Gt part_gt(const float* __restrict__ img /* [3][H][W] of sampl
 
 __device__ inline float smooth_l1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
 
+// Round 6: a workgroup owns a tile of 256 consecutive pixels of ONE sample and walks its 256 x 24 (pixel, joint) items (consecutive lanes =
+// consecutive joints of a pixel: the prediction is read in order); the sample's ground-truth image -- 3 x H x W floats, 48 KB at 64 x 64 --
+// is copied to LDS first, so the four bilinear taps of every item (12 gathers at addresses that differ from joint to joint) are LDS reads
+// instead of scattered global loads (IMG_LDS; larger images: the global loads as before).  The padded layout's 24 channels of an item
+// travel as three 16-byte accesses (load_pred24 / store24) instead of 21 - 24 two-byte ones.  One atomic triple per tile instead of one
+// per 256 items.  fwd 136 -> see DESIGN 3.2b; the arithmetic per item is unchanged.
+constexpr int PL_TILE = 256;
+constexpr int PL_LDS_FLOATS = 3 * 4096;          // largest image kept in LDS: 64 x 64
+
+template <bool IMG_LDS>
 __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
                                                         const float* __restrict__ theta, const float* __restrict__ wsample,
                                                         const int* __restrict__ sel, int B, int H, int W, int align, int cpj,
                                                         double* __restrict__ sums /* [NREP][3] */)
 {
-    const int HW = H * W;
-    const long total = (long)B * HW * NJ;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float simg[IMG_LDS ? PL_LDS_FLOATS : 4];
+    const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
+    const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * PL_TILE, t = threadIdx.x;
+    const float* gimg = img + (size_t)b * 3 * HW;
+    if (IMG_LDS) {
+        for (int i = t; i < 3 * HW / 4; i += 256) reinterpret_cast<float4*>(simg)[i] = reinterpret_cast<const float4*>(gimg)[i];
+        __syncthreads();
+    }
+    const float w = wsample ? wsample[b] : 1.f;
+    const int npix = HW - hw0 < PL_TILE ? HW - hw0 : PL_TILE;
     float lu = 0.f, lv = 0.f, li = 0.f;
-    if (i < total) {
-        const int j = (int)(i % NJ);
-        const long pix = i / NJ;
-        const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
-        const float w = wsample ? wsample[b] : 1.f;
-        const Pred p = load_pred(pred + (pix * NJ + j) * cpj);
-        const Gt g = part_gt(img + (size_t)b * 3 * HW, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
+    for (int i = t; i < npix * NJ; i += 256) {
+        const int j = i % NJ, hw = hw0 + i / NJ;
+        const long pix = (long)b * HW + hw;
+        const bf16_t* src = pred + (pix * NJ + j) * cpj;
+        const Pred p = cpj == 24 ? load_pred24(src) : load_pred(src);
+        const Gt g = part_gt(IMG_LDS ? simg : gimg, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float fg = g.I[c] > 0.f ? w : 0.f;
@@ -181,7 +219,7 @@ __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) se += expf(p.ix[c] - mx);
-        li = (logf(se) + mx - p.ix[tgt]) * w;
+        li += (logf(se) + mx - p.ix[tgt]) * w;
     }
     __shared__ float red[3][4];
 #pragma unroll
@@ -196,39 +234,54 @@ __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict
     }
 }
 
+template <bool IMG_LDS>
 __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
                                                             const float* __restrict__ theta, const float* __restrict__ wsample,
                                                             const int* __restrict__ sel, const float* __restrict__ scale /* [3] */,
                                                             int B, int H, int W, int align, int cpj, bf16_t* __restrict__ gpred)
 {
-    const int HW = H * W;
-    const long total = (long)B * HW * NJ;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i % NJ);
-    const long pix = i / NJ;
-    const int b = (int)(pix / HW), hw = (int)(pix - (long)b * HW);
+    __shared__ float simg[IMG_LDS ? PL_LDS_FLOATS : 4];
+    const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
+    const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * PL_TILE, t = threadIdx.x;
+    const float* gimg = img + (size_t)b * 3 * HW;
+    if (IMG_LDS) {
+        for (int i = t; i < 3 * HW / 4; i += 256) reinterpret_cast<float4*>(simg)[i] = reinterpret_cast<const float4*>(gimg)[i];
+        __syncthreads();
+    }
     const float w = wsample ? wsample[b] : 1.f;
     const float su = scale[0], sv = scale[1], si = scale[2];
-    const Pred p = load_pred(pred + (pix * NJ + j) * cpj);
-    const Gt g = part_gt(img + (size_t)b * 3 * HW, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
-    const int tgt = argmax7(g.I);
-    float mx = p.ix[0];
+    const int npix = HW - hw0 < PL_TILE ? HW - hw0 : PL_TILE;
+    for (int i = t; i < npix * NJ; i += 256) {
+        const int j = i % NJ, hw = hw0 + i / NJ;
+        const long pix = (long)b * HW + hw;
+        const bf16_t* src = pred + (pix * NJ + j) * cpj;
+        const Pred p = cpj == 24 ? load_pred24(src) : load_pred(src);
+        const Gt g = part_gt(IMG_LDS ? simg : gimg, theta + ((size_t)b * NJ + j) * 6, sel + j * 6, H, W, hw / W, hw % W, align);
+        const int tgt = argmax7(g.I);
+        float mx = p.ix[0];
 #pragma unroll
-    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, p.ix[c]);
-    float ex[NC], se = 0.f;
+        for (int c = 1; c < NC; ++c) mx = fmaxf(mx, p.ix[c]);
+        float ex[NC], se = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { ex[c] = expf(p.ix[c] - mx); se += ex[c]; }
-    const float inv = 1.f / se;
-    bf16_t* dst = gpred + (pix * NJ + j) * cpj;
-    for (int c = 3 * NC; c < cpj; ++c) dst[c] = 0;
+        for (int c = 0; c < NC; ++c) { ex[c] = expf(p.ix[c] - mx); se += ex[c]; }
+        const float inv = 1.f / se;
+        float out[24];
+        out[21] = out[22] = out[23] = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float fg = g.I[c] > 0.f ? w : 0.f;
-        const float du = fminf(fmaxf(p.u[c] - g.U[c], -1.f), 1.f), dv = fminf(fmaxf(p.v[c] - g.V[c], -1.f), 1.f);
-        dst[c] = f2bf(su * fg * du);
-        dst[NC + c] = f2bf(sv * fg * dv);
-        dst[2 * NC + c] = f2bf(si * w * (ex[c] * inv - (c == tgt ? 1.f : 0.f)));
+        for (int c = 0; c < NC; ++c) {
+            const float fg = g.I[c] > 0.f ? w : 0.f;
+            const float du = fminf(fmaxf(p.u[c] - g.U[c], -1.f), 1.f), dv = fminf(fmaxf(p.v[c] - g.V[c], -1.f), 1.f);
+            out[c] = su * fg * du;
+            out[NC + c] = sv * fg * dv;
+            out[2 * NC + c] = si * w * (ex[c] * inv - (c == tgt ? 1.f : 0.f));
+        }
+        bf16_t* dst = gpred + (pix * NJ + j) * cpj;
+        if (cpj == 24) store24(dst, out);
+        else {
+#pragma unroll
+            for (int c = 0; c < 3 * NC; ++c) dst[c] = f2bf(out[c]);
+            for (int c = 3 * NC; c < cpj; ++c) dst[c] = 0;
+        }
     }
 }
 
@@ -262,9 +315,13 @@ extern "C" int danet_part_loss_forward(const void* pred, const float* iuv_img, c
 {
     DANET_ENTER();
     DANET_CHECK_ARG(pred && iuv_img && theta && sel && sums && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_loss_forward: bad arguments");
-    const long total = (long)B * H * W * NJ;
-    hipLaunchKernelGGL(part_loss_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, B, H, W, align, cpj, sums);
+    const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
+    if (3 * HW <= PL_LDS_FLOATS && HW % 4 == 0)
+        hipLaunchKernelGGL(part_loss_kernel<true>, dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)pred, iuv_img, theta, sample_w, sel, B, H, W, align, cpj, sums);
+    else
+        hipLaunchKernelGGL(part_loss_kernel<false>, dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)pred, iuv_img, theta, sample_w, sel, B, H, W, align, cpj, sums);
     DANET_CHECK_LAUNCH("part_loss_kernel");
     return DANET_OK;
 }
@@ -274,9 +331,13 @@ extern "C" int danet_part_loss_backward(const void* pred, const float* iuv_img, 
 {
     DANET_ENTER();
     DANET_CHECK_ARG(pred && iuv_img && theta && sel && scale && gpred && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_loss_backward: bad arguments");
-    const long total = (long)B * H * W * NJ;
-    hipLaunchKernelGGL(part_loss_bwd_kernel, dim3((unsigned)danet::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred);
+    const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
+    if (3 * HW <= PL_LDS_FLOATS && HW % 4 == 0)
+        hipLaunchKernelGGL(part_loss_bwd_kernel<true>, dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred);
+    else
+        hipLaunchKernelGGL(part_loss_bwd_kernel<false>, dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred);
     DANET_CHECK_LAUNCH("part_loss_bwd_kernel");
     return DANET_OK;
 }
