@@ -103,6 +103,7 @@ _SIGNATURES = {
     'danet_part_clean_backward': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     'danet_part_loss_forward': (c_i, [c_f] * 5 + [c_i] * 5 + [c_f, c_f]),
     'danet_part_loss_backward': (c_i, [c_f] * 6 + [c_i] * 5 + [c_f, c_f]),
+    'danet_part_backward_fused': (c_i, [c_f] * 8 + [c_i] * 5 + [c_f, c_f]),
     'danet_iuv_global_forward': (c_i, [c_f] * 4 + [c_i, c_i] + [c_f] * 3 + [c_i] * 4 + [c_f] * 5),
     'danet_iuv_global_backward': (c_i, [c_f] * 4 + [c_i, c_i] + [c_f] * 6 + [c_i] * 4 + [c_f] * 5),
     'danet_softargmax_forward': (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),

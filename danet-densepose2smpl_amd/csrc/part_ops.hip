@@ -234,11 +234,15 @@ __global__ __launch_bounds__(256) void part_loss_kernel(const bf16_t* __restrict
     }
 }
 
-template <bool IMG_LDS>
+// CLEAN: the gradient that arrives through part_clean (g24 [B*24][HW][24], keep [B][24][7] or NULL) is added in the same pass -- the two
+// consumers of the prediction (the three losses, the regressor's cleaned operand) then cost ONE read of the prediction and ONE write of its
+// gradient instead of two kernels and autograd's add over the 151 MB tensors (round 6: 93 + 125 + 74 us -> one launch).
+template <bool IMG_LDS, bool CLEAN>
 __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ img,
                                                             const float* __restrict__ theta, const float* __restrict__ wsample,
                                                             const int* __restrict__ sel, const float* __restrict__ scale /* [3] */,
-                                                            int B, int H, int W, int align, int cpj, bf16_t* __restrict__ gpred)
+                                                            int B, int H, int W, int align, int cpj, bf16_t* __restrict__ gpred,
+                                                            const bf16_t* __restrict__ g24, const float* __restrict__ keep)
 {
     __shared__ float simg[IMG_LDS ? PL_LDS_FLOATS : 4];
     const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
@@ -274,6 +278,16 @@ __global__ __launch_bounds__(256) void part_loss_bwd_kernel(const bf16_t* __rest
             out[c] = su * fg * du;
             out[NC + c] = sv * fg * dv;
             out[2 * NC + c] = si * w * (ex[c] * inv - (c == tgt ? 1.f : 0.f));
+        }
+        if (CLEAN) {          // part_clean_bwd_kernel's term: the arg-max class of keep * index receives keep * d x24 on its U and V channels
+            float k[NC], sx[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { k[c] = keep ? keep[((size_t)b * NJ + j) * NC + c] : 1.f; sx[c] = p.ix[c] * k[c]; }
+            const int am = argmax7(sx);
+            const Pred g = load_pred24(g24 + (((size_t)b * NJ + j) * HW + hw) * 24);       // (.u / .v = the gradient's U / V channels)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c == am) { out[c] += bf2f(f2bf(g.u[c] * k[c])); out[NC + c] += bf2f(f2bf(g.v[c] * k[c])); }
         }
         bf16_t* dst = gpred + (pix * NJ + j) * cpj;
         if (cpj == 24) store24(dst, out);
@@ -326,18 +340,35 @@ extern "C" int danet_part_loss_forward(const void* pred, const float* iuv_img, c
     return DANET_OK;
 }
 
+static int part_bwd_launch(const void* pred, const float* iuv_img, const float* theta, const float* sample_w, const int* sel, const float* scale,
+                           int B, int H, int W, int align, int cpj, void* gpred, const void* g24, const float* keep, void* stream)
+{
+    const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
+    const bool lds = 3 * HW <= PL_LDS_FLOATS && HW % 4 == 0;
+#define PART_BWD(L, C) hipLaunchKernelGGL((part_loss_bwd_kernel<L, C>), dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, \
+                                          iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred, (const bf16_t*)g24, keep)
+    if (g24) { if (lds) PART_BWD(true, true); else PART_BWD(false, true); }
+    else { if (lds) PART_BWD(true, false); else PART_BWD(false, false); }
+#undef PART_BWD
+    DANET_CHECK_LAUNCH("part_loss_bwd_kernel");
+    return DANET_OK;
+}
+
 extern "C" int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
                                         const int* sel, const float* scale, int B, int H, int W, int align, int cpj, void* gpred, void* stream)
 {
     DANET_ENTER();
     DANET_CHECK_ARG(pred && iuv_img && theta && sel && scale && gpred && B > 0 && H > 0 && W > 0 && cpj >= 3 * NC, "part_loss_backward: bad arguments");
-    const int HW = H * W, tiles = (HW + PL_TILE - 1) / PL_TILE;
-    if (3 * HW <= PL_LDS_FLOATS && HW % 4 == 0)
-        hipLaunchKernelGGL(part_loss_bwd_kernel<true>, dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred);
-    else
-        hipLaunchKernelGGL(part_loss_bwd_kernel<false>, dim3((unsigned)(B * tiles)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, (bf16_t*)gpred);
-    DANET_CHECK_LAUNCH("part_loss_bwd_kernel");
-    return DANET_OK;
+    return part_bwd_launch(pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, gpred, nullptr, nullptr, stream);
+}
+
+// d pred of BOTH consumers of the prediction in one pass: danet_part_loss_backward + danet_part_clean_backward (g24 [B*24,H,W,24] bf16,
+// keep [B,24,7] or NULL); the padded layout only (cpj == 24).
+extern "C" int danet_part_backward_fused(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
+                                         const int* sel, const float* scale, const void* g24, const float* keep,
+                                         int B, int H, int W, int align, int cpj, void* gpred, void* stream)
+{
+    DANET_ENTER();
+    DANET_CHECK_ARG(pred && iuv_img && theta && sel && scale && gpred && g24 && B > 0 && H > 0 && W > 0 && cpj == 24, "part_backward_fused: bad arguments (cpj must be 24)");
+    return part_bwd_launch(pred, iuv_img, theta, sample_w, sel, scale, B, H, W, align, cpj, gpred, g24, keep, stream);
 }

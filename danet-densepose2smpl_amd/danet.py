@@ -94,8 +94,14 @@ class DaNet(nn.Module):
         if self.training and D.PARTDROP_RATE > 0:                            # danet.py:194-203
             keep = (torch.rand(B, 24, device=image.device) >= D.PARTDROP_RATE).to(torch.float32)
             keep25 = torch.cat([torch.ones(B, 1, device=image.device), keep], dim=1)
+        from . import conv as _conv
+        pk = None
+        if keep is not None:                                                  # danet.py:264-274
+            pk = keep25[:, self._partial_src]                                # [B,24,7]
+        # (the cleaned partial maps are made together with the partial losses when the regressor will run: part_ops.part_joint)
+        want_x24 = FUSED_PART_OPS and image.is_cuda and _conv.PRECISION != 'fp32' and not in_dict.get('pretrain_mode', False)
         uv = self.img2iuv(image, uv_image_gt, target_smpl_kps, uvia_dp_gt=in_dict.get('dp_dict'), has_iuv=has_iuv, has_dp=has_dp,
-                          keep25=keep25)
+                          keep25=keep25, part_clean=(pk,) if want_x24 else None)
         u_pred, v_pred, index_pred, ann_pred = uv['uvia_pred']
         segments.note_losses(uv.get('losses', {}).keys())            # the estimator's losses hang off the segment open now
 
@@ -121,14 +127,12 @@ class DaNet(nn.Module):
         smpl_rd = None
         if not in_dict.get('pretrain_mode', False):
             part_pred = uv['part_iuv_pred']
-            pk = None
-            if keep is not None:                                              # danet.py:264-274
-                pk = keep25[:, self._partial_src]                            # [B,24,7]
-            from . import conv as _conv
             # the IUV -> SMPL regressor is a backward-pass segment of its own (segments.py: its gradient buckets are on the wire
             # while the estimator's and the backbone's backward run); identity unless a data-parallel trainer asked for cuts
             if FUSED_PART_OPS and part_pred.is_cuda and _conv.PRECISION != 'fp32':
-                _, x24 = part_ops.part_clean(part_pred, pk)                   # one kernel; bf16, channels 21..23 zero
+                x24 = uv.get('part_x24')                                      # made beside the partial losses (one autograd node)
+                if x24 is None:
+                    _, x24 = part_ops.part_clean(part_pred, pk)               # one kernel; bf16, channels 21..23 zero
                 iuv_map, x24 = segments.cut([iuv_map, x24])
                 part_iuv_map = part_ops.padded_part_view(x24)                 # the [B,24,3,7,H,W] view of the padded operand
                 part_iuv_map._nhwc_padded = x24

@@ -53,6 +53,7 @@ def load_learned_ratio(path=None):
 
 
 FUSED_STN_THETA = True       # visibility score + affine_para as one HIP launch (False: the tensor-op formulation)
+PART_JOINT = bool(int(os.environ.get('DANET_PART_JOINT', '1')))            # the partial losses and the regressor's cleaned operand as one autograd node (A-B knob)
 LOSS_FINALIZE = bool(int(os.environ.get('DANET_LOSS_FINALIZE', '1')))     # the estimator's losses leave their fused ops finished (glue.loss_finalize); 0: tensor-op scaling (A-B)
 
 
@@ -238,9 +239,11 @@ class IUV_Estimator(nn.Module):
 
     # --------------------------------------------------------------------------------------
     def forward(self, data, iuv_image_gt=None, smpl_kps_gt=None, kps3d_gt=None, uvia_dp_gt=None, has_iuv=None, has_dp=None,
-                keep25=None):
+                keep25=None, part_clean=None):
         """keep25 [B,25] (optional): DaNet's part-drop mask; with it the fused global-IUV op also produces the cleaned,
-        concatenated regressor input (rd['iuv_map'], rd['iuv_argmax']) in the same launch."""
+        concatenated regressor input (rd['iuv_map'], rd['iuv_argmax']) in the same launch.  part_clean = (keep [B,24,7] or None,)
+        (optional): the caller will feed the cleaned partial maps to the regressor -- they come back as rd['part_x24'], made by the same
+        autograd node as the partial losses (part_ops.part_joint)."""
         rd = {'losses': {}, 'metrics': {}, 'visualization': {}}
         align = bool(cfg.DANET.get('ALIGN_CORNERS', True))
         est = self.iuv_est(data)
@@ -345,8 +348,14 @@ class IUV_Estimator(nn.Module):
             w = None if has_iuv is None else has_iuv.to(torch.float32)
             if LOSS_FINALIZE:
                 pr = cfg.DANET.POINT_REGRESSION_WEIGHTS / (24. * B)          # (sum / B * weight) / 24 joints
-                lU, lV, lI = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align,
-                                                  scales=((pr, 0.), (pr, 0.), (1., 24. * Sp * Sp)))
+                scales = ((pr, 0.), (pr, 0.), (1., 24. * Sp * Sp))
+                if PART_JOINT and part_clean is not None:
+                    # the caller (DaNet) will clean this prediction for the regressor: both consumers in one autograd node, so that the
+                    # backward is one launch (part_ops.PartJointFunction); part_clean = (keep [B,24,7] or None,)
+                    x24, lU, lV, lI = part_ops.part_joint(part_pred, part_clean[0], iuv_image_gt, thetas, w, self._dp_sel, align, scales)
+                    rd['part_x24'] = x24
+                else:
+                    lU, lV, lI = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align, scales=scales)
                 rd['losses'].update({'loss_pU': lU, 'loss_pV': lV, 'loss_pIndexUV': lI})
             else:
                 sums = part_ops.part_losses(part_pred, iuv_image_gt, thetas, w, self._dp_sel, align)

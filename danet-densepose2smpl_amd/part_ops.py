@@ -124,3 +124,77 @@ def part_losses(pred, iuv_img, theta, sample_w, sel, align, scales=None):
         B, J, T, K, H, W = pred.shape
         pred = getattr(pred, '_padded', None) if getattr(pred, '_padded', None) is not None else pred.reshape(B, J * T * K, H, W)
     return PartLossFunction.apply(pred, iuv_img, theta, sample_w, sel, align, scales)
+
+
+class PartJointFunction(torch.autograd.Function):
+    """part_clean AND part_losses of one prediction as ONE autograd node (round 6): the prediction has two consumers -- the three losses and
+    the regressor's cleaned operand -- and autograd summed their gradients with an add over three 151 MB tensors after two separate
+    backward kernels; here the backward is one launch (danet_part_backward_fused) that reads the prediction once and writes its gradient once.
+    Outputs: (x24, loss_pU, loss_pV, loss_pIndexUV) -- the finished losses (`scales`, see part_losses)."""
+
+    @staticmethod
+    def forward(ctx, pred, keep, iuv_img, theta, sample_w, sel, align, scales):
+        from .glue import loss_finalize
+        pred = nhwc_bf16(pred)
+        B, C, H, W = pred.shape
+        cpj = _cpj(C)
+        L = _lib.lib()
+        k = None if keep is None else keep.detach().to(torch.float32).contiguous()
+        x24 = torch.empty(B * NJ, H, W, 24, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
+        check(L.danet_part_clean_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, cpj, ptr(x24.permute(0, 2, 3, 1)), stream()), 'danet_part_clean_forward')
+        img = iuv_img.detach().to(torch.float32).contiguous()
+        th = theta.detach().to(torch.float32).contiguous()
+        w = None if sample_w is None else sample_w.detach().to(torch.float32).contiguous()
+        sel = sel.to(torch.int32).contiguous()
+        if img.shape != (B, 3, H, W) or th.shape != (B, NJ, 2, 3) or sel.shape != (NJ, 6):
+            raise ValueError('part_joint: bad shapes %s %s %s' % (tuple(img.shape), tuple(th.shape), tuple(sel.shape)))
+        sums = ARENA.alloc(32 * 3 * 2)
+        if sums is None:
+            sums = torch.zeros(32 * 3 * 2, dtype=torch.float32, device=pred.device)
+        check(L.danet_part_loss_forward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), B, H, W, int(align), cpj, ptr(sums), stream()),
+              'danet_part_loss_forward')
+        out = loss_finalize(3, scales, w, B, sums=sums, rows=32)
+        ctx.save_for_backward(pred, k, img, th, w, sel)
+        ctx.align, ctx.scales, ctx.cpj = int(align), scales, cpj
+        ctx.set_materialize_grads(False)
+        return x24, out[0:1], out[1:2], out[2:3]
+
+    @staticmethod
+    def backward(ctx, g24, *gl):
+        from .glue import loss_finalize
+        pred, k, img, th, w, sel = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        L = _lib.lib()
+        none = (None,) * 8
+        have_loss = any(g is not None for g in gl)
+        if g24 is None and not have_loss:
+            return none
+        gp = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=pred.device).permute(0, 3, 1, 2)
+        if g24 is not None:
+            g24 = nhwc_bf16(g24)
+        if not have_loss:
+            check(L.danet_part_clean_backward(ptr(g24.permute(0, 2, 3, 1)), ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, ctx.cpj,
+                                              ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_clean_backward')
+            return (gp,) + none[1:]
+        scale = loss_finalize(3, ctx.scales, w, B, grads=list(gl))
+        if g24 is None or ctx.cpj != 24:
+            check(L.danet_part_loss_backward(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), ptr(scale),
+                                             B, H, W, ctx.align, ctx.cpj, ptr(gp.permute(0, 2, 3, 1)), stream()), 'danet_part_loss_backward')
+            if g24 is not None:              # (the unpadded layout: two kernels and an add, as autograd would)
+                gc = torch.empty_like(gp)
+                check(L.danet_part_clean_backward(ptr(g24.permute(0, 2, 3, 1)), ptr(pred.permute(0, 2, 3, 1)), ptr(k), B, H, W, ctx.cpj,
+                                                  ptr(gc.permute(0, 2, 3, 1)), stream()), 'danet_part_clean_backward')
+                gp = gp + gc
+            return (gp,) + none[1:]
+        check(L.danet_part_backward_fused(ptr(pred.permute(0, 2, 3, 1)), ptr(img), ptr(th), ptr(w), ptr(sel), ptr(scale),
+                                          ptr(g24.permute(0, 2, 3, 1)), ptr(k), B, H, W, ctx.align, ctx.cpj, ptr(gp.permute(0, 2, 3, 1)), stream()),
+              'danet_part_backward_fused')
+        return (gp,) + none[1:]
+
+
+def part_joint(pred, keep, iuv_img, theta, sample_w, sel, align, scales):
+    """-> (x24, lU, lV, lI): part_clean(pred, keep)[1] and part_losses(..., scales=scales) as one autograd node."""
+    if pred.dim() == 6:
+        B, J, T, K, H, W = pred.shape
+        pred = getattr(pred, '_padded', None) if getattr(pred, '_padded', None) is not None else pred.reshape(B, J * T * K, H, W)
+    return PartJointFunction.apply(pred, keep, iuv_img, theta, sample_w, sel, align, scales)

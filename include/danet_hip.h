@@ -261,6 +261,11 @@ int danet_part_loss_forward(const void* pred, const float* iuv_img, const float*
                             const int* sel, int B, int H, int W, int align, int cpj, double* sums, void* stream);
 int danet_part_loss_backward(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
                              const int* sel, const float* scale, int B, int H, int W, int align, int cpj, void* gpred, void* stream);
+/* d pred of BOTH consumers of the prediction in one pass (round 6): danet_part_loss_backward's three terms plus danet_part_clean_backward's
+ * (g24 = d x24, keep as there); cpj == 24 only.  What autograd did as two kernels and an add over three 151 MB tensors. */
+int danet_part_backward_fused(const void* pred, const float* iuv_img, const float* theta, const float* sample_w,
+                              const int* sel, const float* scale, const void* g24, const float* keep,
+                              int B, int H, int W, int align, int cpj, void* gpred, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution (replaces the cuDNN/ATen kernels behind every nn.Conv2d on the hot path:

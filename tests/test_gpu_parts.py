@@ -176,3 +176,55 @@ def test_part_losses_vs_reference_golden(align):
         pytest.fail('thetas rebuilt from the golden centres / index head do not reproduce the reference ground-truth maps')
     for ours, k in ((lU, 'loss_pU'), (lV, 'loss_pV'), (lI, 'loss_pIndexUV')):
         assert abs(ours - ref[k]) <= 2e-3 * abs(ref[k]) + 1e-6, (k, ours, ref[k])
+
+
+@pytest.mark.parametrize('with_keep,with_w,S', [(True, True, 16), (False, False, 64), (True, False, 12)])
+def test_part_joint_equals_the_two_separate_ops(with_keep, with_w, S):
+    """part_ops.part_joint (ONE autograd node: its backward is one launch, danet_part_backward_fused) == part_clean + part_losses with
+    autograd's add of their two gradients: x24 and the three finished losses bit for bit, d pred within one bf16 rounding of the sum
+    (the separate path rounds each term and their sum to bf16, the fused one the sum once); also with only one of the two consumers
+    carrying a gradient.  S = 64: the ground-truth image in LDS; S = 12: H * W = 144 is no multiple of 256 (ragged last tile)."""
+    from danet_densepose2smpl_amd import part_ops
+    from danet_densepose2smpl_amd.iuv_estimator import DP2SMPL_MAPPING
+    B = 2
+    pred, keep = _inputs(B, S, 21, with_keep)
+    pad = torch.zeros(B, S, S, 24, 24, dtype=torch.bfloat16, device='cuda')
+    pad[..., :21] = pred.permute(0, 2, 3, 1).reshape(B, S, S, 24, 21)
+    pad = pad.reshape(B, S, S, 576).permute(0, 3, 1, 2)
+    g = torch.Generator().manual_seed(5)
+    img = torch.stack([torch.randint(0, 25, (B, S, S), generator=g).float() / 24., torch.rand(B, S, S, generator=g),
+                       torch.rand(B, S, S, generator=g)], 1).cuda()
+    theta = torch.zeros(B, 24, 2, 3)
+    theta[:, :, 0, 0] = theta[:, :, 1, 1] = 0.6
+    theta[:, :, :, 2] = torch.rand(B, 24, 2, generator=g) - 0.5
+    theta = theta.cuda()
+    w = torch.tensor([1., 0.5]).cuda() if with_w else None
+    sel = torch.tensor(DP2SMPL_MAPPING, dtype=torch.long).cuda()
+    scales = ((0.3, 0.), (0.7, 0.), (1., 24. * S * S))
+    gx = torch.randn(B * 24, 24, S, S, generator=g).cuda().bfloat16()
+    cw = torch.tensor([1.3, 0.4, 2.0]).cuda()
+    for use_x24, use_loss in ((True, True), (True, False), (False, True)):
+        res = []
+        for joint in (False, True):
+            p = pad.clone().requires_grad_(True)
+            v6 = part_ops.padded_view6(p)
+            if joint:
+                x24, lU, lV, lI = part_ops.part_joint(v6, keep, img, theta, w, sel, True, scales)
+            else:
+                _, x24 = part_ops.part_clean(v6, keep)
+                lU, lV, lI = part_ops.part_losses(v6, img, theta, w, sel, True, scales=scales)
+            loss = 0
+            if use_x24:
+                loss = loss + (x24.float() * gx.float()).sum()
+            if use_loss:
+                loss = loss + lU.sum() * cw[0] + lV.sum() * cw[1] + lI.sum() * cw[2]
+            loss.backward()
+            res.append((x24.detach(), torch.cat([lU, lV, lI]).detach(), p.grad.float()))
+        assert torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1])
+        d, ref = res[1][2] - res[0][2], res[0][2]
+        assert float(d.abs().max()) <= 2 ** -7 * float(ref.abs().max()) + 1e-12, (use_x24, use_loss, float(d.abs().max()), float(ref.abs().max()))
+        if not (use_x24 and use_loss):
+            assert torch.equal(res[0][2], res[1][2])                       # one consumer: the same kernel as the separate op
+        gr = res[1][2].permute(0, 2, 3, 1).reshape(B, S, S, 24, 24)
+        assert float(gr[..., 21:].abs().max()) == 0.0
