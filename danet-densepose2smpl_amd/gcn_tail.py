@@ -48,6 +48,11 @@ def applicable(pred, rot_feats):
         if tuple(gc.weight.shape) != d or gc.bias is None or not isinstance(bn, torch.nn.BatchNorm1d) or bn.momentum is None \
                 or not bn.affine or not bn.track_running_stats or bn.num_features != 24:
             return False
+    bns = [bn for _, bn in _layers(pred)]
+    if any(bn.momentum != bns[0].momentum or bn.eps != bns[0].eps for bn in bns):
+        return False                                   # (the kernel takes one momentum / eps for the five BatchNorm1d modules)
+    if any(p.dtype != torch.float32 for p in _params(pred)) or rot_feats.dtype != torch.float32:
+        return False
     from . import nn as _nn
     return _nn._onepass_bar(rot_feats.device) is not None
 
